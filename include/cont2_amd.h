@@ -1,0 +1,257 @@
+/*
+ * cont2_amd.h -- C-ABI of the MI355X-native contour-context hot path.
+ *
+ * This is the drop-in boundary of the build.  The reference has no
+ * FFI layer: its interface is the C++ class API of the `cont2contops` library.  Every entry
+ * point below names the reference function(s) it replaces (file:line under the reference
+ * tree), and `contour-context_amd/hostcpp/` re-creates the reference classes on top of it.
+ *
+ * All functions return 0 on success, a negative CC_E* code otherwise; they never abort.
+ * Pointers named d_* are device (HBM) pointers, h_* host pointers.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  No torch types cross this boundary.
+ *
+ * Layout structs (cc_contour_t, cc_bci_t, cc_scan_desc_t ...) are plain-old-data shared by the
+ * device kernels, the host mirror and -- for comparison only -- the CPU oracle under oracle/.
+ */
+#ifndef CONT2_AMD_H
+#define CONT2_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- compile-time shape ---- */
+#define CC_NLEV 6          /* lv_grads_.size(); both shipped configs use 6 (yaml :30-31)        */
+#define CC_KEY_DIM 10      /* RET_KEY_DIM, contour_mng.h:89                                     */
+#define CC_NPIV 6          /* piv_firsts_ upper bound (anchors per level), contour_mng.h:107    */
+#define CC_NDIST 10        /* dist_firsts_ upper bound, contour_mng.h:108                       */
+#define CC_BCI_LAYERS 4    /* NUM_BIN_KEY_LAYER: DIST_BIN_LAYERS = {1,2,3,4}, contour_mng.h:113 */
+#define CC_BITS_PER_LAYER 64 /* contour_mng.h:112                                               */
+#define CC_BCI_MAXPTS 40   /* 4 layers x 10 neighbours                                          */
+#define CC_MAXC 320        /* stored contours per level per scan (sorted, largest first)        */
+#define CC_MAX_CELLS 22500 /* n_row_*n_col_ upper bound (150x150), LDS-resident BEV             */
+#define CC_NQLEV 3         /* q_levels_.size() upper bound ([1,2,3], yaml :11)                  */
+#define CC_KNN_MAX 64      /* nnk_ upper bound (shipped 50)                                     */
+#define CC_GMM_LEVELS 4    /* GMMOptConfig::levels_ = {1,2,3,4}, correlation.h:18               */
+
+enum {
+  CC_OK = 0,
+  CC_EINVAL = -1,   /* bad argument / unsupported configuration            */
+  CC_EHIP = -2,     /* a HIP runtime call failed (see cc_last_error)       */
+  CC_ENOMEM = -3,
+  CC_ECAPACITY = -4 /* a fixed capacity (DB size, batch size) was exceeded */
+};
+
+/* ------------------------------------------------------------------------- configs ------ */
+/* ContourManagerConfig (contour_mng.h:92-110) + ContourViewStatConfig (contour.h:32-37). */
+typedef struct {
+  float lv_grads[CC_NLEV];
+  float reso_row, reso_col;
+  int32_t n_row, n_col;
+  float lidar_height;
+  float blind_sq;
+  int32_t min_cont_key_cnt;
+  int32_t min_cont_cell_cnt;
+  int32_t piv_firsts;
+  int32_t dist_firsts;
+  float roi_radius;
+  /* ContourViewStatConfig */
+  int32_t min_cell_cov;
+  float point_sigma;
+  float com_bias_thres;
+} cc_manager_cfg_t;
+
+/* ContourSimThresConfig (contour.h:40-45). */
+typedef struct {
+  float ta_cell_cnt, tp_cell_cnt, tp_eigval, ta_h_bar, ta_rcom, tp_rcom;
+} cc_sim_cfg_t;
+
+/* CandidateScoreEnsemble (contour_db.h:244-250) = the three score unions
+ * (contour_mng.h:121-219) flattened. */
+typedef struct {
+  int32_t i_ovlp_sum, i_ovlp_max_one, i_in_ang_rng; /* ScoreConstellSim */
+  int32_t i_indiv_sim, i_orie_sim;                  /* ScorePairwiseSim */
+  float correlation, area_perc, neg_est_dist;       /* ScorePostProc    */
+} cc_score_t;
+
+/* ContourDBConfig (contour_db.h:658-669) + TreeBucketConfig (:54-57). */
+typedef struct {
+  int32_t nnk;
+  int32_t max_fine_opt;
+  int32_t n_q_levels;
+  int32_t q_levels[CC_NQLEV];
+  cc_sim_cfg_t cont_sim;
+  double max_elapse, min_elapse;
+} cc_db_cfg_t;
+
+void cc_default_manager_cfg(cc_manager_cfg_t *cfg); /* shipped KITTI values, yaml :27-47 */
+void cc_default_db_cfg(cc_db_cfg_t *cfg);           /* yaml :6-23                        */
+void cc_default_thresholds(cc_score_t *lb, cc_score_t *ub); /* yaml :69-87              */
+
+/* ------------------------------------------------------------------ per-scan records ---- */
+/* ContourView (contour.h:97-119).  eig_vecs is column-major like Eigen: [v00 v10 v01 v11],
+ * column 1 (v01,v11) belongs to the larger eigenvalue. pos_cov likewise column-major. */
+typedef struct {
+  int16_t level;
+  int16_t poi[2];
+  int16_t cell_cnt;
+  float pos_mean[2];
+  float pos_cov[4];
+  float eig_vals[2];
+  float eig_vecs[4];
+  float eccen;
+  float vol3_mean;
+  float com[2];
+  uint8_t ecc_feat;
+  uint8_t com_feat;
+  uint8_t pad_[2];
+} cc_contour_t; /* 76 bytes */
+
+/* BCI::RelativePoint (contour_mng.h:245-258). */
+typedef struct {
+  int8_t level;
+  int8_t seq;
+  int16_t bit_pos;
+  float r;
+  float theta;
+} cc_relpt_t; /* 12 bytes */
+
+/* BCI (contour_mng.h:243-281).  dist_bin word w bit b  <=>  std::bitset bit 64*w+b.
+ * n_segs = nei_idx_segs_.size() (0 when nei_pts_ is empty, else #distinct bit_pos + 1). */
+typedef struct {
+  uint64_t dist_bin[CC_BCI_LAYERS];
+  int8_t piv_seq;
+  int8_t level;
+  uint8_t n_pts;
+  uint8_t n_segs;
+  uint16_t segs[CC_BCI_MAXPTS + 2];
+  cc_relpt_t pts[CC_BCI_MAXPTS];
+} cc_bci_t; /* 32 + 4 + 84 + 480 = 600 bytes */
+
+/* Everything ContourManager keeps after makeContoursRecurs() + clearImage()
+ * (contour_mng.h:426-436): sorted contour tables, per-level totals, 36 keys, 36 BCIs.
+ * cont_perc_[l][j] is not stored: it is cell_cnt * 1.0f / layer_cell_cnt[l]
+ * (contour_mng.h:607) and is recomputed bit-identically where needed. */
+typedef struct {
+  int32_t n_cont[CC_NLEV];         /* cont_views_[l].size() (true count)                  */
+  int32_t n_stored[CC_NLEV];       /* min(n_cont, CC_MAXC)                                */
+  int32_t layer_cell_cnt[CC_NLEV]; /* layer_cell_cnt_                                     */
+  float max_bin_val, min_bin_val;  /* contour_mng.h:436,524-525                           */
+  int32_t n_pix;                   /* bev_pixfs_.size()                                   */
+  int32_t flags;                   /* bit0: some level overflowed CC_MAXC                 */
+  float keys[CC_NLEV][CC_NPIV][CC_KEY_DIM];
+  cc_bci_t bcis[CC_NLEV][CC_NPIV];
+  cc_contour_t cont[CC_NLEV][CC_MAXC];
+} cc_scan_desc_t;
+
+/* Optional parity/debug outputs of ingest (device pointers, any may be NULL):
+ *   bev     [n_scans][n_row*n_col] f32  : bev_ image (contour_mng.h:432), -1000 = empty
+ *   pix_rc  [n_scans][n_row*n_col][2] f32: continuous (row_f,col_f) of the arg-max point of
+ *                                          each occupied cell (Pixelf, contour_mng.h:392-411)
+ *   labels  [n_scans][CC_NLEV][n_row*n_col] i16: canonical label image L_l(r,c) = seq of the
+ *                                          owning contour after the size sort, -1 = none
+ *                                          (SURVEY.md 8(a) "integer contour labels bit-exact") */
+typedef struct {
+  float *d_bev;
+  float *d_pix_rc;
+  int16_t *d_labels;
+} cc_ingest_debug_t;
+
+/* --------------------------------------------------------------------- query records ---- */
+/* One KNN hit: IndexOfKey (contour_db.h:59-65) + squared distance. */
+typedef struct {
+  int32_t gidx; /* index of the scan in the DB (all_bevs_ position)  */
+  int16_t level;
+  int16_t seq;
+  float dist_sq;
+} cc_knn_hit_t;
+
+/* Result of one query scan = what queryRangedKNN returns (contour_db.h:698-811) plus the
+ * integer gate scores the parity contract compares. */
+typedef struct {
+  int32_t n_res;        /* 0 or 1 (CHECK(ptr_cands.size() < 2), batch_bin_test.cpp:187)      */
+  int32_t cand_gidx;    /* DB index of the matched scan, -1 if none                          */
+  double correlation;   /* cand_corr[0]                                                      */
+  double tf[3];         /* T_delta = (x, y, theta) in BEV pixel units / radians              */
+  int32_t cand_aft_check1, cand_aft_check2, cand_aft_check3; /* contour_db.h:357-359         */
+  int32_t n_cand_pose;  /* candidates_.size() before tidyUpCandidates                        */
+  int32_t n_cand_tidy;  /* candidates_.size() after tidyUpCandidates                         */
+  int32_t n_knn_hits;   /* total KNN results over all query keys                             */
+} cc_query_result_t;
+
+/* ------------------------------------------------------------------------ context ------- */
+typedef struct cc_ctx cc_ctx; /* opaque: device id, configs, scratch, streams */
+typedef struct cc_db cc_db;   /* opaque: device-resident scan descriptors + key matrices +
+                                 the host-side LayerDB bookkeeping                           */
+
+const char *cc_last_error(void);
+int cc_version(void);
+
+/* Replaces ContourManager::ContourManager (contour_mng.h:478-498): validates the config
+ * (n_row,n_col even, <= 150x150, 6 increasing levels) and allocates per-device scratch. */
+int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_ctx **out);
+int cc_destroy(cc_ctx *ctx);
+
+/* ------------------------------------------------------------------------- ingest ------- */
+/* Replaces, for a batch of scans, readKITTIPointCloudBin's point stream
+ * (tools/pointcloud_util.h:9-47) -> ContourManager::makeBEV (contour_mng.h:505-556) ->
+ * makeContoursRecurs (contour_mng.h:588-960, src/cont2/contour_mng.cpp:274-353).
+ *   d_xyzi     : [total_points][4] f32 KITTI layout (x,y,z,intensity), device memory
+ *   h_offsets  : [n_scans+1] point offsets of each scan into d_xyzi (host memory)
+ *   d_out      : [n_scans] cc_scan_desc_t, device memory
+ * Scans with <= 10 points violate CHECK_GT(size,10) (contour_mng.h:507) -> CC_EINVAL. */
+int cc_ingest_batch(cc_ctx *ctx, const float *d_xyzi, const int64_t *h_offsets, int n_scans,
+                    cc_scan_desc_t *d_out, const cc_ingest_debug_t *dbg, void *stream);
+
+/* Same, from a host buffer (one H2D copy, then the device path); result copied back to
+ * h_out.  This is what the ContourManager host mirror calls for a single scan. */
+int cc_ingest_host(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offsets, int n_scans,
+                   cc_scan_desc_t *h_out);
+
+/* ---------------------------------------------------------------------- database -------- */
+/* Replaces ContourDB::ContourDB (contour_db.h:680-684). */
+int cc_db_create(cc_ctx *ctx, const cc_db_cfg_t *cfg, int capacity_scans, cc_db **out);
+int cc_db_destroy(cc_db *db);
+int cc_db_size(const cc_db *db);
+
+/* Replaces ContourDB::addScan + ContourDB::pushAndBalance (contour_db.h:814-843) and
+ * LayerDB::rebuild (src/cont2/contour_db.cpp:63-317) for n consecutive scans:
+ * for i in [0,n): addScan(desc[i], h_ts[i]); pushAndBalance(h_seed[i], h_ts[i]).
+ * The descriptors are appended to the device-resident DB; the bucket bookkeeping (which key
+ * is searchable from which epoch on, bucket ranges per epoch) runs on the host.
+ * Epoch e = state after e scans have been added and balanced. */
+int cc_db_add_scans(cc_db *db, const cc_scan_desc_t *d_desc, int n, const double *h_ts,
+                    const int32_t *h_seed, void *stream);
+
+/* Replaces ContourDB::queryRangedKNN (contour_db.h:698-811) for a batch of query scans.
+ * Query i is answered against DB epoch h_epoch[i] (use cc_db_size() for "now"); in the
+ * reference loop scan i queries epoch i (batch_bin_test.cpp:179 runs before :234-237).
+ *   d_qdesc : [nq] query descriptors (device)
+ *   h_res   : [nq] results (host)
+ *   d_knn   : optional [nq][CC_NQLEV][CC_NPIV][CC_KNN_MAX] hits + d_knn_cnt [nq][3][6] i32
+ *             (parity/debug; NULL to skip) */
+int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const int32_t *h_epoch,
+                      const cc_score_t *thres_lb, const cc_score_t *thres_ub,
+                      cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,
+                      void *stream);
+
+/* Device pointer of the DB's descriptor array ([cc_db_size()] cc_scan_desc_t) and raw
+ * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
+ * device buffer, then cc_db_add_scans consumes it). */
+const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
+
+/* Host-side introspection of the K0 bookkeeping for parity tests:
+ * tree sizes per (layer, bucket) and bucket ranges at the current epoch. */
+int cc_db_bucket_state(const cc_db *db, int32_t *tree_sizes /*[3][6]*/, float *ranges /*[3][7]*/);
+
+/* ------------------------------------------------------------ pose helpers (host) ------- */
+/* ConstellCorrelation::getEstSensTF (correlation.h:287-296): BEV-frame T_delta -> sensor
+ * frame. in/out = (x, y, theta). */
+void cc_est_sens_tf(const double tf_bev[3], int n_row, int n_col, double tf_sens[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONT2_AMD_H */
