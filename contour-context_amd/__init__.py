@@ -1,0 +1,146 @@
+"""contour-context_amd: MI355X-native hot path of lewisjiang/contour-context (cont2contops).
+
+Python host glue over the C-ABI shared library `libcont2_amd.so` (include/cont2_amd.h).  PyTorch is
+used only for device memory, streams and torch.distributed plumbing; all compute is in the HIP
+kernels under csrc/.  There is no CPU fallback: creating a Context without a HIP device fails.
+
+The directory name carries a hyphen (it mirrors the reference's name), so it is loaded by path:
+    import importlib.util; spec = importlib.util.spec_from_file_location("contour_context_amd", ".../__init__.py")
+`load()` in the repo-root helper `cc_amd.py` does exactly that.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _HERE)
+import layouts as L  # noqa: E402
+import synth  # noqa: E402,F401
+
+LIB_PATH = os.path.join(_HERE, "libcont2_amd.so")
+_SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "k_rasterize.h", "k_contours.h",
+         "k_query.h", "cc_hostdb.h", "cc_db_api.inc"]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", s) for s in _SRCS] + [os.path.join(_HERE, "..", "include", "cont2_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-unused-value", os.path.join(_HERE, "csrc", "cont2_amd.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+# every symbol include/cont2_amd.h declares
+EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
+           "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
+           "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcont2_amd.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cc_last_error.restype = C.c_char_p
+        _lib.cc_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.cc_destroy.argtypes = [C.c_void_p]
+        _lib.cc_ingest_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_ingest_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.cc_db_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.cc_db_destroy.argtypes = [C.c_void_p]
+        _lib.cc_db_size.argtypes = [C.c_void_p]
+        _lib.cc_db_add_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        _lib.cc_db_desc_ptr.argtypes = [C.c_void_p]
+        _lib.cc_db_desc_ptr.restype = C.c_void_p
+        _lib.cc_db_bucket_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_est_sens_tf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    return _lib
+
+
+class CCError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise CCError("%s failed (%d): %s" % (what, rc, lib().cc_last_error().decode()))
+
+
+class IngestDebug(C.Structure):
+    _fields_ = [("d_bev", C.c_void_p), ("d_pix_rc", C.c_void_p), ("d_labels", C.c_void_p)]
+
+
+DESC_BYTES = L.scan_desc_dt.itemsize
+
+
+class Context:
+    """cc_ctx: per-device ingest context (ContourManager constructor's role, contour_mng.h:478-498)."""
+
+    def __init__(self, device=0, cfg=None, max_batch=512):
+        import torch
+        if not torch.cuda.is_available():
+            raise CCError("no HIP device: the product path has no CPU fallback")
+        self.cfg = cfg or L.default_manager_cfg()
+        self.device = device
+        self.max_batch = max_batch
+        h = C.c_void_p()
+        _chk(lib().cc_create(device, C.addressof(self.cfg), max_batch, C.byref(h)), "cc_create")
+        self.h = h
+        self.n_cell = self.cfg.n_row * self.cfg.n_col
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ingest(self, xyzi, offsets, out=None, debug=False):
+        """xyzi: torch float32 CUDA tensor [total_points, 4]; offsets: int64 host array [n+1].
+        Returns a torch uint8 CUDA tensor [n, DESC_BYTES] (array of cc_scan_desc_t) (+ debug dict)."""
+        import torch
+        assert xyzi.is_cuda and xyzi.dtype == torch.float32 and xyzi.is_contiguous()
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        if out is None:
+            out = torch.empty((n, DESC_BYTES), dtype=torch.uint8, device=xyzi.device)
+        dbg_p, dbg = None, None
+        if debug:
+            dbg = {"bev": torch.empty((n, self.n_cell), dtype=torch.float32, device=xyzi.device),
+                   "pix_rc": torch.empty((n, self.n_cell, 2), dtype=torch.float32, device=xyzi.device),
+                   "labels": torch.empty((n, L.NLEV, self.n_cell), dtype=torch.int16, device=xyzi.device)}
+            st = IngestDebug(dbg["bev"].data_ptr(), dbg["pix_rc"].data_ptr(), dbg["labels"].data_ptr())
+            dbg_p = C.addressof(st)
+        stream = torch.cuda.current_stream(xyzi.device).cuda_stream
+        _chk(lib().cc_ingest_batch(self.h, xyzi.data_ptr(), offsets.ctypes.data, n, out.data_ptr(), dbg_p, stream),
+             "cc_ingest_batch")
+        return (out, dbg) if debug else out
+
+    def ingest_host(self, xyzi, offsets):
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        out = np.zeros(n, L.scan_desc_dt)
+        _chk(lib().cc_ingest_host(self.h, xyzi.ctypes.data, offsets.ctypes.data, n, out.ctypes.data), "cc_ingest_host")
+        return out
+
+
+def desc_to_numpy(desc_tensor):
+    """torch uint8 [n, DESC_BYTES] (any device) -> numpy structured array of cc_scan_desc_t."""
+    return desc_tensor.cpu().numpy().view(L.scan_desc_dt).reshape(-1)

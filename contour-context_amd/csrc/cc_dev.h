@@ -1,0 +1,43 @@
+// Shared device-side definitions of the MI355X contour-context kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cont2_amd.h"
+
+// Launch-time constants derived on the host from cc_manager_cfg_t exactly as the reference's
+// ContourManager constructor derives them (contour_mng.h:478-498, :448-472).
+struct cc_dev_cfg {
+  float x_lo, x_hi, y_lo, y_hi;  // x_min_+padding, x_max_-padding, ... evaluated in f32 on the host
+  float blind_sq;
+  float reso_row, reso_col;
+  float lidar_height;
+  int n_row, n_col, half_row, half_col, n_cell;
+  float lv_grads[CC_NLEV];
+  int min_cont_key_cnt, min_cont_cell_cnt, piv_firsts, dist_firsts;
+  float roi_radius;
+  int min_cell_cov;
+  float point_sigma, com_bias_thres;
+};
+
+#define CC_BEV_EMPTY (-1000.0f)  // VAL_ABS_INF_, contour_mng.h:418,488
+
+// order-preserving map f32 -> u32 (total order of finite floats), used for LDS atomicMax on heights
+__device__ __forceinline__ unsigned cc_fkey(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float cc_funkey(unsigned k) {
+  unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+// hashPointToImage (contour_mng.h:448-463).  Returns cell index or -1 (rejected or row 0:
+// makeBEV only uses points with rc.first > 0, contour_mng.h:515).
+__device__ __forceinline__ int cc_point_cell(const cc_dev_cfg &c, float x, float y) {
+  if (x < c.x_lo || x > c.x_hi || y < c.y_lo || y > c.y_hi || (y * y + x * x) < c.blind_sq) return -1;
+  int row = (int)floorf(x / c.reso_row) + c.half_row;
+  int col = (int)floorf(y / c.reso_col) + c.half_col;
+  if (row <= 0) return -1;
+  return row * c.n_col + col;
+}

@@ -1,0 +1,170 @@
+// Per-contour descriptor maths on the device: ContourView::calcStatVals (contour.h:142-255),
+// including a restatement of Eigen 3.3 SelfAdjointEigenSolver<Matrix2f>::compute (scale, trivial
+// 2x2 tridiagonalisation, implicit symmetric QR with Wilkinson shift, ascending sort).
+// Compiled with -ffp-contract=off: every operation below is an individually rounded IEEE f32/f64
+// operation in the order the reference performs it.
+#pragma once
+#include "cc_dev.h"
+
+// evals ascending; evecs column-major [v00 v10 v01 v11], column c <-> evals[c]
+__device__ __forceinline__ void cc_eigen2f(float m00, float m10, float m11, float evals[2], float evecs[4]) {
+  float d0 = m00, d1 = m11, e = m10;
+  float scale = fabsf(d0);
+  if (fabsf(e) > scale) scale = fabsf(e);
+  if (fabsf(d1) > scale) scale = fabsf(d1);
+  if (scale == 0.f) scale = 1.f;
+  d0 /= scale;
+  e /= scale;
+  d1 /= scale;
+  float q00 = 1.f, q01 = 0.f, q10 = 0.f, q11 = 1.f;
+  const float considerAsZero = 1.17549435e-38f;
+  const float precision = 2.f * 1.1920929e-07f;
+  int iter = 0;
+  while (true) {
+    if (fabsf(e) <= (fabsf(d0) + fabsf(d1)) * precision || fabsf(e) <= considerAsZero) e = 0.f;
+    if (e == 0.f) break;
+    iter++;
+    if (iter > 60) break;
+    float td = (d0 - d1) * 0.5f;
+    float mu = d1;
+    if (td == 0.f) {
+      mu -= fabsf(e);
+    } else {
+      float e2 = e * e;
+      float ax = fabsf(td), ay = fabsf(e), p, qp;
+      if (ax > ay) {
+        p = ax;
+        qp = ay / p;
+      } else {
+        p = ay;
+        qp = ax / p;
+      }
+      float h = (p == 0.f) ? 0.f : p * sqrtf(1.f + qp * qp);
+      if (e2 == 0.f)
+        mu -= (e / (td + (td > 0.f ? 1.f : -1.f))) * (e / h);
+      else
+        mu -= e2 / (td + (td > 0.f ? h : -h));
+    }
+    float x = d0 - mu;
+    float z = e;
+    float c, s;
+    if (z == 0.f) {
+      c = x < 0.f ? -1.f : 1.f;
+      s = 0.f;
+    } else if (x == 0.f) {
+      c = 0.f;
+      s = z < 0.f ? 1.f : -1.f;
+    } else if (fabsf(x) > fabsf(z)) {
+      float t = z / x;
+      float u = sqrtf(1.f + t * t);
+      if (x < 0.f) u = -u;
+      c = 1.f / u;
+      s = -t * c;
+    } else {
+      float t = x / z;
+      float u = sqrtf(1.f + t * t);
+      if (z < 0.f) u = -u;
+      s = -1.f / u;
+      c = -t * s;
+    }
+    float sdk = s * d0 + c * e;
+    float dkp1 = s * e + c * d1;
+    d0 = c * (c * d0 - s * e) - s * (c * e - s * d1);
+    d1 = s * sdk + c * dkp1;
+    e = c * sdk - s * dkp1;
+    float x0 = q00, y0 = q01, x1 = q10, y1 = q11;
+    q00 = c * x0 - s * y0;
+    q01 = s * x0 + c * y0;
+    q10 = c * x1 - s * y1;
+    q11 = s * x1 + c * y1;
+  }
+  if (d1 < d0) {
+    float t = d0;
+    d0 = d1;
+    d1 = t;
+    t = q00;
+    q00 = q01;
+    q01 = t;
+    t = q10;
+    q10 = q11;
+    q11 = t;
+  }
+  evals[0] = d0 * scale;
+  evals[1] = d1 * scale;
+  evecs[0] = q00;
+  evecs[1] = q10;
+  evecs[2] = q01;
+  evecs[3] = q11;
+}
+
+// RunningStatRecorder (contour.h:48-95) accumulated by the caller in raster order
+struct cc_running_stat {
+  int cnt;
+  double ps_x, ps_y;
+  double t_xx, t_xy, t_yy;
+  float vol3;
+  double tq_x, tq_y;
+};
+
+__device__ __forceinline__ bool cc_diff_perc(float a, float b, float perc) {
+  return fabsf((a - b) / (a < b ? b : a)) > perc;  // tools/algos.h:13-15 (std::max(a,b) returns b if a<b)
+}
+__device__ __forceinline__ bool cc_diff_delt(float a, float b, float delta) { return fabsf(a - b) > delta; }
+
+__device__ __forceinline__ void cc_calc_stat_vals(const cc_dev_cfg &cfg, const cc_running_stat &rec, int level, int poi_r,
+                                                  int poi_c, cc_contour_t *o) {
+  o->level = (int16_t)level;
+  o->poi[0] = (int16_t)poi_r;
+  o->poi[1] = (int16_t)poi_c;
+  o->cell_cnt = (int16_t)rec.cnt;
+  const float cntf = (float)rec.cnt;
+  const float pm0 = (float)rec.ps_x / cntf, pm1 = (float)rec.ps_y / cntf;
+  o->pos_mean[0] = pm0;
+  o->pos_mean[1] = pm1;
+  o->vol3_mean = rec.vol3 / cntf;
+  const float com0 = (float)rec.tq_x / rec.vol3, com1 = (float)rec.tq_y / rec.vol3;
+  o->com[0] = com0;
+  o->com[1] = com1;
+  o->pad_[0] = o->pad_[1] = 0;
+  if (rec.cnt < cfg.min_cell_cov) {
+    const float ss = 1.f * cfg.point_sigma * cfg.point_sigma;
+    const float zz = 0.f * cfg.point_sigma * cfg.point_sigma;
+    o->pos_cov[0] = ss;
+    o->pos_cov[1] = zz;
+    o->pos_cov[2] = zz;
+    o->pos_cov[3] = ss;
+    o->eig_vals[0] = cfg.point_sigma;
+    o->eig_vals[1] = cfg.point_sigma;
+    o->eig_vecs[0] = 1.f;
+    o->eig_vecs[1] = 0.f;
+    o->eig_vecs[2] = 0.f;
+    o->eig_vecs[3] = 1.f;
+    o->eccen = 0.f;
+    o->ecc_feat = 0;
+    o->com_feat = 0;
+  } else {
+    const float denom = (float)(rec.cnt - 1);
+    const float c00 = ((float)rec.t_xx - (pm0 * pm0) * cntf) / denom;
+    const float c01 = ((float)rec.t_xy - (pm0 * pm1) * cntf) / denom;
+    const float c10 = ((float)rec.t_xy - (pm1 * pm0) * cntf) / denom;
+    const float c11 = ((float)rec.t_yy - (pm1 * pm1) * cntf) / denom;
+    o->pos_cov[0] = c00;
+    o->pos_cov[1] = c10;
+    o->pos_cov[2] = c01;
+    o->pos_cov[3] = c11;
+    float ev[2], vec[4];
+    cc_eigen2f(c00, c01, c11, ev, vec);  // selfadjointView<Upper>: the (0,1) entry is used for both off-diagonals
+    if (ev[0] < cfg.point_sigma) ev[0] = cfg.point_sigma;
+    if (ev[1] < cfg.point_sigma) ev[1] = cfg.point_sigma;
+    o->eig_vals[0] = ev[0];
+    o->eig_vals[1] = ev[1];
+    o->eig_vecs[0] = vec[0];
+    o->eig_vecs[1] = vec[1];
+    o->eig_vecs[2] = vec[2];
+    o->eig_vecs[3] = vec[3];
+    o->eccen = sqrtf(ev[1] * ev[1] - ev[0] * ev[0]) / ev[1];
+    o->ecc_feat = (rec.cnt > 5 && cc_diff_perc(ev[0], ev[1], 0.2f) && ev[1] > 2.5f) ? 1 : 0;
+    const float dx = com0 - pm0, dy = com1 - pm1;
+    o->com_feat = (sqrtf(dx * dx + dy * dy) > cfg.com_bias_thres) ? 1 : 0;
+  }
+}

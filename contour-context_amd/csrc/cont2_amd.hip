@@ -1,0 +1,207 @@
+// libcont2_amd.so -- C-ABI of the MI355X-native contour-context hot path (include/cont2_amd.h).
+// Host code: device memory ownership, launches, the LayerDB bookkeeping timeline.  Kernels live in
+// the k_*.h headers next to this file.  Built for gfx950 only:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC cont2_amd.hip -o libcont2_amd.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cont2_amd.h"
+#include "cc_hostcfg.h"
+#include "k_rasterize.h"
+#include "k_contours.h"
+#include "k_query.h"
+#include "cc_hostdb.h"
+
+static thread_local std::string g_err;
+static int set_err(int code, const char *what, hipError_t e = hipSuccess) {
+  g_err = what;
+  if (e != hipSuccess) {
+    g_err += ": ";
+    g_err += hipGetErrorString(e);
+  }
+  return code;
+}
+#define HIPCHK(call)                                          \
+  do {                                                        \
+    hipError_t e_ = (call);                                   \
+    if (e_ != hipSuccess) return set_err(CC_EHIP, #call, e_); \
+  } while (0)
+
+struct cc_ctx {
+  int device = 0;
+  cc_manager_cfg_t mcfg;
+  cc_dev_cfg dcfg;
+  int max_batch = 0;
+  float *d_bev = nullptr;
+  float2 *d_pix = nullptr;
+  cc_k1_scan_out *d_k1 = nullptr;
+  cc_k2_scratch *d_scr = nullptr;
+  long long *d_offsets = nullptr;
+  size_t lds1 = 0, lds2 = 0;
+};
+
+extern "C" {
+
+const char *cc_last_error(void) { return g_err.c_str(); }
+int cc_version(void) { return 100; }
+
+void cc_default_manager_cfg(cc_manager_cfg_t *c) {
+  const float g[CC_NLEV] = {1.5f, 2.f, 2.5f, 3.f, 3.5f, 4.f};
+  for (int i = 0; i < CC_NLEV; i++) c->lv_grads[i] = g[i];
+  c->reso_row = c->reso_col = 1.0f;
+  c->n_row = c->n_col = 150;
+  c->lidar_height = 2.0f;
+  c->blind_sq = 9.0f;
+  c->min_cont_key_cnt = 9;
+  c->min_cont_cell_cnt = 3;
+  c->piv_firsts = 6;
+  c->dist_firsts = 10;
+  c->roi_radius = 10.0f;
+  c->min_cell_cov = 4;
+  c->point_sigma = 1.0f;
+  c->com_bias_thres = 0.5f;
+}
+void cc_default_db_cfg(cc_db_cfg_t *d) {
+  d->nnk = 50;
+  d->max_fine_opt = 10;
+  d->n_q_levels = 3;
+  d->q_levels[0] = 1;
+  d->q_levels[1] = 2;
+  d->q_levels[2] = 3;
+  d->cont_sim.ta_cell_cnt = 6.0f;
+  d->cont_sim.tp_cell_cnt = 0.2f;
+  d->cont_sim.tp_eigval = 0.2f;
+  d->cont_sim.ta_h_bar = 0.3f;
+  d->cont_sim.ta_rcom = 0.4f;
+  d->cont_sim.tp_rcom = 0.25f;
+  d->max_elapse = 25.0;
+  d->min_elapse = 15.0;
+}
+void cc_default_thresholds(cc_score_t *lb, cc_score_t *ub) {
+  lb->i_ovlp_sum = lb->i_ovlp_max_one = lb->i_in_ang_rng = lb->i_indiv_sim = 3;
+  lb->i_orie_sim = 4;
+  lb->correlation = 0.3f;
+  lb->area_perc = 0.03f;
+  lb->neg_est_dist = -5.01f;
+  ub->i_ovlp_sum = ub->i_ovlp_max_one = ub->i_in_ang_rng = ub->i_indiv_sim = ub->i_orie_sim = 6;
+  ub->correlation = 0.75f;
+  ub->area_perc = 0.15f;
+  ub->neg_est_dist = -5.0f;
+}
+
+int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_ctx **out) {
+  if (!cfg || !out || max_batch_scans < 1) return set_err(CC_EINVAL, "cc_create: bad argument");
+  cc_dev_cfg dc;
+  if (cc_make_dev_cfg(cfg, &dc) != 0)
+    return set_err(CC_EINVAL, "cc_create: unsupported ContourManagerConfig (need even n_row/n_col <= 150x150, 6 increasing lv_grads_)");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0 || device < 0 || device >= ndev) return set_err(CC_EHIP, "cc_create: no such HIP device (this library has no CPU path)");
+  HIPCHK(hipSetDevice(device));
+  cc_ctx *c = new cc_ctx();
+  c->device = device;
+  c->mcfg = *cfg;
+  c->dcfg = dc;
+  c->max_batch = max_batch_scans;
+  const size_t nc = (size_t)dc.n_cell;
+  HIPCHK(hipMalloc(&c->d_bev, sizeof(float) * nc * max_batch_scans));
+  HIPCHK(hipMalloc(&c->d_pix, sizeof(float2) * nc * max_batch_scans));
+  HIPCHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
+  HIPCHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
+  HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
+  c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
+  c->lds2 = ((nc * 4 + 15) & ~(size_t)15) + CC_K2_R_BYTES;
+  HIPCHK(hipFuncSetAttribute((const void *)cc_k_rasterize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  HIPCHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
+  *out = c;
+  return CC_OK;
+}
+
+int cc_destroy(cc_ctx *c) {
+  if (!c) return CC_OK;
+  hipSetDevice(c->device);
+  hipFree(c->d_bev);
+  hipFree(c->d_pix);
+  hipFree(c->d_k1);
+  hipFree(c->d_scr);
+  hipFree(c->d_offsets);
+  delete c;
+  return CC_OK;
+}
+
+__global__ void cc_k_fill_f32(float *p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *d_out,
+                    const cc_ingest_debug_t *dbg, void *stream_) {
+  if (!c || !d_xyzi || !h_offsets || !d_out || n_scans < 0) return set_err(CC_EINVAL, "cc_ingest_batch: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n_scans; i++) {
+    const int64_t n = h_offsets[i + 1] - h_offsets[i];
+    if (!(n > 10)) return set_err(CC_EINVAL, "cc_ingest_batch: scan with <= 10 points (CHECK_GT(size, 10), contour_mng.h:507)");
+    if (n >= (1 << CC_K1_IDX_BITS)) return set_err(CC_EINVAL, "cc_ingest_batch: scan with >= 2^21 points");
+  }
+  const size_t nc = (size_t)c->dcfg.n_cell;
+  for (int b0 = 0; b0 < n_scans; b0 += c->max_batch) {
+    const int nb = (n_scans - b0 < c->max_batch) ? n_scans - b0 : c->max_batch;
+    // offsets relative to the chunk's first point
+    std::vector<long long> off(nb + 1);
+    for (int i = 0; i <= nb; i++) off[i] = (long long)(h_offsets[b0 + i] - h_offsets[b0]);
+    HIPCHK(hipMemcpyAsync(c->d_offsets, off.data(), sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // `off` is a stack-lifetime staging buffer
+    const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
+    if (dbg && dbg->d_pix_rc) cc_k_fill_f32<<<512, 256, 0, stream>>>((float *)c->d_pix, -1.f, nc * 2 * nb);
+    cc_k_rasterize<<<nb, 1024, c->lds1, stream>>>(c->dcfg, pts, c->d_offsets, c->d_bev, c->d_pix, c->d_k1);
+    int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
+    cc_k_contours<<<nb, 1024, c->lds2, stream>>>(c->dcfg, c->d_bev, c->d_pix, c->d_k1, c->d_scr, d_out + b0, lab);
+    HIPCHK(hipGetLastError());
+    if (dbg && dbg->d_bev)
+      HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, c->d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));
+    if (dbg && dbg->d_pix_rc)
+      HIPCHK(hipMemcpyAsync(dbg->d_pix_rc + (size_t)b0 * nc * 2, c->d_pix, sizeof(float2) * nc * nb, hipMemcpyDeviceToDevice, stream));
+  }
+  return CC_OK;
+}
+
+int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *h_out) {
+  if (!c || !h_xyzi || !h_offsets || !h_out || n_scans < 1) return set_err(CC_EINVAL, "cc_ingest_host: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t base = h_offsets[0], total = h_offsets[n_scans] - base;
+  float *d_x = nullptr;
+  cc_scan_desc_t *d_o = nullptr;
+  HIPCHK(hipMalloc(&d_x, sizeof(float) * 4 * (size_t)total));
+  HIPCHK(hipMalloc(&d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans));
+  int rc = CC_OK;
+  std::vector<int64_t> off(n_scans + 1);
+  for (int i = 0; i <= n_scans; i++) off[i] = h_offsets[i] - base;
+  hipError_t e = hipMemcpy(d_x, h_xyzi + 4 * base, sizeof(float) * 4 * (size_t)total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: H2D", e);
+  if (rc == CC_OK) rc = cc_ingest_batch(c, d_x, off.data(), n_scans, d_o, nullptr, nullptr);
+  if (rc == CC_OK) {
+    e = hipMemcpy(h_out, d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: D2H", e);
+  }
+  hipFree(d_x);
+  hipFree(d_o);
+  return rc;
+}
+
+void cc_est_sens_tf(const double tf_bev[3], int n_row, int n_col, double tf_sens[3]) {
+  // T_to_tsen^-1 * T_delta * T_so_ssen with T_so_ssen = translate(n_row/2 - 0.5, n_col/2 - 0.5)
+  const double ox = n_row / 2 - 0.5, oy = n_col / 2 - 0.5;
+  const double c = cos(tf_bev[2]), s = sin(tf_bev[2]);
+  tf_sens[0] = c * ox - s * oy + tf_bev[0] - ox;
+  tf_sens[1] = s * ox + c * oy + tf_bev[1] - oy;
+  tf_sens[2] = tf_bev[2];
+}
+
+#include "cc_db_api.inc"
+
+}  // extern "C"

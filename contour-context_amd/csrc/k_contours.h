@@ -1,0 +1,565 @@
+// K2 -- multi-level contour extraction + descriptors + retrieval keys + BCIs, one workgroup per
+// scan, BEV grid and label image resident in LDS.  Replaces
+//   ContourManager::makeContourRecursiveHelper   src/cont2/contour_mng.cpp:274-353
+//   RunningStatRecorder / ContourView::calcStatVals   contour.h:48-95,142-255
+//   ContourManager::makeContoursRecurs           contour_mng.h:588-895 (sort, keys, BCI)
+//
+// How the recursion is flattened: the level sets bev > lv_grads_[l] are nested,
+// so the recursive "threshold inside the parent's mask + CCL" equals, per level, a global 8-connected
+// labelling of bev > lv_grads_[l] keeping components of >= min_cont_cell_cnt_ cells.  What the
+// recursion adds is the INSERTION ORDER into cont_views_[l] (depth-first, children in OpenCV label
+// order = order of the first 2x2 block in block-raster order relative to the parent's bounding
+// box).  Levels are processed top-down so that a child's parent is a plain label lookup; the
+// insertion rank is then rebuilt bottom-up from (parent rank, first-block key), and the reference's
+// unstable size sort is replayed with the libstdc++ introsort replica (cc_sort.h).
+//
+// Exactness: the reference accumulates cell_vol3_ (f32) and the ring-bin divisions (f32) in raster
+// order; f32 addition is not associative, so those sums are evaluated by ONE lane per contour /
+// per (anchor, division) in the same order.  Parallelism comes from contours x levels x anchors.
+#pragma once
+#include "cc_dev.h"
+#include "cc_sort.h"
+#include "cc_stats.h"
+
+#define CC_NC CC_MAXC          // kept components per level handled exactly
+#define CC_LAB_NONE 0xFFFFu
+
+struct cc_comp_t {  // per kept component, spilled to global scratch between levels
+  uint16_t root, area, parent, rank;
+  uint8_t r0, r1, c0, c1, cA, cB, pad[2];
+};  // 16 B
+
+struct cc_k2_scratch {  // per workgroup
+  cc_comp_t comp[CC_NLEV][CC_NC];
+  cc_contour_t cont[CC_NLEV][CC_NC];
+};
+
+struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
+  float pm[2];
+  float ev[2];
+  int cnt;
+};
+
+#define CC_K2_R_BYTES 65536
+// dynamic LDS = n_cell*4 (H) + CC_K2_R_BYTES
+
+__device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
+
+__global__ void __launch_bounds__(1024)
+cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+              const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
+              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int scan = blockIdx.x;
+
+  float *H = (float *)smem;
+  char *R = smem + (((size_t)n_cell * 4 + 15) & ~(size_t)15);
+  // ---- region R, phase "levels" ----
+  uint16_t *LAB = (uint16_t *)R;                                   // n_cell u16 (45000)
+  unsigned *W = (unsigned *)(R + 45056);                           // 7 * CC_NC u32 working arrays / CNT2 alias (8960)
+  uint16_t *roots = (uint16_t *)(R + 45056 + 8960);                // CC_NC u16
+  uint16_t *cand = roots + CC_NC;                                  // CC_NC u16
+  uint16_t *prev_root = cand + CC_NC;                              // CC_NC u16
+  int *sh = (int *)(R + 45056 + 8960 + 3 * CC_NC * 2 + 64);        // small scalars
+  // sh[0]=changed flag  sh[1]=n_cand  sh[2]=flags  sh[8+l]=n_kept[l]  sh[16+l]=layer_cell_cnt[l]
+  unsigned *CNT2 = W;  // 2-bit saturating counters, (n_cell+15)/16 words (5628 B <= 8960)
+
+  const float *bev = bev_in + (size_t)scan * n_cell;
+  const float2 *pix = pix_in + (size_t)scan * n_cell;
+  cc_k2_scratch *scr = scratch_all + scan;
+  cc_scan_desc_t *desc = desc_out + scan;
+
+  for (int c = tid; c < n_cell; c += nt) H[c] = bev[c];
+  if (tid < 32) sh[tid] = 0;
+  __syncthreads();
+
+  int prev_n = 0;
+  for (int l = CC_NLEV - 1; l >= 0; --l) {
+    const float g = cfg.lv_grads[l];
+    // (a) init labels: cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+    for (int c = tid; c < n_cell; c += nt) LAB[c] = (H[c] > g) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
+    __syncthreads();
+    // (b) 8-connected labelling: min-propagation with pointer jumping until stable
+    while (true) {
+      if (tid == 0) sh[0] = 0;
+      __syncthreads();
+      int changed = 0;
+      for (int c = tid; c < n_cell; c += nt) {
+        unsigned lab = LAB[c];
+        if (lab == CC_LAB_NONE) continue;
+        const int r = c / n_col, cc = c - r * n_col;
+        unsigned m = lab;
+        const bool up = r > 0, dn = r < n_row - 1, lf = cc > 0, rt = cc < n_col - 1;
+        unsigned v;
+        if (up) {
+          if (lf) { v = LAB[c - n_col - 1]; m = v < m ? v : m; }
+          v = LAB[c - n_col]; m = v < m ? v : m;
+          if (rt) { v = LAB[c - n_col + 1]; m = v < m ? v : m; }
+        }
+        if (lf) { v = LAB[c - 1]; m = v < m ? v : m; }
+        if (rt) { v = LAB[c + 1]; m = v < m ? v : m; }
+        if (dn) {
+          if (lf) { v = LAB[c + n_col - 1]; m = v < m ? v : m; }
+          v = LAB[c + n_col]; m = v < m ? v : m;
+          if (rt) { v = LAB[c + n_col + 1]; m = v < m ? v : m; }
+        }
+        while (true) {
+          unsigned m2 = LAB[m];
+          if (m2 >= m) break;
+          m = m2;
+        }
+        if (m < lab) {
+          LAB[c] = (uint16_t)m;
+          changed = 1;
+        }
+      }
+      if (changed) sh[0] = 1;
+      __syncthreads();
+      const int any = sh[0];
+      __syncthreads();
+      if (!any) break;
+    }
+    // (c) which roots own >= min_cont_cell_cnt_ (3) cells: 2-bit saturating counters
+    const int n_w = (n_cell + 15) >> 4;
+    for (int i = tid; i < n_w; i += nt) CNT2[i] = 0;
+    if (tid == 0) sh[1] = 0;
+    __syncthreads();
+    const int need = cfg.min_cont_cell_cnt < 3 ? cfg.min_cont_cell_cnt : 3;
+    for (int c = tid; c < n_cell; c += nt) {
+      unsigned r = LAB[c];
+      if (r == CC_LAB_NONE) continue;
+      const int w = r >> 4, s2 = (r & 15) * 2;
+      unsigned old = CNT2[w];
+      while ((int)((old >> s2) & 3u) < 3) {
+        unsigned got = atomicCAS(&CNT2[w], old, old + (1u << s2));
+        if (got == old) break;
+        old = got;
+      }
+    }
+    __syncthreads();
+    // (d) enumerate kept roots, sorted by cell index
+    for (int c = tid; c < n_cell; c += nt) {
+      if (LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
+        int k = atomicAdd(&sh[1], 1);
+        if (k < CC_NC) cand[k] = (uint16_t)c;
+      }
+    }
+    __syncthreads();
+    int n_kept = sh[1];
+    if (n_kept > CC_NC) {
+      n_kept = CC_NC;
+      if (tid == 0) sh[2] |= 2;  // capacity exceeded: this scan's descriptor is not exact
+    }
+    for (int k = tid; k < n_kept; k += nt) {
+      const unsigned me = cand[k];
+      int rk = 0;
+      for (int j = 0; j < n_kept; j++) rk += (cand[j] < me) ? 1 : 0;
+      roots[rk] = (uint16_t)me;
+    }
+    __syncthreads();
+    // (e) relabel cells with the component index (or NONE).  Each thread touches only its own cells.
+    for (int c = tid; c < n_cell; c += nt) {
+      unsigned r = LAB[c];
+      if (r == CC_LAB_NONE) continue;
+      unsigned j = CC_LAB_NONE;
+      if (cc_cnt2_get(CNT2, r) >= need) {
+        int lo = 0, hi = n_kept - 1;
+        while (lo <= hi) {
+          int mid = (lo + hi) >> 1;
+          unsigned v = roots[mid];
+          if (v == r) {
+            j = mid;
+            break;
+          }
+          if (v < r)
+            lo = mid + 1;
+          else
+            hi = mid - 1;
+        }
+      }
+      LAB[c] = (uint16_t)j;
+    }
+    __syncthreads();
+    // (f) bbox / area / first-block columns via LDS atomics (W aliases CNT2: done with it)
+    unsigned *w_minr = W, *w_maxr = W + CC_NC, *w_minc = W + 2 * CC_NC, *w_maxc = W + 3 * CC_NC, *w_area = W + 4 * CC_NC,
+             *w_cA = W + 5 * CC_NC, *w_cB = W + 6 * CC_NC;
+    for (int k = tid; k < n_kept; k += nt) {
+      w_minr[k] = 0xFFFFu;
+      w_maxr[k] = 0;
+      w_minc[k] = 0xFFFFu;
+      w_maxc[k] = 0;
+      w_area[k] = 0;
+      w_cA[k] = 255;
+      w_cB[k] = 255;
+    }
+    __syncthreads();
+    for (int c = tid; c < n_cell; c += nt) {
+      unsigned j = LAB[c];
+      if (j == CC_LAB_NONE) continue;
+      const int r = c / n_col, cc = c - r * n_col;
+      atomicMin(&w_minr[j], (unsigned)r);
+      atomicMax(&w_maxr[j], (unsigned)r);
+      atomicMin(&w_minc[j], (unsigned)cc);
+      atomicMax(&w_maxc[j], (unsigned)cc);
+      atomicAdd(&w_area[j], 1u);
+    }
+    __syncthreads();
+    for (int c = tid; c < n_cell; c += nt) {
+      unsigned j = LAB[c];
+      if (j == CC_LAB_NONE) continue;
+      const int r = c / n_col, cc = c - r * n_col;
+      if ((unsigned)r == w_minr[j]) atomicMin(&w_cA[j], (unsigned)cc);
+      if ((unsigned)r == w_minr[j] + 1) atomicMin(&w_cB[j], (unsigned)cc);
+    }
+    __syncthreads();
+    // (g) parents of the level above (processed in the previous iteration)
+    for (int k = tid; k < prev_n; k += nt) scr->comp[l + 1][k].parent = LAB[prev_root[k]];
+    // (h) one lane per contour: raster-order running statistics (contour_mng.cpp:317-331) + descriptor
+    for (int k = tid; k < n_kept; k += nt) {
+      const int r0 = w_minr[k], r1 = w_maxr[k], c0 = w_minc[k], c1 = w_maxc[k];
+      cc_running_stat rec;
+      rec.cnt = 0;
+      rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
+      rec.vol3 = 0.f;
+      int poi_r = -1, poi_c = -1;
+      for (int r = r0; r <= r1; r++) {
+        const int base = r * n_col;
+        for (int c = c0; c <= c1; c++) {
+          if (LAB[base + c] != (unsigned)k) continue;
+          const float2 rc = pix[base + c];
+          const float h = H[base + c];
+          const double vr = (double)rc.x, vc = (double)rc.y;
+          rec.cnt += 1;
+          rec.ps_x += vr;
+          rec.ps_y += vc;
+          rec.t_xx += vr * vr;
+          rec.t_xy += vr * vc;
+          rec.t_yy += vc * vc;
+          rec.vol3 += h;
+          rec.tq_x += (double)h * vr;
+          rec.tq_y += (double)h * vc;
+          poi_r = r;
+          poi_c = c;
+        }
+      }
+      cc_contour_t cv;
+      cc_calc_stat_vals(cfg, rec, l, poi_r, poi_c, &cv);
+      scr->cont[l][k] = cv;
+      cc_comp_t cp;
+      cp.root = roots[k];
+      cp.area = (uint16_t)w_area[k];
+      cp.parent = 0xFFFF;
+      cp.rank = 0;
+      cp.r0 = (uint8_t)r0;
+      cp.r1 = (uint8_t)r1;
+      cp.c0 = (uint8_t)c0;
+      cp.c1 = (uint8_t)c1;
+      cp.cA = (uint8_t)w_cA[k];
+      cp.cB = (uint8_t)w_cB[k];
+      cp.pad[0] = cp.pad[1] = 0;
+      scr->comp[l][k] = cp;
+    }
+    // (i) parity/debug: component index image of this level (mapped to sorted seq at the end)
+    if (labels_dbg) {
+      int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
+      for (int c = tid; c < n_cell; c += nt) {
+        unsigned j = LAB[c];
+        ld[c] = (j == CC_LAB_NONE) ? (int16_t)-1 : (int16_t)j;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < n_kept; k += nt) prev_root[k] = roots[k];
+    if (tid == 0) sh[8 + l] = n_kept;
+    prev_n = n_kept;
+    __syncthreads();
+  }
+
+  // =========================== phase "order": region R re-carved ===========================
+  __threadfence_block();
+  __syncthreads();
+  int n_lev[CC_NLEV];
+  for (int l = 0; l < CC_NLEV; l++) n_lev[l] = sh[8 + l];
+  const int flags0 = sh[2];
+  __syncthreads();
+  cc_comp_t *T = (cc_comp_t *)R;                                            // [6][NC] 30720 B
+  unsigned *skey = (unsigned *)(R + 30720);                                 // [6][NC] u32 7680 B
+  unsigned *arr = (unsigned *)(R + 30720 + 7680);                           // [6][NC] u32 7680 B
+  cc_anchor_lds *top = (cc_anchor_lds *)(R + 30720 + 2 * 7680);             // [6][10] 1200 B
+  int *sh2 = (int *)(R + 30720 + 2 * 7680 + 1280);                          // scalars (64 ints)
+  char *R2 = R + 30720 + 2 * 7680 + 1280 + 256;                             // free for keys / BCI (~17.8 KB) -- see below
+  for (int l = 0; l < CC_NLEV; l++)
+    for (int k = tid; k < n_lev[l]; k += nt) T[l * CC_NC + k] = scr->comp[l][k];
+  __syncthreads();
+  // insertion rank, bottom-up
+  for (int l = 0; l < CC_NLEV; l++) {
+    const int n = n_lev[l];
+    for (int k = tid; k < n; k += nt) {
+      const cc_comp_t cp = T[l * CC_NC + k];
+      int py0 = 0, px0 = 0, prank = 0;
+      if (l > 0) {
+        unsigned p = cp.parent;
+        if (p < (unsigned)n_lev[l - 1]) {
+          const cc_comp_t pp = T[(l - 1) * CC_NC + p];
+          py0 = pp.r0;
+          px0 = pp.c0;
+          prank = pp.rank;
+        }
+      }
+      const int rmin = cp.r0;
+      const int brow = (rmin - py0) >> 1;
+      const int ra = py0 + 2 * brow;
+      int cm = cp.cA;
+      if (ra == rmin && cp.cB < cm) cm = cp.cB;
+      const int bcol = (cm - px0) >> 1;
+      skey[l * CC_NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+      const unsigned me = skey[l * CC_NC + k];
+      int rk = 0;
+      for (int j = 0; j < n; j++) rk += (skey[l * CC_NC + j] < me) ? 1 : 0;
+      T[l * CC_NC + k].rank = (uint16_t)rk;
+      // pre-sort sequence: element at insertion position rk is component k
+      arr[l * CC_NC + rk] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+    }
+    __syncthreads();
+  }
+  // size sort, bigger first (contour_mng.h:596-599): one lane per level replays libstdc++ std::sort
+  {
+    const int lane_l = (nt >= 64 * CC_NLEV) ? ((tid & 63) == 0 ? (tid >> 6) : -1) : (tid < CC_NLEV ? tid : -1);
+    if (lane_l >= 0 && lane_l < CC_NLEV) {
+      unsigned *a = arr + lane_l * CC_NC;
+      ccsort::std_sort(a, n_lev[lane_l], [](unsigned x, unsigned y) { return (x >> 16) > (y >> 16); });
+      int tot = 0;
+      for (int i = 0; i < n_lev[lane_l]; i++) tot += (int)(a[i] >> 16);
+      sh2[lane_l] = tot;
+    }
+  }
+  __syncthreads();
+  // emit sorted contour tables + header
+  for (int l = 0; l < CC_NLEV; l++) {
+    const int n = n_lev[l] < CC_MAXC ? n_lev[l] : CC_MAXC;
+    const int n_words = n * (int)(sizeof(cc_contour_t) / 4);
+    const unsigned *src = (const unsigned *)&scr->cont[l][0];
+    unsigned *dst = (unsigned *)&desc->cont[l][0];
+    for (int w = tid; w < n_words; w += nt) {
+      const int seq = w / 19, off = w - seq * 19;
+      const int k = (int)(arr[l * CC_NC + seq] & 0xFFFFu);
+      dst[w] = src[k * 19 + off];
+    }
+    for (int seq = tid; seq < CC_NDIST && seq < n; seq += nt) {
+      const int k = (int)(arr[l * CC_NC + seq] & 0xFFFFu);
+      const cc_contour_t *cv = &scr->cont[l][k];
+      cc_anchor_lds a;
+      a.pm[0] = cv->pos_mean[0];
+      a.pm[1] = cv->pos_mean[1];
+      a.ev[0] = cv->eig_vals[0];
+      a.ev[1] = cv->eig_vals[1];
+      a.cnt = cv->cell_cnt;
+      top[l * CC_NDIST + seq] = a;
+    }
+  }
+  if (tid < CC_NLEV) {
+    desc->n_cont[tid] = n_lev[tid];
+    desc->n_stored[tid] = n_lev[tid] < CC_MAXC ? n_lev[tid] : CC_MAXC;
+    desc->layer_cell_cnt[tid] = sh2[tid];
+  }
+  if (tid == 0) {
+    const cc_k1_scan_out k1 = k1_out[scan];
+    desc->max_bin_val = k1.max_bin_val;
+    desc->min_bin_val = k1.min_bin_val;
+    desc->n_pix = k1.n_pix;
+    desc->flags = flags0;
+  }
+  if (labels_dbg) {
+    // component index -> seq (position after the size sort); skey is free now
+    for (int l = 0; l < CC_NLEV; l++)
+      for (int seq = tid; seq < n_lev[l]; seq += nt) skey[l * CC_NC + (arr[l * CC_NC + seq] & 0xFFFFu)] = (unsigned)seq;
+    __syncthreads();
+    for (int l = 0; l < CC_NLEV; l++) {
+      int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
+      for (int c = tid; c < n_cell; c += nt) {
+        int16_t v = ld[c];
+        if (v >= 0) ld[c] = (int16_t)skey[l * CC_NC + v];
+      }
+    }
+  }
+  __syncthreads();
+
+  // =========================== phase "keys" (contour_mng.h:693-830) ===========================
+  // R2 layout: divs f32 [36][35] (5040) | cntp int[36] | valid int[36] | acc int[36] | bci tmp | bci pts
+  float *divs = (float *)R2;
+  int *cntp = (int *)(R2 + 5056);
+  int *valid = cntp + 36;
+  int *accum = valid + 36;
+  const int NA = CC_NLEV * CC_NPIV;
+  if (tid < NA) {
+    const int ll = tid / CC_NPIV, seq = tid - ll * CC_NPIV;
+    int ok = 0, acc = 0;
+    if (seq < cfg.piv_firsts) {
+      for (int s = 0; s <= seq; s++)
+        if (s < n_lev[ll]) acc += top[ll * CC_NDIST + s].cnt;  // accumulate_cell_cnt (contour_mng.h:705-706)
+      ok = (seq < n_lev[ll] && top[ll * CC_NDIST + seq].cnt >= cfg.min_cont_key_cnt) ? 1 : 0;
+    }
+    valid[tid] = ok;
+    accum[tid] = acc;
+    cntp[tid] = 0;
+  }
+  __syncthreads();
+  const int roi_pad = (int)ceilf(cfg.roi_radius + 1.f);
+  const float div_len = cfg.roi_radius / (float)(7 * 5);
+  const float bin_len = cfg.roi_radius / (float)7;
+  const float g1 = cfg.lv_grads[1];  // DIST_BIN_LAYERS[0] == 1
+  const double r_lim = (double)cfg.roi_radius - 1e-2;
+  for (int t = tid; t < NA * 35; t += nt) {
+    const int a = t / 35, d = t - a * 35;
+    float acc = 0.f;
+    int cp = 0;
+    if (valid[a]) {
+      const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+      const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
+      const int r_cen = (int)vcx, c_cen = (int)vcy;
+      const int r_min = r_cen - roi_pad > 0 ? r_cen - roi_pad : 0;
+      const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
+      const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
+      const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
+      // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56)
+      const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
+      const double norm = sqrt(2 * 3.14159265358979323846 * 1.0 * 1.0);
+      for (int rr = r_min; rr <= r_max; rr++) {
+        for (int cc = c_min; cc <= c_max; cc++) {
+          const float h = H[rr * n_col + cc];
+          if (h < g1) continue;
+          const float2 rc = pix[rr * n_col + cc];
+          const float dx = rc.x - vcx, dy = rc.y - vcy;
+          const float dist = sqrtf(dx * dx + dy * dy);
+          if ((double)dist < r_lim && h > g1) {
+            int higher = 0;
+            for (int e = 1; e < CC_NLEV; e++) higher += (h > cfg.lv_grads[e]) ? 1 : 0;
+            cp++;
+            const float u = (xg - dist) / 1.0f;
+            const float pdf = (float)(exp(-0.5 * (double)u * (double)u) / norm);
+            acc += (float)higher * pdf;
+          }
+        }
+      }
+    }
+    divs[t] = acc;
+    if (d == 0) cntp[a] = cp;
+  }
+  __syncthreads();
+  for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {
+    const int a = t / CC_KEY_DIM, kd = t - a * CC_KEY_DIM;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    float v = 0.f;
+    if (valid[a]) {
+      const cc_anchor_lds an = top[ll * CC_NDIST + seq];
+      if (kd == 0)
+        v = sqrtf(an.ev[1] * (float)an.cnt);
+      else if (kd == 1)
+        v = sqrtf(an.ev[0] * (float)an.cnt);
+      else if (kd == 2)
+        v = (float)sqrt((double)accum[a]);
+      else {
+        const int b = kd - 3;
+        float ring = 0.f;
+        for (int d = 0; d < 5; d++) ring += divs[a * 35 + b * 5 + d];
+        ring = (float)((double)ring * ((double)bin_len / sqrt((double)cntp[a])));
+        v = ring;
+      }
+    }
+    desc->keys[ll][seq][kd] = v;
+  }
+  __syncthreads();
+
+  // =========================== phase "BCI" (contour_mng.h:848-883) ===========================
+  struct bci_tmp {
+    int ok;
+    int bit;
+    float r, theta;
+  };
+  cc_relpt_t *bpts = (cc_relpt_t *)(R + 0);                        // [36][40] 17280 B  (T is dead now)
+  bci_tmp *btmp = (bci_tmp *)(R + 17280);                          // [36][40] 23040 B  (T/skey/arr dead; ends < top)
+  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
+    const int a = t / CC_BCI_MAXPTS, q = t - a * CC_BCI_MAXPTS;
+    const int bl = q / CC_NDIST, j = q - bl * CC_NDIST;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    bci_tmp o;
+    o.ok = 0;
+    o.bit = 0;
+    o.r = 0.f;
+    o.theta = 0.f;
+    const int lev = bl + 1;  // DIST_BIN_LAYERS = {1,2,3,4}
+    const int lim = cfg.dist_firsts < n_lev[lev] ? cfg.dist_firsts : n_lev[lev];
+    if (valid[a] && j < lim && !(ll == lev && j == seq)) {
+      const float vx = top[lev * CC_NDIST + j].pm[0] - top[ll * CC_NDIST + seq].pm[0];
+      const float vy = top[lev * CC_NDIST + j].pm[1] - top[ll * CC_NDIST + seq].pm[1];
+      const float dist = sqrtf(vx * vx + vy * vy);
+      const double dd = (double)dist;
+      if (!(dd > (CC_BITS_PER_LAYER - 1) * 1.01 + 5.43 - 1e-3 || dd <= 5.43)) {
+        const float orie = atan2f(vy, vx);
+        double fl = floor((dd - 5.43) / 1.01);
+        if (fl > CC_BITS_PER_LAYER - 1.0) fl = CC_BITS_PER_LAYER - 1.0;
+        o.ok = 1;
+        o.bit = (int)(fl + (double)(bl * CC_BITS_PER_LAYER));
+        o.r = dist;
+        o.theta = orie;
+      }
+    }
+    btmp[t] = o;
+  }
+  __syncthreads();
+  if (tid < NA) {
+    const int a = tid;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    cc_relpt_t *p = bpts + a * CC_BCI_MAXPTS;
+    int n = 0;
+    unsigned long long bits[CC_BCI_LAYERS] = {0, 0, 0, 0};
+    for (int q = 0; q < CC_BCI_MAXPTS; q++) {
+      const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
+      if (!o.ok) continue;
+      cc_relpt_t rp;
+      rp.level = (int8_t)(q / CC_NDIST + 1);
+      rp.seq = (int8_t)(q % CC_NDIST);
+      rp.bit_pos = (int16_t)o.bit;
+      rp.r = o.r;
+      rp.theta = o.theta;
+      p[n++] = rp;
+      bits[o.bit >> 6] |= 1ull << (o.bit & 63);
+    }
+    ccsort::std_sort(p, n, [](const cc_relpt_t &x, const cc_relpt_t &y) { return x.bit_pos < y.bit_pos; });
+    cc_bci_t *ob = &desc->bcis[ll][seq];
+    for (int w = 0; w < CC_BCI_LAYERS; w++) ob->dist_bin[w] = bits[w];
+    ob->piv_seq = (int8_t)seq;
+    ob->level = (int8_t)ll;
+    ob->n_pts = (uint8_t)n;
+    int ns = 0;
+    if (n > 0) {
+      ob->segs[ns++] = 0;
+      int last = 0;
+      for (int i = 0; i < n; i++)
+        if (p[last].bit_pos != p[i].bit_pos) {
+          ob->segs[ns++] = (uint16_t)i;
+          last = i;
+        }
+      ob->segs[ns++] = (uint16_t)n;
+    }
+    ob->n_segs = (uint8_t)ns;
+    for (int i = ns; i < CC_BCI_MAXPTS + 2; i++) ob->segs[i] = 0;
+    for (int i = 0; i < CC_BCI_MAXPTS; i++) {
+      cc_relpt_t rp;
+      if (i < n)
+        rp = p[i];
+      else {
+        rp.level = 0;
+        rp.seq = 0;
+        rp.bit_pos = 0;
+        rp.r = 0.f;
+        rp.theta = 0.f;
+      }
+      ob->pts[i] = rp;
+    }
+  }
+}

@@ -1,0 +1,164 @@
+// K1 -- BEV rasterisation.  Replaces ContourManager::makeBEV (contour_mng.h:505-556) for a batch
+// of scans: one workgroup per scan, the 150x150 max-height grid lives in LDS.
+//
+//   pass 1: stream the scan's (x,y,z,i) records with coalesced 16-B loads, LDS atomicMax of the
+//           order-preserving height key per cell                                    (90 KB LDS)
+//   pass 2: re-stream; among the points whose height equals the cell maximum keep the smallest
+//           point index -- the reference updates a cell only on `bev < height` (strict), so the
+//           FIRST point in file order wins ties (contour_mng.h:517).  Indices are 21-bit fields,
+//           three per 64-bit LDS word, updated with a CAS loop                       (60 KB LDS)
+//   out   : dense bev image + continuous (row_f,col_f) of the winning point per occupied cell
+//           (pointToContRowCol, contour_mng.h:468-472), max/min accepted height, #occupied cells.
+//
+// Roofline: HBM.  Algorithmic bytes = 16 B x points; this two-pass form reads the
+// stream twice (second pass partly from L2/MALL).
+#pragma once
+#include "cc_dev.h"
+
+#define CC_K1_IDX_BITS 21
+#define CC_K1_IDX_MASK 0x1FFFFFull
+
+struct cc_k1_scan_out {
+  float max_bin_val, min_bin_val;
+  int n_pix;
+  int pad;
+};
+
+__device__ __forceinline__ float cc_wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    float t = __shfl_xor(v, o);
+    v = v < t ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float cc_wave_min(float v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    float t = __shfl_xor(v, o);
+    v = v > t ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int cc_wave_sum(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// grid = n_scans, block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
+__global__ void __launch_bounds__(1024)
+cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
+               float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  const int n_cell = cfg.n_cell;
+  unsigned *hmax = (unsigned *)smem;
+  const int n_w3 = (n_cell + 2) / 3;
+  unsigned long long *idx3 = (unsigned long long *)(smem + (((size_t)n_cell * 4 + 15) & ~(size_t)15));
+  unsigned *red = (unsigned *)(idx3 + n_w3);  // [0]=max key [1]=min key [2]=n_pix
+
+  const int scan = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const long long p0 = offsets[scan];
+  const int n_pts = (int)(offsets[scan + 1] - p0);
+  const float4 *P = pts + p0;
+
+  const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
+  for (int i = tid; i < n_cell; i += nt) hmax[i] = KEY_EMPTY;
+  for (int i = tid; i < n_w3; i += nt) idx3[i] = ~0ull;
+  if (tid == 0) {
+    red[0] = cc_fkey(CC_BEV_EMPTY);   // max_bin_val_ starts at -VAL_ABS_INF_ (contour_mng.h:436)
+    red[1] = cc_fkey(-CC_BEV_EMPTY);  // min_bin_val_ starts at +VAL_ABS_INF_
+    red[2] = 0;
+  }
+  __syncthreads();
+
+  // ---- pass 1: per-cell max height ----
+  float vmax = CC_BEV_EMPTY, vmin = -CC_BEV_EMPTY;
+  for (int i = tid; i < n_pts; i += 4 * nt) {
+    float4 q[4];
+    int cell[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int j = i + u * nt;
+      q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      cell[u] = cc_point_cell(cfg, q[u].x, q[u].y);
+      if (cell[u] >= 0) {
+        float h = cfg.lidar_height + q[u].z;
+        atomicMax(&hmax[cell[u]], cc_fkey(h));
+        vmax = vmax < h ? h : vmax;
+        vmin = vmin > h ? h : vmin;
+      }
+    }
+  }
+  vmax = cc_wave_max(vmax);
+  vmin = cc_wave_min(vmin);
+  if ((tid & 63) == 0) {
+    atomicMax(&red[0], cc_fkey(vmax));
+    atomicMin(&red[1], cc_fkey(vmin));
+  }
+  __syncthreads();
+
+  // ---- pass 2: first point (smallest index) attaining the maximum ----
+  for (int i = tid; i < n_pts; i += 4 * nt) {
+    float4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int j = i + u * nt;
+      q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int j = i + u * nt;
+      int cell = cc_point_cell(cfg, q[u].x, q[u].y);
+      if (cell >= 0) {
+        float h = cfg.lidar_height + q[u].z;
+        unsigned k = cc_fkey(h);
+        if (k == hmax[cell] && k != KEY_EMPTY) {
+          const int w = cell / 3, sh = (cell - 3 * w) * CC_K1_IDX_BITS;
+          unsigned long long old = idx3[w];
+          while (true) {
+            unsigned long long cur = (old >> sh) & CC_K1_IDX_MASK;
+            if ((unsigned long long)j >= cur) break;
+            unsigned long long nw = (old & ~(CC_K1_IDX_MASK << sh)) | ((unsigned long long)j << sh);
+            unsigned long long got = atomicCAS(&idx3[w], old, nw);
+            if (got == old) break;
+            old = got;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- outputs ----
+  float *bev = bev_out + (size_t)scan * n_cell;
+  float2 *pix = pix_out + (size_t)scan * n_cell;
+  int npix = 0;
+  for (int c = tid; c < n_cell; c += nt) {
+    unsigned k = hmax[c];
+    bev[c] = cc_funkey(k);
+    if (k != KEY_EMPTY) {
+      const int w = c / 3, sh = (c - 3 * w) * CC_K1_IDX_BITS;
+      int j = (int)((idx3[w] >> sh) & CC_K1_IDX_MASK);
+      float4 q = P[j];
+      // pointToContRowCol: x / reso + n_row/2 - 0.5f, left to right in f32
+      float2 rc;
+      rc.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
+      rc.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;
+      pix[c] = rc;
+      npix++;
+    }
+  }
+  npix = cc_wave_sum(npix);
+  if ((tid & 63) == 0) atomicAdd(&red[2], (unsigned)npix);
+  __syncthreads();
+  if (tid == 0) {
+    cc_k1_scan_out o;
+    o.max_bin_val = cc_funkey(red[0]);
+    o.min_bin_val = cc_funkey(red[1]);
+    o.n_pix = (int)red[2];
+    o.pad = 0;
+    scan_out[scan] = o;
+  }
+}

@@ -1,0 +1,219 @@
+// TEST INFRASTRUCTURE: a tiny CPU execution harness for the HIP kernels of this repo.
+//
+// There is no GPU in the build container, so kernel *logic* is exercised on the CPU before a
+// GPU slot is spent: the kernel headers under contour-context_amd/csrc/ are compiled unchanged
+// with g++ against this stand-in for <hip/hip_runtime.h> (tests/emu is put first on the include
+// path).  One OS thread per HIP thread, pthread barriers for __syncthreads(), per-wave barriers
+// for the 64-lane cross-lane ops, __atomic builtins for atomics.  It is never part of the product:
+// nothing under contour-context_amd/ includes or links it.
+#pragma once
+#include <pthread.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct float2 {
+  float x, y;
+};
+struct float4 {
+  float x, y, z, w;
+};
+struct int2 {
+  int x, y;
+};
+struct double2 {
+  double x, y;
+};
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline int2 make_int2(int a, int b) { return {a, b}; }
+
+namespace emu {
+struct WaveCtx {
+  pthread_barrier_t bar;
+  unsigned long long scratch64[64];
+};
+struct BlockCtx {
+  pthread_barrier_t bar;
+  std::vector<WaveCtx> waves;
+  char *dyn_smem = nullptr;
+};
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local BlockCtx *t_block;
+extern thread_local WaveCtx *t_wave;
+extern thread_local int t_lane;
+}  // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)emu::t_block->dyn_smem;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline int __lane_id() { return emu::t_lane; }
+
+// ---- cross-lane (wave = 64).  All 64 lanes of the wave must call these together. ----
+static inline unsigned long long __ballot(int pred) {
+  emu::WaveCtx *w = emu::t_wave;
+  w->scratch64[emu::t_lane] = pred ? 1ull : 0ull;
+  pthread_barrier_wait(&w->bar);
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; i++) m |= (w->scratch64[i] & 1ull) << i;
+  pthread_barrier_wait(&w->bar);
+  return m;
+}
+template <typename T>
+static inline T emu_shfl_any(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  emu::WaveCtx *w = emu::t_wave;
+  unsigned long long raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  w->scratch64[emu::t_lane] = raw;
+  pthread_barrier_wait(&w->bar);
+  unsigned long long r = w->scratch64[src & 63];
+  pthread_barrier_wait(&w->bar);
+  T out;
+  std::memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+  (void)width;
+  return emu_shfl_any(v, src);
+}
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  (void)width;
+  int src = emu::t_lane + (int)delta;
+  return emu_shfl_any(v, src < 64 ? src : emu::t_lane);
+}
+template <typename T>
+static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  (void)width;
+  int src = emu::t_lane - (int)delta;
+  return emu_shfl_any(v, src >= 0 ? src : emu::t_lane);
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+  (void)width;
+  return emu_shfl_any(v, emu::t_lane ^ mask);
+}
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+
+// ---- atomics ----
+template <typename T>
+static inline T emu_atomic_minmax(T *p, T v, bool is_max) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (true) {
+    T want = is_max ? (old > v ? old : v) : (old < v ? old : v);
+    if (want == old) return old;
+    if (__atomic_compare_exchange_n(p, &old, want, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return old;
+  }
+}
+static inline unsigned atomicMax(unsigned *p, unsigned v) { return emu_atomic_minmax(p, v, true); }
+static inline unsigned atomicMin(unsigned *p, unsigned v) { return emu_atomic_minmax(p, v, false); }
+static inline int atomicMax(int *p, int v) { return emu_atomic_minmax(p, v, true); }
+static inline int atomicMin(int *p, int v) { return emu_atomic_minmax(p, v, false); }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { return emu_atomic_minmax(p, v, true); }
+static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { return emu_atomic_minmax(p, v, false); }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicAnd(unsigned *p, unsigned v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+static inline int atomicCAS(int *p, int cmp, int val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+
+static inline float __int_as_float(int x) {
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+static inline int __float_as_int(float f) {
+  int x;
+  std::memcpy(&x, &f, 4);
+  return x;
+}
+static inline unsigned __float_as_uint(float f) {
+  unsigned x;
+  std::memcpy(&x, &f, 4);
+  return x;
+}
+static inline float __uint_as_float(unsigned x) {
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+namespace emu {
+// Run `kernel(args...)` over grid x block (1-D), one block at a time.
+template <typename K, typename... Args>
+void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args) {
+  if (block % 64 != 0) {
+    fprintf(stderr, "emu: block size must be a multiple of 64\n");
+    abort();
+  }
+  for (unsigned b = 0; b < grid; b++) {
+    BlockCtx ctx;
+    pthread_barrier_init(&ctx.bar, nullptr, block);
+    ctx.waves.resize(block / 64);
+    for (auto &w : ctx.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+    std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
+    ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+    std::vector<std::thread> th;
+    th.reserve(block);
+    for (unsigned t = 0; t < block; t++) {
+      th.emplace_back([&, t]() {
+        t_threadIdx = dim3(t);
+        t_blockIdx = dim3(b);
+        t_blockDim = dim3(block);
+        t_gridDim = dim3(grid);
+        t_block = &ctx;
+        t_wave = &ctx.waves[t / 64];
+        t_lane = t % 64;
+        kernel(args...);
+      });
+    }
+    for (auto &x : th) x.join();
+    pthread_barrier_destroy(&ctx.bar);
+    for (auto &w : ctx.waves) pthread_barrier_destroy(&w.bar);
+  }
+}
+}  // namespace emu

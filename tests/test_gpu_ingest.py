@@ -1,0 +1,78 @@
+"""GPU parity of the ingest path (K1 rasterise + K2 contours/keys/BCI) against the CPU oracle,
+through the C-ABI (cc_ingest_batch)."""
+import numpy as np
+import pytest
+
+from parity import compare_desc, terrain_scan
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cc, oracle, scans, cfg=None):
+    import torch
+    cfg = cfg or cc.L.default_manager_cfg()
+    ctx = cc.Context(0, cfg, max_batch=8)
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
+    x = torch.from_numpy(np.concatenate(scans, 0)).cuda()
+    desc, dbg = ctx.ingest(x, offs, debug=True)
+    torch.cuda.synchronize()
+    d = cc.desc_to_numpy(desc)
+    report = []
+    for i, s in enumerate(scans):
+        o = oracle.Scan(s, cfg)
+        ob, opix = o.bev()
+        if not np.array_equal(ob, dbg["bev"][i].cpu().numpy()):
+            report.append("scan %d: bev differs" % i)
+        if not np.array_equal(opix, dbg["pix_rc"][i].cpu().numpy()):
+            report.append("scan %d: pix_rc differs" % i)
+        if not np.array_equal(o.labels(), dbg["labels"][i].cpu().numpy()):
+            report.append("scan %d: canonical label images differ" % i)
+        report += ["scan %d: %s" % (i, m) for m in compare_desc(o.desc()[0], d[i], float_exact=False)]
+    ctx.close()
+    return report, d
+
+
+def test_ingest_synthetic_velodyne(cc, oracle):
+    w = cc.synth.World(loop_len=200.0)
+    xyzi, _, _ = cc.synth.make_sequence(3, world=w, device="cuda", start=11)
+    scans = [xyzi[i].cpu().numpy() for i in range(3)]
+    report, d = _run(cc, oracle, scans)
+    assert not report, "\n".join(report[:40])
+    assert (d["flags"] == 0).all()
+
+
+def test_ingest_terrain_many_contours(cc, oracle):
+    scans = [terrain_scan(s) for s in range(4)] + [terrain_scan(100 + s, n=30000, scale=2.2, quant=0.25) for s in range(3)]
+    report, d = _run(cc, oracle, scans)
+    assert not report, "\n".join(report[:40])
+    assert d["n_cont"].max() > 16  # exercises the introsort partition path
+
+
+def test_ingest_ragged_and_edge(cc, oracle):
+    rng = np.random.default_rng(5)
+    tiny = np.zeros((11, 4), np.float32)                      # minimum accepted size, all in the blind zone
+    far = np.full((50, 4), 1000.0, np.float32)                # every point rejected
+    ties = np.tile(np.array([[10.2, 3.3, 1.0, 0], [10.7, 3.9, 1.0, 0], [10.4, 3.1, 1.0, 0]], np.float32), (40, 1))
+    ties[:, :2] += rng.normal(0, 1e-3, ties[:, :2].shape).astype(np.float32)   # equal heights in one cell: first wins
+    edge = np.array([[74.98, 74.98, 2.0, 0], [-74.98, -74.98, 2.0, 0], [74.995, 0, 2, 0], [-74.0, 10, 2, 0]] * 5, np.float32)
+    scans = [tiny, far, ties, edge, terrain_scan(9, n=2000)]
+    report, _ = _run(cc, oracle, scans)
+    assert not report, "\n".join(report[:40])
+
+
+def test_ingest_rejects_short_scan(cc):
+    import torch
+    ctx = cc.Context(0, max_batch=2)
+    x = torch.zeros((10, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(cc.CCError):
+        ctx.ingest(x, np.array([0, 10], np.int64))
+    ctx.close()
+
+
+def test_ingest_host_matches_device(cc, oracle):
+    scans = [terrain_scan(21, n=20000)]
+    ctx = cc.Context(0, max_batch=2)
+    out = ctx.ingest_host(scans[0], np.array([0, len(scans[0])], np.int64))
+    o = oracle.Scan(scans[0])
+    assert not compare_desc(o.desc()[0], out[0], float_exact=False)
+    ctx.close()
