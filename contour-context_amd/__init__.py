@@ -144,3 +144,67 @@ class Context:
 def desc_to_numpy(desc_tensor):
     """torch uint8 [n, DESC_BYTES] (any device) -> numpy structured array of cc_scan_desc_t."""
     return desc_tensor.cpu().numpy().view(L.scan_desc_dt).reshape(-1)
+
+
+class Database:
+    """cc_db: device-resident ContourDB (contour_db.h:673-845) + batched queryRangedKNN."""
+
+    def __init__(self, ctx, cfg=None, capacity=8192):
+        self.ctx = ctx
+        self.cfg = cfg or L.default_db_cfg()
+        h = C.c_void_p()
+        _chk(lib().cc_db_create(ctx.h, C.addressof(self.cfg), capacity, C.byref(h)), "cc_db_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cc_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().cc_db_size(self.h)
+
+    def add_scans(self, desc, ts, seeds):
+        """desc: torch uint8 CUDA [n, DESC_BYTES]; ts float64 [n]; seeds int32 [n] (the reference passes the scan's
+        assigned seq to pushAndBalance, batch_bin_test.cpp:236)."""
+        import torch
+        ts = np.ascontiguousarray(ts, np.float64)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        n = desc.shape[0]
+        assert desc.is_cuda and desc.dtype == torch.uint8 and desc.is_contiguous() and len(ts) == n and len(seeds) == n
+        stream = torch.cuda.current_stream(desc.device).cuda_stream
+        _chk(lib().cc_db_add_scans(self.h, desc.data_ptr(), n, ts.ctypes.data, seeds.ctypes.data, stream), "cc_db_add_scans")
+
+    def query(self, qdesc, epochs, lb=None, ub=None, want_knn=False):
+        """qdesc: torch uint8 CUDA [nq, DESC_BYTES]; epochs int32 [nq] (DB state each query sees).
+        Returns numpy structured array of cc_query_result_t (+ knn hits / counts as torch tensors)."""
+        import torch
+        if lb is None:
+            lb, ub = L.default_thresholds()
+        epochs = np.ascontiguousarray(epochs, np.int32)
+        nq = qdesc.shape[0]
+        assert qdesc.is_cuda and qdesc.is_contiguous() and len(epochs) == nq
+        res = np.zeros(nq, L.query_result_dt)
+        knn = cnt = None
+        if want_knn:
+            knn = torch.zeros((nq, L.NQLEV, L.NPIV, L.KNN_MAX, L.knn_hit_dt.itemsize), dtype=torch.uint8, device=qdesc.device)
+            cnt = torch.zeros((nq, L.NQLEV, L.NPIV), dtype=torch.int32, device=qdesc.device)
+        stream = torch.cuda.current_stream(qdesc.device).cuda_stream
+        _chk(lib().cc_db_query_batch(self.h, qdesc.data_ptr(), nq, epochs.ctypes.data, C.addressof(lb), C.addressof(ub),
+                                     res.ctypes.data, knn.data_ptr() if want_knn else None,
+                                     cnt.data_ptr() if want_knn else None, stream), "cc_db_query_batch")
+        if want_knn:
+            return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
+        return res
+
+    def bucket_state(self):
+        sizes = np.zeros((3, 6), np.int32)
+        ranges = np.zeros((3, 7), np.float32)
+        _chk(lib().cc_db_bucket_state(self.h, sizes.ctypes.data, ranges.ctypes.data), "cc_db_bucket_state")
+        return sizes, ranges

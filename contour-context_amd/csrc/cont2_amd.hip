@@ -4,9 +4,13 @@
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC cont2_amd.hip -o libcont2_amd.so
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <array>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -16,6 +20,10 @@
 #include "k_contours.h"
 #include "k_query.h"
 #include "cc_hostdb.h"
+
+#ifndef CC_INGEST_BLOCK
+#define CC_INGEST_BLOCK 1024  // threads per workgroup of the per-scan ingest kernels
+#endif
 
 static thread_local std::string g_err;
 static int set_err(int code, const char *what, hipError_t e = hipSuccess) {
@@ -157,10 +165,13 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     HIPCHK(hipMemcpyAsync(c->d_offsets, off.data(), sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));  // `off` is a stack-lifetime staging buffer
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
-    if (dbg && dbg->d_pix_rc) cc_k_fill_f32<<<512, 256, 0, stream>>>((float *)c->d_pix, -1.f, nc * 2 * nb);
-    cc_k_rasterize<<<nb, 1024, c->lds1, stream>>>(c->dcfg, pts, c->d_offsets, c->d_bev, c->d_pix, c->d_k1);
+    if (dbg && dbg->d_pix_rc)
+      hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)c->d_pix, -1.f, nc * 2 * nb);
+    hipLaunchKernelGGL(cc_k_rasterize, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
+                       c->d_bev, c->d_pix, c->d_k1);
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
-    cc_k_contours<<<nb, 1024, c->lds2, stream>>>(c->dcfg, c->d_bev, c->d_pix, c->d_k1, c->d_scr, d_out + b0, lab);
+    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
+                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab);
     HIPCHK(hipGetLastError());
     if (dbg && dbg->d_bev)
       HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, c->d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));

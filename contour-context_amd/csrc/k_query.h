@@ -1,3 +1,1088 @@
-// query kernels (KNN / constellation checks / GMM) -- filled in below
+// Query-side kernels.  Replace, for a batch of query scans against the device-resident DB,
+//   K3  LayerDB::layerKNNSearch / TreeBucket::knnSearch / nanoflann kNN     src/cont2/contour_db.cpp:319-403
+//   K4  CandidateManager::checkCandWithHint: ContourView::checkSim,           contour_db.h:374-488
+//       BCI::checkConstellSim, checkConstellCorrespSim, getTFFromConstell     contour.h:278-329, contour_mng.h:288-388,1124-1277
+//   K5  GMMPair / ConstellCorrelation::initProblem + calcCorrelation          correlation.h:42-238
+// The sequential bookkeeping between them (CandidatePoseData::addProposal, tidyUpCandidates'
+// selection, fineOptimize's ordering) runs on the host in cc_db_api.inc.
 #pragma once
 #include "cc_dev.h"
+#include "cc_sort.h"
+
+// ------------------------------------------------------------------------------------------------
+// K3: exhaustive top-k over the layer's key matrix with the reference's visibility rules.
+// ------------------------------------------------------------------------------------------------
+#define CC_KNN_CAP 2048  // LDS candidate buffer (entries of 8 B)
+
+struct cc_knn_params {
+  const float *keys[CC_NQLEV];        // SoA [CC_KEY_DIM][cap_k]
+  const int *kgidx[CC_NQLEV];         // scan index of each key
+  const unsigned char *kseq[CC_NQLEV];
+  const int *kactive[CC_NQLEV];       // first epoch at which the key sits in a tree
+  int cap_k;
+  int nnk;
+  int n_q_levels;
+  int q_levels[CC_NQLEV];
+};
+
+struct cc_query_meta {  // per query scan, host-built
+  int epoch;
+  int n_keys[CC_NQLEV];            // keys appended to the layer before this epoch (scan bound)
+  float ranges[CC_NQLEV][7];       // LayerDB::bucket_ranges_ at this epoch
+};
+
+__device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n_pow2, int tid, int nt) {
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n_pow2; i += nt) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long x = a[i], y = a[ixj];
+          bool up = ((i & k) == 0);
+          if ((x > y) == up) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// grid = nq * CC_NQLEV * CC_NPIV, block = 256
+__global__ void __launch_bounds__(256)
+cc_k_knn(cc_knn_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_query_meta *__restrict__ qmeta,
+         cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
+  __shared__ unsigned long long buf[CC_KNN_CAP];
+  __shared__ int s_cnt;
+  __shared__ float s_ub;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int slot = blockIdx.x % (CC_NQLEV * CC_NPIV);
+  const int q = blockIdx.x / (CC_NQLEV * CC_NPIV);
+  const int ll = slot / CC_NPIV, seq = slot - ll * CC_NPIV;
+  cc_knn_hit_t *out = hits + (size_t)blockIdx.x * CC_KNN_MAX;
+  if (ll >= P.n_q_levels) {
+    if (tid == 0) hit_cnt[blockIdx.x] = 0;
+    return;
+  }
+  const int level = P.q_levels[ll];
+  const float *qk = &qdesc[q].keys[level][seq][0];
+  float k[CC_KEY_DIM];
+  float sum = 0.f;
+  for (int d = 0; d < CC_KEY_DIM; d++) {
+    k[d] = qk[d];
+    sum += k[d];
+  }
+  if (!(sum != 0.f)) {  // q_keys[seq].sum() != 0 (contour_db.h:726)
+    if (tid == 0) hit_cnt[blockIdx.x] = 0;
+    return;
+  }
+  const cc_query_meta qm = qmeta[q];
+  // dist_ub (contour_db.h:733-749), f32 results of f64 products exactly as written there
+  const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
+  const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
+  const float b20 = (float)((double)k[2] * 0.8 * 0.75), b21 = (float)((double)k[2] / (0.8 * 0.75));
+  const float t0a = (k[0] - b00) * (k[0] - b00), t0b = (k[0] - b01) * (k[0] - b01);
+  const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
+  const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
+  const float dist_ub = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
+  // mid bucket and the buckets layerKNNSearch actually visits (src/cont2/contour_db.cpp:322-369):
+  // {0..mid} and {mid+i : i > mid, mid+i < 6}
+  float rg[7];
+  for (int i = 0; i < 7; i++) rg[i] = qm.ranges[ll][i];
+  int mid = 0;
+  for (int i = 0; i < 6; i++)
+    if (rg[i] <= k[0] && rg[i + 1] > k[0]) {
+      mid = i;
+      break;
+    }
+  unsigned vis = 0;
+  for (int b = 0; b < 6; b++)
+    if (b <= mid || b >= 2 * mid + 1) vis |= 1u << b;
+  if (tid == 0) {
+    s_cnt = 0;
+    s_ub = dist_ub;
+  }
+  __syncthreads();
+  const int nk = qm.n_keys[ll];
+  const float *K = P.keys[ll];
+  const int *act = P.kactive[ll];
+  const int cap = P.cap_k;
+  const int epoch = qm.epoch;
+  const int nnk = P.nnk;
+  for (int base = 0; base < nk; base += nt) {
+    const int id = base + tid;
+    if (id < nk && act[id] <= epoch) {
+      const float c0 = K[id];
+      int bk = -1;
+      for (int b = 0; b < 6; b++)
+        if (rg[b] <= c0 && c0 < rg[b + 1]) {
+          bk = b;
+          break;
+        }
+      if (bk >= 0 && ((vis >> bk) & 1u)) {
+        // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+        float d0 = k[0] - c0, d1 = k[1] - K[cap + id], d2 = k[2] - K[2 * cap + id], d3 = k[3] - K[3 * cap + id];
+        float res = 0.f;
+        res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        d0 = k[4] - K[4 * cap + id];
+        d1 = k[5] - K[5 * cap + id];
+        d2 = k[6] - K[6 * cap + id];
+        d3 = k[7] - K[7 * cap + id];
+        res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        d0 = k[8] - K[8 * cap + id];
+        res += d0 * d0;
+        d0 = k[9] - K[9 * cap + id];
+        res += d0 * d0;
+        if (res < s_ub) {
+          int p = atomicAdd(&s_cnt, 1);
+          buf[p] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)id;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_cnt > CC_KNN_CAP - nt) {  // uniform: shrink to the best nnk and tighten the radius
+      const int n = s_cnt;
+      for (int i = n + tid; i < CC_KNN_CAP; i += nt) buf[i] = ~0ull;
+      __syncthreads();
+      cc_bitonic_sort_u64(buf, CC_KNN_CAP, tid, nt);
+      if (tid == 0) {
+        s_cnt = n < nnk ? n : nnk;
+        if (n >= nnk) s_ub = __uint_as_float((unsigned)(buf[nnk - 1] >> 32));
+      }
+      __syncthreads();
+    }
+  }
+  {
+    const int n = s_cnt;
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += nt) buf[i] = ~0ull;
+    __syncthreads();
+    cc_bitonic_sort_u64(buf, np2, tid, nt);
+    const int m = n < nnk ? n : nnk;
+    for (int i = tid; i < m; i += nt) {
+      const unsigned id = (unsigned)(buf[i] & 0xFFFFFFFFu);
+      cc_knn_hit_t h;
+      h.gidx = P.kgidx[ll][id];
+      h.level = (int16_t)level;
+      h.seq = (int16_t)P.kseq[ll][id];
+      h.dist_sq = __uint_as_float((unsigned)(buf[i] >> 32));
+      out[i] = h;
+    }
+    if (tid == 0) hit_cnt[blockIdx.x] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: the four-stage gate per (candidate scan, anchor pair).  One lane per check.
+// ------------------------------------------------------------------------------------------------
+#define CC_PP_MAX 256      // potential (src,tgt) neighbour pairs per check
+#define CC_CSTL_MAX 64     // pairs kept in a constellation
+#define CC_PASS_CAP 1024   // >= nnk * 18: every check of a query may pass
+
+struct cc_pass_rec {
+  int q;           // query index within the launch
+  int order;       // slot * CC_KNN_MAX + j : position in the reference's candidate iteration order
+  int gidx;        // candidate scan
+  int n_pairs;     // tmp_pairs2.size() (vote weight)
+  int flags;       // bit0: a capacity (CC_PP_MAX / CC_CSTL_MAX) was hit
+  int pad;
+  double tf[3];    // T_pass = (x, y, theta)
+  unsigned long long bits[7];  // constellation pairs as a set: bit (level-1)*100 + seq_src*10 + seq_tgt
+};
+
+struct cc_check_params {
+  cc_sim_cfg_t sim;
+  cc_score_t lb;
+  int n_q_levels;
+  int q_levels[CC_NQLEV];
+};
+
+struct cc_dsp {  // BCI::DistSimPair
+  float orie;
+  signed char l, s, t, pad;
+};
+
+__device__ __forceinline__ bool cc_check_sim(const cc_contour_t &a, const cc_contour_t &b, const cc_sim_cfg_t &th) {
+  const float ca = (float)a.cell_cnt, cb = (float)b.cell_cnt;
+  if ((fabsf((ca - cb) / (ca < cb ? cb : ca)) > th.tp_cell_cnt) && (fabsf(ca - cb) > th.ta_cell_cnt)) return false;
+  {
+    const float ea = a.eig_vals[1], eb = b.eig_vals[1];
+    if ((ea < eb ? eb : ea) > 2.0f) {
+      const float sa = sqrtf(ea), sb = sqrtf(eb);
+      if (fabsf((sa - sb) / (sa < sb ? sb : sa)) > th.tp_eigval) return false;
+    }
+  }
+  {
+    const float ea = a.eig_vals[0], eb = b.eig_vals[0];
+    if ((ea < eb ? eb : ea) > 2.0f) {
+      const float sa = sqrtf(ea), sb = sqrtf(eb);
+      if (fabsf((sa - sb) / (sa < sb ? sb : sa)) > th.tp_eigval) return false;
+    }
+  }
+  if ((a.cell_cnt < b.cell_cnt ? b.cell_cnt : a.cell_cnt) > 15 && fabsf(a.vol3_mean - b.vol3_mean) > th.ta_h_bar) return false;
+  const float ax = a.com[0] - a.pos_mean[0], ay = a.com[1] - a.pos_mean[1];
+  const float bx = b.com[0] - b.pos_mean[0], by = b.com[1] - b.pos_mean[1];
+  const float r1 = sqrtf(ax * ax + ay * ay), r2 = sqrtf(bx * bx + by * by);
+  if (fabsf(r1 - r2) > th.ta_rcom && fabsf((r1 - r2) / (r1 < r2 ? r2 : r1)) > th.tp_rcom) return false;
+  return true;
+}
+
+__device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * x + y * y); }
+
+// returns true when the check passed all four stages; fills rec
+__device__ bool cc_check_cand(const cc_scan_desc_t *__restrict__ src, const cc_scan_desc_t *__restrict__ tgt, int level,
+                              int seq_src, int seq_tgt, const cc_check_params &P, int *stage, cc_pass_rec *rec) {
+  *stage = 0;
+  rec->flags = 0;
+  // (1/4) anchor similarity
+  if (!cc_check_sim(src->cont[level][seq_src], tgt->cont[level][seq_tgt], P.sim)) return false;
+  *stage = 1;
+  // (2/4) BCI::checkConstellSim
+  const cc_bci_t *bs = &src->bcis[level][seq_src];
+  const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
+  unsigned long long S[4], T[4];
+  for (int w = 0; w < 4; w++) {
+    S[w] = bs->dist_bin[w];
+    T[w] = bt->dist_bin[w];
+  }
+  int ov1 = 0, ov2 = 0, ov3 = 0;
+  for (int w = 0; w < 4; w++) {
+    const unsigned long long shl = (S[w] << 1) | (w > 0 ? (S[w - 1] >> 63) : 0ull);
+    const unsigned long long shr = (S[w] >> 1) | (w < 3 ? (S[w + 1] << 63) : 0ull);
+    ov1 += __popcll(S[w] & T[w]);
+    ov2 += __popcll(shl & T[w]);
+    ov3 += __popcll(shr & T[w]);
+  }
+  const int ovlp_sum = ov1 + ov2 + ov3;
+  int max_one = ov2 < ov3 ? ov3 : ov2;
+  max_one = ov1 < max_one ? max_one : ov1;
+  if (!(ovlp_sum >= P.lb.i_ovlp_sum && max_one >= P.lb.i_ovlp_max_one)) return false;
+  cc_dsp pp[CC_PP_MAX];
+  int npp = 0;
+  {
+    const int ns_seg = (int)bs->n_segs, nt_seg = (int)bt->n_segs;
+    int p11 = 0, p12;
+    for (int p2 = 0; p2 < nt_seg - 1; p2++) {
+      const int tb = bt->pts[bt->segs[p2]].bit_pos;
+      while (p11 < ns_seg - 1 && bs->pts[bs->segs[p11]].bit_pos < tb - 1) p11++;
+      p12 = p11;
+      while (p12 < ns_seg - 1 && bs->pts[bs->segs[p12]].bit_pos <= tb + 1) p12++;
+      for (int i = bt->segs[p2]; i < bt->segs[p2 + 1]; i++) {
+        for (int j = bs->segs[p11]; j < bs->segs[p12]; j++) {
+          if (npp < CC_PP_MAX) {
+            const cc_relpt_t r1 = bs->pts[j], r2 = bt->pts[i];
+            cc_dsp e;
+            e.l = r1.level;
+            e.s = r1.seq;
+            e.t = r2.seq;
+            e.pad = 0;
+            float od = r2.theta - r1.theta;
+            // clampAng<float> (tools/algos.h:49-51)
+            od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
+            e.orie = od;
+            pp[npp++] = e;
+          } else {
+            rec->flags |= 1;
+          }
+        }
+      }
+    }
+  }
+  if (npp == 0) return false;
+  ccsort::std_sort(pp, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
+  const float angular_range = (float)(3.14159265358979323846 / 16);
+  int beg = 0, longest = 1;
+  {
+    int p1 = 0, p2 = 0;
+    while (p1 < npp) {
+      const double v = (double)(pp[p2 % npp].orie - pp[p1].orie) + 2 * 3.14159265358979323846 * (double)(p2 / npp);
+      if (v > (double)angular_range)
+        p1++;
+      else {
+        if (p2 - p1 + 1 > longest) {
+          longest = p2 - p1 + 1;
+          beg = p1;
+        }
+        p2++;
+      }
+    }
+  }
+  if (longest < P.lb.i_in_ang_rng) return false;
+  *stage = 2;
+  // constellation = window pairs + the anchors
+  signed char cs[CC_CSTL_MAX][3];
+  int ncs = 0;
+  // (3/4) checkConstellCorrespSim part 1: individual similarity, in cstl_in order
+  for (int i = beg; i < beg + longest + 1; i++) {
+    int l, s, t;
+    if (i < beg + longest) {
+      const cc_dsp e = pp[i % npp];
+      l = e.l;
+      s = e.s;
+      t = e.t;
+    } else {
+      l = level;
+      s = seq_src;
+      t = seq_tgt;
+    }
+    if (cc_check_sim(src->cont[l][s], tgt->cont[l][t], P.sim)) {
+      if (ncs < CC_CSTL_MAX) {
+        cs[ncs][0] = (signed char)l;
+        cs[ncs][1] = (signed char)s;
+        cs[ncs][2] = (signed char)t;
+        ncs++;
+      } else {
+        rec->flags |= 1;
+      }
+    }
+  }
+  if (ncs < P.lb.i_indiv_sim) return false;
+  // part 2: orientation consistency
+  float shx = 0.f, shy = 0.f, thx = 0.f, thy = 0.f;
+  const int lim = ncs < 10 ? ncs : 10;
+  for (int i = 1; i < lim; i++)
+    for (int j = 0; j < i; j++) {
+      const float *pi = src->cont[cs[i][0]][cs[i][1]].pos_mean, *pj = src->cont[cs[j][0]][cs[j][1]].pos_mean;
+      const float cx = pi[0] - pj[0], cy = pi[1] - pj[1];
+      if (cc_norm2f(cx, cy) > cc_norm2f(shx, shy)) {
+        float z = cx * cx + cy * cy;
+        if (z > 0.f) {
+          const float s = sqrtf(z);
+          shx = cx / s;
+          shy = cy / s;
+        } else {
+          shx = cx;
+          shy = cy;
+        }
+        const float *qi = tgt->cont[cs[i][0]][cs[i][2]].pos_mean, *qj = tgt->cont[cs[j][0]][cs[j][2]].pos_mean;
+        const float tx = qi[0] - qj[0], ty = qi[1] - qj[1];
+        z = tx * tx + ty * ty;
+        if (z > 0.f) {
+          const float s = sqrtf(z);
+          thx = tx / s;
+          thy = ty / s;
+        } else {
+          thx = tx;
+          thy = ty;
+        }
+      }
+    }
+  int num_sim = ncs;
+  const float pi6 = (float)(3.14159265358979323846 / 6);
+  for (int i = 0; i < num_sim;) {
+    const cc_contour_t &sc = src->cont[cs[i][0]][cs[i][1]];
+    const cc_contour_t &tc = tgt->cont[cs[i][0]][cs[i][2]];
+    if (sc.ecc_feat && tc.ecc_feat) {
+      const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
+      const float theta_t = acosf(thx * tc.eig_vecs[2] + thy * tc.eig_vecs[3]);
+      const float pms = (float)(3.14159265358979323846 - (double)theta_s);
+      if (fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6) {
+        for (int c = 0; c < 3; c++) {
+          const signed char tmp = cs[i][c];
+          cs[i][c] = cs[num_sim - 1][c];
+          cs[num_sim - 1][c] = tmp;
+        }
+        num_sim--;
+        continue;
+      }
+    }
+    i++;
+  }
+  ncs = num_sim;
+  if (ncs < P.lb.i_orie_sim) return false;
+  *stage = 3;
+  // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form (see oracle notes / DESIGN.md)
+  const double one_over_n = 1.0 / (double)ncs;
+  double smx = 0, smy = 0, dmx = 0, dmy = 0;
+  for (int i = 0; i < ncs; i++) {
+    const float *a = src->cont[cs[i][0]][cs[i][1]].pos_mean, *b = tgt->cont[cs[i][0]][cs[i][2]].pos_mean;
+    smx += (double)a[0];
+    smy += (double)a[1];
+    dmx += (double)b[0];
+    dmy += (double)b[1];
+  }
+  smx = smx * one_over_n;
+  smy = smy * one_over_n;
+  dmx = dmx * one_over_n;
+  dmy = dmy * one_over_n;
+  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+  for (int i = 0; i < ncs; i++) {
+    const float *a = src->cont[cs[i][0]][cs[i][1]].pos_mean, *b = tgt->cont[cs[i][0]][cs[i][2]].pos_mean;
+    const double ax = (double)a[0] - smx, ay = (double)a[1] - smy, bx = (double)b[0] - dmx, by = (double)b[1] - dmy;
+    s00 += bx * ax;
+    s01 += bx * ay;
+    s10 += by * ax;
+    s11 += by * ay;
+  }
+  s00 *= one_over_n;
+  s01 *= one_over_n;
+  s10 *= one_over_n;
+  s11 *= one_over_n;
+  const double sn = s10 - s01, cs_ = s00 + s11;
+  const double nrm = sqrt(sn * sn + cs_ * cs_);
+  double r00 = 1, r10 = 0;
+  if (nrm > 0) {
+    r00 = cs_ / nrm;
+    r10 = sn / nrm;
+  }
+  rec->tf[0] = dmx - (r00 * smx + (-r10) * smy);
+  rec->tf[1] = dmy - (r10 * smx + r00 * smy);
+  rec->tf[2] = atan2(r10, r00);
+  rec->n_pairs = ncs;
+  for (int w = 0; w < 7; w++) rec->bits[w] = 0ull;
+  for (int i = 0; i < ncs; i++) {
+    const int b = (cs[i][0] - 1) * 100 + cs[i][1] * 10 + cs[i][2];
+    rec->bits[b >> 6] |= 1ull << (b & 63);
+  }
+  return true;
+}
+
+// grid = nq, block = 256.  hits/hit_cnt: K3 output.
+__global__ void __launch_bounds__(256)
+cc_k_check(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
+           const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, cc_pass_rec *__restrict__ pass,
+           int pass_cap, int *__restrict__ pass_total, int *__restrict__ pass_cnt /*[nq][4]: n_pass, chk1, chk2, chk3*/) {
+  __shared__ int pre[CC_NQLEV * CC_NPIV + 1];
+  __shared__ int s_n[4];
+  const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int NS = CC_NQLEV * CC_NPIV;
+  if (tid == 0) {
+    int acc = 0;
+    for (int s = 0; s < NS; s++) {
+      pre[s] = acc;
+      acc += hit_cnt[q * NS + s];
+    }
+    pre[NS] = acc;
+    s_n[0] = s_n[1] = s_n[2] = s_n[3] = 0;
+  }
+  __syncthreads();
+  const int total = pre[NS];
+  const cc_scan_desc_t *tgt = qdesc + q;
+  for (int t = tid; t < total; t += nt) {
+    int slot = 0;
+    while (t >= pre[slot + 1]) slot++;
+    const int j = t - pre[slot];
+    const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+    const int seq_tgt = slot % CC_NPIV;
+    cc_pass_rec rec;
+    int stage;
+    const bool ok = cc_check_cand(db_desc + h.gidx, tgt, h.level, h.seq, seq_tgt, P, &stage, &rec);
+    if (stage >= 1) atomicAdd(&s_n[1], 1);
+    if (stage >= 2) atomicAdd(&s_n[2], 1);
+    if (stage >= 3) atomicAdd(&s_n[3], 1);
+    if (ok) {
+      atomicAdd(&s_n[0], 1);
+      const int p = atomicAdd(pass_total, 1);  // compact list for the whole launch; the host re-orders by (q, order)
+      if (p < pass_cap) {
+        rec.q = q;
+        rec.order = slot * CC_KNN_MAX + j;
+        rec.gidx = h.gidx;
+        rec.pad = 0;
+        pass[p] = rec;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 4) pass_cnt[q * 4 + tid] = s_n[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: GMM-L2 correlation (init) + <= 10 L-BFGS iterations, one wave per (query, candidate) problem.
+// ------------------------------------------------------------------------------------------------
+#define CC_GMM_ECAP 128    // ellipses per (side, level) held in LDS
+#define CC_GMM_PCAP 4096   // selected (src,tgt) ellipse pairs
+
+struct cc_gmm_problem {
+  int q;          // index into qdesc (tgt)
+  int gidx;       // index into db_desc (src)
+  double tf[3];   // T_init = (x, y, theta)
+};
+struct cc_gmm_result {
+  double corr_init;
+  double corr_opt;
+  double tf_opt[3];
+  int optimized;   // 0: init correlation below the bar (no refinement)
+  int iterations;
+  int termination;
+  int flags;       // bit0: ellipse cap hit, bit1: pair cap hit, bit2: contour table truncated (CC_MAXC)
+};
+
+struct cc_ell {
+  double c00, c01, c10, c11, mx, my, w;
+  float maj;
+  int pad;
+};
+
+struct cc_jet {
+  double a, v0, v1, v2;
+};
+__device__ __forceinline__ cc_jet jc(double s) { return cc_jet{s, 0, 0, 0}; }
+__device__ __forceinline__ cc_jet operator+(const cc_jet &f, const cc_jet &g) { return cc_jet{f.a + g.a, f.v0 + g.v0, f.v1 + g.v1, f.v2 + g.v2}; }
+__device__ __forceinline__ cc_jet operator-(const cc_jet &f, const cc_jet &g) { return cc_jet{f.a - g.a, f.v0 - g.v0, f.v1 - g.v1, f.v2 - g.v2}; }
+__device__ __forceinline__ cc_jet operator-(const cc_jet &f) { return cc_jet{-f.a, -f.v0, -f.v1, -f.v2}; }
+__device__ __forceinline__ cc_jet operator*(const cc_jet &f, const cc_jet &g) {
+  return cc_jet{f.a * g.a, f.a * g.v0 + f.v0 * g.a, f.a * g.v1 + f.v1 * g.a, f.a * g.v2 + f.v2 * g.a};
+}
+__device__ __forceinline__ cc_jet operator/(const cc_jet &f, const cc_jet &g) {
+  const double gi = 1.0 / g.a, fg = f.a * gi;
+  return cc_jet{fg, (f.v0 - fg * g.v0) * gi, (f.v1 - fg * g.v1) * gi, (f.v2 - fg * g.v2) * gi};
+}
+__device__ __forceinline__ cc_jet jsqrt(const cc_jet &f) {
+  const double t = sqrt(f.a), h = 1.0 / (2.0 * t);
+  return cc_jet{t, h * f.v0, h * f.v1, h * f.v2};
+}
+__device__ __forceinline__ cc_jet jexp(const cc_jet &f) {
+  const double t = exp(f.a);
+  return cc_jet{t, t * f.v0, t * f.v1, t * f.v2};
+}
+
+__device__ __forceinline__ double cc_wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+struct cc_gmm_lds {
+  cc_ell ell[2][CC_GMM_LEVELS][CC_GMM_ECAP];  // [side: 0 src, 1 tgt]
+  unsigned pairs[CC_GMM_PCAP];                // (li << 28) | (si << 14) | ti
+  int n_ell[2][CC_GMM_LEVELS];
+  int n_pairs;
+  int flags;
+};
+
+// cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the whole wave
+__device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_grad, double *cost, double grad[3]) {
+  const int lane = threadIdx.x & 63;
+  const cc_jet x = cc_jet{p[0], 1, 0, 0}, y = cc_jet{p[1], 0, 1, 0};
+  const double ct = cos(p[2]), st = sin(p[2]);
+  const cc_jet jc_ = cc_jet{ct, 0, 0, -st}, js_ = cc_jet{st, 0, 0, ct};
+  const cc_jet R00 = jc_, R01 = -js_, R10 = js_, R11 = jc_;
+  cc_jet acc = jc(0.0);
+  const int np = S->n_pairs;
+  for (int i = lane; i < np; i += 64) {
+    const unsigned pr = S->pairs[i];
+    const int li = pr >> 28, si = (pr >> 14) & 0x3FFF, ti = pr & 0x3FFF;
+    const cc_ell es = S->ell[0][li][si], et = S->ell[1][li][ti];
+    // new_cov = scale_ * (R cov_s R^T + cov_t), scale_ = 2
+    const cc_jet RC00 = R00 * jc(es.c00) + R01 * jc(es.c10), RC01 = R00 * jc(es.c01) + R01 * jc(es.c11);
+    const cc_jet RC10 = R10 * jc(es.c00) + R11 * jc(es.c10), RC11 = R10 * jc(es.c01) + R11 * jc(es.c11);
+    const cc_jet n00 = jc(2.0) * (RC00 * R00 + RC01 * R01 + jc(et.c00));
+    const cc_jet n01 = jc(2.0) * (RC00 * R10 + RC01 * R11 + jc(et.c01));
+    const cc_jet n10 = jc(2.0) * (RC10 * R00 + RC11 * R01 + jc(et.c10));
+    const cc_jet n11 = jc(2.0) * (RC10 * R10 + RC11 * R11 + jc(et.c11));
+    const cc_jet m0 = R00 * jc(es.mx) + R01 * jc(es.my) + x - jc(et.mx);
+    const cc_jet m1 = R10 * jc(es.mx) + R11 * jc(es.my) + y - jc(et.my);
+    const cc_jet det = n00 * n11 - n10 * n01;
+    const cc_jet invdet = jc(1.0) / det;
+    const cc_jet i00 = n11 * invdet, i01 = -n01 * invdet, i10 = -n10 * invdet, i11 = n00 * invdet;
+    const cc_jet h0 = jc(-0.5) * m0, h1 = jc(-0.5) * m1;
+    const cc_jet r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
+    const cc_jet qua = r0 * m0 + r1 * m1;
+    acc = acc + jc(-et.w) * jc(es.w) * jc(1.0) / jsqrt(det) * jexp(qua);
+  }
+  *cost = cc_wave_sum_d(acc.a);
+  if (want_grad) {
+    grad[0] = cc_wave_sum_d(acc.v0);
+    grad[1] = cc_wave_sum_d(acc.v1);
+    grad[2] = cc_wave_sum_d(acc.v2);
+  }
+}
+
+// ---- Ceres 2.x line search pieces (see oracle/orc_gmm.h for the provenance notes) ----
+struct cc_fs {  // FunctionSample
+  double x, value, gradient;
+  double vx[3], vg[3];
+  bool value_ok, grad_ok;
+};
+
+__device__ __forceinline__ double cc_polyval(const double *p, int n, double x) {
+  double v = 0.0;
+  for (int i = 0; i < n; i++) v = v * x + p[i];
+  return v;
+}
+
+__device__ void cc_solve_fullpiv(double A[4][4], double b[4], int n, double x[4]) {
+  int colperm[4] = {0, 1, 2, 3};
+  for (int k = 0; k < n; k++) {
+    int pr = k, pc = k;
+    double best = -1;
+    for (int i = k; i < n; i++)
+      for (int j = k; j < n; j++)
+        if (fabs(A[i][j]) > best) {
+          best = fabs(A[i][j]);
+          pr = i;
+          pc = j;
+        }
+    if (best == 0.0) break;
+    for (int j = 0; j < n; j++) {
+      double t = A[k][j];
+      A[k][j] = A[pr][j];
+      A[pr][j] = t;
+    }
+    {
+      double t = b[k];
+      b[k] = b[pr];
+      b[pr] = t;
+    }
+    if (pc != k) {
+      for (int i = 0; i < n; i++) {
+        double t = A[i][k];
+        A[i][k] = A[i][pc];
+        A[i][pc] = t;
+      }
+      int t = colperm[k];
+      colperm[k] = colperm[pc];
+      colperm[pc] = t;
+    }
+    for (int i = k + 1; i < n; i++) {
+      const double f = A[i][k] / A[k][k];
+      A[i][k] = 0;
+      for (int j = k + 1; j < n; j++) A[i][j] -= f * A[k][j];
+      b[i] -= f * b[k];
+    }
+  }
+  double yv[4] = {0, 0, 0, 0};
+  for (int i = n - 1; i >= 0; i--) {
+    double s = b[i];
+    for (int j = i + 1; j < n; j++) s -= A[i][j] * yv[j];
+    yv[i] = (A[i][i] != 0.0) ? s / A[i][i] : 0.0;
+  }
+  for (int i = 0; i < n; i++) x[colperm[i]] = yv[i];
+}
+
+// InterpolatingPolynomialMinimizingStepSize for CUBIC with samples {lowerbound, current} (both with gradients)
+__device__ double cc_interp_step(const cc_fs &lo, const cc_fs &cur, double x_min, double x_max) {
+  if (!cur.value_ok) {
+    double s = cur.x * 0.5;
+    s = s < x_min ? x_min : s;
+    return s < x_max ? s : x_max;
+  }
+  const cc_fs *smp[2] = {&lo, &cur};
+  int nc = 0;
+  for (int i = 0; i < 2; i++) {
+    if (smp[i]->value_ok) nc++;
+    if (smp[i]->grad_ok) nc++;
+  }
+  const int degree = nc - 1;
+  double A[4][4], b[4], poly[4];
+  for (int i = 0; i < 4; i++) {
+    b[i] = 0;
+    for (int j = 0; j < 4; j++) A[i][j] = 0;
+  }
+  int row = 0;
+  for (int i = 0; i < 2; i++) {
+    if (smp[i]->value_ok) {
+      for (int j = 0; j <= degree; j++) A[row][j] = pow(smp[i]->x, (double)(degree - j));
+      b[row] = smp[i]->value;
+      row++;
+    }
+    if (smp[i]->grad_ok) {
+      for (int j = 0; j < degree; j++) A[row][j] = (degree - j) * pow(smp[i]->x, (double)(degree - j - 1));
+      b[row] = smp[i]->gradient;
+      row++;
+    }
+  }
+  cc_solve_fullpiv(A, b, nc, poly);
+  const int np = nc;
+  double opt_x = (x_min + x_max) / 2.0;
+  double opt_v = cc_polyval(poly, np, opt_x);
+  const double vmin = cc_polyval(poly, np, x_min);
+  if (vmin < opt_v) {
+    opt_v = vmin;
+    opt_x = x_min;
+  }
+  const double vmax = cc_polyval(poly, np, x_max);
+  if (vmax < opt_v) {
+    opt_v = vmax;
+    opt_x = x_max;
+  }
+  if (np > 2) {
+    double d[3];
+    const int deg = np - 1;
+    for (int i = 0; i < deg; i++) d[i] = (deg - i) * poly[i];
+    int lead = 0;
+    while (lead + 1 < deg && d[lead] == 0.0) lead++;
+    const int dd = deg - lead - 1;  // degree of the derivative after removing leading zeros
+    double roots[2];
+    int nr = 0;
+    if (dd == 1) {
+      roots[nr++] = -d[lead + 1] / d[lead];
+    } else if (dd == 2) {
+      const double a = d[lead], bb = d[lead + 1], c = d[lead + 2];
+      const double D = bb * bb - 4 * a * c;
+      const double sq = sqrt(fabs(D));
+      if (D >= 0) {
+        if (bb >= 0) {
+          roots[nr++] = (-bb - sq) / (2.0 * a);
+          roots[nr++] = (2.0 * c) / (-bb - sq);
+        } else {
+          roots[nr++] = (2.0 * c) / (-bb + sq);
+          roots[nr++] = (-bb + sq) / (2.0 * a);
+        }
+      } else {
+        roots[nr++] = -bb / (2.0 * a);
+        roots[nr++] = -bb / (2.0 * a);
+      }
+    }
+    for (int i = 0; i < nr; i++) {
+      const double r = roots[i];
+      if (r < x_min || r > x_max) continue;
+      const double v = cc_polyval(poly, np, r);
+      if (v < opt_v) {
+        opt_v = v;
+        opt_x = r;
+      }
+    }
+  }
+  for (int i = 0; i < 2; i++) {
+    const double sx = smp[i]->x;
+    if (sx < x_min || sx > x_max) continue;
+    const double v = cc_polyval(poly, np, sx);
+    if (v < opt_v) {
+      opt_x = sx;
+      opt_v = v;
+    }
+  }
+  return opt_x;
+}
+
+__device__ void cc_ls_eval(const cc_gmm_lds *S, const double pos[3], const double dir[3], double x, cc_fs *o) {
+  o->x = x;
+  for (int i = 0; i < 3; i++) o->vx[i] = pos[i] + x * dir[i];
+  cc_gmm_eval(S, o->vx, true, &o->value, o->vg);
+  o->value_ok = isfinite(o->value);
+  o->grad_ok = o->value_ok && isfinite(o->vg[0]) && isfinite(o->vg[1]) && isfinite(o->vg[2]);
+  o->gradient = dir[0] * o->vg[0] + dir[1] * o->vg[1] + dir[2] * o->vg[2];
+}
+
+// WolfeLineSearch::DoSearch (bracketing + zoom).  Returns success; *opt is the accepted sample.
+__device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double dir[3], double step0, double cost0,
+                         double dgrad0, const double g0[3], cc_fs *opt) {
+  const double min_step_size = 1e-9, suff_dec = 1e-4, suff_curv = 0.9, max_expand = 10.0;
+  const int max_it = 20;
+  const double dnorm = fmax(fabs(dir[0]), fmax(fabs(dir[1]), fabs(dir[2])));
+  cc_fs init;
+  init.x = 0;
+  init.value = cost0;
+  init.gradient = dgrad0;
+  init.value_ok = init.grad_ok = true;
+  for (int i = 0; i < 3; i++) {
+    init.vx[i] = pos[i];
+    init.vg[i] = g0[i];
+  }
+  int nit = 0;
+  cc_fs prev = init, cur, lo = init, hi = init;
+  bool zoom = false;
+  cc_ls_eval(S, pos, dir, step0, &cur);
+  while (true) {
+    ++nit;
+    if (cur.value_ok && (cur.value > (init.value + suff_dec * init.gradient * cur.x) || (prev.value_ok && cur.value > prev.value))) {
+      zoom = true;
+      lo = prev;
+      hi = cur;
+      break;
+    }
+    if (cur.value_ok && fabs(cur.gradient) <= -suff_curv * init.gradient) {
+      lo = cur;
+      hi = cur;
+      break;
+    } else if (cur.value_ok && cur.gradient >= 0) {
+      zoom = true;
+      lo = cur;
+      hi = prev;
+      break;
+    } else if (nit >= max_it) {
+      if (cur.value_ok && cur.value < lo.value) lo = cur;
+      break;
+    }
+    const double mn = cur.value_ok ? cur.x : prev.x;
+    const double mx = cur.value_ok ? (cur.x * max_expand) : cur.x;
+    const double step = cc_interp_step(prev, cur, mn, mx);
+    if (step * dnorm < min_step_size) return false;
+    if (cur.value_ok) prev = cur;
+    cc_ls_eval(S, pos, dir, step, &cur);
+  }
+  if (zoom && fabs(hi.x - lo.x) * dnorm < min_step_size) zoom = false;
+  if (!zoom) {
+    *opt = lo;
+    return true;
+  }
+  // zoom phase
+  cc_fs sol;
+  sol.value_ok = false;
+  bool zoom_ok = true;
+  cc_fs blo = lo, bhi = hi;
+  if (blo.gradient * (bhi.x - blo.x) >= 0) {
+    zoom_ok = false;
+  } else {
+    while (true) {
+      sol = blo;
+      if (nit >= max_it) {
+        zoom_ok = false;
+        break;
+      }
+      if (fabs(bhi.x - blo.x) * dnorm < min_step_size) {
+        zoom_ok = false;
+        break;
+      }
+      ++nit;
+      const bool lo_first = blo.x < bhi.x;
+      const cc_fs &lb = lo_first ? blo : bhi;
+      const cc_fs &ub = lo_first ? bhi : blo;
+      const double step = cc_interp_step(lb, ub, lb.x, ub.x);
+      cc_ls_eval(S, pos, dir, step, &sol);
+      if (!sol.value_ok || !sol.grad_ok) {
+        zoom_ok = false;
+        break;
+      }
+      if ((sol.value > (init.value + suff_dec * init.gradient * sol.x)) || (sol.value >= blo.value)) {
+        bhi = sol;
+        continue;
+      }
+      if (fabs(sol.gradient) <= -suff_curv * init.gradient) break;
+      if (sol.gradient * (bhi.x - blo.x) >= 0) bhi = blo;
+      blo = sol;
+    }
+  }
+  if (!zoom_ok && !sol.value_ok) return false;
+  if (!sol.value_ok || sol.value > lo.value)
+    *opt = lo;
+  else
+    *opt = sol;
+  return true;
+}
+
+// grid = n_problems, block = 64
+__global__ void __launch_bounds__(64)
+cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restrict__ qdesc,
+         const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, cc_gmm_result *__restrict__ results) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  cc_gmm_lds *S = (cc_gmm_lds *)smem;
+  const int lane = threadIdx.x;
+  const cc_gmm_problem pb = probs[blockIdx.x];
+  const cc_scan_desc_t *src = db_desc + pb.gidx;
+  const cc_scan_desc_t *tgt = qdesc + pb.q;
+  if (lane == 0) {
+    S->n_pairs = 0;
+    S->flags = 0;
+  }
+  __syncthreads();
+  // ---- ellipses (GMMPair ctor, correlation.h:49-82): contours in sorted order until >= 95 % of the level's cells
+  if (lane < 2 * CC_GMM_LEVELS) {
+    const int side = lane / CC_GMM_LEVELS, li = lane % CC_GMM_LEVELS;
+    const int lev = li + 1;  // GMMOptConfig::levels_ = {1,2,3,4}
+    const cc_scan_desc_t *d = side == 0 ? src : tgt;
+    const int full = d->layer_cell_cnt[lev];
+    int run = 0, n = 0;
+    const int nst = d->n_stored[lev];
+    for (int j = 0; j < d->n_cont[lev]; j++) {
+      if ((double)run * 1.0 / (double)full >= 0.95) break;
+      if (j >= nst) {
+        atomicOr((unsigned *)&S->flags, 4u);
+        break;
+      }
+      if (n >= CC_GMM_ECAP) {
+        atomicOr((unsigned *)&S->flags, 1u);
+        break;
+      }
+      const cc_contour_t &cv = d->cont[lev][j];
+      // getManualCov (contour.h:376-378) in f32, then cast to double
+      const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
+      const float e0 = cv.eig_vals[0], e1 = cv.eig_vals[1];
+      const float a00 = v00 * e0, a01 = v01 * e1, a10 = v10 * e0, a11 = v11 * e1;
+      cc_ell e;
+      e.c00 = (double)(a00 * v00 + a01 * v01);
+      e.c01 = (double)(a00 * v10 + a01 * v11);
+      e.c10 = (double)(a10 * v00 + a11 * v01);
+      e.c11 = (double)(a10 * v10 + a11 * v11);
+      e.mx = (double)cv.pos_mean[0];
+      e.my = (double)cv.pos_mean[1];
+      e.w = (double)cv.cell_cnt;
+      e.maj = sqrtf(e1);
+      e.pad = 0;
+      S->ell[side][li][n++] = e;
+      run += cv.cell_cnt;
+    }
+    S->n_ell[side][li] = n;
+  }
+  __syncthreads();
+  // ---- pair pre-selection (correlation.h:85-96), ordered compaction
+  const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
+  int np = 0;
+  for (int li = 0; li < CC_GMM_LEVELS; li++) {
+    const int ns = S->n_ell[0][li], ntg = S->n_ell[1][li];
+    const int tot = ns * ntg;
+    for (int base = 0; base < tot; base += 64) {
+      const int idx = base + lane;
+      bool sel = false;
+      int si = 0, ti = 0;
+      if (idx < tot) {
+        si = idx / ntg;
+        ti = idx - si * ntg;
+        const cc_ell &es = S->ell[0][li][si], &et = S->ell[1][li][ti];
+        const double dx = (ct0 * es.mx + (-st0) * es.my + pb.tf[0]) - et.mx;
+        const double dy = (st0 * es.mx + ct0 * es.my + pb.tf[1]) - et.my;
+        sel = sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + et.maj);
+      }
+      const unsigned long long m = __ballot(sel);
+      const int off = np + __popcll(m & ((1ull << lane) - 1ull));
+      if (sel) {
+        if (off < CC_GMM_PCAP)
+          S->pairs[off] = ((unsigned)li << 28) | ((unsigned)si << 14) | (unsigned)ti;
+        else
+          atomicOr((unsigned *)&S->flags, 2u);
+      }
+      np += __popcll(m);
+    }
+  }
+  if (np > CC_GMM_PCAP) np = CC_GMM_PCAP;
+  if (lane == 0) S->n_pairs = np;
+  // ---- auto-correlation (correlation.h:102-119)
+  double ac[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    double acc = 0;
+    for (int li = 0; li < CC_GMM_LEVELS; li++) {
+      const int n = S->n_ell[side][li];
+      for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        const cc_ell &a = S->ell[side][li][i], &b = S->ell[side][li][j];
+        const double n00 = 2.0 * (a.c00 + b.c00), n01 = 2.0 * (a.c01 + b.c01), n10 = 2.0 * (a.c10 + b.c10), n11 = 2.0 * (a.c11 + b.c11);
+        const double mx = a.mx - b.mx, my = a.my - b.my;
+        const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
+        const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
+        const double h0 = -0.5 * mx, h1 = -0.5 * my;
+        const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
+        acc += a.w * b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+      }
+    }
+    ac[side] = cc_wave_sum_d(acc);
+  }
+  __syncthreads();
+  // ---- initial correlation (tryProblem, correlation.h:196-202)
+  double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
+  double cost, g[3];
+  cc_gmm_eval(S, x, true, &cost, g);
+  const double denom = sqrt(ac[0] * ac[1]);
+  cc_gmm_result R;
+  R.corr_init = -cost / denom;
+  R.corr_opt = R.corr_init;
+  R.tf_opt[0] = x[0];
+  R.tf_opt[1] = x[1];
+  R.tf_opt[2] = x[2];
+  R.optimized = 0;
+  R.iterations = 0;
+  R.termination = 0;
+  if (!((float)R.corr_init < corr_lb)) {
+    // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations
+    R.optimized = 1;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    double cur_cost = cost, cur_g[3] = {g[0], g[1], g[2]};
+    double prev_cost = 0, prev_g[3] = {0, 0, 0}, prev_dir[3] = {0, 0, 0}, prev_step = 0;
+    double dxh[10][3], dgh[10][3], dxdg[10];
+    int ncorr = 0;
+    int restarts = 0;
+    int term = 0, iter = 0;
+    double gmax = fmax(fabs(cur_g[0]), fmax(fabs(cur_g[1]), fabs(cur_g[2])));
+    double final_cost = cur_cost;
+    if (gmax <= gradient_tolerance) {
+      term = 1;
+    } else {
+      while (true) {
+        if (iter >= 10) {
+          term = 0;
+          break;
+        }
+        iter++;
+        double dir[3];
+        bool ls_status = true;
+        if (iter == 1) {
+          for (int i = 0; i < 3; i++) dir[i] = -cur_g[i];
+        } else {
+          double ddx[3], ddg[3];
+          for (int i = 0; i < 3; i++) {
+            ddx[i] = prev_dir[i] * prev_step;
+            ddg[i] = cur_g[i] - prev_g[i];
+          }
+          const double dd = ddx[0] * ddg[0] + ddx[1] * ddg[1] + ddx[2] * ddg[2];
+          if (dd > 1e-14 && ncorr < 10) {
+            for (int i = 0; i < 3; i++) {
+              dxh[ncorr][i] = ddx[i];
+              dgh[ncorr][i] = ddg[i];
+            }
+            dxdg[ncorr] = dd;
+            ncorr++;
+          }
+          double sd[3] = {cur_g[0], cur_g[1], cur_g[2]}, alpha[10];
+          for (int k = ncorr - 1; k >= 0; k--) {
+            const double al = (dxh[k][0] * sd[0] + dxh[k][1] * sd[1] + dxh[k][2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] -= al * dgh[k][i];
+            alpha[k] = al;
+          }
+          for (int k = 0; k < ncorr; k++) {
+            const double beta = (dgh[k][0] * sd[0] + dgh[k][1] * sd[1] + dgh[k][2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] += dxh[k][i] * (alpha[k] - beta);
+          }
+          for (int i = 0; i < 3; i++) dir[i] = -1.0 * sd[i];
+          if (dir[0] * cur_g[0] + dir[1] * cur_g[1] + dir[2] * cur_g[2] >= 0.0) ls_status = false;
+        }
+        if (!ls_status && restarts >= 5) {
+          term = -1;
+          break;
+        } else if (!ls_status) {
+          restarts++;
+          ncorr = 0;
+          for (int i = 0; i < 3; i++) dir[i] = -cur_g[i];
+        }
+        const double dderiv = cur_g[0] * dir[0] + cur_g[1] * dir[1] + cur_g[2] * dir[2];
+        const double step0 = (iter == 1 || !ls_status) ? fmin(1.0, 1.0 / gmax) : fmin(1.0, 2.0 * (cur_cost - prev_cost) / dderiv);
+        if (step0 < 0.0) {
+          term = -1;
+          break;
+        }
+        cc_fs opt;
+        if (!cc_wolfe(S, x, dir, step0, cur_cost, dderiv, cur_g, &opt)) {
+          term = -1;
+          break;
+        }
+        prev_cost = cur_cost;
+        for (int i = 0; i < 3; i++) {
+          prev_g[i] = cur_g[i];
+          prev_dir[i] = dir[i];
+        }
+        prev_step = opt.x;
+        cur_cost = opt.value;
+        for (int i = 0; i < 3; i++) cur_g[i] = opt.vg[i];
+        gmax = fmax(fabs(cur_g[0]), fmax(fabs(cur_g[1]), fabs(cur_g[2])));
+        const double xnorm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        double sn = 0;
+        for (int i = 0; i < 3; i++) sn += (opt.vx[i] - x[i]) * (opt.vx[i] - x[i]);
+        sn = sqrt(sn);
+        for (int i = 0; i < 3; i++) x[i] = opt.vx[i];
+        final_cost = cur_cost;
+        if (sn <= parameter_tolerance * (xnorm + parameter_tolerance)) {
+          term = 3;
+          break;
+        }
+        if (gmax <= gradient_tolerance) {
+          term = 1;
+          break;
+        }
+        if (fabs(prev_cost - cur_cost) <= function_tolerance * fabs(prev_cost)) {
+          term = 2;
+          break;
+        }
+      }
+    }
+    R.iterations = iter;
+    R.termination = term;
+    R.corr_opt = -final_cost / denom;
+    R.tf_opt[0] = x[0];
+    R.tf_opt[1] = x[1];
+    R.tf_opt[2] = x[2];
+  }
+  __syncthreads();
+  R.flags = S->flags;
+  if (lane == 0) results[blockIdx.x] = R;
+}

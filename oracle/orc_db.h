@@ -191,7 +191,9 @@ struct LayerDB {
       });
       int num_to_move = 0;
       KeyFloatType split_val = tr1.buc_end_;
-      if (tr1.data_tree_[sort_permu[sz1 - to_move_mid]](bucket_chann_) !=
+      if (to_move_mid <= 0 || to_move_mid >= sz1) {
+        // reference reads one past the end here (UB); treated as "cannot split"
+      } else if (tr1.data_tree_[sort_permu[sz1 - to_move_mid]](bucket_chann_) !=
           tr1.data_tree_[sort_permu[sz1 - to_move_mid - 1]](bucket_chann_)) {
         num_to_move = to_move_mid;
         split_val = tr1.data_tree_[sort_permu[sz1 - to_move_mid]](bucket_chann_);
@@ -263,7 +265,9 @@ struct LayerDB {
       });
       int num_to_move = 0;
       KeyFloatType split_val = tr1.buc_end_;
-      if (tr2.data_tree_[sort_permu[sz2 - to_move_mid]](bucket_chann_) !=
+      if (to_move_mid <= 0 || to_move_mid >= sz2) {
+        // reference reads one past the end here (UB); treated as "cannot split"
+      } else if (tr2.data_tree_[sort_permu[sz2 - to_move_mid]](bucket_chann_) !=
           tr2.data_tree_[sort_permu[sz2 - to_move_mid - 1]](bucket_chann_)) {
         num_to_move = to_move_mid;
         split_val = tr2.data_tree_[sort_permu[sz2 - to_move_mid - 1]](bucket_chann_);

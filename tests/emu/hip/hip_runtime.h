@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+using std::isfinite;
 #define __global__
 #define __device__
 #define __host__
@@ -182,8 +183,32 @@ static inline float __uint_as_float(unsigned x) {
   return f;
 }
 
+// ---- host runtime API stand-ins: "device memory" is host memory ----
+typedef int hipError_t;
+static const hipError_t hipSuccess = 0;
+typedef void *hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+template <typename T>
+static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) emu::launch(kernel, (grid).x, (block).x, (size_t)(smem), __VA_ARGS__)
+
 namespace emu {
 // Run `kernel(args...)` over grid x block (1-D), one block at a time.
+template <typename K, typename... Args>
+void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args);
+}  // namespace emu
+namespace emu {
 template <typename K, typename... Args>
 void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args) {
   if (block % 64 != 0) {

@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE: numpy-pointer driver of the cc_* C-ABI for the CPU-emulated build
+(tests/emu/libcc_emu.so).  "Device" pointers are host pointers there."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "emu", "libcc_emu.so")
+
+
+def build():
+    srcs = [os.path.join(HERE, "emu", "emu_main.cpp"), os.path.join(HERE, "emu", "hip", "hip_runtime.h")]
+    csrc = os.path.join(HERE, "..", "contour-context_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    srcs.append(os.path.join(HERE, "..", "include", "cont2_amd.h"))
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+        subprocess.check_call(["sh", os.path.join(HERE, "emu", "build.sh")])
+    return SO
+
+
+class EmuApi:
+    def __init__(self, L):
+        self.L = L
+        self.lib = C.CDLL(build())
+        self.lib.cc_last_error.restype = C.c_char_p
+        self.lib.cc_db_desc_ptr.restype = C.c_void_p
+        for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
+                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state"):
+            getattr(self.lib, f).restype = C.c_int
+
+    def chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.cc_last_error().decode()))
+
+    def create(self, cfg=None, max_batch=8):
+        cfg = cfg or self.L.default_manager_cfg()
+        h = C.c_void_p()
+        self.chk(self.lib.cc_create(0, C.byref(cfg), max_batch, C.byref(h)), "cc_create")
+        self._cfg = cfg
+        return h
+
+    def ingest(self, ctx, xyzi, offsets, debug=False):
+        L = self.L
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        desc = np.zeros(n, L.scan_desc_dt)
+        ncell = self._cfg.n_row * self._cfg.n_col
+        dbg = None
+        dbg_p = None
+        if debug:
+            dbg = {"bev": np.zeros((n, ncell), np.float32), "pix_rc": np.zeros((n, ncell, 2), np.float32),
+                   "labels": np.zeros((n, L.NLEV, ncell), np.int16)}
+            st = (C.c_void_p * 3)(dbg["bev"].ctypes.data, dbg["pix_rc"].ctypes.data, dbg["labels"].ctypes.data)
+            dbg_p = C.cast(st, C.c_void_p)
+        self.chk(self.lib.cc_ingest_batch(ctx, C.c_void_p(xyzi.ctypes.data), C.c_void_p(offsets.ctypes.data), n,
+                                          C.c_void_p(desc.ctypes.data), dbg_p, None), "cc_ingest_batch")
+        return (desc, dbg) if debug else desc
+
+    def db_create(self, ctx, cfg=None, cap=1024):
+        cfg = cfg or self.L.default_db_cfg()
+        h = C.c_void_p()
+        self.chk(self.lib.cc_db_create(ctx, C.byref(cfg), cap, C.byref(h)), "cc_db_create")
+        return h
+
+    def db_add(self, db, desc, ts, seeds):
+        desc = np.ascontiguousarray(desc)
+        ts = np.ascontiguousarray(ts, np.float64)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        self.chk(self.lib.cc_db_add_scans(db, C.c_void_p(desc.ctypes.data), len(desc), C.c_void_p(ts.ctypes.data),
+                                          C.c_void_p(seeds.ctypes.data), None), "cc_db_add_scans")
+
+    def db_query(self, db, qdesc, epochs, lb=None, ub=None, want_knn=False):
+        L = self.L
+        if lb is None:
+            lb, ub = L.default_thresholds()
+        qdesc = np.ascontiguousarray(qdesc)
+        epochs = np.ascontiguousarray(epochs, np.int32)
+        nq = len(qdesc)
+        res = np.zeros(nq, L.query_result_dt)
+        knn = np.zeros((nq, 3, L.NPIV, L.KNN_MAX), L.knn_hit_dt) if want_knn else None
+        cnt = np.zeros((nq, 3, L.NPIV), np.int32) if want_knn else None
+        self.chk(self.lib.cc_db_query_batch(db, C.c_void_p(qdesc.ctypes.data), nq, C.c_void_p(epochs.ctypes.data), C.byref(lb),
+                                            C.byref(ub), C.c_void_p(res.ctypes.data),
+                                            C.c_void_p(knn.ctypes.data) if want_knn else None,
+                                            C.c_void_p(cnt.ctypes.data) if want_knn else None, None), "cc_db_query_batch")
+        return (res, knn, cnt) if want_knn else res
+
+    def bucket_state(self, db):
+        sizes = np.zeros((3, 6), np.int32)
+        ranges = np.zeros((3, 7), np.float32)
+        self.chk(self.lib.cc_db_bucket_state(db, C.c_void_p(sizes.ctypes.data), C.c_void_p(ranges.ctypes.data)), "bucket_state")
+        return sizes, ranges

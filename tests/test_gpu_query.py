@@ -1,0 +1,97 @@
+"""GPU parity of the full path (ingest -> DB -> batched query) against the CPU oracle's replay of the
+reference driver loop (test/batch_bin_test.cpp:105-247), through the C-ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy",
+              "n_knn_hits"]
+
+
+@pytest.fixture(scope="module")
+def loop_sequence(cc):
+    """420 synthetic Velodyne-64 scans (120k points each) on a 200 m loop: laps 2+ revisit lap 1."""
+    import torch
+    w = cc.synth.World(loop_len=200.0)
+    xyzi, poses, ts = cc.synth.make_sequence(420, world=w, device="cuda")
+    torch.cuda.synchronize()
+    return xyzi, poses, ts
+
+
+def test_sequence_matches_oracle(cc, oracle, loop_sequence):
+    import torch
+    xyzi, poses, ts = loop_sequence
+    n, P = xyzi.shape[0], xyzi.shape[1]
+    offs = np.arange(n + 1, dtype=np.int64) * P
+    seeds = np.arange(n, dtype=np.int32)
+    ctx = cc.Context(0, max_batch=128)
+    desc = ctx.ingest(xyzi.reshape(-1, 4), offs)
+    db = cc.Database(ctx, capacity=512)
+    db.add_scans(desc, ts, seeds)
+    res, knn, cnt = db.query(desc, seeds, want_knn=True)   # scan i queries the DB as it was after i scans
+    torch.cuda.synchronize()
+    ores, timers, odesc = oracle.run_sequence(xyzi.cpu().numpy().reshape(-1, 4), offs, ts, seeds, want_desc=True)
+    # bookkeeping state
+    odb = oracle.DB()
+    for i in range(n):
+        s = oracle.Scan(xyzi[i].cpu().numpy(), int_id=i, keep_cells=False)
+        s.clear_image()
+        odb.add_scan(s, ts[i])
+        odb.push_and_balance(i, ts[i])
+    osz, org = odb.bucket_state()
+    gsz, grg = db.bucket_state()
+    assert np.array_equal(osz, gsz) and np.array_equal(org, grg)
+    assert (ores["n_res"] > 0).sum() > 50, "sequence should contain loop closures"
+    bad = []
+    for i in range(n):
+        for f in INT_FIELDS:
+            if ores[f][i] != res[f][i]:
+                bad.append("query %d: %s oracle=%d got=%d" % (i, f, ores[f][i], res[f][i]))
+        if ores["n_res"][i]:
+            if abs(ores["correlation"][i] - res["correlation"][i]) > 1e-4:
+                bad.append("query %d: correlation %g vs %g" % (i, ores["correlation"][i], res["correlation"][i]))
+            if np.abs(ores["tf"][i] - res["tf"][i]).max() > 1e-4:
+                bad.append("query %d: tf %s vs %s" % (i, ores["tf"][i], res["tf"][i]))
+    assert not bad, "%d mismatches\n" % len(bad) + "\n".join(bad[:40])
+    # loop closures are geometrically right
+    hit = np.nonzero(res["n_res"] > 0)[0]
+    d = np.hypot(poses[hit, 0] - poses[res["cand_gidx"][hit], 0], poses[hit, 1] - poses[res["cand_gidx"][hit], 1])
+    assert (d < 5.0).mean() > 0.9
+    db.close()
+    ctx.close()
+
+
+def test_knn_matches_oracle_db(cc, oracle, loop_sequence):
+    """K3 hit lists (ids, order, squared distances) vs the oracle's bucketed search at a few epochs."""
+    xyzi, poses, ts = loop_sequence
+    n, P = 330, xyzi.shape[1]
+    offs = np.arange(n + 1, dtype=np.int64) * P
+    ctx = cc.Context(0, max_batch=128)
+    desc = ctx.ingest(xyzi[:n].reshape(-1, 4), offs)
+    db = cc.Database(ctx, capacity=512)
+    db.add_scans(desc, ts[:n], np.arange(n, dtype=np.int32))
+    odb = oracle.DB()
+    scans = []
+    qs = [260, 300, 329]
+    expect = {}
+    for i in range(n):
+        s = oracle.Scan(xyzi[i].cpu().numpy(), int_id=i, keep_cells=False)
+        s.clear_image()
+        scans.append(s)
+        if i in qs:
+            expect[i] = odb.query(s, want_knn=True)
+        odb.add_scan(s, ts[i])
+        odb.push_and_balance(i, ts[i])
+    res, knn, cnt = db.query(desc[qs], np.asarray(qs, np.int32), want_knn=True)
+    for k, qi in enumerate(qs):
+        ores, oknn, ocnt = expect[qi]
+        assert np.array_equal(ocnt, cnt[k]), (qi, ocnt, cnt[k])
+        for ll in range(3):
+            for seq in range(6):
+                m = ocnt[ll, seq]
+                a, b = oknn[ll, seq, :m], knn[k, ll, seq, :m]
+                assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"]), (qi, ll, seq)
+                assert np.allclose(a["dist_sq"], b["dist_sq"], rtol=1e-5, atol=1e-6)
+    db.close()
+    ctx.close()
