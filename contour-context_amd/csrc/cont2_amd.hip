@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -51,7 +52,27 @@ struct cc_ctx {
   cc_k2_scratch *d_scr = nullptr;
   long long *d_offsets = nullptr;
   size_t lds1 = 0, lds2 = 0;
+  // optional per-kernel timing (cc_profile_*)
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // triplets (before K1, between, after K2)
+  size_t ev_used = 0;
+  double ms_acc[2] = {0, 0};
+  int launches = 0;
 };
+
+static int prof_flush(cc_ctx *c) {
+  for (size_t i = 0; i + 2 < c->ev_used + 1 && i + 2 < c->ev.size() + 1 && i < c->ev_used; i += 3) {
+    float a = 0, b = 0;
+    if (hipEventSynchronize(c->ev[i + 2]) != hipSuccess) return CC_EHIP;
+    hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]);
+    hipEventElapsedTime(&b, c->ev[i + 1], c->ev[i + 2]);
+    c->ms_acc[0] += a;
+    c->ms_acc[1] += b;
+    c->launches++;
+  }
+  c->ev_used = 0;
+  return CC_OK;
+}
 
 extern "C" {
 
@@ -130,9 +151,32 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   return CC_OK;
 }
 
+int cc_profile_enable(cc_ctx *c, int on) {
+  if (!c) return set_err(CC_EINVAL, "cc_profile_enable: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (on && c->ev.empty()) {
+    c->ev.resize(3 * 64);
+    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+  }
+  c->prof = on != 0;
+  return CC_OK;
+}
+int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
+  if (!c || !ms_out) return set_err(CC_EINVAL, "cc_profile_read: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (prof_flush(c) != CC_OK) return set_err(CC_EHIP, "cc_profile_read: event sync failed");
+  ms_out[0] = c->ms_acc[0];
+  ms_out[1] = c->ms_acc[1];
+  if (n_launches) *n_launches = c->launches;
+  c->ms_acc[0] = c->ms_acc[1] = 0;
+  c->launches = 0;
+  return CC_OK;
+}
+
 int cc_destroy(cc_ctx *c) {
   if (!c) return CC_OK;
   hipSetDevice(c->device);
+  for (auto &e : c->ev) hipEventDestroy(e);
   hipFree(c->d_bev);
   hipFree(c->d_pix);
   hipFree(c->d_k1);
@@ -167,11 +211,20 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
     if (dbg && dbg->d_pix_rc)
       hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)c->d_pix, -1.f, nc * 2 * nb);
+    hipEvent_t *pe = nullptr;
+    if (c->prof) {
+      if (c->ev_used + 3 > c->ev.size() && prof_flush(c) != CC_OK) return set_err(CC_EHIP, "profiling event sync failed");
+      pe = &c->ev[c->ev_used];
+      c->ev_used += 3;
+      HIPCHK(hipEventRecord(pe[0], stream));
+    }
     hipLaunchKernelGGL(cc_k_rasterize, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
                        c->d_bev, c->d_pix, c->d_k1);
+    if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
                        (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab);
+    if (pe) HIPCHK(hipEventRecord(pe[2], stream));
     HIPCHK(hipGetLastError());
     if (dbg && dbg->d_bev)
       HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, c->d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));

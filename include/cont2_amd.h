@@ -194,6 +194,13 @@ int cc_version(void);
 int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_ctx **out);
 int cc_destroy(cc_ctx *ctx);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline figures).
+ * enable: subsequent cc_ingest_batch calls bracket K1 (rasterise) and K2 (contours) with events.
+ * read  : synchronises, returns accumulated milliseconds {K1, K2} and the number of launches of
+ *         each since the last read, then resets the accumulators. */
+int cc_profile_enable(cc_ctx *ctx, int on);
+int cc_profile_read(cc_ctx *ctx, double ms_out[2], int *n_launches);
+
 /* ------------------------------------------------------------------------- ingest ------- */
 /* Replaces, for a batch of scans, readKITTIPointCloudBin's point stream
  * (tools/pointcloud_util.h:9-47) -> ContourManager::makeBEV (contour_mng.h:505-556) ->
@@ -241,6 +248,10 @@ int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const in
  * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
  * device buffer, then cc_db_add_scans consumes it). */
 const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
+
+/* Same for the query kernels: accumulated ms {K3 knn, K4 check, K5 gmm, host merge} + launch count. */
+int cc_db_profile_enable(cc_db *db, int on);
+int cc_db_profile_read(cc_db *db, double ms_out[4], int *n_launches);
 
 /* Host-side introspection of the K0 bookkeeping for parity tests:
  * tree sizes per (layer, bucket) and bucket ranges at the current epoch. */

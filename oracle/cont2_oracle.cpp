@@ -365,5 +365,14 @@ int orc_knn_scan(const float *keys, int n, const float *q, int k, float max_dist
   return cnt;
 }
 size_t orc_sizeof_desc(void) { return sizeof(cc_scan_desc_t); }
+// install / remove the real-nanoflann kd-tree backend (function pointers from oracle/_ref/libref_knn.so)
+void orc_set_knn_backend(void *create, void *destroy, void *build, void *query) {
+  KnnBackend &b = knn_backend();
+  b.create = (void *(*)())create;
+  b.destroy = (void (*)(void *))destroy;
+  b.build = (void (*)(void *, const float *, int))build;
+  b.query = (void (*)(void *, const float *, int, float, size_t *, float *))query;
+}
+int orc_knn_backend_active(void) { return knn_backend().create != nullptr; }
 
 }  // extern "C"

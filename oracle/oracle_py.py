@@ -252,6 +252,26 @@ def sort_asc_perm_f(keys):
 _ref = None
 
 
+def use_ref_kdtree(on=True):
+    """Route the oracle's bucket searches through the reference's real nanoflann (oracle/_ref) -- used for
+    the timed CPU baseline so that "KNN search" is a kd-tree like the reference's, not an exact scan.
+    Returns True if the backend is active."""
+    global _ref
+    so = os.path.join(_HERE, "_ref", "libref_knn.so")
+    if not on:
+        lib().orc_set_knn_backend(None, None, None, None)
+        return False
+    if not os.path.exists(so):
+        return False
+    if _ref is None:
+        _ref = C.CDLL(so)
+        _ref.ref_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    lib().orc_set_knn_backend.argtypes = [C.c_void_p] * 4
+    f = lambda n: C.cast(getattr(_ref, n), C.c_void_p)
+    lib().orc_set_knn_backend(f("refkd_create"), f("refkd_free"), f("refkd_build"), f("refkd_query"))
+    return bool(lib().orc_knn_backend_active())
+
+
 def ref_knn(keys, q, k, max_dist_sq):
     """Real nanoflann (reference's vendored header) kNN-with-max-dist; None if oracle/_ref was not built."""
     global _ref

@@ -53,6 +53,21 @@ inline KeyFloatType l2_nanoflann(const KeyFloatType *a, const KeyFloatType *b) {
   return result;
 }
 
+// Optional kd-tree backend: the REAL vendored nanoflann of the reference, compiled into
+// oracle/_ref/libref_knn.so (see oracle/ref_knn.cpp).  When installed (orc_set_knn_backend) the
+// buckets build and query real kd-trees exactly like TreeBucket::rebuildTree / knnSearch; without it
+// the exact scan below is used (same result set; tie order may differ).
+struct KnnBackend {
+  void *(*create)() = nullptr;
+  void (*destroy)(void *) = nullptr;
+  void (*build)(void *, const float *, int) = nullptr;
+  void (*query)(void *, const float *, int, float, size_t *, float *) = nullptr;
+};
+inline KnnBackend &knn_backend() {
+  static KnnBackend b;
+  return b;
+}
+
 // contour_db.h:68-156
 struct TreeBucket {
   struct RetrTriplet {
@@ -67,6 +82,7 @@ struct TreeBucket {
   bool tree_built = false;  // tree_ptr != nullptr
   std::vector<RetrTriplet> buffer_;
   std::vector<IndexOfKey> gkidx_tree_;
+  std::shared_ptr<void> kd_;  // backend tree handle
 
   TreeBucket(const TreeBucketConfig &config, KeyFloatType beg, KeyFloatType end) : cfg_(config), buc_beg_(beg), buc_end_(end) {}
   size_t getTreeSize() const { return data_tree_.size(); }
@@ -76,7 +92,15 @@ struct TreeBucket {
     if (buffer_.empty() || buffer_[0].ts > ts_overflow) return false;
     return true;
   }
-  void rebuildTree() { tree_built = true; }
+  void rebuildTree() {
+    tree_built = true;
+    KnnBackend &be = knn_backend();
+    if (be.create) {
+      if (!kd_) kd_ = std::shared_ptr<void>(be.create(), be.destroy);
+      static_assert(sizeof(RetrievalKey) == 40, "key layout");
+      be.build(kd_.get(), data_tree_.empty() ? nullptr : data_tree_[0].array, (int)data_tree_.size());
+    }
+  }
   // contour_db.h:121-143
   void popBufferMax(double curr_ts) {
     double ts_cutoff = curr_ts - cfg_.min_elapse_;
@@ -101,6 +125,12 @@ struct TreeBucket {
     if (!tree_built) return;
     ret_idx.reserve(num_res);
     std::vector<size_t> idx(num_res, 0);
+    if (knn_backend().create && kd_) {
+      if (!data_tree_.empty()) knn_backend().query(kd_.get(), q_key.array, num_res, max_dist_sq, idx.data(), out_dist_sq.data());
+      else out_dist_sq[num_res - 1] = max_dist_sq;
+      for (int i = 0; i < num_res; i++) ret_idx.emplace_back(gkidx_tree_.empty() ? IndexOfKey(0, 0, 0) : gkidx_tree_[idx[i]]);
+      return;
+    }
     // MyKNNResSet::init
     size_t count = 0;
     const size_t capacity = num_res;

@@ -50,3 +50,29 @@ extern "C" int ref_knn(const float *keys, int n, const float *q, int k, float ma
   }
   return cnt;
 }
+
+// ---- persistent tree: what TreeBucket keeps (data_tree_ + tree_ptr), rebuilt like rebuildTree()
+struct RefTree {
+  vov_t data;
+  kd_t *tree = nullptr;
+  ~RefTree() { delete tree; }
+};
+extern "C" void *refkd_create() { return new RefTree(); }
+extern "C" void refkd_free(void *h) { delete (RefTree *)h; }
+// TreeBucket::rebuildTree (contour_db.h:109-117): first call constructs the adaptor (which builds
+// the index), later calls buildIndex() on the changed data.
+extern "C" void refkd_build(void *h, const float *keys, int n) {
+  RefTree *t = (RefTree *)h;
+  t->data.resize(n);
+  for (int i = 0; i < n; i++) std::memcpy(t->data[i].array, keys + 10 * i, 40);
+  if (t->tree)
+    t->tree->index->buildIndex();
+  else
+    t->tree = new kd_t(10, t->data, 10);
+}
+extern "C" void refkd_query(void *h, const float *q, int k, float max_dist_sq, size_t *idx, float *dist) {
+  RefTree *t = (RefTree *)h;
+  MyKNNResSet<float> rs(k);
+  rs.init(idx, dist, max_dist_sq);
+  t->tree->index->findNeighbors(rs, q, nanoflann::SearchParams(10));
+}
