@@ -6,7 +6,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdio>

@@ -492,8 +492,12 @@ cc_k_check(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc
 // ------------------------------------------------------------------------------------------------
 // K5: GMM-L2 correlation (init) + <= 10 L-BFGS iterations, one wave per (query, candidate) problem.
 // ------------------------------------------------------------------------------------------------
-#define CC_GMM_ECAP 128    // ellipses per (side, level) held in LDS
-#define CC_GMM_PCAP 4096   // selected (src,tgt) ellipse pairs
+// LDS caps of the GMM kernel: the common instance keeps 8 workgroups per CU resident; problems that
+// overflow it (flags bit0/bit1) are re-run by the host with the large instance.
+#define CC_GMM_ECAP_S 32
+#define CC_GMM_PCAP_S 1024
+#define CC_GMM_ECAP_L 128  // ellipses per (side, level) held in LDS
+#define CC_GMM_PCAP_L 4096 // selected (src,tgt) ellipse pairs
 
 struct cc_gmm_problem {
   int q;          // index into qdesc (tgt)
@@ -544,13 +548,18 @@ __device__ __forceinline__ double cc_wave_sum_d(double v) {
   return v;
 }
 
+// LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance)
 struct cc_gmm_lds {
-  cc_ell ell[2][CC_GMM_LEVELS][CC_GMM_ECAP];  // [side: 0 src, 1 tgt]
-  unsigned pairs[CC_GMM_PCAP];                // (li << 28) | (si << 14) | ti
-  int n_ell[2][CC_GMM_LEVELS];
-  int n_pairs;
-  int flags;
+  cc_ell *ell;      // [2][CC_GMM_LEVELS][ecap]   side 0 = src, 1 = tgt
+  unsigned *pairs;  // [pcap]  (li << 28) | (si << 14) | ti
+  int *n_ell;       // [2][CC_GMM_LEVELS]
+  int *n_pairs;
+  int *flags;
+  int ecap, pcap;
+  __device__ __forceinline__ const cc_ell &E(int side, int li, int i) const { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
+  __device__ __forceinline__ cc_ell &E(int side, int li, int i) { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
 };
+#define CC_GMM_LDS_BYTES(ecap, pcap) (2 * CC_GMM_LEVELS * (ecap) * sizeof(cc_ell) + (pcap) * 4 + 64)
 
 // cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the whole wave
 __device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_grad, double *cost, double grad[3]) {
@@ -560,11 +569,11 @@ __device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_gr
   const cc_jet jc_ = cc_jet{ct, 0, 0, -st}, js_ = cc_jet{st, 0, 0, ct};
   const cc_jet R00 = jc_, R01 = -js_, R10 = js_, R11 = jc_;
   cc_jet acc = jc(0.0);
-  const int np = S->n_pairs;
+  const int np = *S->n_pairs;
   for (int i = lane; i < np; i += 64) {
     const unsigned pr = S->pairs[i];
     const int li = pr >> 28, si = (pr >> 14) & 0x3FFF, ti = pr & 0x3FFF;
-    const cc_ell es = S->ell[0][li][si], et = S->ell[1][li][ti];
+    const cc_ell es = S->E(0, li, si), et = S->E(1, li, ti);
     // new_cov = scale_ * (R cov_s R^T + cov_t), scale_ = 2
     const cc_jet RC00 = R00 * jc(es.c00) + R01 * jc(es.c10), RC01 = R00 * jc(es.c01) + R01 * jc(es.c11);
     const cc_jet RC10 = R10 * jc(es.c00) + R11 * jc(es.c10), RC11 = R10 * jc(es.c01) + R11 * jc(es.c11);
@@ -854,19 +863,28 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
   return true;
 }
 
-// grid = n_problems, block = 64
+// grid = n_problems, block = 64, dynamic LDS = CC_GMM_LDS_BYTES(ecap, pcap)
 __global__ void __launch_bounds__(64)
-cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restrict__ qdesc,
-         const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, cc_gmm_result *__restrict__ results) {
+cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_idx, const cc_scan_desc_t *__restrict__ qdesc,
+         const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, int ecap, int pcap, cc_gmm_result *__restrict__ results) {
   HIP_DYNAMIC_SHARED(char, smem)
-  cc_gmm_lds *S = (cc_gmm_lds *)smem;
+  cc_gmm_lds Sv;
+  Sv.ell = (cc_ell *)smem;
+  Sv.pairs = (unsigned *)(smem + 2 * CC_GMM_LEVELS * (size_t)ecap * sizeof(cc_ell));
+  Sv.n_ell = (int *)(Sv.pairs + pcap);
+  Sv.n_pairs = Sv.n_ell + 2 * CC_GMM_LEVELS;
+  Sv.flags = Sv.n_pairs + 1;
+  Sv.ecap = ecap;
+  Sv.pcap = pcap;
+  cc_gmm_lds *S = &Sv;
   const int lane = threadIdx.x;
-  const cc_gmm_problem pb = probs[blockIdx.x];
+  const int pidx = prob_idx ? prob_idx[blockIdx.x] : (int)blockIdx.x;
+  const cc_gmm_problem pb = probs[pidx];
   const cc_scan_desc_t *src = db_desc + pb.gidx;
   const cc_scan_desc_t *tgt = qdesc + pb.q;
   if (lane == 0) {
-    S->n_pairs = 0;
-    S->flags = 0;
+    *S->n_pairs = 0;
+    *S->flags = 0;
   }
   __syncthreads();
   // ---- ellipses (GMMPair ctor, correlation.h:49-82): contours in sorted order until >= 95 % of the level's cells
@@ -880,11 +898,11 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restr
     for (int j = 0; j < d->n_cont[lev]; j++) {
       if ((double)run * 1.0 / (double)full >= 0.95) break;
       if (j >= nst) {
-        atomicOr((unsigned *)&S->flags, 4u);
+        atomicOr((unsigned *)S->flags, 4u);
         break;
       }
-      if (n >= CC_GMM_ECAP) {
-        atomicOr((unsigned *)&S->flags, 1u);
+      if (n >= ecap) {
+        atomicOr((unsigned *)S->flags, 1u);
         break;
       }
       const cc_contour_t &cv = d->cont[lev][j];
@@ -902,17 +920,17 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restr
       e.w = (double)cv.cell_cnt;
       e.maj = sqrtf(e1);
       e.pad = 0;
-      S->ell[side][li][n++] = e;
+      S->E(side, li, n++) = e;
       run += cv.cell_cnt;
     }
-    S->n_ell[side][li] = n;
+    S->n_ell[side * CC_GMM_LEVELS + li] = n;
   }
   __syncthreads();
   // ---- pair pre-selection (correlation.h:85-96), ordered compaction
   const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
   int np = 0;
   for (int li = 0; li < CC_GMM_LEVELS; li++) {
-    const int ns = S->n_ell[0][li], ntg = S->n_ell[1][li];
+    const int ns = S->n_ell[li], ntg = S->n_ell[CC_GMM_LEVELS + li];
     const int tot = ns * ntg;
     for (int base = 0; base < tot; base += 64) {
       const int idx = base + lane;
@@ -921,7 +939,7 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restr
       if (idx < tot) {
         si = idx / ntg;
         ti = idx - si * ntg;
-        const cc_ell &es = S->ell[0][li][si], &et = S->ell[1][li][ti];
+        const cc_ell &es = S->E(0, li, si), &et = S->E(1, li, ti);
         const double dx = (ct0 * es.mx + (-st0) * es.my + pb.tf[0]) - et.mx;
         const double dy = (st0 * es.mx + ct0 * es.my + pb.tf[1]) - et.my;
         sel = sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + et.maj);
@@ -929,25 +947,25 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restr
       const unsigned long long m = __ballot(sel);
       const int off = np + __popcll(m & ((1ull << lane) - 1ull));
       if (sel) {
-        if (off < CC_GMM_PCAP)
+        if (off < pcap)
           S->pairs[off] = ((unsigned)li << 28) | ((unsigned)si << 14) | (unsigned)ti;
         else
-          atomicOr((unsigned *)&S->flags, 2u);
+          atomicOr((unsigned *)S->flags, 2u);
       }
       np += __popcll(m);
     }
   }
-  if (np > CC_GMM_PCAP) np = CC_GMM_PCAP;
-  if (lane == 0) S->n_pairs = np;
+  if (np > pcap) np = pcap;
+  if (lane == 0) *S->n_pairs = np;
   // ---- auto-correlation (correlation.h:102-119)
   double ac[2] = {0, 0};
   for (int side = 0; side < 2; side++) {
     double acc = 0;
     for (int li = 0; li < CC_GMM_LEVELS; li++) {
-      const int n = S->n_ell[side][li];
+      const int n = S->n_ell[side * CC_GMM_LEVELS + li];
       for (int idx = lane; idx < n * n; idx += 64) {
         const int i = idx / n, j = idx - i * n;
-        const cc_ell &a = S->ell[side][li][i], &b = S->ell[side][li][j];
+        const cc_ell &a = S->E(side, li, i), &b = S->E(side, li, j);
         const double n00 = 2.0 * (a.c00 + b.c00), n01 = 2.0 * (a.c01 + b.c01), n10 = 2.0 * (a.c10 + b.c10), n11 = 2.0 * (a.c11 + b.c11);
         const double mx = a.mx - b.mx, my = a.my - b.my;
         const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
@@ -1083,6 +1101,6 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const cc_scan_desc_t *__restr
     R.tf_opt[2] = x[2];
   }
   __syncthreads();
-  R.flags = S->flags;
-  if (lane == 0) results[blockIdx.x] = R;
+  R.flags = *S->flags;
+  if (lane == 0) results[pidx] = R;
 }
