@@ -43,7 +43,8 @@ _lib = None
 # every symbol include/cont2_amd.h declares
 EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-           "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf"]
+           "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf",
+           "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read"]
 
 
 def lib():
@@ -66,6 +67,10 @@ def lib():
         _lib.cc_db_desc_ptr.restype = C.c_void_p
         _lib.cc_db_bucket_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_est_sens_tf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.cc_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        _lib.cc_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        _lib.cc_db_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 

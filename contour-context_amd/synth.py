@@ -77,12 +77,14 @@ def trajectory(n_scans, step=1.0, loop_len=1500.0, tile=1000.0, seed=7, jitter=T
     y2 = np.interp(ds + 0.5, s, py)
     yaw = np.arctan2(y2 - y, x2 - x)
     n_lap = lap.max() + 1
+    # independent streams so that scan i's pose does not depend on how many scans are requested
     off = rng.normal(0, 0.6, (n_lap, 2))
     off[0] = 0
     if jitter:
         x = x + off[lap, 0]
         y = y + off[lap, 1]
-        yaw = yaw + rng.normal(0, 0.01, n_scans)
+        rng_yaw = np.random.Generator(np.random.PCG64(seed + 1000))
+        yaw = yaw + rng_yaw.normal(0, 0.01, n_scans)
     return x, y, yaw
 
 

@@ -81,6 +81,55 @@ void *orc_scan_create(const float *xyzi, int64_t n_pts, const cc_manager_cfg_t *
   h->cm->makeContoursRecurs();
   return h;
 }
+// Rebuild a ContourManager from a descriptor (contour tables, keys, BCIs): lets the oracle's DB / query code run on
+// descriptors produced elsewhere (e.g. hand-made keys for bookkeeping tests, or the device's output).
+void *orc_scan_from_desc(const cc_scan_desc_t *d, const cc_manager_cfg_t *cfg, int int_id) {
+  auto *h = new ScanH();
+  h->cm = std::make_shared<ContourManager>(toMngCfg(cfg), int_id);
+  ContourManager &cm = *h->cm;
+  cm.clearImage();
+  cm.max_bin_val_ = d->max_bin_val;
+  cm.min_bin_val_ = d->min_bin_val;
+  for (int l = 0; l < CC_NLEV; l++) {
+    cm.layer_cell_cnt_[l] = d->layer_cell_cnt[l];
+    for (int j = 0; j < d->n_stored[l]; j++) {
+      const cc_contour_t &c = d->cont[l][j];
+      auto v = std::make_shared<ContourView>(c.level, c.poi[0], c.poi[1]);
+      v->cell_cnt_ = c.cell_cnt;
+      v->pos_mean_ = V2F(c.pos_mean[0], c.pos_mean[1]);
+      v->pos_cov_.a[0][0] = c.pos_cov[0];
+      v->pos_cov_.a[1][0] = c.pos_cov[1];
+      v->pos_cov_.a[0][1] = c.pos_cov[2];
+      v->pos_cov_.a[1][1] = c.pos_cov[3];
+      v->eig_vals_ = V2F(c.eig_vals[0], c.eig_vals[1]);
+      v->eig_vecs_.a[0][0] = c.eig_vecs[0];
+      v->eig_vecs_.a[1][0] = c.eig_vecs[1];
+      v->eig_vecs_.a[0][1] = c.eig_vecs[2];
+      v->eig_vecs_.a[1][1] = c.eig_vecs[3];
+      v->eccen_ = c.eccen;
+      v->vol3_mean_ = c.vol3_mean;
+      v->com_ = V2F(c.com[0], c.com[1]);
+      v->ecc_feat_ = c.ecc_feat != 0;
+      v->com_feat_ = c.com_feat != 0;
+      cm.cont_views_[l].push_back(v);
+      cm.cont_perc_[l].push_back(c.cell_cnt * 1.0f / d->layer_cell_cnt[l]);
+    }
+    for (int s = 0; s < cm.cfg_.piv_firsts_; s++) {
+      RetrievalKey k;
+      for (int q = 0; q < CC_KEY_DIM; q++) k.array[q] = d->keys[l][s][q];
+      cm.layer_keys_[l].push_back(k);
+      const cc_bci_t &b = d->bcis[l][s];
+      BCI bci(b.piv_seq, b.level);
+      for (int w = 0; w < CC_BCI_LAYERS; w++)
+        for (int bit = 0; bit < 64; bit++)
+          if ((b.dist_bin[w] >> bit) & 1ull) bci.dist_bin_.set(w * 64 + bit, true);
+      for (int q = 0; q < b.n_pts; q++) bci.nei_pts_.emplace_back(b.pts[q].level, b.pts[q].seq, b.pts[q].bit_pos, b.pts[q].r, b.pts[q].theta);
+      for (int q = 0; q < b.n_segs; q++) bci.nei_idx_segs_.push_back(b.segs[q]);
+      cm.layer_key_bcis_[l].push_back(bci);
+    }
+  }
+  return h;
+}
 void orc_scan_free(void *h) { delete (ScanH *)h; }
 void orc_scan_export(void *h, cc_scan_desc_t *out) { ((ScanH *)h)->cm->exportDesc(out); }
 int orc_scan_ncont(void *h, int level) { return (int)((ScanH *)h)->cm->cont_views_[level].size(); }

@@ -47,6 +47,8 @@ def lib():
         for name in ("orc_scan_free", "orc_db_free"):
             getattr(_lib, name).argtypes = [C.c_void_p]
             getattr(_lib, name).restype = None
+        _lib.orc_scan_from_desc.restype = C.c_void_p
+        _lib.orc_scan_from_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.orc_scan_export.argtypes = [C.c_void_p, C.c_void_p]
         _lib.orc_scan_bev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_scan_labels.argtypes = [C.c_void_p, C.c_void_p]
@@ -75,6 +77,16 @@ def _p(a):
 
 class Scan:
     """ContourManager of one scan (ctor + makeBEV + makeContoursRecurs)."""
+
+    @classmethod
+    def from_desc(cls, desc, cfg=None, int_id=0):
+        """Oracle-side ContourManager rebuilt from one cc_scan_desc_t record (numpy structured scalar/array of 1)."""
+        self = cls.__new__(cls)
+        self.cfg = cfg or L.default_manager_cfg()
+        d = np.ascontiguousarray(np.asarray(desc).reshape(1))
+        self.h = lib().orc_scan_from_desc(_p(d), C.addressof(self.cfg), int_id)
+        self.ncell = self.cfg.n_row * self.cfg.n_col
+        return self
 
     def __init__(self, xyzi, cfg=None, int_id=0, keep_cells=True):
         self.cfg = cfg or L.default_manager_cfg()

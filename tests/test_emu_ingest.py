@@ -1,0 +1,53 @@
+"""Kernel logic of the ingest path on the CPU: the product's HIP translation unit compiled against the CPU
+execution harness (tests/emu) and driven through the same C-ABI, compared with the oracle bit for bit
+(same libm on both sides here)."""
+import os
+
+import numpy as np
+
+import emu_api
+from parity import compare_desc, terrain_scan
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _check(oracle, scans):
+    api = emu_api.EmuApi(oracle.L)
+    ctx = api.create(max_batch=len(scans))
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
+    desc, dbg = api.ingest(ctx, np.concatenate(scans, 0), offs, debug=True)
+    for i, s in enumerate(scans):
+        o = oracle.Scan(s)
+        ob, opix = o.bev()
+        assert np.array_equal(ob, dbg["bev"][i])
+        assert np.array_equal(opix, dbg["pix_rc"][i])
+        assert np.array_equal(o.labels(), dbg["labels"][i]), "integer contour labels must be bit-exact"
+        bad = compare_desc(o.desc()[0], desc[i], float_exact=True)
+        assert not bad, bad[:10]
+    return desc
+
+
+def test_terrain_scans_bit_exact(oracle):
+    d = _check(oracle, [terrain_scan(2, n=30000), terrain_scan(101, n=20000, scale=2.2, quant=0.25)])
+    assert d["n_cont"].max() > 16 and (d["flags"] == 0).all()
+
+
+def test_edge_cases(oracle):
+    tiny = np.zeros((11, 4), np.float32)
+    far = np.full((40, 4), 1000.0, np.float32)
+    ties = np.tile(np.array([[10.2, 3.3, 1.0, 0], [10.7, 3.9, 1.0, 0], [10.4, 3.1, 1.0, 0]], np.float32), (30, 1))
+    _check(oracle, [tiny, far, ties])
+
+
+def test_golden_fixture(oracle):
+    """Committed inputs + expected descriptors (tests/golden/make_golden.py): the oracle still reproduces them and the
+    emulated kernels match them."""
+    z = np.load(os.path.join(G, "ingest_fixture.npz"))
+    scans = [z["scan0"], z["scan1"]]
+    exp = np.frombuffer(z["desc"].tobytes(), dtype=oracle.L.scan_desc_dt)
+    for i, s in enumerate(scans):
+        od = oracle.Scan(s).desc()[0]
+        assert not compare_desc(exp[i], od, float_exact=True)
+    d = _check(oracle, scans)
+    for i in range(2):
+        assert not compare_desc(exp[i], d[i], float_exact=True)

@@ -1,0 +1,80 @@
+"""K0: the host-side LayerDB bookkeeping of the product (bucket membership timeline, re-balancing, bucket ranges)
+against the oracle's restatement of TreeBucket/LayerDB, on thousands of hand-made keys that force every bucket to
+be used.  Runs the product's C-ABI through the CPU build (tests/emu)."""
+import numpy as np
+
+import emu_api
+
+
+def _fake_desc(L, rng, n, key0_lo=3.0, key0_hi=90.0):
+    d = np.zeros(n, L.scan_desc_dt)
+    k = rng.uniform(1.0, 20.0, (n, L.NLEV, L.NPIV, L.KEY_DIM)).astype(np.float32)
+    k[..., 0] = rng.uniform(key0_lo, key0_hi, (n, L.NLEV, L.NPIV)).astype(np.float32)
+    # duplicates of key dimension 0 exercise the "contagious value" split search
+    k[..., 0] = np.round(k[..., 0] * 4) / 4
+    drop = rng.uniform(size=(n, L.NLEV, L.NPIV)) < 0.25     # all-zero keys are never stored
+    k[drop] = 0
+    d["keys"] = k
+    # dummy (all-zero) contour rows so that the anchor lookups of the candidate checks stay in range
+    d["n_cont"][:] = L.NPIV
+    d["n_stored"][:] = L.NPIV
+    d["layer_cell_cnt"][:] = 1
+    return d
+
+
+def test_bucket_timeline_matches_oracle(oracle):
+    L = oracle.L
+    rng = np.random.default_rng(11)
+    n = 1500
+    desc = _fake_desc(L, rng, n)
+    ts = np.cumsum(rng.uniform(0.05, 0.15, n))
+    seeds = np.arange(n, dtype=np.int32)
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=4)
+    db = api.db_create(ctx, cap=n)
+    odb = oracle.DB()
+    cfg = L.default_manager_cfg()
+    step = 100
+    for i0 in range(0, n, step):
+        api.db_add(db, desc[i0:i0 + step], ts[i0:i0 + step], seeds[i0:i0 + step])
+        for i in range(i0, i0 + step):
+            s = oracle.Scan.from_desc(desc[i], cfg, int_id=i)
+            odb.add_scan(s, ts[i])
+            odb.push_and_balance(int(seeds[i]), ts[i])
+        osz, org = odb.bucket_state()
+        esz, erg = api.bucket_state(db)
+        assert np.array_equal(osz, esz), (i0, osz, esz)
+        assert np.array_equal(org, erg), (i0, org, erg)
+    assert (osz > 0).sum() >= 12, "the test should populate most buckets"
+
+
+def test_knn_with_buckets_matches_oracle(oracle):
+    """K3 through the C-ABI (CPU build) on a DB spread over several buckets, incl. the bucket-skip quirk of
+    layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
+    L = oracle.L
+    rng = np.random.default_rng(5)
+    n = 900
+    desc = _fake_desc(L, rng, n, 3.0, 40.0)
+    ts = np.arange(n) * 0.1
+    seeds = np.arange(n, dtype=np.int32)
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=4)
+    db = api.db_create(ctx, cap=n)
+    api.db_add(db, desc, ts, seeds)
+    odb = oracle.DB()
+    cfg = L.default_manager_cfg()
+    for i in range(n):
+        odb.add_scan(oracle.Scan.from_desc(desc[i], cfg, int_id=i), ts[i])
+        odb.push_and_balance(i, ts[i])
+    q = _fake_desc(L, np.random.default_rng(6), 3, 3.0, 40.0)
+    res, knn, cnt = api.db_query(db, q, np.full(3, n, np.int32), want_knn=True)
+    for k in range(3):
+        ores, oknn, ocnt = odb.query(oracle.Scan.from_desc(q[k], cfg, int_id=10000 + k), want_knn=True)
+        assert np.array_equal(ocnt, cnt[k])
+        assert ocnt.sum() > 0
+        for ll in range(3):
+            for seq in range(6):
+                m = ocnt[ll, seq]
+                a, b = oknn[ll, seq, :m], knn[k, ll, seq, :m]
+                assert np.array_equal(a["dist_sq"], b["dist_sq"])
+                assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])

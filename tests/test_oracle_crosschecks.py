@@ -1,0 +1,159 @@
+"""Pins of the CPU oracle (oracle/) against independent references available in this image:
+scipy.ndimage.label (CCL partition), numpy.linalg.eigh (2x2 eigenpairs), numpy SVD Kabsch (umeyama),
+finite differences + scipy.optimize (GMM gradient / optimum), the reference's vendored nanoflann (oracle/_ref)."""
+import numpy as np
+import pytest
+from scipy import ndimage, optimize
+
+from parity import terrain_scan
+
+
+def test_ccl_partition_matches_scipy(oracle):
+    cfg = oracle.L.default_manager_cfg()
+    for seed in (0, 3):
+        s = oracle.Scan(terrain_scan(seed, n=40000))
+        bev, _ = s.bev()
+        lab = s.labels()
+        d = s.desc()[0]
+        img = bev.reshape(150, 150)
+        for l in range(6):
+            comp, n = ndimage.label(img > cfg.lv_grads[l], structure=np.ones((3, 3)))
+            sizes = ndimage.sum(np.ones_like(comp), comp, index=np.arange(1, n + 1)).astype(int)
+            keep = [i + 1 for i in range(n) if sizes[i] >= 3]
+            assert d["n_cont"][l] == len(keep)
+            L = lab[l].reshape(150, 150)
+            assert ((L >= 0) == np.isin(comp, keep)).all()
+            # each scipy component maps to exactly one oracle seq, with the same size, sizes non-increasing in seq
+            seqs = []
+            for k in keep:
+                u = np.unique(L[comp == k])
+                assert len(u) == 1
+                seqs.append(int(u[0]))
+                assert d["cont"][l][u[0]]["cell_cnt"] == sizes[k - 1]
+            assert sorted(seqs) == list(range(len(keep)))
+            cc_ = d["cont"][l][:len(keep)]["cell_cnt"]
+            assert (np.diff(cc_.astype(int)) <= 0).all()
+            assert d["layer_cell_cnt"][l] == sizes[[k - 1 for k in keep]].sum()
+
+
+def test_label_order_first_block_rule(oracle):
+    """Components tie in size -> insertion order decides: it must follow the first 2x2 block in block-raster order."""
+    pts = []
+    def blob(r0, c0, h):  # 3 cells in a row at rows r0, cols c0..c0+2 (sensor x = row - 75 + .5)
+        for dc in range(3):
+            pts.append([r0 - 75 + 0.5, c0 + dc - 75 + 0.5, h - 2.0, 0])
+    blob(11, 40, 1.8)   # block row 5
+    blob(10, 90, 1.8)   # block row 5 too (rows 10,11 share block row 5) but later column
+    blob(10, 20, 1.8)   # block row 5, earliest column -> first
+    blob(30, 10, 1.8)
+    x = np.asarray(pts * 4, np.float32)
+    s = oracle.Scan(x)
+    d = s.desc()[0]
+    assert d["n_cont"][0] == 4
+    cols = d["cont"][0][:4]["pos_mean"][:, 1]
+    # all have 3 cells: std::sort (insertion sort for n<=16) keeps insertion order = block-raster order
+    assert list(np.round(cols).astype(int)) == [21, 41, 91, 11]
+
+
+def test_eigen2f_vs_numpy(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        a = rng.normal(size=(2, 2)) * rng.uniform(0.1, 50)
+        m = (a @ a.T).astype(np.float32)
+        ev, vec = oracle.eigen2f(m)
+        w, v = np.linalg.eigh(m.astype(np.float64))
+        assert np.allclose(ev, w, rtol=2e-5, atol=4e-6 * np.abs(w).max())  # f32 QR: absolute error ~ eps * |lambda|max
+        for c in range(2):
+            assert abs(abs(np.dot(vec[:, c], v[:, c])) - 1) < 1e-4 or abs(w[0] - w[1]) < 1e-3 * abs(w[1])
+        assert abs(np.linalg.det(vec.astype(np.float64))) == pytest.approx(1.0, abs=1e-5)
+
+
+def _pair_scans(oracle):
+    base = terrain_scan(7, n=50000)
+    th, tx, ty = 0.12, 1.3, -0.8
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    moved = base.copy()
+    moved[:, :2] = base[:, :2] @ R.T + [tx, ty]
+    return oracle.Scan(base, int_id=0), oracle.Scan(moved, int_id=1), (th, tx, ty)
+
+
+def test_umeyama_vs_kabsch(oracle):
+    a, b, _ = _pair_scans(oracle)
+    da, db = a.desc()[0], b.desc()[0]
+    pairs = [(1, i, i) for i in range(min(5, da["n_cont"][1], db["n_cont"][1]))]
+    tf = oracle.umeyama(a, b, np.asarray(pairs, np.int8))
+    P = np.array([da["cont"][l][s]["pos_mean"] for l, s, t in pairs], np.float64)
+    Q = np.array([db["cont"][l][t]["pos_mean"] for l, s, t in pairs], np.float64)
+    pc, qc = P.mean(0), Q.mean(0)
+    H = (Q - qc).T @ (P - pc)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    t = qc - R @ pc
+    assert np.allclose([tf[0], tf[1]], t, atol=1e-9)
+    assert abs(tf[2] - np.arctan2(R[1, 0], R[0, 0])) < 1e-10
+
+
+def test_gmm_gradient_and_optimum(oracle):
+    a, b, (th, tx, ty) = _pair_scans(oracle)
+    # BEV-frame transform of the sensor motion (rotation about the image centre 74.5)
+    c = 74.5
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    t_bev = np.array([tx, ty]) + np.array([c, c]) - R @ np.array([c, c])
+    tf0 = np.array([t_bev[0] + 0.4, t_bev[1] - 0.3, th + 0.01])
+    cost, grad, ac = oracle.gmm_eval(a, b, tf0, tf0)
+    for k in range(3):
+        h = 1e-6
+        p1, p2 = tf0.copy(), tf0.copy()
+        p1[k] += h
+        p2[k] -= h
+        fd = (oracle.gmm_eval(a, b, tf0, p1)[0] - oracle.gmm_eval(a, b, tf0, p2)[0]) / (2 * h)
+        assert abs(fd - grad[k]) < 1e-5 * max(1.0, abs(grad[k])), (k, fd, grad[k])
+    ci, co, tf_opt, it = oracle.gmm(a, b, tf0)
+    assert co >= ci - 1e-12 and 0 < co <= 1.0 + 1e-9
+    f = lambda p: oracle.gmm_eval(a, b, tf0, p)[0]
+    ref = optimize.minimize(f, tf0, method="BFGS", options={"gtol": 1e-10})
+    corr_ref = -ref.fun / np.sqrt(ac[0] * ac[1])
+    # <= 10 L-BFGS iterations land on the same local optimum as a converged quasi-Newton run
+    assert abs(co - corr_ref) < 1e-4, (co, corr_ref, it)
+    assert np.abs(tf_opt - ref.x).max() < 5e-3
+
+
+def test_knn_scan_vs_reference_nanoflann(oracle):
+    if oracle.ref_knn(np.zeros((1, 10), np.float32), np.zeros(10, np.float32), 1, 1.0) is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(3)
+    for n in (5, 60, 2000):
+        keys = rng.uniform(0, 30, (n, 10)).astype(np.float32)
+        for _ in range(20):
+            q = rng.uniform(0, 30, 10).astype(np.float32)
+            ub = float(rng.uniform(50, 2500))
+            i1, d1 = oracle.knn_scan(keys, q, 50, ub)
+            i2, d2 = oracle.ref_knn(keys, q, 50, ub)
+            assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+            assert (d1 < ub).all() and (np.diff(d1) >= 0).all()
+            full = ((keys.astype(np.float64) - q) ** 2).sum(1)
+            assert len(i1) == min(50, int((full < ub).sum())) or abs(len(i1) - min(50, int((full < ub).sum()))) <= 1
+
+
+def test_kdtree_backend_same_results(oracle):
+    """The whole driver loop gives identical answers with the exact scan and with the reference's kd-tree."""
+    import cc_amd
+    cc = cc_amd.load()
+    dcfg = oracle.L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
+    w = cc.synth.World(loop_len=40.0)
+    x, _, ts = cc.synth.make_sequence(70, world=w, beams=16, azim=450)
+    n, P = x.shape[0], x.shape[1]
+    offs = np.arange(n + 1, dtype=np.int64) * P
+    xs = x.numpy().reshape(-1, 4)
+    r0, _, _ = oracle.run_sequence(xs, offs, ts, np.arange(n, dtype=np.int32), dcfg=dcfg)
+    if not oracle.use_ref_kdtree(True):
+        pytest.skip("oracle/_ref not built")
+    try:
+        r1, _, _ = oracle.run_sequence(xs, offs, ts, np.arange(n, dtype=np.int32), dcfg=dcfg)
+    finally:
+        oracle.use_ref_kdtree(False)
+    for f in ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check3", "n_knn_hits"]:
+        assert np.array_equal(r0[f], r1[f]), f
+    assert np.array_equal(r0["correlation"], r1["correlation"])
