@@ -1,0 +1,130 @@
+// Host mirror of include/cont2/contour_db.h (ContourDB, configs, CandidateScoreEnsemble) and of the two
+// ConstellCorrelation statics the drivers call (include/cont2/correlation.h:241-296), on top of the C-ABI.
+#pragma once
+#include "contour_mng.h"
+
+// contour_db.h:54-57
+struct TreeBucketConfig {
+  double max_elapse_ = 25.0;
+  double min_elapse_ = 15.0;
+};
+// contour_db.h:244-250
+struct CandidateScoreEnsemble {
+  ScoreConstellSim sim_constell;
+  ScorePairwiseSim sim_pair;
+  ScorePostProc sim_post;
+};
+// contour_db.h:658-669
+struct ContourDBConfig {
+  int nnk_ = 50;
+  int max_fine_opt_ = 10;
+  std::vector<int> q_levels_;
+  ContourSimThresConfig cont_sim_cfg_;
+  TreeBucketConfig tb_cfg_;
+};
+
+class ContourDB {
+  const ContourDBConfig cfg_;
+  cc_db *db_ = nullptr;
+  int capacity_;
+  std::vector<std::shared_ptr<const ContourManager>> all_bevs_;
+
+  static cc_score_t to_c(const CandidateScoreEnsemble &e) {
+    cc_score_t s;
+    s.i_ovlp_sum = e.sim_constell.i_ovlp_sum;
+    s.i_ovlp_max_one = e.sim_constell.i_ovlp_max_one;
+    s.i_in_ang_rng = e.sim_constell.i_in_ang_rng;
+    s.i_indiv_sim = e.sim_pair.i_indiv_sim;
+    s.i_orie_sim = e.sim_pair.i_orie_sim;
+    s.correlation = e.sim_post.correlation;
+    s.area_perc = e.sim_post.area_perc;
+    s.neg_est_dist = e.sim_post.neg_est_dist;
+    return s;
+  }
+  void ensure(const ContourManager &cm) {
+    if (db_) return;
+    cc_db_cfg_t d;
+    cc_default_db_cfg(&d);
+    d.nnk = cfg_.nnk_;
+    d.max_fine_opt = cfg_.max_fine_opt_;
+    d.n_q_levels = (int)cfg_.q_levels_.size();
+    for (int i = 0; i < d.n_q_levels && i < CC_NQLEV; i++) d.q_levels[i] = cfg_.q_levels_[i];
+    d.cont_sim.ta_cell_cnt = cfg_.cont_sim_cfg_.ta_cell_cnt;
+    d.cont_sim.tp_cell_cnt = cfg_.cont_sim_cfg_.tp_cell_cnt;
+    d.cont_sim.tp_eigval = cfg_.cont_sim_cfg_.tp_eigval;
+    d.cont_sim.ta_h_bar = cfg_.cont_sim_cfg_.ta_h_bar;
+    d.cont_sim.ta_rcom = cfg_.cont_sim_cfg_.ta_rcom;
+    d.cont_sim.tp_rcom = cfg_.cont_sim_cfg_.tp_rcom;
+    d.max_elapse = cfg_.tb_cfg_.max_elapse_;
+    d.min_elapse = cfg_.tb_cfg_.min_elapse_;
+    if (cc_db_create(cc_host::context(cm.ccfg()), &d, capacity_, &db_) != CC_OK) {
+      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+      abort();
+    }
+  }
+
+ public:
+  explicit ContourDB(const ContourDBConfig &config, int capacity_scans = 65536) : cfg_(config), capacity_(capacity_scans) {
+    CC_CHECK(!cfg_.q_levels_.empty());
+  }
+  ~ContourDB() { cc_db_destroy(db_); }
+
+  // contour_db.h:698-703
+  void queryRangedKNN(const std::shared_ptr<const ContourManager> &q_ptr, const CandidateScoreEnsemble &thres_lb,
+                      const CandidateScoreEnsemble &thres_ub, std::vector<std::shared_ptr<const ContourManager>> &cand_ptrs,
+                      std::vector<double> &cand_corr, std::vector<Eigen::Isometry2d> &cand_tf) {
+    cand_ptrs.clear();
+    cand_corr.clear();
+    cand_tf.clear();
+    ensure(*q_ptr);
+    const cc_score_t lb = to_c(thres_lb), ub = to_c(thres_ub);
+    cc_query_result_t r;
+    if (cc_db_query_host(db_, &q_ptr->desc(), &lb, &ub, &r) != CC_OK) {  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.
+      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+      abort();
+    }
+    if (r.n_res > 0) {
+      cand_ptrs.push_back(all_bevs_[r.cand_gidx]);
+      cand_corr.push_back(r.correlation);
+      Eigen::Isometry2d T;
+      T.rotate(r.tf[2]);
+      T.pretranslate(r.tf[0], r.tf[1]);
+      cand_tf.push_back(T);
+    }
+  }
+  // contour_db.h:814 and :827
+  void addScan(const std::shared_ptr<ContourManager> &added, double curr_timestamp) {
+    ensure(*added);
+    pending_ = added;
+    pending_ts_ = curr_timestamp;
+  }
+  void pushAndBalance(int seed, double curr_timestamp) {
+    // the C-ABI couples addScan + pushAndBalance (they are always called back to back, batch_bin_test.cpp:234-237)
+    CC_CHECK(pending_);
+    (void)curr_timestamp;
+    if (cc_db_add_scan_host(db_, &pending_->desc(), pending_ts_, seed) != CC_OK) {
+      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+      abort();
+    }
+    all_bevs_.push_back(pending_);
+    pending_.reset();
+  }
+
+ private:
+  std::shared_ptr<ContourManager> pending_;
+  double pending_ts_ = 0;
+};
+
+// correlation.h:287-296
+struct ConstellCorrelation {
+  static Eigen::Isometry2d getEstSensTF(const Eigen::Isometry2d &T_delta, const ContourManagerConfig &bev_config) {
+    CC_CHECK(bev_config.reso_row_ == bev_config.reso_col_);
+    const double in[3] = {T_delta(0, 2), T_delta(1, 2), std::atan2(T_delta(1, 0), T_delta(0, 0))};
+    double out[3];
+    cc_est_sens_tf(in, bev_config.n_row_, bev_config.n_col_, out);
+    Eigen::Isometry2d T;
+    T.rotate(out[2]);
+    T.pretranslate(out[0], out[1]);
+    return T;
+  }
+};

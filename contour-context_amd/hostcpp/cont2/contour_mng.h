@@ -1,0 +1,211 @@
+// Host mirror of the reference's include/cont2/contour.h + contour_mng.h public surface, on top of the C-ABI
+// (include/cont2_amd.h).  Same names, argument meaning and error behaviour (CHECK -> abort) as used by
+// test/batch_bin_test.cpp and include/eval/evaluator.h; the work itself runs in the HIP kernels.
+#pragma once
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/cont2_amd.h"
+#include "../compat/compat.h"
+
+typedef float KeyFloatType;
+const int RET_KEY_DIM = CC_KEY_DIM;
+
+// contour_mng.h:39-90
+template <size_t sz>
+struct ArrayAsKey {
+  enum { SizeAtCompileTime = sz };
+  KeyFloatType array[sz]{};
+  KeyFloatType *data() { return array; }
+  KeyFloatType &operator()(size_t i) { return array[i]; }
+  const KeyFloatType &operator()(size_t i) const { return array[i]; }
+  KeyFloatType &operator[](size_t i) { return array[i]; }
+  const KeyFloatType &operator[](size_t i) const { return array[i]; }
+  size_t size() const { return sz; }
+  KeyFloatType sum() const {
+    KeyFloatType ret(0);
+    for (const auto &dat : array) ret += dat;
+    return ret;
+  }
+};
+using RetrievalKey = ArrayAsKey<RET_KEY_DIM>;
+
+// contour.h:40-45
+struct ContourSimThresConfig {
+  float ta_cell_cnt = 6, tp_cell_cnt = 0.2;
+  float tp_eigval = 0.2;
+  float ta_h_bar = 0.3;
+  float ta_rcom = 0.4, tp_rcom = 0.25;
+};
+
+// contour_mng.h:92-110
+struct ContourManagerConfig {
+  std::vector<float> lv_grads_;
+  float reso_row_ = 1.0f, reso_col_ = 1.0f;
+  int n_row_ = 150, n_col_ = 150;
+  float lidar_height_ = 2.0f;
+  float blind_sq_ = 9.0f;
+  int min_cont_key_cnt_ = 9;
+  int min_cont_cell_cnt_ = 3;
+  int piv_firsts_ = 6;
+  int dist_firsts_ = 10;
+  float roi_radius_ = 10.0f;
+};
+
+// contour_mng.h:121-219 (the three score unions; same member names)
+union ScoreConstellSim {
+  enum { SizeAtCompileTime = 3 };
+  int data[SizeAtCompileTime]{};
+  struct {
+    int i_ovlp_sum, i_ovlp_max_one, i_in_ang_rng;
+  };
+};
+union ScorePairwiseSim {
+  enum { SizeAtCompileTime = 2 };
+  int data[SizeAtCompileTime]{};
+  struct {
+    int i_indiv_sim, i_orie_sim;
+  };
+};
+union ScorePostProc {
+  enum { SizeAtCompileTime = 3 };
+  float data[SizeAtCompileTime]{};
+  struct {
+    float correlation, area_perc, neg_est_dist;
+  };
+};
+
+// contour.h:97-119, read-only view over one cc_contour_t
+struct ContourView {
+  int16_t level_, poi_[2], cell_cnt_;
+  float pos_mean_[2], pos_cov_[4], eig_vals_[2], eig_vecs_[4], eccen_, vol3_mean_, com_[2];
+  bool ecc_feat_, com_feat_;
+};
+
+namespace cc_host {
+inline cc_manager_cfg_t to_c(const ContourManagerConfig &c) {
+  cc_manager_cfg_t m;
+  cc_default_manager_cfg(&m);
+  CC_CHECK(c.lv_grads_.size() == CC_NLEV);  // this build handles the shipped 6-level configs
+  for (int i = 0; i < CC_NLEV; i++) m.lv_grads[i] = c.lv_grads_[i];
+  m.reso_row = c.reso_row_;
+  m.reso_col = c.reso_col_;
+  m.n_row = c.n_row_;
+  m.n_col = c.n_col_;
+  m.lidar_height = c.lidar_height_;
+  m.blind_sq = c.blind_sq_;
+  m.min_cont_key_cnt = c.min_cont_key_cnt_;
+  m.min_cont_cell_cnt = c.min_cont_cell_cnt_;
+  m.piv_firsts = c.piv_firsts_;
+  m.dist_firsts = c.dist_firsts_;
+  m.roi_radius = c.roi_radius_;
+  return m;
+}
+// one device context per process and config (the reference has no such object: created lazily)
+inline cc_ctx *context(const cc_manager_cfg_t &m) {
+  static std::map<std::string, cc_ctx *> pool;
+  std::string key((const char *)&m, sizeof(m));
+  auto it = pool.find(key);
+  if (it != pool.end()) return it->second;
+  cc_ctx *c = nullptr;
+  if (cc_create(0, &m, 8, &c) != CC_OK) {
+    fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+    abort();
+  }
+  pool[key] = c;
+  return c;
+}
+}  // namespace cc_host
+
+// contour_mng.h:414-1314 (public surface used by the drivers)
+class ContourManager {
+  const ContourManagerConfig cfg_;
+  cc_manager_cfg_t ccfg_;
+  int int_id_;
+  std::string str_id_;
+  std::vector<float> xyzi_;  // staged by makeBEV, consumed by makeContoursRecurs
+  std::unique_ptr<cc_scan_desc_t> desc_;
+  mutable std::vector<std::vector<RetrievalKey>> keys_cache_;
+
+ public:
+  explicit ContourManager(const ContourManagerConfig &config, int int_id) : cfg_(config), int_id_(int_id) {
+    CC_CHECK(cfg_.n_col_ % 2 == 0);
+    CC_CHECK(cfg_.n_row_ % 2 == 0);
+    ccfg_ = cc_host::to_c(cfg_);
+  }
+
+  // contour_mng.h:505: keeps x,y,z of every point (KITTI layout, intensity unused)
+  template <typename PointType>
+  void makeBEV(typename pcl::PointCloud<PointType>::ConstPtr &ptr_gapc, std::string str_id = "") {
+    CC_CHECK(ptr_gapc);
+    CC_CHECK(ptr_gapc->size() > 10);
+    xyzi_.resize(ptr_gapc->size() * 4);
+    for (size_t i = 0; i < ptr_gapc->size(); i++) {
+      xyzi_[4 * i] = ptr_gapc->points[i].x;
+      xyzi_[4 * i + 1] = ptr_gapc->points[i].y;
+      xyzi_[4 * i + 2] = ptr_gapc->points[i].z;
+      xyzi_[4 * i + 3] = 0.f;
+    }
+    str_id_ = !str_id.empty() ? std::move(str_id) : std::to_string(ptr_gapc->header.stamp);
+  }
+
+  // contour_mng.h:588: rasterise + contours + keys + BCIs on the device
+  void makeContoursRecurs() {
+    CC_CHECK(!xyzi_.empty());
+    desc_.reset(new cc_scan_desc_t);
+    const int64_t off[2] = {0, (int64_t)(xyzi_.size() / 4)};
+    if (cc_ingest_host(cc_host::context(ccfg_), xyzi_.data(), off, 1, desc_.get()) != CC_OK) {
+      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+      abort();
+    }
+    xyzi_.clear();
+    xyzi_.shrink_to_fit();
+  }
+  void clearImage() {}  // the BEV image never leaves the device
+
+  const cc_scan_desc_t &desc() const {
+    CC_CHECK(desc_);
+    return *desc_;
+  }
+  const cc_manager_cfg_t &ccfg() const { return ccfg_; }
+  std::vector<RetrievalKey> getLevRetrievalKey(int level) const {
+    std::vector<RetrievalKey> r(cfg_.piv_firsts_);
+    for (int s = 0; s < cfg_.piv_firsts_; s++) std::memcpy(r[s].array, desc().keys[level][s], sizeof(float) * RET_KEY_DIM);
+    return r;
+  }
+  RetrievalKey getRetrievalKey(int level, int seq) const { return getLevRetrievalKey(level)[seq]; }
+  std::vector<ContourView> getLevContours(int level) const {
+    const cc_scan_desc_t &d = desc();
+    std::vector<ContourView> v(d.n_stored[level]);
+    for (int j = 0; j < d.n_stored[level]; j++) {
+      const cc_contour_t &c = d.cont[level][j];
+      ContourView &o = v[j];
+      o.level_ = c.level;
+      o.poi_[0] = c.poi[0];
+      o.poi_[1] = c.poi[1];
+      o.cell_cnt_ = c.cell_cnt;
+      std::memcpy(o.pos_mean_, c.pos_mean, 8);
+      std::memcpy(o.pos_cov_, c.pos_cov, 16);
+      std::memcpy(o.eig_vals_, c.eig_vals, 8);
+      std::memcpy(o.eig_vecs_, c.eig_vecs, 16);
+      o.eccen_ = c.eccen;
+      o.vol3_mean_ = c.vol3_mean;
+      std::memcpy(o.com_, c.com, 8);
+      o.ecc_feat_ = c.ecc_feat;
+      o.com_feat_ = c.com_feat;
+    }
+    return v;
+  }
+  int getLevTotalPix(int level) const { return desc().layer_cell_cnt[level]; }
+  const cc_bci_t &getBCI(int level, int seq) const { return desc().bcis[level][seq]; }
+  float getAreaPerc(const int8_t &lev, const int8_t &seq) const {
+    return desc().cont[lev][seq].cell_cnt * 1.0f / desc().layer_cell_cnt[lev];
+  }
+  std::string getStrID() const { return str_id_; }
+  int getIntID() const { return int_id_; }
+  const ContourManagerConfig &getConfig() const { return cfg_; }
+};

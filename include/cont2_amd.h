@@ -244,6 +244,13 @@ int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const in
                       cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,
                       void *stream);
 
+/* Host-descriptor variants (one H2D copy each) used by the C++ class mirror, where a ContourManager owns a
+ * host copy of its descriptor: ContourDB::addScan + pushAndBalance for one scan, and queryRangedKNN for one
+ * query against the current DB state. */
+int cc_db_add_scan_host(cc_db *db, const cc_scan_desc_t *h_desc, double ts, int32_t seed);
+int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t *thres_lb, const cc_score_t *thres_ub,
+                     cc_query_result_t *h_res);
+
 /* Device pointer of the DB's descriptor array ([cc_db_size()] cc_scan_desc_t) and raw
  * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
  * device buffer, then cc_db_add_scans consumes it). */
