@@ -440,53 +440,202 @@ __device__ bool cc_check_cand(const cc_scan_desc_t *__restrict__ src, const cc_s
   return true;
 }
 
-// grid = nq, block = 256.  hits/hit_cnt: K3 output.
+#define CC_CHK_STRIDE (CC_NQLEV * CC_NPIV * CC_KNN_MAX)  // dense check slots per query: slot * CC_KNN_MAX + j
+
+// grid = nq, block = 256.  hits/hit_cnt: K3 output.  Every (slot, j) of the query gets a dense record slot whose
+// index IS the reference's candidate iteration order (levels -> anchors -> ascending distance, contour_db.h:721-771),
+// so the merge kernel can replay the passing checks in order without sorting.
 __global__ void __launch_bounds__(256)
 cc_k_check(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
            const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, cc_pass_rec *__restrict__ pass,
-           int pass_cap, int *__restrict__ pass_total, int *__restrict__ pass_cnt /*[nq][4]: n_pass, chk1, chk2, chk3*/) {
-  __shared__ int pre[CC_NQLEV * CC_NPIV + 1];
+           unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt /*[nq][4]: n_pass, chk1, chk2, chk3*/) {
   __shared__ int s_n[4];
   const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int NS = CC_NQLEV * CC_NPIV;
-  if (tid == 0) {
-    int acc = 0;
-    for (int s = 0; s < NS; s++) {
-      pre[s] = acc;
-      acc += hit_cnt[q * NS + s];
-    }
-    pre[NS] = acc;
-    s_n[0] = s_n[1] = s_n[2] = s_n[3] = 0;
-  }
+  if (tid < 4) s_n[tid] = 0;
   __syncthreads();
-  const int total = pre[NS];
   const cc_scan_desc_t *tgt = qdesc + q;
-  for (int t = tid; t < total; t += nt) {
-    int slot = 0;
-    while (t >= pre[slot + 1]) slot++;
-    const int j = t - pre[slot];
-    const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
-    const int seq_tgt = slot % CC_NPIV;
-    cc_pass_rec rec;
-    int stage;
-    const bool ok = cc_check_cand(db_desc + h.gidx, tgt, h.level, h.seq, seq_tgt, P, &stage, &rec);
-    if (stage >= 1) atomicAdd(&s_n[1], 1);
-    if (stage >= 2) atomicAdd(&s_n[2], 1);
-    if (stage >= 3) atomicAdd(&s_n[3], 1);
-    if (ok) {
-      atomicAdd(&s_n[0], 1);
-      const int p = atomicAdd(pass_total, 1);  // compact list for the whole launch; the host re-orders by (q, order)
-      if (p < pass_cap) {
+  for (int t = tid; t < CC_CHK_STRIDE; t += nt) {
+    const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
+    bool ok = false;
+    if (j < hit_cnt[q * NS + slot]) {
+      const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+      const int seq_tgt = slot % CC_NPIV;
+      cc_pass_rec rec;
+      int stage;
+      ok = cc_check_cand(db_desc + h.gidx, tgt, h.level, h.seq, seq_tgt, P, &stage, &rec);
+      if (stage >= 1) atomicAdd(&s_n[1], 1);
+      if (stage >= 2) atomicAdd(&s_n[2], 1);
+      if (stage >= 3) atomicAdd(&s_n[3], 1);
+      if (ok) {
+        atomicAdd(&s_n[0], 1);
         rec.q = q;
-        rec.order = slot * CC_KNN_MAX + j;
+        rec.order = t;
         rec.gidx = h.gidx;
         rec.pad = 0;
-        pass[p] = rec;
+        pass[(size_t)q * CC_CHK_STRIDE + t] = rec;
       }
     }
+    pass_ok[(size_t)q * CC_CHK_STRIDE + t] = ok ? 1 : 0;
   }
   __syncthreads();
   if (tid < 4) pass_cnt[q * 4 + tid] = s_n[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: per query, replay the passing checks in order: CandidatePoseData::addProposal (contour_db.h:286-338) and the
+// part of tidyUpCandidates before the correlation (contour_db.h:503-546).  One lane per query (the work is a short
+// sequential scalar recurrence); surviving (query, candidate) pairs are appended to the GMM problem list.
+// ------------------------------------------------------------------------------------------------
+#define CC_MAXCAND 128  // distinct candidate scans per query that passed the gate
+
+struct cc_gmm_problem {
+  int q;          // index into qdesc (tgt)
+  int gidx;       // index into db_desc (src)
+  double tf[3];   // T_init = (x, y, theta)
+};
+
+struct cc_dprop {  // CandidateAnchorProp (contour_db.h:267-274); constell_ kept as a 400-bit set in key order
+  unsigned long long bits[7];
+  double c, s, tx, ty;  // T_delta_ = [c -s tx; s c ty]
+  int vote_cnt;
+  float area_perc;
+};
+struct cc_dcand {  // CandidatePoseData
+  int gidx, nprops, gmm_idx, pad;
+  cc_dprop props[4];
+};
+struct cc_qstate {
+  int n_cand;  // candidates_.size() before tidyUpCandidates
+  int flags;   // bit0: more than CC_MAXCAND candidate scans
+};
+
+__device__ __forceinline__ void cc_add_proposal(cc_dcand *c, double pc, double ps, double ptx, double pty, const cc_pass_rec *rec) {
+  const int np = rec->n_pairs;
+  for (int i = 0; i < c->nprops; i++) {
+    cc_dprop *p = &c->props[i];
+    // delta_T = T_prop.inverse() * anch_props_[i].T_delta_
+    const double i00 = pc, i01 = ps, i10 = -ps, i11 = pc;  // inverse linear = transpose
+    const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
+    const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
+    const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
+    if (sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3) {
+      for (int w = 0; w < 7; w++) p->bits[w] |= rec->bits[w];
+      p->vote_cnt += np;
+      const int w1 = p->vote_cnt, w2 = np;
+      const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
+      const double ang1 = atan2(p->s, p->c), ang2 = atan2(ps, pc);
+      double diff = ang2 - ang1;
+      if (diff < 0) diff += 2 * 3.14159265358979323846;
+      if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
+      const double ang_bl = diff * w2 / (w1 + w2) + ang1;
+      p->c = cos(ang_bl);
+      p->s = sin(ang_bl);
+      p->tx = bx;
+      p->ty = by;
+      return;
+    }
+  }
+  if (c->nprops > 3) return;
+  cc_dprop *p = &c->props[c->nprops++];
+  for (int w = 0; w < 7; w++) p->bits[w] = rec->bits[w];
+  p->c = pc;
+  p->s = ps;
+  p->tx = ptx;
+  p->ty = pty;
+  p->vote_cnt = np;
+  p->area_perc = 0.f;
+}
+
+// grid = ceil(nq / 64), block = 64
+__global__ void __launch_bounds__(64)
+cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__restrict__ qdesc,
+           const cc_scan_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
+           const int *__restrict__ pass_cnt, cc_dcand *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
+           cc_gmm_problem *__restrict__ probs, int prob_cap, int *__restrict__ n_prob) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  cc_dcand *cands = cands_all + (size_t)q * CC_MAXCAND;
+  int nc = 0, flags = 0;
+  int remaining = pass_cnt[q * 4 + 0];
+  const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
+  for (int t = 0; t < CC_CHK_STRIDE && remaining > 0; t++) {
+    if (!okp[t]) continue;
+    remaining--;
+    const cc_pass_rec *rec = &pass[(size_t)q * CC_CHK_STRIDE + t];
+    const double pc = cos(rec->tf[2]), ps = sin(rec->tf[2]);
+    int k = 0;
+    for (; k < nc; k++)
+      if (cands[k].gidx == rec->gidx) break;
+    if (k == nc) {
+      if (nc >= CC_MAXCAND) {
+        flags |= 1;
+        continue;
+      }
+      cands[nc].gidx = rec->gidx;
+      cands[nc].nprops = 0;
+      cands[nc].gmm_idx = -1;
+      cands[nc].pad = 0;
+      nc++;
+    }
+    cc_add_proposal(&cands[k], pc, ps, rec->tf[0], rec->tf[1], rec);
+  }
+  cc_qstate st;
+  st.n_cand = nc;
+  st.flags = flags;
+  qstate[q] = st;
+  const cc_scan_desc_t *tl = qdesc + q;
+  for (int k = 0; k < nc; k++) {
+    cc_dcand *c = &cands[k];
+    const cc_scan_desc_t *sl = db_desc + c->gidx;
+    int idx_sel = 0;
+    for (int pi = 0; pi < c->nprops; pi++) {
+      float lev_perc[CC_NLEV] = {0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < 7; w++) {
+        unsigned long long m = c->props[pi].bits[w];
+        while (m) {
+          const int b = w * 64 + (__ffsll((unsigned long long)m) - 1);
+          m &= m - 1;
+          const int l = b / 100 + 1, s_ = (b % 100) / 10, t_ = b % 10;
+          const float psrc = (float)sl->cont[l][s_].cell_cnt * 1.0f / (float)sl->layer_cell_cnt[l];
+          const float ptgt = (float)tl->cont[l][t_].cell_cnt * 1.0f / (float)tl->layer_cell_cnt[l];
+          lev_perc[l] += 0.5f * (psrc + ptgt);
+        }
+      }
+      float perc = 0.f;
+      perc += 0.3f * lev_perc[1];
+      perc += 0.3f * lev_perc[2];
+      perc += 0.3f * lev_perc[3];
+      perc += 0.1f * lev_perc[4];
+      c->props[pi].area_perc = perc;
+      if (c->props[pi].vote_cnt > c->props[idx_sel].vote_cnt) idx_sel = pi;
+    }
+    if (idx_sel != 0) {
+      const cc_dprop tmp = c->props[0];
+      c->props[0] = c->props[idx_sel];
+      c->props[idx_sel] = tmp;
+    }
+    const cc_dprop *p0 = &c->props[0];
+    if (p0->area_perc < lb.area_perc) continue;
+    // getEstSensTF: T_so^-1 * T_delta * T_so with T_so = translate(n_row/2 - 0.5, n_col/2 - 0.5)
+    const double ox = n_row / 2 - 0.5, oy = n_col / 2 - 0.5;
+    // (T_delta * T_so): linear = L, t = L*o + t ; then inverse(T_so) * that: t' = (L*o + t) - o   [inverse translation = -(I*o)]
+    const double mx = p0->c * ox + (-p0->s) * oy + p0->tx, my = p0->s * ox + p0->c * oy + p0->ty;
+    const double ex = 1.0 * mx + 0.0 * my + (-(1.0 * ox + 0.0 * oy)), ey = 0.0 * mx + 1.0 * my + (-(0.0 * ox + 1.0 * oy));
+    const double neg = -sqrt(ex * ex + ey * ey);
+    if (neg < (double)lb.neg_est_dist) continue;
+    const int pi = atomicAdd(n_prob, 1);
+    if (pi < prob_cap) {
+      cc_gmm_problem pb;
+      pb.q = q;
+      pb.gidx = c->gidx;
+      pb.tf[0] = p0->tx;
+      pb.tf[1] = p0->ty;
+      pb.tf[2] = atan2(p0->s, p0->c);
+      probs[pi] = pb;
+      c->gmm_idx = pi;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,11 +648,6 @@ cc_k_check(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc
 #define CC_GMM_ECAP_L 128  // ellipses per (side, level) held in LDS
 #define CC_GMM_PCAP_L 4096 // selected (src,tgt) ellipse pairs
 
-struct cc_gmm_problem {
-  int q;          // index into qdesc (tgt)
-  int gidx;       // index into db_desc (src)
-  double tf[3];   // T_init = (x, y, theta)
-};
 struct cc_gmm_result {
   double corr_init;
   double corr_opt;
@@ -863,10 +1007,12 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
   return true;
 }
 
-// grid = n_problems, block = 64, dynamic LDS = CC_GMM_LDS_BYTES(ecap, pcap)
+// grid = any (grid-stride over the device-side problem count), block = 64, dynamic LDS = CC_GMM_LDS_BYTES(ecap, pcap).
+// redo_only: process only problems whose previous result overflowed an LDS cap (flags & 3) -- the large-cap instance.
 __global__ void __launch_bounds__(64)
-cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_idx, const cc_scan_desc_t *__restrict__ qdesc,
-         const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, int ecap, int pcap, cc_gmm_result *__restrict__ results) {
+cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap, int redo_only,
+         const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, int ecap, int pcap,
+         cc_gmm_result *__restrict__ results) {
   HIP_DYNAMIC_SHARED(char, smem)
   cc_gmm_lds Sv;
   Sv.ell = (cc_ell *)smem;
@@ -878,10 +1024,14 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_
   Sv.pcap = pcap;
   cc_gmm_lds *S = &Sv;
   const int lane = threadIdx.x;
-  const int pidx = prob_idx ? prob_idx[blockIdx.x] : (int)blockIdx.x;
+  int n_prob = *n_prob_p;
+  if (n_prob > prob_cap) n_prob = prob_cap;
+  for (int pidx = blockIdx.x; pidx < n_prob; pidx += gridDim.x) {
+  if (redo_only && !(results[pidx].flags & 3)) continue;
   const cc_gmm_problem pb = probs[pidx];
   const cc_scan_desc_t *src = db_desc + pb.gidx;
   const cc_scan_desc_t *tgt = qdesc + pb.q;
+  __syncthreads();
   if (lane == 0) {
     *S->n_pairs = 0;
     *S->flags = 0;
@@ -1103,4 +1253,76 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_
   __syncthreads();
   R.flags = *S->flags;
   if (lane == 0) results[pidx] = R;
+  }  // problem loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: per query, the rest of tidyUpCandidates (correlation bar + order-changing compaction, contour_db.h:560-592) and
+// fineOptimize (contour_db.h:604-648): std::sort on the still-all-zero correlation_ (replayed), take the first
+// max_fine_opt_, adopt their refined score/pose, re-sort those, return the best.  One lane per query.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
+           const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
+           cc_query_result_t *__restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const cc_dcand *cands = cands_all + (size_t)q * CC_MAXCAND;
+  cc_query_result_t r;
+  r.n_res = 0;
+  r.cand_gidx = -1;
+  r.correlation = 0;
+  r.tf[0] = r.tf[1] = r.tf[2] = 0;
+  r.cand_aft_check1 = pass_cnt[q * 4 + 1];
+  r.cand_aft_check2 = pass_cnt[q * 4 + 2];
+  r.cand_aft_check3 = pass_cnt[q * 4 + 3];
+  const int nc = qstate[q].n_cand;
+  r.n_cand_pose = nc;
+  int tot = 0;
+  for (int s2 = 0; s2 < CC_NQLEV * CC_NPIV; s2++) tot += hit_cnt[q * CC_NQLEV * CC_NPIV + s2];
+  r.n_knn_hits = tot;
+  // candidates_ as an index vector; has_corr = corr_est_ != nullptr
+  unsigned char idx[CC_MAXCAND];
+  unsigned char has[CC_MAXCAND];
+  for (int k = 0; k < nc; k++) {
+    idx[k] = (unsigned char)k;
+    const int g = cands[k].gmm_idx;
+    has[k] = (g >= 0 && !((float)gres[g].corr_init < corr_lb)) ? 1 : 0;
+  }
+  int p1 = 0, p2 = nc - 1;
+  while (p1 <= p2) {
+    if (!has[idx[p1]] && has[idx[p2]]) {
+      const unsigned char t = idx[p1];
+      idx[p1] = idx[p2];
+      idx[p2] = t;
+      p1++;
+      p2--;
+    } else {
+      if (has[idx[p1]]) p1++;
+      if (!has[idx[p2]]) p2--;
+    }
+  }
+  const int n = p2 + 1;
+  r.n_cand_tidy = n;
+  if (n > 0) {
+    // first std::sort: every anch_props_[0].correlation_ is still 0 -> comparator is always false
+    ccsort::std_sort(idx, n, [](unsigned char, unsigned char) { return false; });
+    const int pre = max_fine_opt < n ? max_fine_opt : n;
+    float corr[CC_MAXCAND];
+    for (int k = 0; k < nc; k++) corr[k] = 0.f;
+    for (int k = 0; k < pre; k++) corr[idx[k]] = (float)gres[cands[idx[k]].gmm_idx].corr_opt;
+    ccsort::std_sort(idx, pre, [&](unsigned char a, unsigned char b) { return corr[a] > corr[b]; });
+    const cc_dcand *best = &cands[idx[0]];
+    r.n_res = 1;
+    r.cand_gidx = best->gidx;
+    r.correlation = (double)corr[idx[0]];
+    if (pre > 0) {
+      const cc_gmm_result *g = &gres[best->gmm_idx];
+      // T_best_ = Identity.rotate(theta).pretranslate(x, y); reported as (x, y, atan2(T10, T00))
+      r.tf[0] = g->tf_opt[0];
+      r.tf[1] = g->tf_opt[1];
+      r.tf[2] = atan2(sin(g->tf_opt[2]), cos(g->tf_opt[2]));
+    }
+  }
+  out[q] = r;
 }
