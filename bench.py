@@ -127,7 +127,7 @@ def main():
     ms2 = (C.c_double * 2)()
     nl = C.c_int()
     cc.lib().cc_profile_read(ctx.h, ms2, C.byref(nl))
-    ms4 = (C.c_double * 4)()
+    ms4 = (C.c_double * 5)()
     nl2 = C.c_int()
     cc.lib().cc_db_profile_read(db.h, ms4, C.byref(nl2))
 
@@ -157,10 +157,11 @@ def main():
                                    "queries revisit DB places (loop closures found: %d of %d on rank 0)" % (n_db, B, n_found, K * B),
                        "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B)[0], "traffic_source": pmc_traffic(dom, B)[1],
                          "kernels_ms_per_launch": {"cc_k_rasterize": k1_ms, "cc_k_contours": k2_ms,
                                                    "cc_k_knn": ms4[0] / max(nl2.value, 1), "cc_k_check": ms4[1] / max(nl2.value, 1),
-                                                   "cc_k_gmm": ms4[2] / max(nl2.value, 1), "host_merge": ms4[3] / max(nl2.value, 1)},
+                                                   "cc_k_merge": ms4[2] / max(nl2.value, 1), "cc_k_gmm": ms4[3] / max(nl2.value, 1),
+                                                   "cc_k_final": ms4[4] / max(nl2.value, 1)},
                          "rasterize_GBs": k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else None},
             "setup_s": setup_s,
         }
@@ -171,6 +172,19 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_pmc_summary.json; FETCH_SIZE/WRITE_SIZE, gfx950 x2 correction applied where it is calibrated)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    if d.get("batch_scans") != batch or kernel not in d.get("kernels", {}):
+        return None, None
+    return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(cc, wld, n_db, batch0, P, n_q, max_db_seconds=150.0):

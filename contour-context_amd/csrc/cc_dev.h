@@ -41,3 +41,8 @@ __device__ __forceinline__ int cc_point_cell(const cc_dev_cfg &c, float x, float
   if (row <= 0) return -1;
   return row * c.n_col + col;
 }
+
+// value of `v` in lane `src_lane` (wave-uniform index), e.g. the lane found by ffs of a ballot mask
+__device__ __forceinline__ float cc_lane_bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}

@@ -54,6 +54,7 @@ struct cc_ctx {
   cc_k1_scan_out *d_k1 = nullptr;
   cc_k2_scratch *d_scr = nullptr;
   long long *d_offsets = nullptr;
+  long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   size_t lds1 = 0, lds2 = 0;
   // optional per-kernel timing (cc_profile_*)
   bool prof = false;
@@ -146,6 +147,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   HIPCHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
   HIPCHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
   HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
+  if (getenv("CC_K2_PHASES")) HIPCHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = ((nc * 4 + 15) & ~(size_t)15) + CC_K2_R_BYTES;
   HIPCHK(hipFuncSetAttribute((const void *)cc_k_rasterize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
@@ -168,6 +170,25 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
   if (!c || !ms_out) return set_err(CC_EINVAL, "cc_profile_read: bad argument");
   HIPCHK(hipSetDevice(c->device));
   if (prof_flush(c) != CC_OK) return set_err(CC_EHIP, "cc_profile_read: event sync failed");
+  if (c->d_phase_clk) {  // tuning aid: mean phase durations of the last launch, in microseconds (100 MHz wall clock)
+    std::vector<long long> h(16 * (size_t)c->max_batch);
+    HIPCHK(hipMemcpy(h.data(), c->d_phase_clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    const int n = c->max_batch < 256 ? c->max_batch : 256;
+    double ph[9] = {0};
+    for (int i = 0; i < n; i++) {
+      const long long *p = &h[(size_t)i * 16];
+      ph[0] += p[1] * 0.01;
+      ph[1] += p[2] * 0.01;
+      ph[2] += p[3] * 0.01;
+      ph[3] += (p[5] - p[4]) * 0.01;
+      ph[4] += (p[6] - p[5]) * 0.01;
+      ph[5] += (p[7] - p[6]) * 0.01;
+      ph[6] += (p[8] - p[7]) * 0.01;
+      ph[7] += (p[8] - p[0]) * 0.01;
+    }
+    fprintf(stderr, "[cc_k_contours phases, mean us over %d scans] ccl %.1f  enum+bbox %.1f  walk %.1f  order+sort %.1f  emit %.1f  keys %.1f  bci %.1f  | total %.1f\n",
+            n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
+  }
   ms_out[0] = c->ms_acc[0];
   ms_out[1] = c->ms_acc[1];
   if (n_launches) *n_launches = c->launches;
@@ -185,6 +206,7 @@ int cc_destroy(cc_ctx *c) {
   hipFree(c->d_k1);
   hipFree(c->d_scr);
   hipFree(c->d_offsets);
+  hipFree(c->d_phase_clk);
   delete c;
   return CC_OK;
 }
@@ -226,7 +248,7 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
-                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab);
+                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab, c->d_phase_clk);
     if (pe) HIPCHK(hipEventRecord(pe[2], stream));
     HIPCHK(hipGetLastError());
     if (dbg && dbg->d_bev)

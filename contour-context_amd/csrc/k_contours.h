@@ -48,8 +48,14 @@ __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return
 __global__ void __launch_bounds__(1024)
 cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
-              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk) {
   HIP_DYNAMIC_SHARED(char, smem)
+  // optional phase timestamps (tuning aid): phase_clk[scan*16 + i], written by thread 0
+#define CC_K2_STAMP(i)                                                                     \
+  do {                                                                                     \
+    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); \
+  } while (0)
+  CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int scan = blockIdx.x;
@@ -76,10 +82,27 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   __syncthreads();
 
   int prev_n = 0;
+  long long acc_ccl = 0, acc_enum = 0, acc_walk = 0, tmark = phase_clk ? (long long)wall_clock64() : 0;
+#define CC_K2_LAP(acc)                                     \
+  do {                                                     \
+    if (phase_clk) {                                       \
+      const long long now_ = (long long)wall_clock64();    \
+      acc += now_ - tmark;                                 \
+      tmark = now_;                                        \
+    }                                                      \
+  } while (0)
+  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
   for (int l = CC_NLEV - 1; l >= 0; --l) {
     const float g = cfg.lv_grads[l];
-    // (a) init labels: cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
-    for (int c = tid; c < n_cell; c += nt) LAB[c] = (H[c] > g) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
+    // (a) init labels: cv::threshold BINARY is strict `>` (contour_mng.cpp:283).  LAB still holds the converged
+    //     root labels of level l+1 (a subset of this level's cells): keeping them seeds the propagation with the
+    //     already-merged structure, new cells start as their own root.
+    if (l == CC_NLEV - 1) {
+      for (int c = tid; c < n_cell; c += nt) LAB[c] = (H[c] > g) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
+    } else {
+      for (int c = tid; c < n_cell; c += nt)
+        if (LAB[c] == CC_LAB_NONE && H[c] > g) LAB[c] = (uint16_t)c;
+    }
     __syncthreads();
     // (b) 8-connected labelling: min-propagation with pointer jumping until stable
     while (true) {
@@ -121,6 +144,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       __syncthreads();
       if (!any) break;
     }
+    CC_K2_LAP(acc_ccl);
     // (c) which roots own >= min_cont_cell_cnt_ (3) cells: 2-bit saturating counters
     const int n_w = (n_cell + 15) >> 4;
     for (int i = tid; i < n_w; i += nt) CNT2[i] = 0;
@@ -159,32 +183,11 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       roots[rk] = (uint16_t)me;
     }
     __syncthreads();
-    // (e) relabel cells with the component index (or NONE).  Each thread touches only its own cells.
-    for (int c = tid; c < n_cell; c += nt) {
-      unsigned r = LAB[c];
-      if (r == CC_LAB_NONE) continue;
-      unsigned j = CC_LAB_NONE;
-      if (cc_cnt2_get(CNT2, r) >= need) {
-        int lo = 0, hi = n_kept - 1;
-        while (lo <= hi) {
-          int mid = (lo + hi) >> 1;
-          unsigned v = roots[mid];
-          if (v == r) {
-            j = mid;
-            break;
-          }
-          if (v < r)
-            lo = mid + 1;
-          else
-            hi = mid - 1;
-        }
-      }
-      LAB[c] = (uint16_t)j;
-    }
-    __syncthreads();
-    // (f) bbox / area / first-block columns via LDS atomics (W aliases CNT2: done with it)
+    // (f) bbox / area via LDS atomics (W aliases CNT2; the kept test is done before W is re-initialised).
+    //     LAB keeps the root labels (they seed the next level); the component index is looked up in `roots`.
     unsigned *w_minr = W, *w_maxr = W + CC_NC, *w_minc = W + 2 * CC_NC, *w_maxc = W + 3 * CC_NC, *w_area = W + 4 * CC_NC,
              *w_cA = W + 5 * CC_NC, *w_cB = W + 6 * CC_NC;
+    __syncthreads();
     for (int k = tid; k < n_kept; k += nt) {
       w_minr[k] = 0xFFFFu;
       w_maxr[k] = 0;
@@ -196,28 +199,71 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
     __syncthreads();
     for (int c = tid; c < n_cell; c += nt) {
-      unsigned j = LAB[c];
-      if (j == CC_LAB_NONE) continue;
-      const int r = c / n_col, cc = c - r * n_col;
-      atomicMin(&w_minr[j], (unsigned)r);
-      atomicMax(&w_maxr[j], (unsigned)r);
+      const unsigned r = LAB[c];
+      if (r == CC_LAB_NONE) continue;
+      int lo = 0, hi = n_kept - 1, j = -1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned v = roots[mid];
+        if (v == r) {
+          j = mid;
+          break;
+        }
+        if (v < r)
+          lo = mid + 1;
+        else
+          hi = mid - 1;
+      }
+      if (j < 0) continue;  // component with < 3 cells (or beyond the capacity)
+      const int rr = c / n_col, cc = c - rr * n_col;
+      atomicMin(&w_minr[j], (unsigned)rr);
+      atomicMax(&w_maxr[j], (unsigned)rr);
       atomicMin(&w_minc[j], (unsigned)cc);
       atomicMax(&w_maxc[j], (unsigned)cc);
       atomicAdd(&w_area[j], 1u);
     }
     __syncthreads();
-    for (int c = tid; c < n_cell; c += nt) {
-      unsigned j = LAB[c];
-      if (j == CC_LAB_NONE) continue;
-      const int r = c / n_col, cc = c - r * n_col;
-      if ((unsigned)r == w_minr[j]) atomicMin(&w_cA[j], (unsigned)cc);
-      if ((unsigned)r == w_minr[j] + 1) atomicMin(&w_cB[j], (unsigned)cc);
+    // first member column in the component's first row (cA) and in the row below (cB): first-2x2-block key
+    for (int k = tid; k < n_kept; k += nt) {
+      const unsigned root = roots[k];
+      const int r0 = (int)w_minr[k], c0 = (int)w_minc[k], c1 = (int)w_maxc[k];
+      for (int c = c0; c <= c1; c++)
+        if (LAB[r0 * n_col + c] == root) {
+          w_cA[k] = (unsigned)c;
+          break;
+        }
+      if (r0 + 1 <= (int)w_maxr[k])
+        for (int c = c0; c <= c1; c++)
+          if (LAB[(r0 + 1) * n_col + c] == root) {
+            w_cB[k] = (unsigned)c;
+            break;
+          }
+    }
+    CC_K2_LAP(acc_enum);
+    // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
+    for (int k = tid; k < prev_n; k += nt) {
+      const unsigned r = LAB[prev_root[k]];
+      int lo = 0, hi = n_kept - 1, j = 0xFFFF;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned v = roots[mid];
+        if (v == r) {
+          j = mid;
+          break;
+        }
+        if (v < r)
+          lo = mid + 1;
+        else
+          hi = mid - 1;
+      }
+      scr->comp[l + 1][k].parent = (uint16_t)j;
     }
     __syncthreads();
-    // (g) parents of the level above (processed in the previous iteration)
-    for (int k = tid; k < prev_n; k += nt) scr->comp[l + 1][k].parent = LAB[prev_root[k]];
-    // (h) one lane per contour: raster-order running statistics (contour_mng.cpp:317-331) + descriptor
-    for (int k = tid; k < n_kept; k += nt) {
+    // (h) one WAVE per contour: raster-order running statistics (contour_mng.cpp:317-331).  The 64 lanes test 64 cells of a
+    //     bbox row at once; the members found (ballot) are then accumulated one by one, in column order, by all lanes
+    //     redundantly -- the exact sequence of f32/f64 additions of the reference -- with lane broadcasts for the operands.
+    for (int k = wave_id; k < n_kept; k += n_waves) {
+      const unsigned root = roots[k];
       const int r0 = w_minr[k], r1 = w_maxr[k], c0 = w_minc[k], c1 = w_maxc[k];
       cc_running_stat rec;
       rec.cnt = 0;
@@ -226,47 +272,78 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int poi_r = -1, poi_c = -1;
       for (int r = r0; r <= r1; r++) {
         const int base = r * n_col;
-        for (int c = c0; c <= c1; c++) {
-          if (LAB[base + c] != (unsigned)k) continue;
-          const float2 rc = pix[base + c];
-          const float h = H[base + c];
-          const double vr = (double)rc.x, vc = (double)rc.y;
-          rec.cnt += 1;
-          rec.ps_x += vr;
-          rec.ps_y += vc;
-          rec.t_xx += vr * vr;
-          rec.t_xy += vr * vc;
-          rec.t_yy += vc * vc;
-          rec.vol3 += h;
-          rec.tq_x += (double)h * vr;
-          rec.tq_y += (double)h * vc;
-          poi_r = r;
-          poi_c = c;
+        for (int cb = c0; cb <= c1; cb += 64) {
+          const int col = cb + lane;
+          const bool mem = col <= c1 && LAB[base + col] == root;
+          unsigned long long mask = __ballot(mem);
+          if (!mask) continue;
+          float h = 0.f, px = 0.f, py = 0.f;
+          if (mem) {
+            h = H[base + col];
+            const float2 rc = pix[base + col];
+            px = rc.x;
+            py = rc.y;
+          }
+          while (mask) {
+            const int src = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            const float hh = cc_lane_bcast(h, src);
+            const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
+            rec.cnt += 1;
+            rec.ps_x += vr;
+            rec.ps_y += vc;
+            rec.t_xx += vr * vr;
+            rec.t_xy += vr * vc;
+            rec.t_yy += vc * vc;
+            rec.vol3 += hh;
+            rec.tq_x += (double)hh * vr;
+            rec.tq_y += (double)hh * vc;
+            poi_r = r;
+            poi_c = cb + src;
+          }
         }
       }
-      cc_contour_t cv;
-      cc_calc_stat_vals(cfg, rec, l, poi_r, poi_c, &cv);
-      scr->cont[l][k] = cv;
-      cc_comp_t cp;
-      cp.root = roots[k];
-      cp.area = (uint16_t)w_area[k];
-      cp.parent = 0xFFFF;
-      cp.rank = 0;
-      cp.r0 = (uint8_t)r0;
-      cp.r1 = (uint8_t)r1;
-      cp.c0 = (uint8_t)c0;
-      cp.c1 = (uint8_t)c1;
-      cp.cA = (uint8_t)w_cA[k];
-      cp.cB = (uint8_t)w_cB[k];
-      cp.pad[0] = cp.pad[1] = 0;
-      scr->comp[l][k] = cp;
+      if (lane == 0) {
+        cc_contour_t cv;
+        cc_calc_stat_vals(cfg, rec, l, poi_r, poi_c, &cv);
+        scr->cont[l][k] = cv;
+        cc_comp_t cp;
+        cp.root = (uint16_t)root;
+        cp.area = (uint16_t)w_area[k];
+        cp.parent = 0xFFFF;
+        cp.rank = 0;
+        cp.r0 = (uint8_t)r0;
+        cp.r1 = (uint8_t)r1;
+        cp.c0 = (uint8_t)c0;
+        cp.c1 = (uint8_t)c1;
+        cp.cA = (uint8_t)w_cA[k];
+        cp.cB = (uint8_t)w_cB[k];
+        cp.pad[0] = cp.pad[1] = 0;
+        scr->comp[l][k] = cp;
+      }
     }
     // (i) parity/debug: component index image of this level (mapped to sorted seq at the end)
     if (labels_dbg) {
       int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
       for (int c = tid; c < n_cell; c += nt) {
-        unsigned j = LAB[c];
-        ld[c] = (j == CC_LAB_NONE) ? (int16_t)-1 : (int16_t)j;
+        const unsigned r = LAB[c];
+        int j = -1;
+        if (r != CC_LAB_NONE) {
+          int lo = 0, hi = n_kept - 1;
+          while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned v = roots[mid];
+            if (v == r) {
+              j = mid;
+              break;
+            }
+            if (v < r)
+              lo = mid + 1;
+            else
+              hi = mid - 1;
+          }
+        }
+        ld[c] = (int16_t)j;
       }
     }
     __syncthreads();
@@ -274,7 +351,14 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     if (tid == 0) sh[8 + l] = n_kept;
     prev_n = n_kept;
     __syncthreads();
+    CC_K2_LAP(acc_walk);
   }
+  if (phase_clk && tid == 0) {
+    phase_clk[(size_t)blockIdx.x * 16 + 1] = acc_ccl;
+    phase_clk[(size_t)blockIdx.x * 16 + 2] = acc_enum;
+    phase_clk[(size_t)blockIdx.x * 16 + 3] = acc_walk;
+  }
+  CC_K2_STAMP(4);
 
   // =========================== phase "order": region R re-carved ===========================
   __threadfence_block();
@@ -338,6 +422,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
   }
   __syncthreads();
+  CC_K2_STAMP(5);
   // emit sorted contour tables + header
   for (int l = 0; l < CC_NLEV; l++) {
     const int n = n_lev[l] < CC_MAXC ? n_lev[l] : CC_MAXC;
@@ -388,6 +473,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   }
   __syncthreads();
 
+  CC_K2_STAMP(6);
   // =========================== phase "keys" (contour_mng.h:693-830) ===========================
   // R2 layout: divs f32 [36][35] (5040) | cntp int[36] | valid int[36] | acc int[36] | bci tmp | bci pts
   float *divs = (float *)R2;
@@ -474,6 +560,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   }
   __syncthreads();
 
+  CC_K2_STAMP(7);
   // =========================== phase "BCI" (contour_mng.h:848-883) ===========================
   struct bci_tmp {
     int ok;
@@ -562,4 +649,5 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       ob->pts[i] = rp;
     }
   }
+  CC_K2_STAMP(8);
 }

@@ -510,82 +510,110 @@ struct cc_qstate {
   int flags;   // bit0: more than CC_MAXCAND candidate scans
 };
 
-__device__ __forceinline__ void cc_add_proposal(cc_dcand *c, double pc, double ps, double ptx, double pty, const cc_pass_rec *rec) {
-  const int np = rec->n_pairs;
-  for (int i = 0; i < c->nprops; i++) {
-    cc_dprop *p = &c->props[i];
-    // delta_T = T_prop.inverse() * anch_props_[i].T_delta_
-    const double i00 = pc, i01 = ps, i10 = -ps, i11 = pc;  // inverse linear = transpose
-    const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
-    const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
-    const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
-    if (sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3) {
-      for (int w = 0; w < 7; w++) p->bits[w] |= rec->bits[w];
-      p->vote_cnt += np;
-      const int w1 = p->vote_cnt, w2 = np;
-      const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
-      const double ang1 = atan2(p->s, p->c), ang2 = atan2(ps, pc);
-      double diff = ang2 - ang1;
-      if (diff < 0) diff += 2 * 3.14159265358979323846;
-      if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
-      const double ang_bl = diff * w2 / (w1 + w2) + ang1;
-      p->c = cos(ang_bl);
-      p->s = sin(ang_bl);
-      p->tx = bx;
-      p->ty = by;
-      return;
-    }
-  }
-  if (c->nprops > 3) return;
-  cc_dprop *p = &c->props[c->nprops++];
-  for (int w = 0; w < 7; w++) p->bits[w] = rec->bits[w];
-  p->c = pc;
-  p->s = ps;
-  p->tx = ptx;
-  p->ty = pty;
-  p->vote_cnt = np;
-  p->area_perc = 0.f;
-}
+// One wave per query.  The candidate/proposal state lives in LDS; the replay over passing checks is sequential (greedy
+// merge), but each step is wave-cooperative: candidate lookup by ballot, the <=4 proposal tests on 4 lanes.
+#define CC_MERGE_LDS_BYTES (sizeof(cc_dcand) * CC_MAXCAND + 64)
 
-// grid = ceil(nq / 64), block = 64
+// grid = nq, block = 64, dynamic LDS = CC_MERGE_LDS_BYTES
 __global__ void __launch_bounds__(64)
 cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__restrict__ qdesc,
            const cc_scan_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
            const int *__restrict__ pass_cnt, cc_dcand *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
            cc_gmm_problem *__restrict__ probs, int prob_cap, int *__restrict__ n_prob) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  HIP_DYNAMIC_SHARED(char, smem)
+  cc_dcand *cands = (cc_dcand *)smem;
+  const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
-  cc_dcand *cands = cands_all + (size_t)q * CC_MAXCAND;
   int nc = 0, flags = 0;
-  int remaining = pass_cnt[q * 4 + 0];
+  const int n_pass = pass_cnt[q * 4 + 0];
   const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
-  for (int t = 0; t < CC_CHK_STRIDE && remaining > 0; t++) {
-    if (!okp[t]) continue;
-    remaining--;
-    const cc_pass_rec *rec = &pass[(size_t)q * CC_CHK_STRIDE + t];
-    const double pc = cos(rec->tf[2]), ps = sin(rec->tf[2]);
-    int k = 0;
-    for (; k < nc; k++)
-      if (cands[k].gidx == rec->gidx) break;
-    if (k == nc) {
-      if (nc >= CC_MAXCAND) {
-        flags |= 1;
-        continue;
+  const cc_pass_rec *recs = pass + (size_t)q * CC_CHK_STRIDE;
+  int seen = 0;
+  for (int base = 0; base < CC_CHK_STRIDE && seen < n_pass; base += 64) {
+    unsigned long long m = __ballot(okp[base + lane] != 0);
+    while (m) {
+      const int t = base + (__ffsll((unsigned long long)m) - 1);
+      m &= m - 1;
+      seen++;
+      const cc_pass_rec *rec = &recs[t];
+      const int gidx = rec->gidx;
+      const int np = rec->n_pairs;
+      const double ptx = rec->tf[0], pty = rec->tf[1];
+      const double pc = cos(rec->tf[2]), ps = sin(rec->tf[2]);
+      // candidate lookup (cand_id_pos_pair_)
+      unsigned long long f0 = __ballot(lane < nc && cands[lane].gidx == gidx);
+      unsigned long long f1 = __ballot(lane + 64 < nc && cands[lane + 64].gidx == gidx);
+      int k = f0 ? (__ffsll((unsigned long long)f0) - 1) : (f1 ? 64 + (__ffsll((unsigned long long)f1) - 1) : -1);
+      if (k < 0) {
+        if (nc >= CC_MAXCAND) {
+          flags |= 1;
+          continue;
+        }
+        k = nc++;
+        if (lane == 0) {
+          cands[k].gidx = gidx;
+          cands[k].nprops = 0;
+          cands[k].gmm_idx = -1;
+          cands[k].pad = 0;
+        }
+        __syncthreads();
       }
-      cands[nc].gidx = rec->gidx;
-      cands[nc].nprops = 0;
-      cands[nc].gmm_idx = -1;
-      cands[nc].pad = 0;
-      nc++;
+      cc_dcand *c = &cands[k];
+      const int nprops = c->nprops;
+      // CandidatePoseData::addProposal: first proposal within 2.0 (pixels) and 0.3 rad
+      bool close = false;
+      if (lane < nprops) {
+        const cc_dprop *p = &c->props[lane];
+        const double i00 = pc, i01 = ps, i10 = -ps, i11 = pc;
+        const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
+        const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
+        const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
+        close = sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3;
+      }
+      const unsigned long long cm = __ballot(close);
+      if (cm) {
+        const int i = __ffsll((unsigned long long)cm) - 1;
+        cc_dprop *p = &c->props[i];
+        if (lane < 7) p->bits[lane] |= rec->bits[lane];
+        if (lane == 0) {
+          p->vote_cnt += np;
+          const int w1 = p->vote_cnt, w2 = np;
+          const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
+          const double ang1 = atan2(p->s, p->c), ang2 = atan2(ps, pc);
+          double diff = ang2 - ang1;
+          if (diff < 0) diff += 2 * 3.14159265358979323846;
+          if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
+          const double ang_bl = diff * w2 / (w1 + w2) + ang1;
+          p->c = cos(ang_bl);
+          p->s = sin(ang_bl);
+          p->tx = bx;
+          p->ty = by;
+        }
+      } else if (nprops <= 3) {
+        cc_dprop *p = &c->props[nprops];
+        if (lane < 7) p->bits[lane] = rec->bits[lane];
+        if (lane == 0) {
+          p->c = pc;
+          p->s = ps;
+          p->tx = ptx;
+          p->ty = pty;
+          p->vote_cnt = np;
+          p->area_perc = 0.f;
+          c->nprops = nprops + 1;
+        }
+      }
+      __syncthreads();
     }
-    cc_add_proposal(&cands[k], pc, ps, rec->tf[0], rec->tf[1], rec);
   }
-  cc_qstate st;
-  st.n_cand = nc;
-  st.flags = flags;
-  qstate[q] = st;
+  if (lane == 0) {
+    cc_qstate st;
+    st.n_cand = nc;
+    st.flags = flags;
+    qstate[q] = st;
+  }
+  // tidyUpCandidates before the correlation (contour_db.h:503-546): one lane per candidate
   const cc_scan_desc_t *tl = qdesc + q;
-  for (int k = 0; k < nc; k++) {
+  for (int k = lane; k < nc; k += 64) {
     cc_dcand *c = &cands[k];
     const cc_scan_desc_t *sl = db_desc + c->gidx;
     int idx_sel = 0;
@@ -616,25 +644,33 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
       c->props[idx_sel] = tmp;
     }
     const cc_dprop *p0 = &c->props[0];
-    if (p0->area_perc < lb.area_perc) continue;
-    // getEstSensTF: T_so^-1 * T_delta * T_so with T_so = translate(n_row/2 - 0.5, n_col/2 - 0.5)
-    const double ox = n_row / 2 - 0.5, oy = n_col / 2 - 0.5;
-    // (T_delta * T_so): linear = L, t = L*o + t ; then inverse(T_so) * that: t' = (L*o + t) - o   [inverse translation = -(I*o)]
-    const double mx = p0->c * ox + (-p0->s) * oy + p0->tx, my = p0->s * ox + p0->c * oy + p0->ty;
-    const double ex = 1.0 * mx + 0.0 * my + (-(1.0 * ox + 0.0 * oy)), ey = 0.0 * mx + 1.0 * my + (-(0.0 * ox + 1.0 * oy));
-    const double neg = -sqrt(ex * ex + ey * ey);
-    if (neg < (double)lb.neg_est_dist) continue;
-    const int pi = atomicAdd(n_prob, 1);
-    if (pi < prob_cap) {
-      cc_gmm_problem pb;
-      pb.q = q;
-      pb.gidx = c->gidx;
-      pb.tf[0] = p0->tx;
-      pb.tf[1] = p0->ty;
-      pb.tf[2] = atan2(p0->s, p0->c);
-      probs[pi] = pb;
-      c->gmm_idx = pi;
+    int gi = -1;
+    if (!(p0->area_perc < lb.area_perc)) {
+      // getEstSensTF: T_so^-1 * T_delta * T_so with T_so = translate(n_row/2 - 0.5, n_col/2 - 0.5)
+      const double ox = n_row / 2 - 0.5, oy = n_col / 2 - 0.5;
+      const double mx = p0->c * ox + (-p0->s) * oy + p0->tx, my = p0->s * ox + p0->c * oy + p0->ty;
+      const double ex = 1.0 * mx + 0.0 * my + (-(1.0 * ox + 0.0 * oy)), ey = 0.0 * mx + 1.0 * my + (-(0.0 * ox + 1.0 * oy));
+      const double neg = -sqrt(ex * ex + ey * ey);
+      if (!(neg < (double)lb.neg_est_dist)) {
+        const int pi = atomicAdd(n_prob, 1);
+        if (pi < prob_cap) {
+          cc_gmm_problem pb;
+          pb.q = q;
+          pb.gidx = c->gidx;
+          pb.tf[0] = p0->tx;
+          pb.tf[1] = p0->ty;
+          pb.tf[2] = atan2(p0->s, p0->c);
+          probs[pi] = pb;
+          gi = pi;
+        }
+      }
     }
+    // what the final-selection kernel needs
+    cc_dcand *o = cands_all + (size_t)q * CC_MAXCAND + k;
+    o->gidx = c->gidx;
+    o->nprops = c->nprops;
+    o->gmm_idx = gi;
+    o->pad = 0;
   }
 }
 

@@ -256,9 +256,9 @@ int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t 
  * device buffer, then cc_db_add_scans consumes it). */
 const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
 
-/* Same for the query kernels: accumulated ms {K3 knn, K4 check, K5 gmm, host merge} + launch count. */
+/* Same for the query kernels: accumulated ms {K3 knn, K4 check, K4b merge, K5 gmm, K6 final} + launch count. */
 int cc_db_profile_enable(cc_db *db, int on);
-int cc_db_profile_read(cc_db *db, double ms_out[4], int *n_launches);
+int cc_db_profile_read(cc_db *db, double ms_out[5], int *n_launches);
 
 /* Host-side introspection of the K0 bookkeeping for parity tests:
  * tree sizes per (layer, bucket) and bucket ranges at the current epoch. */

@@ -10,6 +10,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx *t_block;
 thread_local WaveCtx *t_wave;
 thread_local int t_lane;
+thread_local unsigned t_coll;
 }  // namespace emu
 
 extern "C" {

@@ -49,7 +49,7 @@ static inline int2 make_int2(int a, int b) { return {a, b}; }
 namespace emu {
 struct WaveCtx {
   pthread_barrier_t bar;
-  unsigned long long scratch64[64];
+  unsigned long long scratch64[2][64];  // ping-pong: one barrier per collective is enough
 };
 struct BlockCtx {
   pthread_barrier_t bar;
@@ -60,6 +60,7 @@ extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockCtx *t_block;
 extern thread_local WaveCtx *t_wave;
 extern thread_local int t_lane;
+extern thread_local unsigned t_coll;  // per-thread count of wave collectives (selects the ping-pong buffer)
 }  // namespace emu
 
 #define threadIdx (emu::t_threadIdx)
@@ -72,27 +73,30 @@ static inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int __lane_id() { return emu::t_lane; }
+static inline long long wall_clock64() { return 0; }
 
 // ---- cross-lane (wave = 64).  All 64 lanes of the wave must call these together. ----
+// A lane can only reach its (n+2)-th collective (which reuses buffer n%2) after passing the barrier of collective
+// n+1, i.e. after every lane has finished reading buffer n%2 -- so no second barrier is needed.
 static inline unsigned long long __ballot(int pred) {
   emu::WaveCtx *w = emu::t_wave;
-  w->scratch64[emu::t_lane] = pred ? 1ull : 0ull;
+  unsigned long long *buf = w->scratch64[emu::t_coll++ & 1];
+  buf[emu::t_lane] = pred ? 1ull : 0ull;
   pthread_barrier_wait(&w->bar);
   unsigned long long m = 0;
-  for (int i = 0; i < 64; i++) m |= (w->scratch64[i] & 1ull) << i;
-  pthread_barrier_wait(&w->bar);
+  for (int i = 0; i < 64; i++) m |= (buf[i] & 1ull) << i;
   return m;
 }
 template <typename T>
 static inline T emu_shfl_any(T v, int src) {
   static_assert(sizeof(T) <= 8, "shfl payload");
   emu::WaveCtx *w = emu::t_wave;
+  unsigned long long *buf = w->scratch64[emu::t_coll++ & 1];
   unsigned long long raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
-  w->scratch64[emu::t_lane] = raw;
+  buf[emu::t_lane] = raw;
   pthread_barrier_wait(&w->bar);
-  unsigned long long r = w->scratch64[src & 63];
-  pthread_barrier_wait(&w->bar);
+  unsigned long long r = buf[src & 63];
   T out;
   std::memcpy(&out, &r, sizeof(T));
   return out;
@@ -119,6 +123,7 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
   (void)width;
   return emu_shfl_any(v, emu::t_lane ^ mask);
 }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl_any(v, lane); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
@@ -240,6 +245,7 @@ void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... ar
         t_block = &ctx;
         t_wave = &ctx.waves[t / 64];
         t_lane = t % 64;
+        t_coll = 0;
         kernel(args...);
       });
     }

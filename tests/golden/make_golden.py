@@ -17,7 +17,7 @@ cc = cc_amd.load()
 w = cc.synth.World(loop_len=200.0)
 x, _, _ = cc.synth.make_sequence(1, world=w, beams=16, azim=600, start=5)
 scan0 = x[0].numpy()
-scan1 = terrain_scan(42, n=12000, scale=1.8, quant=0.2)
+scan1 = terrain_scan(42, n=5000, scale=1.6, quant=0.2)
 desc = np.concatenate([O.Scan(scan0).desc(), O.Scan(scan1).desc()])
 np.savez_compressed(os.path.join(HERE, "ingest_fixture.npz"), scan0=scan0, scan1=scan1,
                     desc=np.frombuffer(desc.tobytes(), np.uint8))

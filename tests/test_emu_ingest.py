@@ -28,7 +28,7 @@ def _check(oracle, scans):
 
 
 def test_terrain_scans_bit_exact(oracle):
-    d = _check(oracle, [terrain_scan(2, n=30000), terrain_scan(101, n=20000, scale=2.2, quant=0.25)])
+    d = _check(oracle, [terrain_scan(2, n=20000, scale=1.2), terrain_scan(101, n=5000, scale=2.0, quant=0.25)])
     assert d["n_cont"].max() > 16 and (d["flags"] == 0).all()
 
 
