@@ -190,6 +190,8 @@ struct cc_pass_rec {
   int flags;       // bit0: a capacity (CC_PP_MAX / CC_CSTL_MAX) was hit
   int pad;
   double tf[3];    // T_pass = (x, y, theta)
+  double cs[3];    // cos(theta), sin(theta), atan2(sin, cos): entries of the Isometry2d built by rotate(theta), hoisted out of
+                   // the sequential merge
   unsigned long long bits[7];  // constellation pairs as a set: bit (level-1)*100 + seq_src*10 + seq_tgt
 };
 
@@ -431,6 +433,9 @@ __device__ bool cc_check_cand(const cc_scan_desc_t *__restrict__ src, const cc_s
   rec->tf[0] = dmx - (r00 * smx + (-r10) * smy);
   rec->tf[1] = dmy - (r10 * smx + r00 * smy);
   rec->tf[2] = atan2(r10, r00);
+  rec->cs[0] = cos(rec->tf[2]);
+  rec->cs[1] = sin(rec->tf[2]);
+  rec->cs[2] = atan2(rec->cs[1], rec->cs[0]);
   rec->n_pairs = ncs;
   for (int w = 0; w < 7; w++) rec->bits[w] = 0ull;
   for (int i = 0; i < ncs; i++) {
@@ -539,7 +544,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
       const int gidx = rec->gidx;
       const int np = rec->n_pairs;
       const double ptx = rec->tf[0], pty = rec->tf[1];
-      const double pc = cos(rec->tf[2]), ps = sin(rec->tf[2]);
+      const double pc = rec->cs[0], ps = rec->cs[1];
       // candidate lookup (cand_id_pos_pair_)
       unsigned long long f0 = __ballot(lane < nc && cands[lane].gidx == gidx);
       unsigned long long f1 = __ballot(lane + 64 < nc && cands[lane + 64].gidx == gidx);
@@ -579,7 +584,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
           p->vote_cnt += np;
           const int w1 = p->vote_cnt, w2 = np;
           const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
-          const double ang1 = atan2(p->s, p->c), ang2 = atan2(ps, pc);
+          const double ang1 = atan2(p->s, p->c), ang2 = rec->cs[2];
           double diff = ang2 - ang1;
           if (diff < 0) diff += 2 * 3.14159265358979323846;
           if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
@@ -1301,9 +1306,35 @@ __global__ void __launch_bounds__(64)
 cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
            const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
            cc_query_result_t *__restrict__ out) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per query: lanes fetch the per-candidate inputs in parallel, lane 0 replays the order-dependent part on LDS
+  __shared__ unsigned char idx[CC_MAXCAND];
+  __shared__ unsigned char has[CC_MAXCAND];
+  __shared__ float corr_o[CC_MAXCAND];
+  __shared__ int gm[CC_MAXCAND];
+  __shared__ int s_tot;
+  const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
   const cc_dcand *cands = cands_all + (size_t)q * CC_MAXCAND;
+  const int nc = qstate[q].n_cand;
+  for (int k = lane; k < nc; k += 64) {
+    const int g = cands[k].gmm_idx;
+    idx[k] = (unsigned char)k;
+    gm[k] = g;
+    bool h = false;
+    float co = 0.f;
+    if (g >= 0) {
+      h = !((float)gres[g].corr_init < corr_lb);
+      co = (float)gres[g].corr_opt;
+    }
+    has[k] = h ? 1 : 0;
+    corr_o[k] = co;
+  }
+  int tot = 0;
+  for (int s2 = lane; s2 < CC_NQLEV * CC_NPIV; s2 += 64) tot += hit_cnt[q * CC_NQLEV * CC_NPIV + s2];
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if (lane == 0) s_tot = tot;
+  __syncthreads();
+  if (lane != 0) return;
   cc_query_result_t r;
   r.n_res = 0;
   r.cand_gidx = -1;
@@ -1312,19 +1343,9 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__
   r.cand_aft_check1 = pass_cnt[q * 4 + 1];
   r.cand_aft_check2 = pass_cnt[q * 4 + 2];
   r.cand_aft_check3 = pass_cnt[q * 4 + 3];
-  const int nc = qstate[q].n_cand;
   r.n_cand_pose = nc;
-  int tot = 0;
-  for (int s2 = 0; s2 < CC_NQLEV * CC_NPIV; s2++) tot += hit_cnt[q * CC_NQLEV * CC_NPIV + s2];
-  r.n_knn_hits = tot;
-  // candidates_ as an index vector; has_corr = corr_est_ != nullptr
-  unsigned char idx[CC_MAXCAND];
-  unsigned char has[CC_MAXCAND];
-  for (int k = 0; k < nc; k++) {
-    idx[k] = (unsigned char)k;
-    const int g = cands[k].gmm_idx;
-    has[k] = (g >= 0 && !((float)gres[g].corr_init < corr_lb)) ? 1 : 0;
-  }
+  r.n_knn_hits = s_tot;
+  // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592
   int p1 = 0, p2 = nc - 1;
   while (p1 <= p2) {
     if (!has[idx[p1]] && has[idx[p2]]) {
@@ -1344,16 +1365,14 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__
     // first std::sort: every anch_props_[0].correlation_ is still 0 -> comparator is always false
     ccsort::std_sort(idx, n, [](unsigned char, unsigned char) { return false; });
     const int pre = max_fine_opt < n ? max_fine_opt : n;
-    float corr[CC_MAXCAND];
-    for (int k = 0; k < nc; k++) corr[k] = 0.f;
-    for (int k = 0; k < pre; k++) corr[idx[k]] = (float)gres[cands[idx[k]].gmm_idx].corr_opt;
-    ccsort::std_sort(idx, pre, [&](unsigned char a, unsigned char b) { return corr[a] > corr[b]; });
-    const cc_dcand *best = &cands[idx[0]];
+    // candidates beyond `pre` keep correlation_ = 0
+    ccsort::std_sort(idx, pre, [&](unsigned char a, unsigned char b) { return corr_o[a] > corr_o[b]; });
+    const int b = idx[0];
     r.n_res = 1;
-    r.cand_gidx = best->gidx;
-    r.correlation = (double)corr[idx[0]];
+    r.cand_gidx = cands[b].gidx;
+    r.correlation = pre > 0 ? (double)corr_o[b] : 0.0;
     if (pre > 0) {
-      const cc_gmm_result *g = &gres[best->gmm_idx];
+      const cc_gmm_result *g = &gres[gm[b]];
       // T_best_ = Identity.rotate(theta).pretranslate(x, y); reported as (x, y, atan2(T10, T00))
       r.tf[0] = g->tf_opt[0];
       r.tf[1] = g->tf_opt[1];
