@@ -234,257 +234,402 @@ __device__ __forceinline__ bool cc_check_sim(const cc_contour_t &a, const cc_con
 
 __device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * x + y * y); }
 
-// returns true when the check passed all four stages; fills rec
-__device__ bool cc_check_cand(const cc_scan_desc_t *__restrict__ src, const cc_scan_desc_t *__restrict__ tgt, int level,
-                              int seq_src, int seq_tgt, const cc_check_params &P, int *stage, cc_pass_rec *rec) {
-  *stage = 0;
-  rec->flags = 0;
-  // (1/4) anchor similarity
-  if (!cc_check_sim(src->cont[level][seq_src], tgt->cont[level][seq_tgt], P.sim)) return false;
-  *stage = 1;
-  // (2/4) BCI::checkConstellSim
-  const cc_bci_t *bs = &src->bcis[level][seq_src];
-  const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
-  unsigned long long S[4], T[4];
-  for (int w = 0; w < 4; w++) {
-    S[w] = bs->dist_bin[w];
-    T[w] = bt->dist_bin[w];
-  }
-  int ov1 = 0, ov2 = 0, ov3 = 0;
-  for (int w = 0; w < 4; w++) {
-    const unsigned long long shl = (S[w] << 1) | (w > 0 ? (S[w - 1] >> 63) : 0ull);
-    const unsigned long long shr = (S[w] >> 1) | (w < 3 ? (S[w + 1] << 63) : 0ull);
-    ov1 += __popcll(S[w] & T[w]);
-    ov2 += __popcll(shl & T[w]);
-    ov3 += __popcll(shr & T[w]);
-  }
-  const int ovlp_sum = ov1 + ov2 + ov3;
-  int max_one = ov2 < ov3 ? ov3 : ov2;
-  max_one = ov1 < max_one ? max_one : ov1;
-  if (!(ovlp_sum >= P.lb.i_ovlp_sum && max_one >= P.lb.i_ovlp_max_one)) return false;
-  cc_dsp pp[CC_PP_MAX];
-  int npp = 0;
-  {
-    const int ns_seg = (int)bs->n_segs, nt_seg = (int)bt->n_segs;
-    int p11 = 0, p12;
-    for (int p2 = 0; p2 < nt_seg - 1; p2++) {
-      const int tb = bt->pts[bt->segs[p2]].bit_pos;
-      while (p11 < ns_seg - 1 && bs->pts[bs->segs[p11]].bit_pos < tb - 1) p11++;
-      p12 = p11;
-      while (p12 < ns_seg - 1 && bs->pts[bs->segs[p12]].bit_pos <= tb + 1) p12++;
-      for (int i = bt->segs[p2]; i < bt->segs[p2 + 1]; i++) {
-        for (int j = bs->segs[p11]; j < bs->segs[p12]; j++) {
-          if (npp < CC_PP_MAX) {
-            const cc_relpt_t r1 = bs->pts[j], r2 = bt->pts[i];
-            cc_dsp e;
-            e.l = r1.level;
-            e.s = r1.seq;
-            e.t = r2.seq;
-            e.pad = 0;
-            float od = r2.theta - r1.theta;
-            // clampAng<float> (tools/algos.h:49-51)
-            od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
-            e.orie = od;
-            pp[npp++] = e;
-          } else {
-            rec->flags |= 1;
-          }
-        }
-      }
-    }
-  }
-  if (npp == 0) return false;
-  ccsort::std_sort(pp, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
-  const float angular_range = (float)(3.14159265358979323846 / 16);
-  int beg = 0, longest = 1;
-  {
-    int p1 = 0, p2 = 0;
-    while (p1 < npp) {
-      const double v = (double)(pp[p2 % npp].orie - pp[p1].orie) + 2 * 3.14159265358979323846 * (double)(p2 / npp);
-      if (v > (double)angular_range)
-        p1++;
-      else {
-        if (p2 - p1 + 1 > longest) {
-          longest = p2 - p1 + 1;
-          beg = p1;
-        }
-        p2++;
-      }
-    }
-  }
-  if (longest < P.lb.i_in_ang_rng) return false;
-  *stage = 2;
-  // constellation = window pairs + the anchors
-  signed char cs[CC_CSTL_MAX][3];
-  int ncs = 0;
-  // (3/4) checkConstellCorrespSim part 1: individual similarity, in cstl_in order
-  for (int i = beg; i < beg + longest + 1; i++) {
-    int l, s, t;
-    if (i < beg + longest) {
-      const cc_dsp e = pp[i % npp];
-      l = e.l;
-      s = e.s;
-      t = e.t;
-    } else {
-      l = level;
-      s = seq_src;
-      t = seq_tgt;
-    }
-    if (cc_check_sim(src->cont[l][s], tgt->cont[l][t], P.sim)) {
-      if (ncs < CC_CSTL_MAX) {
-        cs[ncs][0] = (signed char)l;
-        cs[ncs][1] = (signed char)s;
-        cs[ncs][2] = (signed char)t;
-        ncs++;
-      } else {
-        rec->flags |= 1;
-      }
-    }
-  }
-  if (ncs < P.lb.i_indiv_sim) return false;
-  // part 2: orientation consistency
-  float shx = 0.f, shy = 0.f, thx = 0.f, thy = 0.f;
-  const int lim = ncs < 10 ? ncs : 10;
-  for (int i = 1; i < lim; i++)
-    for (int j = 0; j < i; j++) {
-      const float *pi = src->cont[cs[i][0]][cs[i][1]].pos_mean, *pj = src->cont[cs[j][0]][cs[j][1]].pos_mean;
-      const float cx = pi[0] - pj[0], cy = pi[1] - pj[1];
-      if (cc_norm2f(cx, cy) > cc_norm2f(shx, shy)) {
-        float z = cx * cx + cy * cy;
-        if (z > 0.f) {
-          const float s = sqrtf(z);
-          shx = cx / s;
-          shy = cy / s;
-        } else {
-          shx = cx;
-          shy = cy;
-        }
-        const float *qi = tgt->cont[cs[i][0]][cs[i][2]].pos_mean, *qj = tgt->cont[cs[j][0]][cs[j][2]].pos_mean;
-        const float tx = qi[0] - qj[0], ty = qi[1] - qj[1];
-        z = tx * tx + ty * ty;
-        if (z > 0.f) {
-          const float s = sqrtf(z);
-          thx = tx / s;
-          thy = ty / s;
-        } else {
-          thx = tx;
-          thy = ty;
-        }
-      }
-    }
-  int num_sim = ncs;
-  const float pi6 = (float)(3.14159265358979323846 / 6);
-  for (int i = 0; i < num_sim;) {
-    const cc_contour_t &sc = src->cont[cs[i][0]][cs[i][1]];
-    const cc_contour_t &tc = tgt->cont[cs[i][0]][cs[i][2]];
-    if (sc.ecc_feat && tc.ecc_feat) {
-      const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
-      const float theta_t = acosf(thx * tc.eig_vecs[2] + thy * tc.eig_vecs[3]);
-      const float pms = (float)(3.14159265358979323846 - (double)theta_s);
-      if (fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6) {
-        for (int c = 0; c < 3; c++) {
-          const signed char tmp = cs[i][c];
-          cs[i][c] = cs[num_sim - 1][c];
-          cs[num_sim - 1][c] = tmp;
-        }
-        num_sim--;
-        continue;
-      }
-    }
-    i++;
-  }
-  ncs = num_sim;
-  if (ncs < P.lb.i_orie_sim) return false;
-  *stage = 3;
-  // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form (see oracle notes / DESIGN.md)
-  const double one_over_n = 1.0 / (double)ncs;
-  double smx = 0, smy = 0, dmx = 0, dmy = 0;
-  for (int i = 0; i < ncs; i++) {
-    const float *a = src->cont[cs[i][0]][cs[i][1]].pos_mean, *b = tgt->cont[cs[i][0]][cs[i][2]].pos_mean;
-    smx += (double)a[0];
-    smy += (double)a[1];
-    dmx += (double)b[0];
-    dmy += (double)b[1];
-  }
-  smx = smx * one_over_n;
-  smy = smy * one_over_n;
-  dmx = dmx * one_over_n;
-  dmy = dmy * one_over_n;
-  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-  for (int i = 0; i < ncs; i++) {
-    const float *a = src->cont[cs[i][0]][cs[i][1]].pos_mean, *b = tgt->cont[cs[i][0]][cs[i][2]].pos_mean;
-    const double ax = (double)a[0] - smx, ay = (double)a[1] - smy, bx = (double)b[0] - dmx, by = (double)b[1] - dmy;
-    s00 += bx * ax;
-    s01 += bx * ay;
-    s10 += by * ax;
-    s11 += by * ay;
-  }
-  s00 *= one_over_n;
-  s01 *= one_over_n;
-  s10 *= one_over_n;
-  s11 *= one_over_n;
-  const double sn = s10 - s01, cs_ = s00 + s11;
-  const double nrm = sqrt(sn * sn + cs_ * cs_);
-  double r00 = 1, r10 = 0;
-  if (nrm > 0) {
-    r00 = cs_ / nrm;
-    r10 = sn / nrm;
-  }
-  rec->tf[0] = dmx - (r00 * smx + (-r10) * smy);
-  rec->tf[1] = dmy - (r10 * smx + r00 * smy);
-  rec->tf[2] = atan2(r10, r00);
-  rec->cs[0] = cos(rec->tf[2]);
-  rec->cs[1] = sin(rec->tf[2]);
-  rec->cs[2] = atan2(rec->cs[1], rec->cs[0]);
-  rec->n_pairs = ncs;
-  for (int w = 0; w < 7; w++) rec->bits[w] = 0ull;
-  for (int i = 0; i < ncs; i++) {
-    const int b = (cs[i][0] - 1) * 100 + cs[i][1] * 10 + cs[i][2];
-    rec->bits[b >> 6] |= 1ull << (b & 63);
-  }
-  return true;
-}
-
 #define CC_CHK_STRIDE (CC_NQLEV * CC_NPIV * CC_KNN_MAX)  // dense check slots per query: slot * CC_KNN_MAX + j
+#define CC_CHKB_PER_Q 8                                  // stage-B workgroups per query
 
-// grid = nq, block = 256.  hits/hit_cnt: K3 output.  Every (slot, j) of the query gets a dense record slot whose
-// index IS the reference's candidate iteration order (levels -> anchors -> ascending distance, contour_db.h:721-771),
-// so the merge kernel can replay the passing checks in order without sorting.
+// Stage A (one lane per check slot): (1/4) anchor ContourView::checkSim and the popcount part of (2/4)
+// BCI::checkConstellSim (ovlp_sum / max_one bars).  Survivors are written as an ORDERED list per query; the slot
+// index t = slot * CC_KNN_MAX + j IS the reference's candidate iteration order (levels -> anchors -> ascending
+// distance, contour_db.h:721-771), so later stages can replay checks in order without sorting.
+// grid = nq, block = 256
 __global__ void __launch_bounds__(256)
-cc_k_check(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
-           const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, cc_pass_rec *__restrict__ pass,
-           unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt /*[nq][4]: n_pass, chk1, chk2, chk3*/) {
-  __shared__ int s_n[4];
+cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
+             const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, unsigned short *__restrict__ surv,
+             int *__restrict__ surv_cnt, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt /*[nq][4]*/) {
+  __shared__ int wcnt[4];
+  __shared__ int s_base, s_chk1;
   const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int NS = CC_NQLEV * CC_NPIV;
-  if (tid < 4) s_n[tid] = 0;
-  __syncthreads();
-  const cc_scan_desc_t *tgt = qdesc + q;
-  for (int t = tid; t < CC_CHK_STRIDE; t += nt) {
-    const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
-    bool ok = false;
-    if (j < hit_cnt[q * NS + slot]) {
-      const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
-      const int seq_tgt = slot % CC_NPIV;
-      cc_pass_rec rec;
-      int stage;
-      ok = cc_check_cand(db_desc + h.gidx, tgt, h.level, h.seq, seq_tgt, P, &stage, &rec);
-      if (stage >= 1) atomicAdd(&s_n[1], 1);
-      if (stage >= 2) atomicAdd(&s_n[2], 1);
-      if (stage >= 3) atomicAdd(&s_n[3], 1);
-      if (ok) {
-        atomicAdd(&s_n[0], 1);
-        rec.q = q;
-        rec.order = t;
-        rec.gidx = h.gidx;
-        rec.pad = 0;
-        pass[(size_t)q * CC_CHK_STRIDE + t] = rec;
-      }
-    }
-    pass_ok[(size_t)q * CC_CHK_STRIDE + t] = ok ? 1 : 0;
+  const int wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    s_base = 0;
+    s_chk1 = 0;
   }
   __syncthreads();
-  if (tid < 4) pass_cnt[q * 4 + tid] = s_n[tid];
+  const cc_scan_desc_t *tgt = qdesc + q;
+  for (int t0 = 0; t0 < CC_CHK_STRIDE; t0 += nt) {
+    const int t = t0 + tid;
+    bool anchor_ok = false, keep = false;
+    if (t < CC_CHK_STRIDE) {
+      const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
+      if (j < hit_cnt[q * NS + slot]) {
+        const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+        const int seq_tgt = slot % CC_NPIV;
+        const cc_scan_desc_t *src = db_desc + h.gidx;
+        anchor_ok = cc_check_sim(src->cont[h.level][h.seq], tgt->cont[h.level][seq_tgt], P.sim);
+        if (anchor_ok) {
+          const cc_bci_t *bs = &src->bcis[h.level][h.seq];
+          const cc_bci_t *bt = &tgt->bcis[h.level][seq_tgt];
+          unsigned long long S[4], T[4];
+          for (int w = 0; w < 4; w++) {
+            S[w] = bs->dist_bin[w];
+            T[w] = bt->dist_bin[w];
+          }
+          int ov1 = 0, ov2 = 0, ov3 = 0;
+          for (int w = 0; w < 4; w++) {
+            const unsigned long long shl = (S[w] << 1) | (w > 0 ? (S[w - 1] >> 63) : 0ull);
+            const unsigned long long shr = (S[w] >> 1) | (w < 3 ? (S[w + 1] << 63) : 0ull);
+            ov1 += __popcll(S[w] & T[w]);
+            ov2 += __popcll(shl & T[w]);
+            ov3 += __popcll(shr & T[w]);
+          }
+          const int ovlp_sum = ov1 + ov2 + ov3;
+          int max_one = ov2 < ov3 ? ov3 : ov2;
+          max_one = ov1 < max_one ? max_one : ov1;
+          keep = (ovlp_sum >= P.lb.i_ovlp_sum && max_one >= P.lb.i_ovlp_max_one);
+        }
+      }
+      pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 0;
+    }
+    const unsigned long long mk = __ballot(keep), ma = __ballot(anchor_ok);
+    if (lane == 0) {
+      wcnt[wave] = __popcll(mk);
+      atomicAdd(&s_chk1, __popcll(ma));
+    }
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += wcnt[w];
+    off += __popcll(mk & ((1ull << lane) - 1ull));
+    if (keep) surv[(size_t)q * CC_CHK_STRIDE + off] = (unsigned short)t;
+    __syncthreads();
+    if (tid == 0) s_base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    surv_cnt[q] = s_base;
+    pass_cnt[q * 4 + 0] = 0;
+    pass_cnt[q * 4 + 1] = s_chk1;
+    pass_cnt[q * 4 + 2] = 0;
+    pass_cnt[q * 4 + 3] = 0;
+  }
+}
+
+// Stage B (one wave per surviving check): the rest of BCI::checkConstellSim (neighbour pairing, common-rotation window),
+// checkConstellCorrespSim and getTFFromConstell.  Parallel where the reference's result does not depend on order,
+// sequential (lane 0, on LDS) where it does.
+struct cc_chkb_lds {
+  cc_relpt_t sp[CC_BCI_MAXPTS], tp[CC_BCI_MAXPTS];
+  unsigned short off[CC_BCI_MAXPTS + 1];   // first potential pair of each tgt point
+  unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
+  cc_dsp pp[CC_PP_MAX];                     // generation order
+  cc_dsp sorted[CC_PP_MAX];
+  signed char cs[CC_CSTL_MAX][3];
+  unsigned char keepf[CC_CSTL_MAX];
+  float spm[CC_CSTL_MAX][2], tpm[CC_CSTL_MAX][2];  // pos_mean of the constellation's contours
+  int misc[8];
+};
+
+__global__ void __launch_bounds__(64)
+cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
+             const cc_knn_hit_t *__restrict__ hits, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
+             cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt) {
+  __shared__ cc_chkb_lds L;
+  const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q, lane = threadIdx.x;
+  const int NS = CC_NQLEV * CC_NPIV;
+  const cc_scan_desc_t *tgt = qdesc + q;
+  const int ns = surv_cnt[q];
+  for (int si = part; si < ns; si += CC_CHKB_PER_Q) {
+    const int t = surv[(size_t)q * CC_CHK_STRIDE + si];
+    const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
+    const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+    const int level = h.level, seq_src = h.seq, seq_tgt = slot % CC_NPIV;
+    const cc_scan_desc_t *src = db_desc + h.gidx;
+    const cc_bci_t *bs = &src->bcis[level][seq_src];
+    const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
+    const int nsp = bs->n_pts, ntp = bt->n_pts;
+    __syncthreads();
+    if (lane < nsp) L.sp[lane] = bs->pts[lane];
+    if (lane < ntp) L.tp[lane] = bt->pts[lane];
+    __syncthreads();
+    // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1,
+    // in src order; src points are sorted by bit_pos so the range is contiguous.
+    int cnt_i = 0;
+    if (lane < ntp) {
+      const int tb = L.tp[lane].bit_pos;
+      int lo = 0;
+      while (lo < nsp && L.sp[lo].bit_pos < tb - 1) lo++;
+      int hi = lo;
+      while (hi < nsp && L.sp[hi].bit_pos <= tb + 1) hi++;
+      L.lo[lane] = (unsigned char)lo;
+      L.hi[lane] = (unsigned char)hi;
+      cnt_i = hi - lo;
+    }
+    // exclusive prefix over tgt points
+    int incl = cnt_i;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane < ntp) L.off[lane] = (unsigned short)(incl - cnt_i);
+    const int npp_all = __shfl(incl, 63);
+    int flags = 0;
+    int npp = npp_all;
+    if (npp > CC_PP_MAX) {
+      npp = CC_PP_MAX;
+      flags |= 1;
+    }
+    __syncthreads();
+    if (lane < ntp) {
+      const cc_relpt_t r2 = L.tp[lane];
+      int o = L.off[lane];
+      for (int sj = L.lo[lane]; sj < L.hi[lane]; sj++, o++) {
+        if (o >= CC_PP_MAX) break;
+        const cc_relpt_t r1 = L.sp[sj];
+        cc_dsp e;
+        e.l = r1.level;
+        e.s = r1.seq;
+        e.t = r2.seq;
+        e.pad = 0;
+        float od = r2.theta - r1.theta;
+        od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
+        e.orie = od;
+        L.pp[o] = e;
+      }
+    }
+    __syncthreads();
+    if (npp == 0) continue;
+    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> parallel rank; otherwise replay it.
+    bool tie = false;
+    for (int k = lane; k < npp; k += 64) {
+      const float key = L.pp[k].orie;
+      int rk = 0;
+      for (int m = 0; m < npp; m++) {
+        const float km = L.pp[m].orie;
+        rk += (km < key) ? 1 : 0;
+        tie |= (km == key && m != k);
+      }
+      L.sorted[rk] = L.pp[k];  // only meaningful when there is no tie
+    }
+    const bool any_tie = __ballot(tie) != 0ull;
+    __syncthreads();
+    if (any_tie) {
+      for (int k = lane; k < npp; k += 64) L.sorted[k] = L.pp[k];
+      __syncthreads();
+      if (lane == 0) ccsort::std_sort(L.sorted, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
+      __syncthreads();
+    }
+    // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
+    // that attains the maximum length (what the two-pointer loop records)
+    const float angular_range = (float)(3.14159265358979323846 / 16);
+    int bestL = 0, bestP = 0x7fffffff;
+    for (int p1 = lane; p1 < npp; p1 += 64) {
+      const float v1 = L.sorted[p1].orie;
+      int a = p1, b = p1 + npp - 1;  // window [p1, p2], p2 in [p1, p1+npp)
+      while (a < b) {                // largest p2 with valid(p2); valid is monotone in p2
+        const int mid = (a + b + 1) >> 1;
+        const double v = (double)(L.sorted[mid % npp].orie - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
+        if (v > (double)angular_range)
+          b = mid - 1;
+        else
+          a = mid;
+      }
+      const int len = a - p1 + 1;
+      if (len > bestL || (len == bestL && p1 < bestP)) {
+        bestL = len;
+        bestP = p1;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const int oL = __shfl_xor(bestL, o), oP = __shfl_xor(bestP, o);
+      if (oL > bestL || (oL == bestL && oP < bestP)) {
+        bestL = oL;
+        bestP = oP;
+      }
+    }
+    int longest = bestL, beg = bestP;
+    if (longest <= 1) {  // the loop starts from longest = 1, beg = 0 and only records strictly longer windows
+      longest = 1;
+      beg = 0;
+    }
+    if (longest < P.lb.i_in_ang_rng) continue;
+    if (lane == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
+    // (3/4) individual similarity of the window pairs + the anchors, in cstl_in order
+    int n_in = longest + 1;
+    if (n_in > 64) {  // one lane per pair below
+      n_in = 64;
+      flags |= 1;
+    }
+    int l = 0, s_ = 0, t_ = 0;
+    bool sim = false;
+    if (lane < n_in) {
+      if (lane < longest && lane < n_in - 1) {
+        const cc_dsp e = L.sorted[(beg + lane) % npp];
+        l = e.l;
+        s_ = e.s;
+        t_ = e.t;
+      } else {
+        l = level;
+        s_ = seq_src;
+        t_ = seq_tgt;
+      }
+      sim = cc_check_sim(src->cont[l][s_], tgt->cont[l][t_], P.sim);
+    }
+    const unsigned long long ms = __ballot(sim);
+    int ncs = __popcll(ms);
+    if (ncs > CC_CSTL_MAX) {
+      ncs = CC_CSTL_MAX;
+      flags |= 1;
+    }
+    if (ncs < P.lb.i_indiv_sim) continue;
+    __syncthreads();
+    if (sim) {
+      const int o = __popcll(ms & ((1ull << lane) - 1ull));
+      if (o < CC_CSTL_MAX) {
+        L.cs[o][0] = (signed char)l;
+        L.cs[o][1] = (signed char)s_;
+        L.cs[o][2] = (signed char)t_;
+        const cc_contour_t &sc = src->cont[l][s_];
+        const cc_contour_t &tc = tgt->cont[l][t_];
+        L.spm[o][0] = sc.pos_mean[0];
+        L.spm[o][1] = sc.pos_mean[1];
+        L.tpm[o][0] = tc.pos_mean[0];
+        L.tpm[o][1] = tc.pos_mean[1];
+      }
+    }
+    __syncthreads();
+    // part 2: the "shaft" (sequential: every update renormalises the running vector), contour_mng.h:1173-1184
+    float shx = 0.f, shy = 0.f, thx = 0.f, thy = 0.f;
+    {
+      const int lim = ncs < 10 ? ncs : 10;
+      for (int i = 1; i < lim; i++)
+        for (int jj = 0; jj < i; jj++) {
+          const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
+          if (cc_norm2f(cx, cy) > cc_norm2f(shx, shy)) {
+            float z = cx * cx + cy * cy;
+            if (z > 0.f) {
+              const float sq = sqrtf(z);
+              shx = cx / sq;
+              shy = cy / sq;
+            } else {
+              shx = cx;
+              shy = cy;
+            }
+            const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
+            z = tx * tx + ty * ty;
+            if (z > 0.f) {
+              const float sq = sqrtf(z);
+              thx = tx / sq;
+              thy = ty / sq;
+            } else {
+              thx = tx;
+              thy = ty;
+            }
+          }
+        }
+    }
+    // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
+    if (lane < ncs) {
+      const cc_contour_t &sc = src->cont[L.cs[lane][0]][L.cs[lane][1]];
+      const cc_contour_t &tc = tgt->cont[L.cs[lane][0]][L.cs[lane][2]];
+      bool rm = false;
+      if (sc.ecc_feat && tc.ecc_feat) {
+        const float pi6 = (float)(3.14159265358979323846 / 6);
+        const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
+        const float theta_t = acosf(thx * tc.eig_vecs[2] + thy * tc.eig_vecs[3]);
+        const float pms = (float)(3.14159265358979323846 - (double)theta_s);
+        rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
+      }
+      L.keepf[lane] = rm ? 0 : 1;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int num_sim = ncs;
+      for (int i = 0; i < num_sim;) {
+        if (!L.keepf[i]) {
+          for (int c = 0; c < 3; c++) {
+            const signed char tmp = L.cs[i][c];
+            L.cs[i][c] = L.cs[num_sim - 1][c];
+            L.cs[num_sim - 1][c] = tmp;
+          }
+          for (int c = 0; c < 2; c++) {
+            float tmp = L.spm[i][c];
+            L.spm[i][c] = L.spm[num_sim - 1][c];
+            L.spm[num_sim - 1][c] = tmp;
+            tmp = L.tpm[i][c];
+            L.tpm[i][c] = L.tpm[num_sim - 1][c];
+            L.tpm[num_sim - 1][c] = tmp;
+          }
+          const unsigned char tk = L.keepf[i];
+          L.keepf[i] = L.keepf[num_sim - 1];
+          L.keepf[num_sim - 1] = tk;
+          num_sim--;
+          continue;
+        }
+        i++;
+      }
+      L.misc[0] = num_sim;
+    }
+    __syncthreads();
+    ncs = L.misc[0];
+    if (ncs < P.lb.i_orie_sim) continue;
+    // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order (lane 0)
+    if (lane == 0) {
+      atomicAdd(&pass_cnt[q * 4 + 3], 1);
+      atomicAdd(&pass_cnt[q * 4 + 0], 1);
+      const double one_over_n = 1.0 / (double)ncs;
+      double smx = 0, smy = 0, dmx = 0, dmy = 0;
+      for (int i = 0; i < ncs; i++) {
+        smx += (double)L.spm[i][0];
+        smy += (double)L.spm[i][1];
+        dmx += (double)L.tpm[i][0];
+        dmy += (double)L.tpm[i][1];
+      }
+      smx = smx * one_over_n;
+      smy = smy * one_over_n;
+      dmx = dmx * one_over_n;
+      dmy = dmy * one_over_n;
+      double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+      for (int i = 0; i < ncs; i++) {
+        const double ax = (double)L.spm[i][0] - smx, ay = (double)L.spm[i][1] - smy;
+        const double bx = (double)L.tpm[i][0] - dmx, by = (double)L.tpm[i][1] - dmy;
+        s00 += bx * ax;
+        s01 += bx * ay;
+        s10 += by * ax;
+        s11 += by * ay;
+      }
+      s00 *= one_over_n;
+      s01 *= one_over_n;
+      s10 *= one_over_n;
+      s11 *= one_over_n;
+      const double sn = s10 - s01, cs_ = s00 + s11;
+      const double nrm = sqrt(sn * sn + cs_ * cs_);
+      double r00 = 1, r10 = 0;
+      if (nrm > 0) {
+        r00 = cs_ / nrm;
+        r10 = sn / nrm;
+      }
+      cc_pass_rec rec;
+      rec.q = q;
+      rec.order = t;
+      rec.gidx = h.gidx;
+      rec.flags = flags;
+      rec.pad = 0;
+      rec.tf[0] = dmx - (r00 * smx + (-r10) * smy);
+      rec.tf[1] = dmy - (r10 * smx + r00 * smy);
+      rec.tf[2] = atan2(r10, r00);
+      rec.cs[0] = cos(rec.tf[2]);
+      rec.cs[1] = sin(rec.tf[2]);
+      rec.cs[2] = atan2(rec.cs[1], rec.cs[0]);
+      rec.n_pairs = ncs;
+      for (int w = 0; w < 7; w++) rec.bits[w] = 0ull;
+      for (int i = 0; i < ncs; i++) {
+        const int b = (L.cs[i][0] - 1) * 100 + L.cs[i][1] * 10 + L.cs[i][2];
+        rec.bits[b >> 6] |= 1ull << (b & 63);
+      }
+      pass[(size_t)q * CC_CHK_STRIDE + t] = rec;
+      pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
