@@ -354,15 +354,19 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1,
     // in src order; src points are sorted by bit_pos so the range is contiguous.
     int cnt_i = 0;
-    if (lane < ntp) {
-      const int tb = L.tp[lane].bit_pos;
-      int lo = 0;
-      while (lo < nsp && L.sp[lo].bit_pos < tb - 1) lo++;
-      int hi = lo;
-      while (hi < nsp && L.sp[hi].bit_pos <= tb + 1) hi++;
-      L.lo[lane] = (unsigned char)lo;
-      L.hi[lane] = (unsigned char)hi;
-      cnt_i = hi - lo;
+    {
+      const int tb = lane < ntp ? (int)L.tp[lane].bit_pos : 0;
+      int lo = 0, hi = 0;
+      for (int sj = 0; sj < nsp; sj++) {  // src points are sorted by bit_pos: counts give the contiguous range
+        const int sb = L.sp[sj].bit_pos;
+        lo += (sb < tb - 1) ? 1 : 0;
+        hi += (sb <= tb + 1) ? 1 : 0;
+      }
+      if (lane < ntp) {
+        L.lo[lane] = (unsigned char)lo;
+        L.hi[lane] = (unsigned char)hi;
+        cnt_i = hi - lo;
+      }
     }
     // exclusive prefix over tgt points
     int incl = cnt_i;
@@ -497,41 +501,66 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       }
     }
     __syncthreads();
-    // part 2: the "shaft" (sequential: every update renormalises the running vector), contour_mng.h:1173-1184
+    // part 2: the "shaft" (contour_mng.h:1173-1184).  The reference scans the (i, j<i) pairs of the first <=10 entries in
+    // order, replacing the running (normalised) src vector whenever the candidate is longer than it.  Candidate lengths and
+    // the length the running vector would have after the update are computed one pair per lane; the scan itself is a
+    // 45-step uniform loop over lane broadcasts.
     float shx = 0.f, shy = 0.f, thx = 0.f, thy = 0.f;
     {
       const int lim = ncs < 10 ? ncs : 10;
-      for (int i = 1; i < lim; i++)
-        for (int jj = 0; jj < i; jj++) {
-          const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
-          if (cc_norm2f(cx, cy) > cc_norm2f(shx, shy)) {
-            float z = cx * cx + cy * cy;
-            if (z > 0.f) {
-              const float sq = sqrtf(z);
-              shx = cx / sq;
-              shy = cy / sq;
-            } else {
-              shx = cx;
-              shy = cy;
-            }
-            const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
-            z = tx * tx + ty * ty;
-            if (z > 0.f) {
-              const float sq = sqrtf(z);
-              thx = tx / sq;
-              thy = ty / sq;
-            } else {
-              thx = tx;
-              thy = ty;
-            }
-          }
+      const int npair = lim * (lim - 1) / 2;
+      float cn = 0.f, nn = 0.f, ux = 0.f, uy = 0.f, vx = 0.f, vy = 0.f;
+      if (lane < npair) {
+        int i = 1, acc = 0;  // pair index -> (i, jj) in the reference's loop order: i = 1.., jj = 0..i-1
+        while (acc + i <= lane) {
+          acc += i;
+          i++;
         }
+        const int jj = lane - acc;
+        const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
+        cn = cc_norm2f(cx, cy);
+        float z = cx * cx + cy * cy;
+        if (z > 0.f) {
+          const float sq = sqrtf(z);
+          ux = cx / sq;
+          uy = cy / sq;
+        } else {
+          ux = cx;
+          uy = cy;
+        }
+        nn = cc_norm2f(ux, uy);
+        const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
+        z = tx * tx + ty * ty;
+        if (z > 0.f) {
+          const float sq = sqrtf(z);
+          vx = tx / sq;
+          vy = ty / sq;
+        } else {
+          vx = tx;
+          vy = ty;
+        }
+      }
+      float sn = 0.f;  // norm of the running shaft_src (initially the zero vector)
+      int last = -1;
+      for (int k = 0; k < npair; k++) {
+        const float c_k = cc_lane_bcast(cn, k);
+        if (c_k > sn) {
+          sn = cc_lane_bcast(nn, k);
+          last = k;
+        }
+      }
+      if (last >= 0) {
+        shx = cc_lane_bcast(ux, last);
+        shy = cc_lane_bcast(uy, last);
+        thx = cc_lane_bcast(vx, last);
+        thy = cc_lane_bcast(vy, last);
+      }
     }
     // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
+    bool rm = false;
     if (lane < ncs) {
       const cc_contour_t &sc = src->cont[L.cs[lane][0]][L.cs[lane][1]];
       const cc_contour_t &tc = tgt->cont[L.cs[lane][0]][L.cs[lane][2]];
-      bool rm = false;
       if (sc.ecc_feat && tc.ecc_feat) {
         const float pi6 = (float)(3.14159265358979323846 / 6);
         const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
@@ -539,96 +568,100 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         const float pms = (float)(3.14159265358979323846 - (double)theta_s);
         rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
       }
-      L.keepf[lane] = rm ? 0 : 1;
     }
-    __syncthreads();
-    if (lane == 0) {
-      int num_sim = ncs;
-      for (int i = 0; i < num_sim;) {
-        if (!L.keepf[i]) {
-          for (int c = 0; c < 3; c++) {
-            const signed char tmp = L.cs[i][c];
-            L.cs[i][c] = L.cs[num_sim - 1][c];
-            L.cs[num_sim - 1][c] = tmp;
+    const unsigned long long rmm = __ballot(rm);
+    // element order after the removal loop: position -> original index (identity when nothing is removed)
+    int my_src = lane;
+    if (rmm) {
+      __syncthreads();
+      if (lane < ncs) L.keepf[lane] = (unsigned char)lane;  // reuse as the index vector
+      __syncthreads();
+      if (lane == 0) {
+        int num_sim = ncs;
+        for (int i = 0; i < num_sim;) {
+          const int o = L.keepf[i];
+          if ((rmm >> o) & 1ull) {
+            L.keepf[i] = L.keepf[num_sim - 1];  // std::swap(cstl_out[i], cstl_out[num_sim-1]); the tail is erased afterwards
+            num_sim--;
+            continue;
           }
-          for (int c = 0; c < 2; c++) {
-            float tmp = L.spm[i][c];
-            L.spm[i][c] = L.spm[num_sim - 1][c];
-            L.spm[num_sim - 1][c] = tmp;
-            tmp = L.tpm[i][c];
-            L.tpm[i][c] = L.tpm[num_sim - 1][c];
-            L.tpm[num_sim - 1][c] = tmp;
-          }
-          const unsigned char tk = L.keepf[i];
-          L.keepf[i] = L.keepf[num_sim - 1];
-          L.keepf[num_sim - 1] = tk;
-          num_sim--;
-          continue;
+          i++;
         }
-        i++;
+        L.misc[0] = num_sim;
       }
-      L.misc[0] = num_sim;
+      __syncthreads();
+      ncs = L.misc[0];
+      if (lane < ncs) my_src = L.keepf[lane];
+    }
+    if (ncs < P.lb.i_orie_sim) continue;
+    // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order via lane broadcasts
+    float ax_ = 0.f, ay_ = 0.f, bx_ = 0.f, by_ = 0.f;
+    int bit = 0;
+    if (lane < ncs) {
+      ax_ = L.spm[my_src][0];
+      ay_ = L.spm[my_src][1];
+      bx_ = L.tpm[my_src][0];
+      by_ = L.tpm[my_src][1];
+      bit = (L.cs[my_src][0] - 1) * 100 + L.cs[my_src][1] * 10 + L.cs[my_src][2];
     }
     __syncthreads();
-    ncs = L.misc[0];
-    if (ncs < P.lb.i_orie_sim) continue;
-    // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order (lane 0)
+    if (lane < 8) ((unsigned long long *)L.sorted)[lane] = 0ull;  // pair bitmap staging (sorted[] is dead now)
+    __syncthreads();
+    if (lane < ncs) atomicOr(&((unsigned long long *)L.sorted)[bit >> 6], 1ull << (bit & 63));
+    const double one_over_n = 1.0 / (double)ncs;
+    double smx = 0, smy = 0, dmx = 0, dmy = 0;
+    for (int i = 0; i < ncs; i++) {
+      smx += (double)cc_lane_bcast(ax_, i);
+      smy += (double)cc_lane_bcast(ay_, i);
+      dmx += (double)cc_lane_bcast(bx_, i);
+      dmy += (double)cc_lane_bcast(by_, i);
+    }
+    smx = smx * one_over_n;
+    smy = smy * one_over_n;
+    dmx = dmx * one_over_n;
+    dmy = dmy * one_over_n;
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    for (int i = 0; i < ncs; i++) {
+      const double ax = (double)cc_lane_bcast(ax_, i) - smx, ay = (double)cc_lane_bcast(ay_, i) - smy;
+      const double bx = (double)cc_lane_bcast(bx_, i) - dmx, by = (double)cc_lane_bcast(by_, i) - dmy;
+      s00 += bx * ax;
+      s01 += bx * ay;
+      s10 += by * ax;
+      s11 += by * ay;
+    }
+    s00 *= one_over_n;
+    s01 *= one_over_n;
+    s10 *= one_over_n;
+    s11 *= one_over_n;
+    const double sn2 = s10 - s01, cs_ = s00 + s11;
+    const double nrm = sqrt(sn2 * sn2 + cs_ * cs_);
+    double r00 = 1, r10 = 0;
+    if (nrm > 0) {
+      r00 = cs_ / nrm;
+      r10 = sn2 / nrm;
+    }
+    __syncthreads();
     if (lane == 0) {
       atomicAdd(&pass_cnt[q * 4 + 3], 1);
       atomicAdd(&pass_cnt[q * 4 + 0], 1);
-      const double one_over_n = 1.0 / (double)ncs;
-      double smx = 0, smy = 0, dmx = 0, dmy = 0;
-      for (int i = 0; i < ncs; i++) {
-        smx += (double)L.spm[i][0];
-        smy += (double)L.spm[i][1];
-        dmx += (double)L.tpm[i][0];
-        dmy += (double)L.tpm[i][1];
-      }
-      smx = smx * one_over_n;
-      smy = smy * one_over_n;
-      dmx = dmx * one_over_n;
-      dmy = dmy * one_over_n;
-      double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-      for (int i = 0; i < ncs; i++) {
-        const double ax = (double)L.spm[i][0] - smx, ay = (double)L.spm[i][1] - smy;
-        const double bx = (double)L.tpm[i][0] - dmx, by = (double)L.tpm[i][1] - dmy;
-        s00 += bx * ax;
-        s01 += bx * ay;
-        s10 += by * ax;
-        s11 += by * ay;
-      }
-      s00 *= one_over_n;
-      s01 *= one_over_n;
-      s10 *= one_over_n;
-      s11 *= one_over_n;
-      const double sn = s10 - s01, cs_ = s00 + s11;
-      const double nrm = sqrt(sn * sn + cs_ * cs_);
-      double r00 = 1, r10 = 0;
-      if (nrm > 0) {
-        r00 = cs_ / nrm;
-        r10 = sn / nrm;
-      }
-      cc_pass_rec rec;
-      rec.q = q;
-      rec.order = t;
-      rec.gidx = h.gidx;
-      rec.flags = flags;
-      rec.pad = 0;
-      rec.tf[0] = dmx - (r00 * smx + (-r10) * smy);
-      rec.tf[1] = dmy - (r10 * smx + r00 * smy);
-      rec.tf[2] = atan2(r10, r00);
-      rec.cs[0] = cos(rec.tf[2]);
-      rec.cs[1] = sin(rec.tf[2]);
-      rec.cs[2] = atan2(rec.cs[1], rec.cs[0]);
-      rec.n_pairs = ncs;
-      for (int w = 0; w < 7; w++) rec.bits[w] = 0ull;
-      for (int i = 0; i < ncs; i++) {
-        const int b = (L.cs[i][0] - 1) * 100 + L.cs[i][1] * 10 + L.cs[i][2];
-        rec.bits[b >> 6] |= 1ull << (b & 63);
-      }
-      pass[(size_t)q * CC_CHK_STRIDE + t] = rec;
+      cc_pass_rec *rec = &pass[(size_t)q * CC_CHK_STRIDE + t];
+      rec->q = q;
+      rec->order = t;
+      rec->gidx = h.gidx;
+      rec->n_pairs = ncs;
+      rec->flags = flags;
+      rec->pad = 0;
+      const double th = atan2(r10, r00);
+      const double c_ = cos(th), s_2 = sin(th);
+      rec->tf[0] = dmx - (r00 * smx + (-r10) * smy);
+      rec->tf[1] = dmy - (r10 * smx + r00 * smy);
+      rec->tf[2] = th;
+      rec->cs[0] = c_;
+      rec->cs[1] = s_2;
+      rec->cs[2] = atan2(s_2, c_);
       pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 1;
     }
+    if (lane < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[lane] = ((unsigned long long *)L.sorted)[lane];
   }
 }
 
