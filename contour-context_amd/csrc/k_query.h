@@ -318,6 +318,7 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
 // checkConstellCorrespSim and getTFFromConstell.  Parallel where the reference's result does not depend on order,
 // sequential (lane 0, on LDS) where it does.
 struct cc_chkb_lds {
+  unsigned long long bitsw[8];             // pair bitmap staging (first member: 8-byte aligned for the 64-bit LDS atomics)
   cc_relpt_t sp[CC_BCI_MAXPTS], tp[CC_BCI_MAXPTS];
   unsigned short off[CC_BCI_MAXPTS + 1];   // first potential pair of each tgt point
   unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
@@ -605,9 +606,9 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       bit = (L.cs[my_src][0] - 1) * 100 + L.cs[my_src][1] * 10 + L.cs[my_src][2];
     }
     __syncthreads();
-    if (lane < 8) ((unsigned long long *)L.sorted)[lane] = 0ull;  // pair bitmap staging (sorted[] is dead now)
+    if (lane < 8) L.bitsw[lane] = 0ull;
     __syncthreads();
-    if (lane < ncs) atomicOr(&((unsigned long long *)L.sorted)[bit >> 6], 1ull << (bit & 63));
+    if (lane < ncs) atomicOr(&L.bitsw[bit >> 6], 1ull << (bit & 63));
     const double one_over_n = 1.0 / (double)ncs;
     double smx = 0, smy = 0, dmx = 0, dmy = 0;
     for (int i = 0; i < ncs; i++) {
@@ -661,7 +662,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       rec->cs[2] = atan2(s_2, c_);
       pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 1;
     }
-    if (lane < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[lane] = ((unsigned long long *)L.sorted)[lane];
+    if (lane < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[lane] = L.bitsw[lane];
   }
 }
 
