@@ -863,8 +863,9 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
 // ------------------------------------------------------------------------------------------------
 // LDS caps of the GMM kernel: the common instance keeps 8 workgroups per CU resident; problems that
 // overflow it (flags bit0/bit1) are re-run by the host with the large instance.
-#define CC_GMM_ECAP_S 32
-#define CC_GMM_PCAP_S 1024
+#define CC_GMM_ECAP_S 24
+#define CC_GMM_PCAP_S 512
+#define CC_GMM_PPW_S 4     // problems per wave in the common instance (16 lanes each)
 #define CC_GMM_ECAP_L 128  // ellipses per (side, level) held in LDS
 #define CC_GMM_PCAP_L 4096 // selected (src,tgt) ellipse pairs
 
@@ -878,10 +879,8 @@ struct cc_gmm_result {
   int flags;       // bit0: ellipse cap hit, bit1: pair cap hit, bit2: contour table truncated (CC_MAXC)
 };
 
-struct cc_ell {
-  double c00, c01, c10, c11, mx, my, w;
-  float maj;
-  int pad;
+struct cc_ell {  // values are f32 in the reference too (getManualCov, pos_mean_, cell_cnt_), widened to f64 at use
+  float c00, c01, c10, c11, mx, my, w, maj;
 };
 
 struct cc_jet {
@@ -907,12 +906,9 @@ __device__ __forceinline__ cc_jet jexp(const cc_jet &f) {
   return cc_jet{t, t * f.v0, t * f.v1, t * f.v2};
 }
 
-__device__ __forceinline__ double cc_wave_sum_d(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance)
+// LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance).  A wave handles 64/G
+// problems at once, G lanes each (G = 16 for the common instance, 64 for the large-cap instance); every cross-lane
+// operation below is G-wide, so problems in the same wave may diverge freely.
 struct cc_gmm_lds {
   cc_ell *ell;      // [2][CC_GMM_LEVELS][ecap]   side 0 = src, 1 = tgt
   unsigned *pairs;  // [pcap]  (li << 28) | (si << 14) | ti
@@ -920,46 +916,59 @@ struct cc_gmm_lds {
   int *n_pairs;
   int *flags;
   int ecap, pcap;
+  int G, sl;        // lanes per problem, this lane's index within its group
   __device__ __forceinline__ const cc_ell &E(int side, int li, int i) const { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
   __device__ __forceinline__ cc_ell &E(int side, int li, int i) { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
 };
 #define CC_GMM_LDS_BYTES(ecap, pcap) (2 * CC_GMM_LEVELS * (ecap) * sizeof(cc_ell) + (pcap) * 4 + 64)
 
+__device__ __forceinline__ double cc_group_sum_d(double v, int G) {
+  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+// LDS hand-off between the lanes of one group: the lanes of a wave run in lockstep, so only the compiler has to be kept
+// from reordering; the G-wide shuffle doubles as the rendezvous under the CPU test harness.
+__device__ __forceinline__ void cc_group_sync(int G) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  (void)__shfl(0, 0, G);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the whole wave
 __device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_grad, double *cost, double grad[3]) {
-  const int lane = threadIdx.x & 63;
+  const int G = S->G, sl = S->sl;
   const cc_jet x = cc_jet{p[0], 1, 0, 0}, y = cc_jet{p[1], 0, 1, 0};
   const double ct = cos(p[2]), st = sin(p[2]);
   const cc_jet jc_ = cc_jet{ct, 0, 0, -st}, js_ = cc_jet{st, 0, 0, ct};
   const cc_jet R00 = jc_, R01 = -js_, R10 = js_, R11 = jc_;
   cc_jet acc = jc(0.0);
   const int np = *S->n_pairs;
-  for (int i = lane; i < np; i += 64) {
+  for (int i = sl; i < np; i += G) {
     const unsigned pr = S->pairs[i];
     const int li = pr >> 28, si = (pr >> 14) & 0x3FFF, ti = pr & 0x3FFF;
     const cc_ell es = S->E(0, li, si), et = S->E(1, li, ti);
     // new_cov = scale_ * (R cov_s R^T + cov_t), scale_ = 2
-    const cc_jet RC00 = R00 * jc(es.c00) + R01 * jc(es.c10), RC01 = R00 * jc(es.c01) + R01 * jc(es.c11);
-    const cc_jet RC10 = R10 * jc(es.c00) + R11 * jc(es.c10), RC11 = R10 * jc(es.c01) + R11 * jc(es.c11);
-    const cc_jet n00 = jc(2.0) * (RC00 * R00 + RC01 * R01 + jc(et.c00));
-    const cc_jet n01 = jc(2.0) * (RC00 * R10 + RC01 * R11 + jc(et.c01));
-    const cc_jet n10 = jc(2.0) * (RC10 * R00 + RC11 * R01 + jc(et.c10));
-    const cc_jet n11 = jc(2.0) * (RC10 * R10 + RC11 * R11 + jc(et.c11));
-    const cc_jet m0 = R00 * jc(es.mx) + R01 * jc(es.my) + x - jc(et.mx);
-    const cc_jet m1 = R10 * jc(es.mx) + R11 * jc(es.my) + y - jc(et.my);
+    const cc_jet RC00 = R00 * jc((double)es.c00) + R01 * jc((double)es.c10), RC01 = R00 * jc((double)es.c01) + R01 * jc((double)es.c11);
+    const cc_jet RC10 = R10 * jc((double)es.c00) + R11 * jc((double)es.c10), RC11 = R10 * jc((double)es.c01) + R11 * jc((double)es.c11);
+    const cc_jet n00 = jc(2.0) * (RC00 * R00 + RC01 * R01 + jc((double)et.c00));
+    const cc_jet n01 = jc(2.0) * (RC00 * R10 + RC01 * R11 + jc((double)et.c01));
+    const cc_jet n10 = jc(2.0) * (RC10 * R00 + RC11 * R01 + jc((double)et.c10));
+    const cc_jet n11 = jc(2.0) * (RC10 * R10 + RC11 * R11 + jc((double)et.c11));
+    const cc_jet m0 = R00 * jc((double)es.mx) + R01 * jc((double)es.my) + x - jc((double)et.mx);
+    const cc_jet m1 = R10 * jc((double)es.mx) + R11 * jc((double)es.my) + y - jc((double)et.my);
     const cc_jet det = n00 * n11 - n10 * n01;
     const cc_jet invdet = jc(1.0) / det;
     const cc_jet i00 = n11 * invdet, i01 = -n01 * invdet, i10 = -n10 * invdet, i11 = n00 * invdet;
     const cc_jet h0 = jc(-0.5) * m0, h1 = jc(-0.5) * m1;
     const cc_jet r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
     const cc_jet qua = r0 * m0 + r1 * m1;
-    acc = acc + jc(-et.w) * jc(es.w) * jc(1.0) / jsqrt(det) * jexp(qua);
+    acc = acc + jc(-(double)et.w) * jc((double)es.w) * jc(1.0) / jsqrt(det) * jexp(qua);
   }
-  *cost = cc_wave_sum_d(acc.a);
+  *cost = cc_group_sum_d(acc.a, G);
   if (want_grad) {
-    grad[0] = cc_wave_sum_d(acc.v0);
-    grad[1] = cc_wave_sum_d(acc.v1);
-    grad[2] = cc_wave_sum_d(acc.v2);
+    grad[0] = cc_group_sum_d(acc.v0, G);
+    grad[1] = cc_group_sum_d(acc.v1, G);
+    grad[2] = cc_group_sum_d(acc.v2, G);
   }
 }
 
@@ -1227,39 +1236,46 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
   return true;
 }
 
-// grid = any (grid-stride over the device-side problem count), block = 64, dynamic LDS = CC_GMM_LDS_BYTES(ecap, pcap).
+// grid = any (grid-stride over the device-side problem count), block = 64, `ppw` problems per wave (G = 64/ppw lanes
+// each), dynamic LDS = ppw * CC_GMM_LDS_BYTES(ecap, pcap).
 // redo_only: process only problems whose previous result overflowed an LDS cap (flags & 3) -- the large-cap instance.
 __global__ void __launch_bounds__(64)
 cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap, int redo_only,
          const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, int ecap, int pcap,
-         cc_gmm_result *__restrict__ results) {
+         int ppw, cc_gmm_result *__restrict__ results) {
   HIP_DYNAMIC_SHARED(char, smem)
+  const int lane = threadIdx.x;
+  const int G = 64 / ppw, sub = lane / G, sl = lane - sub * G;
+  char *base_lds = smem + (size_t)sub * CC_GMM_LDS_BYTES(ecap, pcap);
   cc_gmm_lds Sv;
-  Sv.ell = (cc_ell *)smem;
-  Sv.pairs = (unsigned *)(smem + 2 * CC_GMM_LEVELS * (size_t)ecap * sizeof(cc_ell));
+  Sv.ell = (cc_ell *)base_lds;
+  Sv.pairs = (unsigned *)(base_lds + 2 * CC_GMM_LEVELS * (size_t)ecap * sizeof(cc_ell));
   Sv.n_ell = (int *)(Sv.pairs + pcap);
   Sv.n_pairs = Sv.n_ell + 2 * CC_GMM_LEVELS;
   Sv.flags = Sv.n_pairs + 1;
   Sv.ecap = ecap;
   Sv.pcap = pcap;
+  Sv.G = G;
+  Sv.sl = sl;
   cc_gmm_lds *S = &Sv;
-  const int lane = threadIdx.x;
   int n_prob = *n_prob_p;
   if (n_prob > prob_cap) n_prob = prob_cap;
-  for (int pidx = blockIdx.x; pidx < n_prob; pidx += gridDim.x) {
+  for (int pbase = blockIdx.x * ppw; pbase < n_prob; pbase += gridDim.x * ppw) {
+  const int pidx = pbase + sub;
+  if (pidx >= n_prob) continue;
   if (redo_only && !(results[pidx].flags & 3)) continue;
   const cc_gmm_problem pb = probs[pidx];
   const cc_scan_desc_t *src = db_desc + pb.gidx;
   const cc_scan_desc_t *tgt = qdesc + pb.q;
-  __syncthreads();
-  if (lane == 0) {
+  cc_group_sync(G);
+  if (sl == 0) {
     *S->n_pairs = 0;
     *S->flags = 0;
   }
-  __syncthreads();
+  cc_group_sync(G);
   // ---- ellipses (GMMPair ctor, correlation.h:49-82): contours in sorted order until >= 95 % of the level's cells
-  if (lane < 2 * CC_GMM_LEVELS) {
-    const int side = lane / CC_GMM_LEVELS, li = lane % CC_GMM_LEVELS;
+  if (sl < 2 * CC_GMM_LEVELS) {
+    const int side = sl / CC_GMM_LEVELS, li = sl % CC_GMM_LEVELS;
     const int lev = li + 1;  // GMMOptConfig::levels_ = {1,2,3,4}
     const cc_scan_desc_t *d = side == 0 ? src : tgt;
     const int full = d->layer_cell_cnt[lev];
@@ -1276,78 +1292,82 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
         break;
       }
       const cc_contour_t &cv = d->cont[lev][j];
-      // getManualCov (contour.h:376-378) in f32, then cast to double
+      // getManualCov (contour.h:376-378) in f32; the reference then casts to double
       const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
       const float e0 = cv.eig_vals[0], e1 = cv.eig_vals[1];
       const float a00 = v00 * e0, a01 = v01 * e1, a10 = v10 * e0, a11 = v11 * e1;
       cc_ell e;
-      e.c00 = (double)(a00 * v00 + a01 * v01);
-      e.c01 = (double)(a00 * v10 + a01 * v11);
-      e.c10 = (double)(a10 * v00 + a11 * v01);
-      e.c11 = (double)(a10 * v10 + a11 * v11);
-      e.mx = (double)cv.pos_mean[0];
-      e.my = (double)cv.pos_mean[1];
-      e.w = (double)cv.cell_cnt;
+      e.c00 = a00 * v00 + a01 * v01;
+      e.c01 = a00 * v10 + a01 * v11;
+      e.c10 = a10 * v00 + a11 * v01;
+      e.c11 = a10 * v10 + a11 * v11;
+      e.mx = cv.pos_mean[0];
+      e.my = cv.pos_mean[1];
+      e.w = (float)cv.cell_cnt;
       e.maj = sqrtf(e1);
-      e.pad = 0;
       S->E(side, li, n++) = e;
       run += cv.cell_cnt;
     }
     S->n_ell[side * CC_GMM_LEVELS + li] = n;
   }
-  __syncthreads();
-  // ---- pair pre-selection (correlation.h:85-96), ordered compaction
+  cc_group_sync(G);
+  // ---- pair pre-selection (correlation.h:85-96), ordered compaction by a G-wide prefix sum
   const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
   int np = 0;
   for (int li = 0; li < CC_GMM_LEVELS; li++) {
     const int ns = S->n_ell[li], ntg = S->n_ell[CC_GMM_LEVELS + li];
     const int tot = ns * ntg;
-    for (int base = 0; base < tot; base += 64) {
-      const int idx = base + lane;
-      bool sel = false;
+    for (int base = 0; base < tot; base += G) {
+      const int idx = base + sl;
+      int sel = 0;
       int si = 0, ti = 0;
       if (idx < tot) {
         si = idx / ntg;
         ti = idx - si * ntg;
         const cc_ell &es = S->E(0, li, si), &et = S->E(1, li, ti);
-        const double dx = (ct0 * es.mx + (-st0) * es.my + pb.tf[0]) - et.mx;
-        const double dy = (st0 * es.mx + ct0 * es.my + pb.tf[1]) - et.my;
-        sel = sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + et.maj);
+        const double dx = (ct0 * (double)es.mx + (-st0) * (double)es.my + pb.tf[0]) - (double)et.mx;
+        const double dy = (st0 * (double)es.mx + ct0 * (double)es.my + pb.tf[1]) - (double)et.my;
+        sel = sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + et.maj) ? 1 : 0;
       }
-      const unsigned long long m = __ballot(sel);
-      const int off = np + __popcll(m & ((1ull << lane) - 1ull));
+      int incl = sel;
+      for (int o = 1; o < G; o <<= 1) {
+        const int v = __shfl_up(incl, o, G);
+        if (sl >= o) incl += v;
+      }
+      const int off = np + incl - sel;
       if (sel) {
         if (off < pcap)
           S->pairs[off] = ((unsigned)li << 28) | ((unsigned)si << 14) | (unsigned)ti;
         else
           atomicOr((unsigned *)S->flags, 2u);
       }
-      np += __popcll(m);
+      np += __shfl(incl, G - 1, G);
     }
   }
   if (np > pcap) np = pcap;
-  if (lane == 0) *S->n_pairs = np;
+  if (sl == 0) *S->n_pairs = np;
   // ---- auto-correlation (correlation.h:102-119)
   double ac[2] = {0, 0};
   for (int side = 0; side < 2; side++) {
     double acc = 0;
     for (int li = 0; li < CC_GMM_LEVELS; li++) {
       const int n = S->n_ell[side * CC_GMM_LEVELS + li];
-      for (int idx = lane; idx < n * n; idx += 64) {
+      for (int idx = sl; idx < n * n; idx += G) {
         const int i = idx / n, j = idx - i * n;
         const cc_ell &a = S->E(side, li, i), &b = S->E(side, li, j);
-        const double n00 = 2.0 * (a.c00 + b.c00), n01 = 2.0 * (a.c01 + b.c01), n10 = 2.0 * (a.c10 + b.c10), n11 = 2.0 * (a.c11 + b.c11);
-        const double mx = a.mx - b.mx, my = a.my - b.my;
+        const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
+        const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
+        const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
         const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
         const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
         const double h0 = -0.5 * mx, h1 = -0.5 * my;
         const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
-        acc += a.w * b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+        acc += (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
       }
     }
-    ac[side] = cc_wave_sum_d(acc);
+    ac[side] = cc_group_sum_d(acc, G);
   }
-  __syncthreads();
+  cc_group_sync(G);
   // ---- initial correlation (tryProblem, correlation.h:196-202)
   double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
   double cost, g[3];
@@ -1470,9 +1490,9 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
     R.tf_opt[1] = x[1];
     R.tf_opt[2] = x[2];
   }
-  __syncthreads();
+  cc_group_sync(G);
   R.flags = *S->flags;
-  if (lane == 0) results[pidx] = R;
+  if (sl == 0) results[pidx] = R;
   }  // problem loop
 }
 

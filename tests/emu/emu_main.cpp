@@ -11,6 +11,7 @@ thread_local BlockCtx *t_block;
 thread_local WaveCtx *t_wave;
 thread_local int t_lane;
 thread_local unsigned t_coll;
+thread_local unsigned t_gcoll;
 }  // namespace emu
 
 extern "C" {

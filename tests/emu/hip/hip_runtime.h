@@ -50,6 +50,8 @@ namespace emu {
 struct WaveCtx {
   pthread_barrier_t bar;
   unsigned long long scratch64[2][64];  // ping-pong: one barrier per collective is enough
+  pthread_barrier_t gbar[4];            // sub-wave collectives of width 16 (4 groups)
+  unsigned long long gscratch[2][64];
 };
 struct BlockCtx {
   pthread_barrier_t bar;
@@ -61,6 +63,7 @@ extern thread_local BlockCtx *t_block;
 extern thread_local WaveCtx *t_wave;
 extern thread_local int t_lane;
 extern thread_local unsigned t_coll;  // per-thread count of wave collectives (selects the ping-pong buffer)
+extern thread_local unsigned t_gcoll; // same for the width-16 collectives
 }  // namespace emu
 
 #define threadIdx (emu::t_threadIdx)
@@ -101,28 +104,50 @@ static inline T emu_shfl_any(T v, int src) {
   std::memcpy(&out, &r, sizeof(T));
   return out;
 }
+// width-16 variant: only the 16 lanes of the caller's group rendezvous (groups of one wave may diverge)
+template <typename T>
+static inline T emu_shfl_g16(T v, int src_in_group) {
+  emu::WaveCtx *w = emu::t_wave;
+  const int g = emu::t_lane >> 4;
+  unsigned long long *buf = w->gscratch[emu::t_gcoll++ & 1];
+  unsigned long long raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  buf[emu::t_lane] = raw;
+  pthread_barrier_wait(&w->gbar[g]);
+  unsigned long long r = buf[g * 16 + (src_in_group & 15)];
+  T out;
+  std::memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <typename T>
+static inline T emu_shfl_w(T v, int rel_src, int width) {  // rel_src: lane index within the width-sized group
+  if (width == 64) return emu_shfl_any(v, rel_src);
+  if (width == 16) return emu_shfl_g16(v, rel_src);
+  fprintf(stderr, "emu: unsupported shuffle width %d\n", width);
+  abort();
+}
 template <typename T>
 static inline T __shfl(T v, int src, int width = 64) {
-  (void)width;
-  return emu_shfl_any(v, src);
+  return emu_shfl_w(v, src & (width - 1), width);
 }
 template <typename T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
-  (void)width;
-  int src = emu::t_lane + (int)delta;
-  return emu_shfl_any(v, src < 64 ? src : emu::t_lane);
+  const int rel = emu::t_lane & (width - 1);
+  const int src = rel + (int)delta;
+  return emu_shfl_w(v, src < width ? src : rel, width);
 }
 template <typename T>
 static inline T __shfl_up(T v, unsigned delta, int width = 64) {
-  (void)width;
-  int src = emu::t_lane - (int)delta;
-  return emu_shfl_any(v, src >= 0 ? src : emu::t_lane);
+  const int rel = emu::t_lane & (width - 1);
+  const int src = rel - (int)delta;
+  return emu_shfl_w(v, src >= 0 ? src : rel, width);
 }
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
-  (void)width;
-  return emu_shfl_any(v, emu::t_lane ^ mask);
+  const int rel = emu::t_lane & (width - 1);
+  return emu_shfl_w(v, (rel ^ mask) & (width - 1), width);
 }
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl_any(v, lane); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
@@ -231,7 +256,10 @@ void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... ar
     BlockCtx ctx;
     pthread_barrier_init(&ctx.bar, nullptr, block);
     ctx.waves.resize(block / 64);
-    for (auto &w : ctx.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+    for (auto &w : ctx.waves) {
+      pthread_barrier_init(&w.bar, nullptr, 64);
+      for (auto &g : w.gbar) pthread_barrier_init(&g, nullptr, 16);
+    }
     std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
     ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
     std::vector<std::thread> th;
@@ -246,6 +274,7 @@ void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... ar
         t_wave = &ctx.waves[t / 64];
         t_lane = t % 64;
         t_coll = 0;
+        t_gcoll = 0;
         kernel(args...);
       });
     }
