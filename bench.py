@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +119,9 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.stats and rank == 0:
+        for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy"):
+            print("funnel %-16s mean %8.1f  max %6d" % (k, float(res[k].mean()), int(res[k].max())), file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

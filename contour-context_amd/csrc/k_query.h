@@ -668,10 +668,13 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
 
 // ------------------------------------------------------------------------------------------------
 // K4b: per query, replay the passing checks in order: CandidatePoseData::addProposal (contour_db.h:286-338) and the
-// part of tidyUpCandidates before the correlation (contour_db.h:503-546).  One lane per query (the work is a short
-// sequential scalar recurrence); surviving (query, candidate) pairs are appended to the GMM problem list.
+// part of tidyUpCandidates before the correlation (contour_db.h:503-546).  The greedy proposal merge is sequential
+// only among checks that name the SAME candidate scan, so the passing checks are threaded into one ordered list per
+// candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
 // ------------------------------------------------------------------------------------------------
-#define CC_MAXCAND 128  // distinct candidate scans per query that passed the gate
+#define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
+#define CC_MERGE_BLOCK 128
+#define CC_MERGE_PER_T (CC_CHK_STRIDE / CC_MERGE_BLOCK)  // consecutive check slots scanned by one thread
 
 struct cc_gmm_problem {
   int q;          // index into qdesc (tgt)
@@ -685,120 +688,158 @@ struct cc_dprop {  // CandidateAnchorProp (contour_db.h:267-274); constell_ kept
   int vote_cnt;
   float area_perc;
 };
-struct cc_dcand {  // CandidatePoseData
+struct cc_dcand {  // CandidatePoseData (working state of one lane)
   int gidx, nprops, gmm_idx, pad;
   cc_dprop props[4];
 };
+struct cc_cand_out {  // what the final-selection kernel needs of a candidate
+  int gidx, nprops, gmm_idx, pad;
+};
 struct cc_qstate {
   int n_cand;  // candidates_.size() before tidyUpCandidates
-  int flags;   // bit0: more than CC_MAXCAND candidate scans
+  int flags;
+};
+struct cc_merge_lds {
+  cc_dcand st[CC_MERGE_BLOCK];             // lane-private candidate state
+  int gid[CC_CHK_STRIDE];                  // candidate scan of the i-th passing check
+  unsigned short ord[CC_CHK_STRIDE];       // its check slot
+  short next[CC_CHK_STRIDE];               // next passing check naming the same scan, -1 = none
+  unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
+  int wsum[CC_MERGE_BLOCK / 64];
+  int base;
 };
 
-// One wave per query.  The candidate/proposal state lives in LDS; the replay over passing checks is sequential (greedy
-// merge), but each step is wave-cooperative: candidate lookup by ballot, the <=4 proposal tests on 4 lanes.
-#define CC_MERGE_LDS_BYTES (sizeof(cc_dcand) * CC_MAXCAND + 64)
+static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
 
-// grid = nq, block = 64, dynamic LDS = CC_MERGE_LDS_BYTES
-__global__ void __launch_bounds__(64)
+// grid = nq, block = CC_MERGE_BLOCK
+__global__ void __launch_bounds__(CC_MERGE_BLOCK)
 cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__restrict__ qdesc,
            const cc_scan_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
-           const int *__restrict__ pass_cnt, cc_dcand *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
+           const int *__restrict__ pass_cnt, cc_cand_out *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
            cc_gmm_problem *__restrict__ probs, int prob_cap, int *__restrict__ n_prob) {
-  HIP_DYNAMIC_SHARED(char, smem)
-  cc_dcand *cands = (cc_dcand *)smem;
-  const int q = blockIdx.x, lane = threadIdx.x;
+  __shared__ cc_merge_lds L;
+  const int q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (q >= nq) return;
-  int nc = 0, flags = 0;
-  const int n_pass = pass_cnt[q * 4 + 0];
   const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
   const cc_pass_rec *recs = pass + (size_t)q * CC_CHK_STRIDE;
-  int seen = 0;
-  for (int base = 0; base < CC_CHK_STRIDE && seen < n_pass; base += 64) {
-    unsigned long long m = __ballot(okp[base + lane] != 0);
-    while (m) {
-      const int t = base + (__ffsll((unsigned long long)m) - 1);
-      m &= m - 1;
-      seen++;
-      const cc_pass_rec *rec = &recs[t];
-      const int gidx = rec->gidx;
+  // ---- ordered list of the passing checks (slot order = the reference's iteration order)
+  int n;
+  {
+    unsigned okm = 0;
+    int cnt = 0;
+    for (int u = 0; u < CC_MERGE_PER_T; u++) {
+      const int ok = okp[tid * CC_MERGE_PER_T + u] != 0;
+      okm |= (unsigned)ok << u;
+      cnt += ok;
+    }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) L.wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    n = 0;
+    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
+      if (w < wave) off += L.wsum[w];
+      n += L.wsum[w];
+    }
+    for (int u = 0; u < CC_MERGE_PER_T; u++) {
+      if ((okm >> u) & 1u) {
+        const int t = tid * CC_MERGE_PER_T + u;
+        L.ord[off] = (unsigned short)t;
+        L.gid[off] = recs[t].gidx;
+        L.next[off] = -1;
+        off++;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- thread the checks of one scan together; number the candidates in first-appearance order
+  int nc = 0;
+  for (int b0 = 0; b0 < n; b0 += CC_MERGE_BLOCK) {
+    const int i = b0 + tid;
+    bool first = false;
+    if (i < n) {
+      const int g = L.gid[i];
+      int j = i - 1;
+      while (j >= 0 && L.gid[j] != g) j--;
+      if (j >= 0)
+        L.next[j] = (short)i;  // j is the immediately preceding check of this scan: written by exactly one i
+      else
+        first = true;
+    }
+    const unsigned long long m = __ballot(first);
+    if (lane == 0) L.wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = nc + __popcll(m & ((1ull << lane) - 1ull));
+    int tot = 0;
+    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
+      if (w < wave) off += L.wsum[w];
+      tot += L.wsum[w];
+    }
+    if (first) L.firstrec[off] = (unsigned short)i;
+    nc += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    cc_qstate st;
+    st.n_cand = nc;
+    st.flags = 0;
+    qstate[q] = st;
+  }
+  // ---- one lane per candidate
+  const cc_scan_desc_t *tl = qdesc + q;
+  cc_dcand *c = &L.st[tid];
+  for (int k = tid; k < nc; k += CC_MERGE_BLOCK) {
+    int i = L.firstrec[k];
+    c->gidx = L.gid[i];
+    c->nprops = 0;
+    for (; i >= 0; i = L.next[i]) {
+      const cc_pass_rec *rec = &recs[L.ord[i]];
       const int np = rec->n_pairs;
       const double ptx = rec->tf[0], pty = rec->tf[1];
       const double pc = rec->cs[0], ps = rec->cs[1];
-      // candidate lookup (cand_id_pos_pair_)
-      unsigned long long f0 = __ballot(lane < nc && cands[lane].gidx == gidx);
-      unsigned long long f1 = __ballot(lane + 64 < nc && cands[lane + 64].gidx == gidx);
-      int k = f0 ? (__ffsll((unsigned long long)f0) - 1) : (f1 ? 64 + (__ffsll((unsigned long long)f1) - 1) : -1);
-      if (k < 0) {
-        if (nc >= CC_MAXCAND) {
-          flags |= 1;
-          continue;
-        }
-        k = nc++;
-        if (lane == 0) {
-          cands[k].gidx = gidx;
-          cands[k].nprops = 0;
-          cands[k].gmm_idx = -1;
-          cands[k].pad = 0;
-        }
-        __syncthreads();
-      }
-      cc_dcand *c = &cands[k];
       const int nprops = c->nprops;
       // CandidatePoseData::addProposal: first proposal within 2.0 (pixels) and 0.3 rad
-      bool close = false;
-      if (lane < nprops) {
-        const cc_dprop *p = &c->props[lane];
+      int hit = -1;
+      for (int pi = 0; pi < nprops && hit < 0; pi++) {
+        const cc_dprop *p = &c->props[pi];
         const double i00 = pc, i01 = ps, i10 = -ps, i11 = pc;
         const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
         const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
         const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
-        close = sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3;
+        if (sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3) hit = pi;
       }
-      const unsigned long long cm = __ballot(close);
-      if (cm) {
-        const int i = __ffsll((unsigned long long)cm) - 1;
-        cc_dprop *p = &c->props[i];
-        if (lane < 7) p->bits[lane] |= rec->bits[lane];
-        if (lane == 0) {
-          p->vote_cnt += np;
-          const int w1 = p->vote_cnt, w2 = np;
-          const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
-          const double ang1 = atan2(p->s, p->c), ang2 = rec->cs[2];
-          double diff = ang2 - ang1;
-          if (diff < 0) diff += 2 * 3.14159265358979323846;
-          if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
-          const double ang_bl = diff * w2 / (w1 + w2) + ang1;
-          p->c = cos(ang_bl);
-          p->s = sin(ang_bl);
-          p->tx = bx;
-          p->ty = by;
-        }
+      if (hit >= 0) {
+        cc_dprop *p = &c->props[hit];
+        for (int w = 0; w < 7; w++) p->bits[w] |= rec->bits[w];
+        p->vote_cnt += np;
+        const int w1 = p->vote_cnt, w2 = np;
+        const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
+        const double ang1 = atan2(p->s, p->c), ang2 = rec->cs[2];
+        double diff = ang2 - ang1;
+        if (diff < 0) diff += 2 * 3.14159265358979323846;
+        if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
+        const double ang_bl = diff * w2 / (w1 + w2) + ang1;
+        p->c = cos(ang_bl);
+        p->s = sin(ang_bl);
+        p->tx = bx;
+        p->ty = by;
       } else if (nprops <= 3) {
         cc_dprop *p = &c->props[nprops];
-        if (lane < 7) p->bits[lane] = rec->bits[lane];
-        if (lane == 0) {
-          p->c = pc;
-          p->s = ps;
-          p->tx = ptx;
-          p->ty = pty;
-          p->vote_cnt = np;
-          p->area_perc = 0.f;
-          c->nprops = nprops + 1;
-        }
+        for (int w = 0; w < 7; w++) p->bits[w] = rec->bits[w];
+        p->c = pc;
+        p->s = ps;
+        p->tx = ptx;
+        p->ty = pty;
+        p->vote_cnt = np;
+        p->area_perc = 0.f;
+        c->nprops = nprops + 1;
       }
-      __syncthreads();
     }
-  }
-  if (lane == 0) {
-    cc_qstate st;
-    st.n_cand = nc;
-    st.flags = flags;
-    qstate[q] = st;
-  }
-  // tidyUpCandidates before the correlation (contour_db.h:503-546): one lane per candidate
-  const cc_scan_desc_t *tl = qdesc + q;
-  for (int k = lane; k < nc; k += 64) {
-    cc_dcand *c = &cands[k];
+    // tidyUpCandidates before the correlation (contour_db.h:503-546)
     const cc_scan_desc_t *sl = db_desc + c->gidx;
     int idx_sel = 0;
     for (int pi = 0; pi < c->nprops; pi++) {
@@ -822,12 +863,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
       c->props[pi].area_perc = perc;
       if (c->props[pi].vote_cnt > c->props[idx_sel].vote_cnt) idx_sel = pi;
     }
-    if (idx_sel != 0) {
-      const cc_dprop tmp = c->props[0];
-      c->props[0] = c->props[idx_sel];
-      c->props[idx_sel] = tmp;
-    }
-    const cc_dprop *p0 = &c->props[0];
+    const cc_dprop *p0 = &c->props[idx_sel];  // std::swap(anch_props_[0], anch_props_[idx_sel]): only [0] is used afterwards
     int gi = -1;
     if (!(p0->area_perc < lb.area_perc)) {
       // getEstSensTF: T_so^-1 * T_delta * T_so with T_so = translate(n_row/2 - 0.5, n_col/2 - 0.5)
@@ -849,12 +885,12 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_scan_desc_t *__
         }
       }
     }
-    // what the final-selection kernel needs
-    cc_dcand *o = cands_all + (size_t)q * CC_MAXCAND + k;
-    o->gidx = c->gidx;
-    o->nprops = c->nprops;
-    o->gmm_idx = gi;
-    o->pad = 0;
+    cc_cand_out o;
+    o.gidx = c->gidx;
+    o.nprops = c->nprops;
+    o.gmm_idx = gi;
+    o.pad = 0;
+    cands_all[(size_t)q * CC_MAXCAND + k] = o;
   }
 }
 
@@ -1502,22 +1538,22 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
 // max_fine_opt_, adopt their refined score/pose, re-sort those, return the best.  One lane per query.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
+cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
            const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
            cc_query_result_t *__restrict__ out) {
   // one wave per query: lanes fetch the per-candidate inputs in parallel, lane 0 replays the order-dependent part on LDS
-  __shared__ unsigned char idx[CC_MAXCAND];
+  __shared__ unsigned short idx[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
   __shared__ float corr_o[CC_MAXCAND];
   __shared__ int gm[CC_MAXCAND];
   __shared__ int s_tot;
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
-  const cc_dcand *cands = cands_all + (size_t)q * CC_MAXCAND;
+  const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
   const int nc = qstate[q].n_cand;
   for (int k = lane; k < nc; k += 64) {
     const int g = cands[k].gmm_idx;
-    idx[k] = (unsigned char)k;
+    idx[k] = (unsigned short)k;
     gm[k] = g;
     bool h = false;
     float co = 0.f;
@@ -1548,7 +1584,7 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__
   int p1 = 0, p2 = nc - 1;
   while (p1 <= p2) {
     if (!has[idx[p1]] && has[idx[p2]]) {
-      const unsigned char t = idx[p1];
+      const unsigned short t = idx[p1];
       idx[p1] = idx[p2];
       idx[p2] = t;
       p1++;
@@ -1562,10 +1598,10 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_dcand *__restrict__
   r.n_cand_tidy = n;
   if (n > 0) {
     // first std::sort: every anch_props_[0].correlation_ is still 0 -> comparator is always false
-    ccsort::std_sort(idx, n, [](unsigned char, unsigned char) { return false; });
+    ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; });
     const int pre = max_fine_opt < n ? max_fine_opt : n;
     // candidates beyond `pre` keep correlation_ = 0
-    ccsort::std_sort(idx, pre, [&](unsigned char a, unsigned char b) { return corr_o[a] > corr_o[b]; });
+    ccsort::std_sort(idx, pre, [&](unsigned short a, unsigned short b) { return corr_o[a] > corr_o[b]; });
     const int b = idx[0];
     r.n_res = 1;
     r.cand_gidx = cands[b].gidx;
