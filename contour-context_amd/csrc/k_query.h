@@ -9,6 +9,14 @@
 #include "cc_dev.h"
 #include "cc_sort.h"
 
+// LDS hand-off between the lanes of one group: the lanes of a wave run in lockstep, so only the compiler has to be kept
+// from reordering; the G-wide shuffle doubles as the rendezvous under the CPU test harness.
+__device__ __forceinline__ void cc_group_sync(int G) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  (void)__shfl(0, 0, G);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: exhaustive top-k over the layer's key matrix with the reference's visibility rules.
 // ------------------------------------------------------------------------------------------------
@@ -235,7 +243,6 @@ __device__ __forceinline__ bool cc_check_sim(const cc_contour_t &a, const cc_con
 __device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * x + y * y); }
 
 #define CC_CHK_STRIDE (CC_NQLEV * CC_NPIV * CC_KNN_MAX)  // dense check slots per query: slot * CC_KNN_MAX + j
-#define CC_CHKB_PER_Q 8                                  // stage-B workgroups per query
 
 // Stage A (one lane per check slot): (1/4) anchor ContourView::checkSim and the popcount part of (2/4)
 // BCI::checkConstellSim (ovlp_sum / max_one bars).  Survivors are written as an ORDERED list per query; the slot
@@ -314,32 +321,75 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
   }
 }
 
-// Stage B (one wave per surviving check): the rest of BCI::checkConstellSim (neighbour pairing, common-rotation window),
-// checkConstellCorrespSim and getTFFromConstell.  Parallel where the reference's result does not depend on order,
-// sequential (lane 0, on LDS) where it does.
-struct cc_chkb_lds {
+// Stage B (16 lanes per surviving check, 4 checks per wave): the rest of BCI::checkConstellSim (neighbour pairing,
+// common-rotation window), checkConstellCorrespSim and getTFFromConstell.  Parallel where the reference's result does
+// not depend on order, sequential (uniform loops on LDS) where it does.  All control flow is uniform per 16-lane group;
+// the groups of a wave diverge freely, so every hand-off goes through cc_group_sync / 16-wide shuffles.
+#define CC_CHKB_G 16
+#define CC_CHKB_GPW (64 / CC_CHKB_G)
+#define CC_CHKB_PER_Q 8  // stage-B workgroups (waves) per query
+
+struct cc_chkb_lds {  // per group
   unsigned long long bitsw[8];             // pair bitmap staging (first member: 8-byte aligned for the 64-bit LDS atomics)
+  unsigned long long pp[CC_PP_MAX];        // potential pairs, sortable: fkey(orie) << 32 | l | s << 8 | t << 16 | gen << 24
   cc_relpt_t sp[CC_BCI_MAXPTS], tp[CC_BCI_MAXPTS];
-  unsigned short off[CC_BCI_MAXPTS + 1];   // first potential pair of each tgt point
+  unsigned short off[CC_BCI_MAXPTS + 2];   // first potential pair of each tgt point
   unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
-  cc_dsp pp[CC_PP_MAX];                     // generation order
-  cc_dsp sorted[CC_PP_MAX];
   signed char cs[CC_CSTL_MAX][3];
   unsigned char keepf[CC_CSTL_MAX];
   float spm[CC_CSTL_MAX][2], tpm[CC_CSTL_MAX][2];  // pos_mean of the constellation's contours
-  int misc[8];
+  float cn[48], nn[48];                    // shaft candidates: length, length after normalisation
+  int misc[4];
 };
 
+__device__ __forceinline__ unsigned cc_group_ballot(bool pred, int sl) {  // bit i = pred of group lane i
+  int v = pred ? (1 << sl) : 0;
+  for (int o = 1; o < CC_CHKB_G; o <<= 1) v |= __shfl_xor(v, o, CC_CHKB_G);
+  return (unsigned)v;
+}
+
+// potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1, in
+// src order.  AS_DSP = the reference's records in generation order (input of the replayed std::sort).
+template <bool AS_DSP>
+__device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds &L, int ntp, int sl) {
+  for (int i = sl; i < ntp; i += CC_CHKB_G) {
+    const cc_relpt_t r2 = L.tp[i];
+    int o = L.off[i];
+    for (int sj = L.lo[i]; sj < L.hi[i]; sj++, o++) {
+      if (o >= CC_PP_MAX) break;
+      const cc_relpt_t r1 = L.sp[sj];
+      float od = r2.theta - r1.theta;
+      od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
+      if (AS_DSP) {
+        cc_dsp e;
+        e.l = r1.level;
+        e.s = r1.seq;
+        e.t = r2.seq;
+        e.pad = 0;
+        e.orie = od;
+        ((cc_dsp *)L.pp)[o] = e;
+      } else {
+        L.pp[o] = ((unsigned long long)cc_fkey(od) << 32) | (unsigned long long)((unsigned)(r1.level & 0xFF) | ((unsigned)(r1.seq & 0xFF) << 8) |
+                                                                                   ((unsigned)(r2.seq & 0xFF) << 16) | ((unsigned)(o & 0xFF) << 24));
+      }
+    }
+  }
+}
+
+// grid = nq * CC_CHKB_PER_Q, block = 64
 __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ hits, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt) {
-  __shared__ cc_chkb_lds L;
-  const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q, lane = threadIdx.x;
+  __shared__ cc_chkb_lds LG[CC_CHKB_GPW];
+  const int G = CC_CHKB_G;
+  const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q;
+  const int sub = threadIdx.x / CC_CHKB_G, sl = threadIdx.x % CC_CHKB_G;
+  cc_chkb_lds &L = LG[sub];
   const int NS = CC_NQLEV * CC_NPIV;
   const cc_scan_desc_t *tgt = qdesc + q;
   const int ns = surv_cnt[q];
-  for (int si = part; si < ns; si += CC_CHKB_PER_Q) {
+  for (int si = part * CC_CHKB_GPW + sub; si < ns; si += CC_CHKB_PER_Q * CC_CHKB_GPW) {
     const int t = surv[(size_t)q * CC_CHK_STRIDE + si];
     const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
     const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
@@ -348,91 +398,99 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     const cc_bci_t *bs = &src->bcis[level][seq_src];
     const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
     const int nsp = bs->n_pts, ntp = bt->n_pts;
-    __syncthreads();
-    if (lane < nsp) L.sp[lane] = bs->pts[lane];
-    if (lane < ntp) L.tp[lane] = bt->pts[lane];
-    __syncthreads();
-    // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1,
-    // in src order; src points are sorted by bit_pos so the range is contiguous.
-    int cnt_i = 0;
-    {
-      const int tb = lane < ntp ? (int)L.tp[lane].bit_pos : 0;
-      int lo = 0, hi = 0;
-      for (int sj = 0; sj < nsp; sj++) {  // src points are sorted by bit_pos: counts give the contiguous range
-        const int sb = L.sp[sj].bit_pos;
-        lo += (sb < tb - 1) ? 1 : 0;
-        hi += (sb <= tb + 1) ? 1 : 0;
+    cc_group_sync(G);
+    for (int i = sl; i < nsp; i += G) L.sp[i] = bs->pts[i];
+    for (int i = sl; i < ntp; i += G) L.tp[i] = bt->pts[i];
+    cc_group_sync(G);
+    // src points are sorted by bit_pos: the partners of a tgt point are the contiguous range [lo, hi)
+    int npp_all = 0;
+    for (int r0 = 0; r0 < ntp; r0 += G) {
+      const int i = r0 + sl;
+      int cnt_i = 0;
+      if (i < ntp) {
+        const int tb = (int)L.tp[i].bit_pos;
+        int a = 0, b = nsp;
+        while (a < b) {  // #(sb < tb - 1)
+          const int mid = (a + b) >> 1;
+          if ((int)L.sp[mid].bit_pos < tb - 1)
+            a = mid + 1;
+          else
+            b = mid;
+        }
+        const int lo = a;
+        b = nsp;
+        while (a < b) {  // #(sb <= tb + 1)
+          const int mid = (a + b) >> 1;
+          if ((int)L.sp[mid].bit_pos <= tb + 1)
+            a = mid + 1;
+          else
+            b = mid;
+        }
+        L.lo[i] = (unsigned char)lo;
+        L.hi[i] = (unsigned char)a;
+        cnt_i = a - lo;
       }
-      if (lane < ntp) {
-        L.lo[lane] = (unsigned char)lo;
-        L.hi[lane] = (unsigned char)hi;
-        cnt_i = hi - lo;
+      int incl = cnt_i;
+      for (int o = 1; o < G; o <<= 1) {
+        const int v = __shfl_up(incl, o, G);
+        if (sl >= o) incl += v;
       }
+      if (i < ntp) L.off[i] = (unsigned short)(npp_all + incl - cnt_i);
+      npp_all += __shfl(incl, G - 1, G);
     }
-    // exclusive prefix over tgt points
-    int incl = cnt_i;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    if (lane < ntp) L.off[lane] = (unsigned short)(incl - cnt_i);
-    const int npp_all = __shfl(incl, 63);
     int flags = 0;
     int npp = npp_all;
     if (npp > CC_PP_MAX) {
       npp = CC_PP_MAX;
       flags |= 1;
     }
-    __syncthreads();
-    if (lane < ntp) {
-      const cc_relpt_t r2 = L.tp[lane];
-      int o = L.off[lane];
-      for (int sj = L.lo[lane]; sj < L.hi[lane]; sj++, o++) {
-        if (o >= CC_PP_MAX) break;
-        const cc_relpt_t r1 = L.sp[sj];
-        cc_dsp e;
-        e.l = r1.level;
-        e.s = r1.seq;
-        e.t = r2.seq;
-        e.pad = 0;
-        float od = r2.theta - r1.theta;
-        od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
-        e.orie = od;
-        L.pp[o] = e;
-      }
-    }
-    __syncthreads();
+    cc_group_sync(G);
     if (npp == 0) continue;
-    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> parallel rank; otherwise replay it.
-    bool tie = false;
-    for (int k = lane; k < npp; k += 64) {
-      const float key = L.pp[k].orie;
-      int rk = 0;
-      for (int m = 0; m < npp; m++) {
-        const float km = L.pp[m].orie;
-        rk += (km < key) ? 1 : 0;
-        tie |= (km == key && m != k);
+    cc_chkb_gen_pairs<false>(L, ntp, sl);
+    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> bitonic network; otherwise replay it.
+    int n2 = G;
+    while (n2 < npp) n2 <<= 1;
+    for (int i = npp + sl; i < n2; i += G) L.pp[i] = ~0ull;
+    cc_group_sync(G);
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        for (int idx = sl; idx < (n2 >> 1); idx += G) {
+          const int a = ((idx & ~(jj - 1)) << 1) | (idx & (jj - 1)), b = a | jj;
+          const unsigned long long x = L.pp[a], y = L.pp[b];
+          const bool up = ((a & k) == 0);
+          if ((x > y) == up) {
+            L.pp[a] = y;
+            L.pp[b] = x;
+          }
+        }
+        cc_group_sync(G);
       }
-      L.sorted[rk] = L.pp[k];  // only meaningful when there is no tie
     }
-    const bool any_tie = __ballot(tie) != 0ull;
-    __syncthreads();
-    if (any_tie) {
-      for (int k = lane; k < npp; k += 64) L.sorted[k] = L.pp[k];
-      __syncthreads();
-      if (lane == 0) ccsort::std_sort(L.sorted, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
-      __syncthreads();
+    bool tie = false;
+    for (int k = 1 + sl; k < npp; k += G) tie |= (cc_funkey((unsigned)(L.pp[k] >> 32)) == cc_funkey((unsigned)(L.pp[k - 1] >> 32)));
+    if (cc_group_ballot(tie, sl)) {
+      cc_group_sync(G);
+      cc_chkb_gen_pairs<true>(L, ntp, sl);
+      cc_group_sync(G);
+      if (sl == 0) ccsort::std_sort((cc_dsp *)L.pp, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
+      cc_group_sync(G);
+      for (int k = sl; k < npp; k += G) {
+        const cc_dsp e = ((cc_dsp *)L.pp)[k];
+        L.pp[k] = ((unsigned long long)cc_fkey(e.orie) << 32) |
+                  (unsigned long long)((unsigned)(e.l & 0xFF) | ((unsigned)(e.s & 0xFF) << 8) | ((unsigned)(e.t & 0xFF) << 16));
+      }
+      cc_group_sync(G);
     }
     // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
     // that attains the maximum length (what the two-pointer loop records)
     const float angular_range = (float)(3.14159265358979323846 / 16);
     int bestL = 0, bestP = 0x7fffffff;
-    for (int p1 = lane; p1 < npp; p1 += 64) {
-      const float v1 = L.sorted[p1].orie;
+    for (int p1 = sl; p1 < npp; p1 += G) {
+      const float v1 = cc_funkey((unsigned)(L.pp[p1] >> 32));
       int a = p1, b = p1 + npp - 1;  // window [p1, p2], p2 in [p1, p1+npp)
       while (a < b) {                // largest p2 with valid(p2); valid is monotone in p2
         const int mid = (a + b + 1) >> 1;
-        const double v = (double)(L.sorted[mid % npp].orie - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
+        const double v = (double)(cc_funkey((unsigned)(L.pp[mid % npp] >> 32)) - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
         if (v > (double)angular_range)
           b = mid - 1;
         else
@@ -444,8 +502,8 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         bestP = p1;
       }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const int oL = __shfl_xor(bestL, o), oP = __shfl_xor(bestP, o);
+    for (int o = G >> 1; o > 0; o >>= 1) {
+      const int oL = __shfl_xor(bestL, o, G), oP = __shfl_xor(bestP, o, G);
       if (oL > bestL || (oL == bestL && oP < bestP)) {
         bestL = oL;
         bestP = oP;
@@ -457,70 +515,72 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       beg = 0;
     }
     if (longest < P.lb.i_in_ang_rng) continue;
-    if (lane == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
+    if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
     // (3/4) individual similarity of the window pairs + the anchors, in cstl_in order
     int n_in = longest + 1;
-    if (n_in > 64) {  // one lane per pair below
-      n_in = 64;
+    if (n_in > CC_CSTL_MAX) {
+      n_in = CC_CSTL_MAX;
       flags |= 1;
     }
-    int l = 0, s_ = 0, t_ = 0;
-    bool sim = false;
-    if (lane < n_in) {
-      if (lane < longest && lane < n_in - 1) {
-        const cc_dsp e = L.sorted[(beg + lane) % npp];
-        l = e.l;
-        s_ = e.s;
-        t_ = e.t;
-      } else {
-        l = level;
-        s_ = seq_src;
-        t_ = seq_tgt;
+    int ncs = 0;
+    for (int r0 = 0; r0 < n_in; r0 += G) {
+      const int e = r0 + sl;
+      int l = 0, s_ = 0, t_ = 0;
+      bool sim = false;
+      if (e < n_in) {
+        if (e < longest && e < n_in - 1) {
+          const unsigned w = (unsigned)L.pp[(beg + e) % npp];
+          l = (int)(signed char)(w & 0xFF);
+          s_ = (int)(signed char)((w >> 8) & 0xFF);
+          t_ = (int)(signed char)((w >> 16) & 0xFF);
+        } else {
+          l = level;
+          s_ = seq_src;
+          t_ = seq_tgt;
+        }
+        sim = cc_check_sim(src->cont[l][s_], tgt->cont[l][t_], P.sim);
       }
-      sim = cc_check_sim(src->cont[l][s_], tgt->cont[l][t_], P.sim);
+      const unsigned ms = cc_group_ballot(sim, sl);
+      if (sim) {
+        const int o = ncs + __popc(ms & ((1u << sl) - 1u));
+        if (o < CC_CSTL_MAX) {
+          L.cs[o][0] = (signed char)l;
+          L.cs[o][1] = (signed char)s_;
+          L.cs[o][2] = (signed char)t_;
+          const cc_contour_t &sc = src->cont[l][s_];
+          const cc_contour_t &tc = tgt->cont[l][t_];
+          L.spm[o][0] = sc.pos_mean[0];
+          L.spm[o][1] = sc.pos_mean[1];
+          L.tpm[o][0] = tc.pos_mean[0];
+          L.tpm[o][1] = tc.pos_mean[1];
+        }
+      }
+      ncs += __popc(ms);
     }
-    const unsigned long long ms = __ballot(sim);
-    int ncs = __popcll(ms);
     if (ncs > CC_CSTL_MAX) {
       ncs = CC_CSTL_MAX;
       flags |= 1;
     }
     if (ncs < P.lb.i_indiv_sim) continue;
-    __syncthreads();
-    if (sim) {
-      const int o = __popcll(ms & ((1ull << lane) - 1ull));
-      if (o < CC_CSTL_MAX) {
-        L.cs[o][0] = (signed char)l;
-        L.cs[o][1] = (signed char)s_;
-        L.cs[o][2] = (signed char)t_;
-        const cc_contour_t &sc = src->cont[l][s_];
-        const cc_contour_t &tc = tgt->cont[l][t_];
-        L.spm[o][0] = sc.pos_mean[0];
-        L.spm[o][1] = sc.pos_mean[1];
-        L.tpm[o][0] = tc.pos_mean[0];
-        L.tpm[o][1] = tc.pos_mean[1];
-      }
-    }
-    __syncthreads();
+    cc_group_sync(G);
     // part 2: the "shaft" (contour_mng.h:1173-1184).  The reference scans the (i, j<i) pairs of the first <=10 entries in
     // order, replacing the running (normalised) src vector whenever the candidate is longer than it.  Candidate lengths and
     // the length the running vector would have after the update are computed one pair per lane; the scan itself is a
-    // 45-step uniform loop over lane broadcasts.
+    // uniform loop over them.
     float shx = 0.f, shy = 0.f, thx = 0.f, thy = 0.f;
     {
       const int lim = ncs < 10 ? ncs : 10;
       const int npair = lim * (lim - 1) / 2;
-      float cn = 0.f, nn = 0.f, ux = 0.f, uy = 0.f, vx = 0.f, vy = 0.f;
-      if (lane < npair) {
+      for (int pr = sl; pr < npair; pr += G) {
         int i = 1, acc = 0;  // pair index -> (i, jj) in the reference's loop order: i = 1.., jj = 0..i-1
-        while (acc + i <= lane) {
+        while (acc + i <= pr) {
           acc += i;
           i++;
         }
-        const int jj = lane - acc;
+        const int jj = pr - acc;
         const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
-        cn = cc_norm2f(cx, cy);
-        float z = cx * cx + cy * cy;
+        float ux, uy;
+        const float z = cx * cx + cy * cy;
         if (z > 0.f) {
           const float sq = sqrtf(z);
           ux = cx / sq;
@@ -529,55 +589,69 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           ux = cx;
           uy = cy;
         }
-        nn = cc_norm2f(ux, uy);
-        const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
-        z = tx * tx + ty * ty;
-        if (z > 0.f) {
-          const float sq = sqrtf(z);
-          vx = tx / sq;
-          vy = ty / sq;
-        } else {
-          vx = tx;
-          vy = ty;
-        }
+        L.cn[pr] = cc_norm2f(cx, cy);
+        L.nn[pr] = cc_norm2f(ux, uy);
       }
+      cc_group_sync(G);
       float sn = 0.f;  // norm of the running shaft_src (initially the zero vector)
       int last = -1;
       for (int k = 0; k < npair; k++) {
-        const float c_k = cc_lane_bcast(cn, k);
-        if (c_k > sn) {
-          sn = cc_lane_bcast(nn, k);
+        if (L.cn[k] > sn) {
+          sn = L.nn[k];
           last = k;
         }
       }
       if (last >= 0) {
-        shx = cc_lane_bcast(ux, last);
-        shy = cc_lane_bcast(uy, last);
-        thx = cc_lane_bcast(vx, last);
-        thy = cc_lane_bcast(vy, last);
+        int i = 1, acc = 0;
+        while (acc + i <= last) {
+          acc += i;
+          i++;
+        }
+        const int jj = last - acc;
+        const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
+        float z = cx * cx + cy * cy;
+        if (z > 0.f) {
+          const float sq = sqrtf(z);
+          shx = cx / sq;
+          shy = cy / sq;
+        } else {
+          shx = cx;
+          shy = cy;
+        }
+        const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
+        z = tx * tx + ty * ty;
+        if (z > 0.f) {
+          const float sq = sqrtf(z);
+          thx = tx / sq;
+          thy = ty / sq;
+        } else {
+          thx = tx;
+          thy = ty;
+        }
       }
     }
     // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
-    bool rm = false;
-    if (lane < ncs) {
-      const cc_contour_t &sc = src->cont[L.cs[lane][0]][L.cs[lane][1]];
-      const cc_contour_t &tc = tgt->cont[L.cs[lane][0]][L.cs[lane][2]];
-      if (sc.ecc_feat && tc.ecc_feat) {
-        const float pi6 = (float)(3.14159265358979323846 / 6);
-        const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
-        const float theta_t = acosf(thx * tc.eig_vecs[2] + thy * tc.eig_vecs[3]);
-        const float pms = (float)(3.14159265358979323846 - (double)theta_s);
-        rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
+    unsigned long long rmm = 0ull;
+    for (int r0 = 0; r0 < ncs; r0 += G) {
+      const int e = r0 + sl;
+      bool rm = false;
+      if (e < ncs) {
+        const cc_contour_t &sc = src->cont[L.cs[e][0]][L.cs[e][1]];
+        const cc_contour_t &tc = tgt->cont[L.cs[e][0]][L.cs[e][2]];
+        if (sc.ecc_feat && tc.ecc_feat) {
+          const float pi6 = (float)(3.14159265358979323846 / 6);
+          const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
+          const float theta_t = acosf(thx * tc.eig_vecs[2] + thy * tc.eig_vecs[3]);
+          const float pms = (float)(3.14159265358979323846 - (double)theta_s);
+          rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
+        }
+        L.keepf[e] = (unsigned char)e;  // position -> original index (identity when nothing is removed)
       }
+      rmm |= (unsigned long long)cc_group_ballot(rm, sl) << r0;
     }
-    const unsigned long long rmm = __ballot(rm);
-    // element order after the removal loop: position -> original index (identity when nothing is removed)
-    int my_src = lane;
+    cc_group_sync(G);
     if (rmm) {
-      __syncthreads();
-      if (lane < ncs) L.keepf[lane] = (unsigned char)lane;  // reuse as the index vector
-      __syncthreads();
-      if (lane == 0) {
+      if (sl == 0) {
         int num_sim = ncs;
         for (int i = 0; i < num_sim;) {
           const int o = L.keepf[i];
@@ -590,32 +664,26 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         }
         L.misc[0] = num_sim;
       }
-      __syncthreads();
+      cc_group_sync(G);
       ncs = L.misc[0];
-      if (lane < ncs) my_src = L.keepf[lane];
     }
     if (ncs < P.lb.i_orie_sim) continue;
-    // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order via lane broadcasts
-    float ax_ = 0.f, ay_ = 0.f, bx_ = 0.f, by_ = 0.f;
-    int bit = 0;
-    if (lane < ncs) {
-      ax_ = L.spm[my_src][0];
-      ay_ = L.spm[my_src][1];
-      bx_ = L.tpm[my_src][0];
-      by_ = L.tpm[my_src][1];
-      bit = (L.cs[my_src][0] - 1) * 100 + L.cs[my_src][1] * 10 + L.cs[my_src][2];
+    // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order (uniform loops on LDS)
+    if (sl < 8) L.bitsw[sl] = 0ull;
+    cc_group_sync(G);
+    for (int e = sl; e < ncs; e += G) {
+      const int o = L.keepf[e];
+      const int bit = (L.cs[o][0] - 1) * 100 + L.cs[o][1] * 10 + L.cs[o][2];
+      atomicOr(&L.bitsw[bit >> 6], 1ull << (bit & 63));
     }
-    __syncthreads();
-    if (lane < 8) L.bitsw[lane] = 0ull;
-    __syncthreads();
-    if (lane < ncs) atomicOr(&L.bitsw[bit >> 6], 1ull << (bit & 63));
     const double one_over_n = 1.0 / (double)ncs;
     double smx = 0, smy = 0, dmx = 0, dmy = 0;
     for (int i = 0; i < ncs; i++) {
-      smx += (double)cc_lane_bcast(ax_, i);
-      smy += (double)cc_lane_bcast(ay_, i);
-      dmx += (double)cc_lane_bcast(bx_, i);
-      dmy += (double)cc_lane_bcast(by_, i);
+      const int o = L.keepf[i];
+      smx += (double)L.spm[o][0];
+      smy += (double)L.spm[o][1];
+      dmx += (double)L.tpm[o][0];
+      dmy += (double)L.tpm[o][1];
     }
     smx = smx * one_over_n;
     smy = smy * one_over_n;
@@ -623,8 +691,9 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     dmy = dmy * one_over_n;
     double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
     for (int i = 0; i < ncs; i++) {
-      const double ax = (double)cc_lane_bcast(ax_, i) - smx, ay = (double)cc_lane_bcast(ay_, i) - smy;
-      const double bx = (double)cc_lane_bcast(bx_, i) - dmx, by = (double)cc_lane_bcast(by_, i) - dmy;
+      const int o = L.keepf[i];
+      const double ax = (double)L.spm[o][0] - smx, ay = (double)L.spm[o][1] - smy;
+      const double bx = (double)L.tpm[o][0] - dmx, by = (double)L.tpm[o][1] - dmy;
       s00 += bx * ax;
       s01 += bx * ay;
       s10 += by * ax;
@@ -641,8 +710,8 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       r00 = cs_ / nrm;
       r10 = sn2 / nrm;
     }
-    __syncthreads();
-    if (lane == 0) {
+    cc_group_sync(G);
+    if (sl == 0) {
       atomicAdd(&pass_cnt[q * 4 + 3], 1);
       atomicAdd(&pass_cnt[q * 4 + 0], 1);
       cc_pass_rec *rec = &pass[(size_t)q * CC_CHK_STRIDE + t];
@@ -662,7 +731,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       rec->cs[2] = atan2(s_2, c_);
       pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 1;
     }
-    if (lane < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[lane] = L.bitsw[lane];
+    if (sl < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[sl] = L.bitsw[sl];
   }
 }
 
@@ -962,15 +1031,7 @@ __device__ __forceinline__ double cc_group_sum_d(double v, int G) {
   for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
   return v;
 }
-// LDS hand-off between the lanes of one group: the lanes of a wave run in lockstep, so only the compiler has to be kept
-// from reordering; the G-wide shuffle doubles as the rendezvous under the CPU test harness.
-__device__ __forceinline__ void cc_group_sync(int G) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  (void)__shfl(0, 0, G);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-
-// cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the whole wave
+// cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the lanes of the problem's group
 __device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_grad, double *cost, double grad[3]) {
   const int G = S->G, sl = S->sl;
   const cc_jet x = cc_jet{p[0], 1, 0, 0}, y = cc_jet{p[1], 0, 1, 0};
