@@ -208,6 +208,7 @@ struct cc_check_params {
   cc_score_t lb;
   int n_q_levels;
   int q_levels[CC_NQLEV];
+  int dbg_cut;  // tuning aid (env CC_CHKB_CUT): stage B stops after phase dbg_cut, 0 = run everything
 };
 
 struct cc_dsp {  // BCI::DistSimPair
@@ -329,18 +330,33 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
 #define CC_CHKB_GPW (64 / CC_CHKB_G)
 #define CC_CHKB_PER_Q 8  // stage-B workgroups (waves) per query
 
-struct cc_chkb_lds {  // per group
+struct cc_chkb_lds {  // per group; the unions hold data of phases that never overlap in time
   unsigned long long bitsw[8];             // pair bitmap staging (first member: 8-byte aligned for the 64-bit LDS atomics)
-  unsigned long long pp[CC_PP_MAX];        // potential pairs, sortable: fkey(orie) << 32 | l | s << 8 | t << 16 | gen << 24
-  cc_relpt_t sp[CC_BCI_MAXPTS], tp[CC_BCI_MAXPTS];
-  unsigned short off[CC_BCI_MAXPTS + 2];   // first potential pair of each tgt point
-  unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
-  signed char cs[CC_CSTL_MAX][3];
-  unsigned char keepf[CC_CSTL_MAX];
-  float spm[CC_CSTL_MAX][2], tpm[CC_CSTL_MAX][2];  // pos_mean of the constellation's contours
-  float cn[48], nn[48];                    // shaft candidates: length, length after normalisation
-  int misc[4];
+  unsigned long long pp[CC_PP_MAX];        // potential pairs in generation order: fkey(orie) << 32 | l | s << 8 | t << 16
+  union {
+    int hist[256];                         // sort: orientation bins (count -> start -> end)
+    struct {
+      float spm[CC_CSTL_MAX][2], tpm[CC_CSTL_MAX][2];  // pos_mean of the constellation's contours
+    } m;
+  };
+  union {
+    struct {                               // pair generation
+      cc_relpt_t sp[CC_BCI_MAXPTS], tp[CC_BCI_MAXPTS];
+      unsigned short off[CC_BCI_MAXPTS + 2];  // first potential pair of each tgt point
+      unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
+    } g;
+    float skey[CC_PP_MAX];                 // sort result -> window search: orie in sorted order
+    struct {                               // constellation checks
+      signed char cs[CC_CSTL_MAX][3];
+      unsigned char keepf[CC_CSTL_MAX];
+      float cn[48], nn[48];                // shaft candidates: length, length after normalisation
+      int misc[4];
+    } c;
+  };
+  unsigned char binidx[CC_PP_MAX];         // pair indices grouped by bin
+  unsigned char sidx[CC_PP_MAX];           // pair indices in sorted order
 };
+static_assert(CC_PP_MAX <= 256, "pair indices are bytes");
 
 __device__ __forceinline__ unsigned cc_group_ballot(bool pred, int sl) {  // bit i = pred of group lane i
   int v = pred ? (1 << sl) : 0;
@@ -349,31 +365,27 @@ __device__ __forceinline__ unsigned cc_group_ballot(bool pred, int sl) {  // bit
 }
 
 // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1, in
-// src order.  AS_DSP = the reference's records in generation order (input of the replayed std::sort).
-template <bool AS_DSP>
+// src order.
 __device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds &L, int ntp, int sl) {
   for (int i = sl; i < ntp; i += CC_CHKB_G) {
-    const cc_relpt_t r2 = L.tp[i];
-    int o = L.off[i];
-    for (int sj = L.lo[i]; sj < L.hi[i]; sj++, o++) {
+    const cc_relpt_t r2 = L.g.tp[i];
+    int o = L.g.off[i];
+    for (int sj = L.g.lo[i]; sj < L.g.hi[i]; sj++, o++) {
       if (o >= CC_PP_MAX) break;
-      const cc_relpt_t r1 = L.sp[sj];
+      const cc_relpt_t r1 = L.g.sp[sj];
       float od = r2.theta - r1.theta;
       od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
-      if (AS_DSP) {
-        cc_dsp e;
-        e.l = r1.level;
-        e.s = r1.seq;
-        e.t = r2.seq;
-        e.pad = 0;
-        e.orie = od;
-        ((cc_dsp *)L.pp)[o] = e;
-      } else {
-        L.pp[o] = ((unsigned long long)cc_fkey(od) << 32) | (unsigned long long)((unsigned)(r1.level & 0xFF) | ((unsigned)(r1.seq & 0xFF) << 8) |
-                                                                                   ((unsigned)(r2.seq & 0xFF) << 16) | ((unsigned)(o & 0xFF) << 24));
-      }
+      L.pp[o] = ((unsigned long long)cc_fkey(od) << 32) |
+                (unsigned long long)((unsigned)(r1.level & 0xFF) | ((unsigned)(r1.seq & 0xFF) << 8) | ((unsigned)(r2.seq & 0xFF) << 16));
     }
   }
+}
+
+// orientation bin of the counting sort: monotone non-decreasing in od (f32 add, multiply by a positive constant and
+// truncation all preserve order), so bins partition the sorted sequence
+__device__ __forceinline__ int cc_chkb_bin(float od) {
+  int b = (int)((od + 3.14159274f) * 40.7436638f);
+  return b < 0 ? 0 : (b > 255 ? 255 : b);
 }
 
 // grid = nq * CC_CHKB_PER_Q, block = 64
@@ -399,8 +411,9 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
     const int nsp = bs->n_pts, ntp = bt->n_pts;
     cc_group_sync(G);
-    for (int i = sl; i < nsp; i += G) L.sp[i] = bs->pts[i];
-    for (int i = sl; i < ntp; i += G) L.tp[i] = bt->pts[i];
+    for (int i = sl; i < nsp; i += G) L.g.sp[i] = bs->pts[i];
+    for (int i = sl; i < ntp; i += G) L.g.tp[i] = bt->pts[i];
+    if (P.dbg_cut == 1) continue;
     cc_group_sync(G);
     // src points are sorted by bit_pos: the partners of a tgt point are the contiguous range [lo, hi)
     int npp_all = 0;
@@ -408,11 +421,11 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       const int i = r0 + sl;
       int cnt_i = 0;
       if (i < ntp) {
-        const int tb = (int)L.tp[i].bit_pos;
+        const int tb = (int)L.g.tp[i].bit_pos;
         int a = 0, b = nsp;
         while (a < b) {  // #(sb < tb - 1)
           const int mid = (a + b) >> 1;
-          if ((int)L.sp[mid].bit_pos < tb - 1)
+          if ((int)L.g.sp[mid].bit_pos < tb - 1)
             a = mid + 1;
           else
             b = mid;
@@ -421,13 +434,13 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         b = nsp;
         while (a < b) {  // #(sb <= tb + 1)
           const int mid = (a + b) >> 1;
-          if ((int)L.sp[mid].bit_pos <= tb + 1)
+          if ((int)L.g.sp[mid].bit_pos <= tb + 1)
             a = mid + 1;
           else
             b = mid;
         }
-        L.lo[i] = (unsigned char)lo;
-        L.hi[i] = (unsigned char)a;
+        L.g.lo[i] = (unsigned char)lo;
+        L.g.hi[i] = (unsigned char)a;
         cnt_i = a - lo;
       }
       int incl = cnt_i;
@@ -435,9 +448,10 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         const int v = __shfl_up(incl, o, G);
         if (sl >= o) incl += v;
       }
-      if (i < ntp) L.off[i] = (unsigned short)(npp_all + incl - cnt_i);
+      if (i < ntp) L.g.off[i] = (unsigned short)(npp_all + incl - cnt_i);
       npp_all += __shfl(incl, G - 1, G);
     }
+    if (P.dbg_cut == 2) continue;
     int flags = 0;
     int npp = npp_all;
     if (npp > CC_PP_MAX) {
@@ -446,51 +460,76 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     }
     cc_group_sync(G);
     if (npp == 0) continue;
-    cc_chkb_gen_pairs<false>(L, ntp, sl);
-    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> bitonic network; otherwise replay it.
-    int n2 = G;
-    while (n2 < npp) n2 <<= 1;
-    for (int i = npp + sl; i < n2; i += G) L.pp[i] = ~0ull;
+    cc_chkb_gen_pairs(L, ntp, sl);
+    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> counting sort on orientation bins + exact
+    // rank inside a bin; otherwise replay std::sort.
+    for (int i = sl; i < 256; i += G) L.hist[i] = 0;
     cc_group_sync(G);
-    for (int k = 2; k <= n2; k <<= 1) {
-      for (int jj = k >> 1; jj > 0; jj >>= 1) {
-        for (int idx = sl; idx < (n2 >> 1); idx += G) {
-          const int a = ((idx & ~(jj - 1)) << 1) | (idx & (jj - 1)), b = a | jj;
-          const unsigned long long x = L.pp[a], y = L.pp[b];
-          const bool up = ((a & k) == 0);
-          if ((x > y) == up) {
-            L.pp[a] = y;
-            L.pp[b] = x;
-          }
-        }
-        cc_group_sync(G);
+    for (int o = sl; o < npp; o += G) atomicAdd(&L.hist[cc_chkb_bin(cc_funkey((unsigned)(L.pp[o] >> 32)))], 1);
+    cc_group_sync(G);
+    {
+      int loc[256 / CC_CHKB_G];
+      int sum = 0;
+      for (int u = 0; u < 256 / CC_CHKB_G; u++) {
+        loc[u] = L.hist[sl * (256 / CC_CHKB_G) + u];
+        sum += loc[u];
+      }
+      int incl = sum;
+      for (int o = 1; o < G; o <<= 1) {
+        const int v = __shfl_up(incl, o, G);
+        if (sl >= o) incl += v;
+      }
+      int run = incl - sum;
+      for (int u = 0; u < 256 / CC_CHKB_G; u++) {
+        L.hist[sl * (256 / CC_CHKB_G) + u] = run;  // start of the bin; used as the scatter cursor next
+        run += loc[u];
       }
     }
+    cc_group_sync(G);
+    for (int o = sl; o < npp; o += G) {
+      const int pos = atomicAdd(&L.hist[cc_chkb_bin(cc_funkey((unsigned)(L.pp[o] >> 32)))], 1);
+      L.binidx[pos] = (unsigned char)o;
+    }
+    cc_group_sync(G);  // hist[b] is now the END of bin b
     bool tie = false;
-    for (int k = 1 + sl; k < npp; k += G) tie |= (cc_funkey((unsigned)(L.pp[k] >> 32)) == cc_funkey((unsigned)(L.pp[k - 1] >> 32)));
+    for (int p = sl; p < npp; p += G) {
+      const int o = L.binidx[p];
+      const float f = cc_funkey((unsigned)(L.pp[o] >> 32));
+      const int bn = cc_chkb_bin(f);
+      const int start = bn ? L.hist[bn - 1] : 0, end = L.hist[bn];
+      int rank = 0;
+      for (int p2 = start; p2 < end; p2++) {
+        const float f2 = cc_funkey((unsigned)(L.pp[L.binidx[p2]] >> 32));
+        rank += (f2 < f) ? 1 : 0;
+        tie |= (f2 == f && p2 != p);
+      }
+      L.sidx[start + rank] = (unsigned char)o;  // only meaningful when there is no tie
+      L.skey[start + rank] = f;
+    }
     if (cc_group_ballot(tie, sl)) {
       cc_group_sync(G);
-      cc_chkb_gen_pairs<true>(L, ntp, sl);
-      cc_group_sync(G);
-      if (sl == 0) ccsort::std_sort((cc_dsp *)L.pp, npp, [](const cc_dsp &x, const cc_dsp &y) { return x.orie < y.orie; });
+      if (sl == 0)
+        ccsort::std_sort(L.pp, npp, [](const unsigned long long &x, const unsigned long long &y) {
+          return cc_funkey((unsigned)(x >> 32)) < cc_funkey((unsigned)(y >> 32));
+        });
       cc_group_sync(G);
       for (int k = sl; k < npp; k += G) {
-        const cc_dsp e = ((cc_dsp *)L.pp)[k];
-        L.pp[k] = ((unsigned long long)cc_fkey(e.orie) << 32) |
-                  (unsigned long long)((unsigned)(e.l & 0xFF) | ((unsigned)(e.s & 0xFF) << 8) | ((unsigned)(e.t & 0xFF) << 16));
+        L.sidx[k] = (unsigned char)k;
+        L.skey[k] = cc_funkey((unsigned)(L.pp[k] >> 32));
       }
-      cc_group_sync(G);
     }
+    cc_group_sync(G);
+    if (P.dbg_cut == 4) continue;
     // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
     // that attains the maximum length (what the two-pointer loop records)
     const float angular_range = (float)(3.14159265358979323846 / 16);
     int bestL = 0, bestP = 0x7fffffff;
     for (int p1 = sl; p1 < npp; p1 += G) {
-      const float v1 = cc_funkey((unsigned)(L.pp[p1] >> 32));
+      const float v1 = L.skey[p1];
       int a = p1, b = p1 + npp - 1;  // window [p1, p2], p2 in [p1, p1+npp)
       while (a < b) {                // largest p2 with valid(p2); valid is monotone in p2
         const int mid = (a + b + 1) >> 1;
-        const double v = (double)(cc_funkey((unsigned)(L.pp[mid % npp] >> 32)) - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
+        const double v = (double)(L.skey[mid % npp] - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
         if (v > (double)angular_range)
           b = mid - 1;
         else
@@ -509,6 +548,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         bestP = oP;
       }
     }
+    if (P.dbg_cut == 5) continue;
     int longest = bestL, beg = bestP;
     if (longest <= 1) {  // the loop starts from longest = 1, beg = 0 and only records strictly longer windows
       longest = 1;
@@ -529,7 +569,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       bool sim = false;
       if (e < n_in) {
         if (e < longest && e < n_in - 1) {
-          const unsigned w = (unsigned)L.pp[(beg + e) % npp];
+          const unsigned w = (unsigned)L.pp[L.sidx[(beg + e) % npp]];
           l = (int)(signed char)(w & 0xFF);
           s_ = (int)(signed char)((w >> 8) & 0xFF);
           t_ = (int)(signed char)((w >> 16) & 0xFF);
@@ -544,19 +584,20 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       if (sim) {
         const int o = ncs + __popc(ms & ((1u << sl) - 1u));
         if (o < CC_CSTL_MAX) {
-          L.cs[o][0] = (signed char)l;
-          L.cs[o][1] = (signed char)s_;
-          L.cs[o][2] = (signed char)t_;
+          L.c.cs[o][0] = (signed char)l;
+          L.c.cs[o][1] = (signed char)s_;
+          L.c.cs[o][2] = (signed char)t_;
           const cc_contour_t &sc = src->cont[l][s_];
           const cc_contour_t &tc = tgt->cont[l][t_];
-          L.spm[o][0] = sc.pos_mean[0];
-          L.spm[o][1] = sc.pos_mean[1];
-          L.tpm[o][0] = tc.pos_mean[0];
-          L.tpm[o][1] = tc.pos_mean[1];
+          L.m.spm[o][0] = sc.pos_mean[0];
+          L.m.spm[o][1] = sc.pos_mean[1];
+          L.m.tpm[o][0] = tc.pos_mean[0];
+          L.m.tpm[o][1] = tc.pos_mean[1];
         }
       }
       ncs += __popc(ms);
     }
+    if (P.dbg_cut == 6) continue;
     if (ncs > CC_CSTL_MAX) {
       ncs = CC_CSTL_MAX;
       flags |= 1;
@@ -578,7 +619,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           i++;
         }
         const int jj = pr - acc;
-        const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
+        const float cx = L.m.spm[i][0] - L.m.spm[jj][0], cy = L.m.spm[i][1] - L.m.spm[jj][1];
         float ux, uy;
         const float z = cx * cx + cy * cy;
         if (z > 0.f) {
@@ -589,15 +630,15 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           ux = cx;
           uy = cy;
         }
-        L.cn[pr] = cc_norm2f(cx, cy);
-        L.nn[pr] = cc_norm2f(ux, uy);
+        L.c.cn[pr] = cc_norm2f(cx, cy);
+        L.c.nn[pr] = cc_norm2f(ux, uy);
       }
       cc_group_sync(G);
       float sn = 0.f;  // norm of the running shaft_src (initially the zero vector)
       int last = -1;
       for (int k = 0; k < npair; k++) {
-        if (L.cn[k] > sn) {
-          sn = L.nn[k];
+        if (L.c.cn[k] > sn) {
+          sn = L.c.nn[k];
           last = k;
         }
       }
@@ -608,7 +649,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           i++;
         }
         const int jj = last - acc;
-        const float cx = L.spm[i][0] - L.spm[jj][0], cy = L.spm[i][1] - L.spm[jj][1];
+        const float cx = L.m.spm[i][0] - L.m.spm[jj][0], cy = L.m.spm[i][1] - L.m.spm[jj][1];
         float z = cx * cx + cy * cy;
         if (z > 0.f) {
           const float sq = sqrtf(z);
@@ -618,7 +659,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           shx = cx;
           shy = cy;
         }
-        const float tx = L.tpm[i][0] - L.tpm[jj][0], ty = L.tpm[i][1] - L.tpm[jj][1];
+        const float tx = L.m.tpm[i][0] - L.m.tpm[jj][0], ty = L.m.tpm[i][1] - L.m.tpm[jj][1];
         z = tx * tx + ty * ty;
         if (z > 0.f) {
           const float sq = sqrtf(z);
@@ -630,14 +671,15 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         }
       }
     }
+    if (P.dbg_cut == 7) continue;
     // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
     unsigned long long rmm = 0ull;
     for (int r0 = 0; r0 < ncs; r0 += G) {
       const int e = r0 + sl;
       bool rm = false;
       if (e < ncs) {
-        const cc_contour_t &sc = src->cont[L.cs[e][0]][L.cs[e][1]];
-        const cc_contour_t &tc = tgt->cont[L.cs[e][0]][L.cs[e][2]];
+        const cc_contour_t &sc = src->cont[L.c.cs[e][0]][L.c.cs[e][1]];
+        const cc_contour_t &tc = tgt->cont[L.c.cs[e][0]][L.c.cs[e][2]];
         if (sc.ecc_feat && tc.ecc_feat) {
           const float pi6 = (float)(3.14159265358979323846 / 6);
           const float theta_s = acosf(shx * sc.eig_vecs[2] + shy * sc.eig_vecs[3]);
@@ -645,7 +687,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           const float pms = (float)(3.14159265358979323846 - (double)theta_s);
           rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
         }
-        L.keepf[e] = (unsigned char)e;  // position -> original index (identity when nothing is removed)
+        L.c.keepf[e] = (unsigned char)e;  // position -> original index (identity when nothing is removed)
       }
       rmm |= (unsigned long long)cc_group_ballot(rm, sl) << r0;
     }
@@ -654,36 +696,37 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       if (sl == 0) {
         int num_sim = ncs;
         for (int i = 0; i < num_sim;) {
-          const int o = L.keepf[i];
+          const int o = L.c.keepf[i];
           if ((rmm >> o) & 1ull) {
-            L.keepf[i] = L.keepf[num_sim - 1];  // std::swap(cstl_out[i], cstl_out[num_sim-1]); the tail is erased afterwards
+            L.c.keepf[i] = L.c.keepf[num_sim - 1];  // std::swap(cstl_out[i], cstl_out[num_sim-1]); the tail is erased afterwards
             num_sim--;
             continue;
           }
           i++;
         }
-        L.misc[0] = num_sim;
+        L.c.misc[0] = num_sim;
       }
       cc_group_sync(G);
-      ncs = L.misc[0];
+      ncs = L.c.misc[0];
     }
+    if (P.dbg_cut == 8) continue;
     if (ncs < P.lb.i_orie_sim) continue;
     // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order (uniform loops on LDS)
     if (sl < 8) L.bitsw[sl] = 0ull;
     cc_group_sync(G);
     for (int e = sl; e < ncs; e += G) {
-      const int o = L.keepf[e];
-      const int bit = (L.cs[o][0] - 1) * 100 + L.cs[o][1] * 10 + L.cs[o][2];
+      const int o = L.c.keepf[e];
+      const int bit = (L.c.cs[o][0] - 1) * 100 + L.c.cs[o][1] * 10 + L.c.cs[o][2];
       atomicOr(&L.bitsw[bit >> 6], 1ull << (bit & 63));
     }
     const double one_over_n = 1.0 / (double)ncs;
     double smx = 0, smy = 0, dmx = 0, dmy = 0;
     for (int i = 0; i < ncs; i++) {
-      const int o = L.keepf[i];
-      smx += (double)L.spm[o][0];
-      smy += (double)L.spm[o][1];
-      dmx += (double)L.tpm[o][0];
-      dmy += (double)L.tpm[o][1];
+      const int o = L.c.keepf[i];
+      smx += (double)L.m.spm[o][0];
+      smy += (double)L.m.spm[o][1];
+      dmx += (double)L.m.tpm[o][0];
+      dmy += (double)L.m.tpm[o][1];
     }
     smx = smx * one_over_n;
     smy = smy * one_over_n;
@@ -691,9 +734,9 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     dmy = dmy * one_over_n;
     double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
     for (int i = 0; i < ncs; i++) {
-      const int o = L.keepf[i];
-      const double ax = (double)L.spm[o][0] - smx, ay = (double)L.spm[o][1] - smy;
-      const double bx = (double)L.tpm[o][0] - dmx, by = (double)L.tpm[o][1] - dmy;
+      const int o = L.c.keepf[i];
+      const double ax = (double)L.m.spm[o][0] - smx, ay = (double)L.m.spm[o][1] - smy;
+      const double bx = (double)L.m.tpm[o][0] - dmx, by = (double)L.m.tpm[o][1] - dmy;
       s00 += bx * ax;
       s01 += bx * ay;
       s10 += by * ax;
