@@ -355,6 +355,7 @@ struct cc_chkb_lds {  // per group; the unions hold data of phases that never ov
   };
   unsigned char binidx[CC_PP_MAX];         // pair indices grouped by bin
   unsigned char sidx[CC_PP_MAX];           // pair indices in sorted order
+  short seg[3][20];                        // sort: pending quicksort segments (first, last, depth left)
 };
 static_assert(CC_PP_MAX <= 256, "pair indices are bytes");
 
@@ -386,6 +387,186 @@ __device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds &L, int ntp, int s
 __device__ __forceinline__ int cc_chkb_bin(float od) {
   int b = (int)((od + 3.14159274f) * 40.7436638f);
   return b < 0 ? 0 : (b > 255 ? 255 : b);
+}
+
+#define CC_CHKB_KEY(w) cc_funkey((unsigned)((w) >> 32))
+
+// std::sort(potential_pairs, orie_diff <) (contour_mng.h:340).  Equal orie_diff are common (contour centres are means of
+// integer cell coordinates, so revisits reproduce them bit for bit) and the reference's order among them is whatever
+// libstdc++'s introsort leaves, so the algorithm is replayed -- in parallel, which its structure allows:
+//   (1) median-of-3 Hoare partitions until every segment has <= 16 elements.  One partition is data-parallel: with the
+//       positions of the elements !(x < pivot) in ascending order (l_k) and of the elements !(pivot < x) in descending
+//       order (r_k), the sequential two-pointer loop swaps exactly the pairs (l_k, r_k) with l_k < r_k -- a prefix k < K --
+//       and returns min(l_K+1, r_K): neither pointer ever re-reads a swapped position before they cross.
+//   (2) the final insertion sort is a STABLE sort of what (1) left: rank = #smaller + #equal-and-earlier.
+// The heapsort branch (depth limit 2*floor(log2 n) exhausted) is replayed serially by one lane on regenerated input.
+// Result: L.sidx[k] = index into L.pp of the k-th pair, L.skey[k] = its orie_diff.
+__device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int sl) {
+  const int G = CC_CHKB_G;
+  unsigned char *lpos = L.binidx, *rasc = L.sidx;  // stopper lists (both arrays are free until step 2)
+  bool deep = false;
+  cc_group_sync(G);  // the pairs are in place
+  if (npp > 16) {
+    int lg = 0;
+    for (int t = npp; t > 1; t >>= 1) lg++;
+    int nseg = 1;
+    L.seg[0][0] = 0;
+    L.seg[1][0] = (short)npp;
+    L.seg[2][0] = (short)(lg * 2);
+    cc_group_sync(G);
+    while (nseg > 0) {
+      nseg--;
+      const int first = L.seg[0][nseg], last = L.seg[1][nseg];
+      int depth = L.seg[2][nseg];
+      if (depth == 0) {
+        deep = true;
+        break;
+      }
+      depth--;
+      const int mid = first + (last - first) / 2;
+      const int ia = first + 1, ib = mid, ic = last - 1;
+      const float ka = CC_CHKB_KEY(L.pp[ia]), kb = CC_CHKB_KEY(L.pp[ib]), kc = CC_CHKB_KEY(L.pp[ic]);
+      int sel;  // __move_median_to_first(first, first+1, mid, last-1)
+      if (ka < kb) {
+        if (kb < kc)
+          sel = ib;
+        else if (ka < kc)
+          sel = ic;
+        else
+          sel = ia;
+      } else if (ka < kc)
+        sel = ia;
+      else if (kb < kc)
+        sel = ic;
+      else
+        sel = ib;
+      cc_group_sync(G);
+      if (sl == 0) {
+        const unsigned long long t = L.pp[first];
+        L.pp[first] = L.pp[sel];
+        L.pp[sel] = t;
+      }
+      cc_group_sync(G);
+      const float piv = CC_CHKB_KEY(L.pp[first]);
+      int nL = 0, nR = 0;
+      for (int r0 = first + 1; r0 < last; r0 += G) {
+        const int i = r0 + sl;
+        bool ls = false, rs = false;
+        if (i < last) {
+          const float k = CC_CHKB_KEY(L.pp[i]);
+          ls = !(k < piv);
+          rs = !(piv < k);
+        }
+        const unsigned mL = cc_group_ballot(ls, sl), mR = cc_group_ballot(rs, sl);
+        if (ls) lpos[nL + __popc(mL & ((1u << sl) - 1u))] = (unsigned char)i;
+        if (rs) rasc[nR + __popc(mR & ((1u << sl) - 1u))] = (unsigned char)i;
+        nL += __popc(mL);
+        nR += __popc(mR);
+      }
+      cc_group_sync(G);
+      const int nmin = nL < nR ? nL : nR;
+      int K = 0;
+      for (int k0 = 0; k0 < nmin; k0 += G) {
+        const int k = k0 + sl;
+        K += __popc(cc_group_ballot(k < nmin && lpos[k] < rasc[nR - 1 - k], sl));
+      }
+      for (int k = sl; k < K; k += G) {
+        const int a = lpos[k], b = rasc[nR - 1 - k];
+        const unsigned long long t = L.pp[a];
+        L.pp[a] = L.pp[b];
+        L.pp[b] = t;
+      }
+      int cut = 0x7fff;
+      if (K < nL) cut = lpos[K];
+      if (K > 0 && (int)rasc[nR - K] < cut) cut = rasc[nR - K];
+      cc_group_sync(G);
+      if (last - cut > 16) {
+        L.seg[0][nseg] = (short)cut;
+        L.seg[1][nseg] = (short)last;
+        L.seg[2][nseg] = (short)depth;
+        nseg++;
+      }
+      if (cut - first > 16) {
+        L.seg[0][nseg] = (short)first;
+        L.seg[1][nseg] = (short)cut;
+        L.seg[2][nseg] = (short)depth;
+        nseg++;
+      }
+      cc_group_sync(G);
+    }
+  }
+  if (deep) {
+    cc_group_sync(G);
+    cc_chkb_gen_pairs(L, ntp, sl);
+    cc_group_sync(G);
+    if (sl == 0)
+      ccsort::std_sort(L.pp, npp, [](const unsigned long long &x, const unsigned long long &y) { return CC_CHKB_KEY(x) < CC_CHKB_KEY(y); });
+    cc_group_sync(G);
+    for (int k = sl; k < npp; k += G) {
+      L.sidx[k] = (unsigned char)k;
+      L.skey[k] = CC_CHKB_KEY(L.pp[k]);
+    }
+    cc_group_sync(G);
+    return;
+  }
+  if (npp <= 48) {
+    for (int p = sl; p < npp; p += G) {
+      const float f = CC_CHKB_KEY(L.pp[p]);
+      int rank = 0;
+      for (int j = 0; j < npp; j++) {
+        const float fj = CC_CHKB_KEY(L.pp[j]);
+        rank += (fj < f || (fj == f && j < p)) ? 1 : 0;
+      }
+      L.sidx[rank] = (unsigned char)p;
+      L.skey[rank] = f;
+    }
+    cc_group_sync(G);
+    return;
+  }
+  // counting sort on orientation bins + exact rank inside a bin
+  for (int i = sl; i < 256; i += G) L.hist[i] = 0;
+  cc_group_sync(G);
+  for (int o = sl; o < npp; o += G) atomicAdd(&L.hist[cc_chkb_bin(CC_CHKB_KEY(L.pp[o]))], 1);
+  cc_group_sync(G);
+  {
+    int loc[256 / CC_CHKB_G];
+    int sum = 0;
+    for (int u = 0; u < 256 / CC_CHKB_G; u++) {
+      loc[u] = L.hist[sl * (256 / CC_CHKB_G) + u];
+      sum += loc[u];
+    }
+    int incl = sum;
+    for (int o = 1; o < G; o <<= 1) {
+      const int v = __shfl_up(incl, o, G);
+      if (sl >= o) incl += v;
+    }
+    int run = incl - sum;
+    for (int u = 0; u < 256 / CC_CHKB_G; u++) {
+      L.hist[sl * (256 / CC_CHKB_G) + u] = run;  // start of the bin; used as the scatter cursor next
+      run += loc[u];
+    }
+  }
+  cc_group_sync(G);
+  for (int o = sl; o < npp; o += G) {
+    const int pos = atomicAdd(&L.hist[cc_chkb_bin(CC_CHKB_KEY(L.pp[o]))], 1);
+    L.binidx[pos] = (unsigned char)o;
+  }
+  cc_group_sync(G);  // hist[b] is now the END of bin b
+  for (int p = sl; p < npp; p += G) {
+    const int o = L.binidx[p];
+    const float f = CC_CHKB_KEY(L.pp[o]);
+    const int bn = cc_chkb_bin(f);
+    const int start = bn ? L.hist[bn - 1] : 0, end = L.hist[bn];
+    int rank = 0;
+    for (int p2 = start; p2 < end; p2++) {
+      const int o2 = L.binidx[p2];
+      const float f2 = CC_CHKB_KEY(L.pp[o2]);
+      rank += (f2 < f || (f2 == f && o2 < o)) ? 1 : 0;
+    }
+    L.sidx[start + rank] = (unsigned char)o;
+    L.skey[start + rank] = f;
+  }
+  cc_group_sync(G);
 }
 
 // grid = nq * CC_CHKB_PER_Q, block = 64
@@ -461,64 +642,12 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     cc_group_sync(G);
     if (npp == 0) continue;
     cc_chkb_gen_pairs(L, ntp, sl);
-    // sort by orie_diff.  With distinct keys the result of std::sort is unique -> counting sort on orientation bins + exact
-    // rank inside a bin; otherwise replay std::sort.
-    for (int i = sl; i < 256; i += G) L.hist[i] = 0;
-    cc_group_sync(G);
-    for (int o = sl; o < npp; o += G) atomicAdd(&L.hist[cc_chkb_bin(cc_funkey((unsigned)(L.pp[o] >> 32)))], 1);
-    cc_group_sync(G);
-    {
-      int loc[256 / CC_CHKB_G];
-      int sum = 0;
-      for (int u = 0; u < 256 / CC_CHKB_G; u++) {
-        loc[u] = L.hist[sl * (256 / CC_CHKB_G) + u];
-        sum += loc[u];
-      }
-      int incl = sum;
-      for (int o = 1; o < G; o <<= 1) {
-        const int v = __shfl_up(incl, o, G);
-        if (sl >= o) incl += v;
-      }
-      int run = incl - sum;
-      for (int u = 0; u < 256 / CC_CHKB_G; u++) {
-        L.hist[sl * (256 / CC_CHKB_G) + u] = run;  // start of the bin; used as the scatter cursor next
-        run += loc[u];
-      }
+    if (P.dbg_cut == 3) continue;
+    if (P.dbg_cut >= 10) {  // tuning aid: per-query sums reported through cand_aft_check2
+      if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], P.dbg_cut == 11 ? npp : 1);
+      continue;
     }
-    cc_group_sync(G);
-    for (int o = sl; o < npp; o += G) {
-      const int pos = atomicAdd(&L.hist[cc_chkb_bin(cc_funkey((unsigned)(L.pp[o] >> 32)))], 1);
-      L.binidx[pos] = (unsigned char)o;
-    }
-    cc_group_sync(G);  // hist[b] is now the END of bin b
-    bool tie = false;
-    for (int p = sl; p < npp; p += G) {
-      const int o = L.binidx[p];
-      const float f = cc_funkey((unsigned)(L.pp[o] >> 32));
-      const int bn = cc_chkb_bin(f);
-      const int start = bn ? L.hist[bn - 1] : 0, end = L.hist[bn];
-      int rank = 0;
-      for (int p2 = start; p2 < end; p2++) {
-        const float f2 = cc_funkey((unsigned)(L.pp[L.binidx[p2]] >> 32));
-        rank += (f2 < f) ? 1 : 0;
-        tie |= (f2 == f && p2 != p);
-      }
-      L.sidx[start + rank] = (unsigned char)o;  // only meaningful when there is no tie
-      L.skey[start + rank] = f;
-    }
-    if (cc_group_ballot(tie, sl)) {
-      cc_group_sync(G);
-      if (sl == 0)
-        ccsort::std_sort(L.pp, npp, [](const unsigned long long &x, const unsigned long long &y) {
-          return cc_funkey((unsigned)(x >> 32)) < cc_funkey((unsigned)(y >> 32));
-        });
-      cc_group_sync(G);
-      for (int k = sl; k < npp; k += G) {
-        L.sidx[k] = (unsigned char)k;
-        L.skey[k] = cc_funkey((unsigned)(L.pp[k] >> 32));
-      }
-    }
-    cc_group_sync(G);
+    cc_chkb_sort(L, npp, ntp, sl);
     if (P.dbg_cut == 4) continue;
     // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
     // that attains the maximum length (what the two-pointer loop records)

@@ -22,6 +22,7 @@ using std::isfinite;
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static
 #define __restrict__ __restrict
