@@ -1160,34 +1160,12 @@ struct cc_ell {  // values are f32 in the reference too (getManualCov, pos_mean_
   float c00, c01, c10, c11, mx, my, w, maj;
 };
 
-struct cc_jet {
-  double a, v0, v1, v2;
-};
-__device__ __forceinline__ cc_jet jc(double s) { return cc_jet{s, 0, 0, 0}; }
-__device__ __forceinline__ cc_jet operator+(const cc_jet &f, const cc_jet &g) { return cc_jet{f.a + g.a, f.v0 + g.v0, f.v1 + g.v1, f.v2 + g.v2}; }
-__device__ __forceinline__ cc_jet operator-(const cc_jet &f, const cc_jet &g) { return cc_jet{f.a - g.a, f.v0 - g.v0, f.v1 - g.v1, f.v2 - g.v2}; }
-__device__ __forceinline__ cc_jet operator-(const cc_jet &f) { return cc_jet{-f.a, -f.v0, -f.v1, -f.v2}; }
-__device__ __forceinline__ cc_jet operator*(const cc_jet &f, const cc_jet &g) {
-  return cc_jet{f.a * g.a, f.a * g.v0 + f.v0 * g.a, f.a * g.v1 + f.v1 * g.a, f.a * g.v2 + f.v2 * g.a};
-}
-__device__ __forceinline__ cc_jet operator/(const cc_jet &f, const cc_jet &g) {
-  const double gi = 1.0 / g.a, fg = f.a * gi;
-  return cc_jet{fg, (f.v0 - fg * g.v0) * gi, (f.v1 - fg * g.v1) * gi, (f.v2 - fg * g.v2) * gi};
-}
-__device__ __forceinline__ cc_jet jsqrt(const cc_jet &f) {
-  const double t = sqrt(f.a), h = 1.0 / (2.0 * t);
-  return cc_jet{t, h * f.v0, h * f.v1, h * f.v2};
-}
-__device__ __forceinline__ cc_jet jexp(const cc_jet &f) {
-  const double t = exp(f.a);
-  return cc_jet{t, t * f.v0, t * f.v1, t * f.v2};
-}
-
 // LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance).  A wave handles 64/G
 // problems at once, G lanes each (G = 16 for the common instance, 64 for the large-cap instance); every cross-lane
 // operation below is G-wide, so problems in the same wave may diverge freely.
 struct cc_gmm_lds {
   cc_ell *ell;      // [2][CC_GMM_LEVELS][ecap]   side 0 = src, 1 = tgt
+  double *hist;     // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
   unsigned *pairs;  // [pcap]  (li << 28) | (si << 14) | ti
   int *n_ell;       // [2][CC_GMM_LEVELS]
   int *n_pairs;
@@ -1197,146 +1175,257 @@ struct cc_gmm_lds {
   __device__ __forceinline__ const cc_ell &E(int side, int li, int i) const { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
   __device__ __forceinline__ cc_ell &E(int side, int li, int i) { return ell[(side * CC_GMM_LEVELS + li) * ecap + i]; }
 };
-#define CC_GMM_LDS_BYTES(ecap, pcap) (2 * CC_GMM_LEVELS * (ecap) * sizeof(cc_ell) + (pcap) * 4 + 64)
+#define CC_GMM_LDS_BYTES(ecap, pcap) (2 * CC_GMM_LEVELS * (ecap) * sizeof(cc_ell) + 80 * 8 + (pcap) * 4 + 64)
 
 __device__ __forceinline__ double cc_group_sum_d(double v, int G) {
   for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
   return v;
 }
 // cost (+ gradient) of GMMPair::operator() at p, summed over the selected pairs by the lanes of the problem's group
+// The reference differentiates GMMPair::operator() with ceres::Jet<double, 3> (correlation.h:123-160).  Every quantity
+// built from the rotation alone has d/dx = d/dy = 0 structurally, so only (value, d/dtheta) is carried for those
+// (cc_j1); the dropped Jet terms are exact zeros (finite * 0, + 0), which leaves every kept component bit-identical to
+// the full Jet arithmetic.  Operation order follows ceres/jet.h: f*g = (fa*ga, fa*gv + fv*ga),
+// f/g = (fa/ga =: q via 1/ga, (fv - q*gv)/ga), sqrt f = (r, fv / (2r)), exp f = (e, e*fv).
+struct cc_j1 {
+  double a, t;
+};
+__device__ __forceinline__ cc_j1 j1_mulc(const cc_j1 &f, double c) { return cc_j1{f.a * c, f.t * c}; }
+__device__ __forceinline__ cc_j1 j1_mul(const cc_j1 &f, const cc_j1 &g) { return cc_j1{f.a * g.a, f.a * g.t + f.t * g.a}; }
+__device__ __forceinline__ cc_j1 j1_add(const cc_j1 &f, const cc_j1 &g) { return cc_j1{f.a + g.a, f.t + g.t}; }
+__device__ __forceinline__ cc_j1 j1_sub(const cc_j1 &f, const cc_j1 &g) { return cc_j1{f.a - g.a, f.t - g.t}; }
+__device__ __forceinline__ cc_j1 j1_neg(const cc_j1 &f) { return cc_j1{-f.a, -f.t}; }
+
 __device__ void cc_gmm_eval(const cc_gmm_lds *S, const double p[3], bool want_grad, double *cost, double grad[3]) {
   const int G = S->G, sl = S->sl;
-  const cc_jet x = cc_jet{p[0], 1, 0, 0}, y = cc_jet{p[1], 0, 1, 0};
+  const double px = p[0], py = p[1];
   const double ct = cos(p[2]), st = sin(p[2]);
-  const cc_jet jc_ = cc_jet{ct, 0, 0, -st}, js_ = cc_jet{st, 0, 0, ct};
-  const cc_jet R00 = jc_, R01 = -js_, R10 = js_, R11 = jc_;
-  cc_jet acc = jc(0.0);
+  const cc_j1 R00{ct, -st}, R01{-st, -ct}, R10{st, ct}, R11{ct, -st};
+  double acc_a = 0.0, acc_x = 0.0, acc_y = 0.0, acc_t = 0.0;
   const int np = *S->n_pairs;
   for (int i = sl; i < np; i += G) {
     const unsigned pr = S->pairs[i];
     const int li = pr >> 28, si = (pr >> 14) & 0x3FFF, ti = pr & 0x3FFF;
     const cc_ell es = S->E(0, li, si), et = S->E(1, li, ti);
     // new_cov = scale_ * (R cov_s R^T + cov_t), scale_ = 2
-    const cc_jet RC00 = R00 * jc((double)es.c00) + R01 * jc((double)es.c10), RC01 = R00 * jc((double)es.c01) + R01 * jc((double)es.c11);
-    const cc_jet RC10 = R10 * jc((double)es.c00) + R11 * jc((double)es.c10), RC11 = R10 * jc((double)es.c01) + R11 * jc((double)es.c11);
-    const cc_jet n00 = jc(2.0) * (RC00 * R00 + RC01 * R01 + jc((double)et.c00));
-    const cc_jet n01 = jc(2.0) * (RC00 * R10 + RC01 * R11 + jc((double)et.c01));
-    const cc_jet n10 = jc(2.0) * (RC10 * R00 + RC11 * R01 + jc((double)et.c10));
-    const cc_jet n11 = jc(2.0) * (RC10 * R10 + RC11 * R11 + jc((double)et.c11));
-    const cc_jet m0 = R00 * jc((double)es.mx) + R01 * jc((double)es.my) + x - jc((double)et.mx);
-    const cc_jet m1 = R10 * jc((double)es.mx) + R11 * jc((double)es.my) + y - jc((double)et.my);
-    const cc_jet det = n00 * n11 - n10 * n01;
-    const cc_jet invdet = jc(1.0) / det;
-    const cc_jet i00 = n11 * invdet, i01 = -n01 * invdet, i10 = -n10 * invdet, i11 = n00 * invdet;
-    const cc_jet h0 = jc(-0.5) * m0, h1 = jc(-0.5) * m1;
-    const cc_jet r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
-    const cc_jet qua = r0 * m0 + r1 * m1;
-    acc = acc + jc(-(double)et.w) * jc((double)es.w) * jc(1.0) / jsqrt(det) * jexp(qua);
+    const cc_j1 RC00 = j1_add(j1_mulc(R00, (double)es.c00), j1_mulc(R01, (double)es.c10));
+    const cc_j1 RC01 = j1_add(j1_mulc(R00, (double)es.c01), j1_mulc(R01, (double)es.c11));
+    const cc_j1 RC10 = j1_add(j1_mulc(R10, (double)es.c00), j1_mulc(R11, (double)es.c10));
+    const cc_j1 RC11 = j1_add(j1_mulc(R10, (double)es.c01), j1_mulc(R11, (double)es.c11));
+    cc_j1 n00 = j1_add(j1_mul(RC00, R00), j1_mul(RC01, R01));
+    cc_j1 n01 = j1_add(j1_mul(RC00, R10), j1_mul(RC01, R11));
+    cc_j1 n10 = j1_add(j1_mul(RC10, R00), j1_mul(RC11, R01));
+    cc_j1 n11 = j1_add(j1_mul(RC10, R10), j1_mul(RC11, R11));
+    n00 = cc_j1{2.0 * (n00.a + (double)et.c00), 2.0 * n00.t};
+    n01 = cc_j1{2.0 * (n01.a + (double)et.c01), 2.0 * n01.t};
+    n10 = cc_j1{2.0 * (n10.a + (double)et.c10), 2.0 * n10.t};
+    n11 = cc_j1{2.0 * (n11.a + (double)et.c11), 2.0 * n11.t};
+    // new_mean = R mean_s + t - mean_t: (value, d/dx, d/dy, d/dtheta) = (m0a, 1, 0, m0t), (m1a, 0, 1, m1t)
+    const double m0a = R00.a * (double)es.mx + R01.a * (double)es.my + px - (double)et.mx;
+    const double m0t = R00.t * (double)es.mx + R01.t * (double)es.my;
+    const double m1a = R10.a * (double)es.mx + R11.a * (double)es.my + py - (double)et.my;
+    const double m1t = R10.t * (double)es.mx + R11.t * (double)es.my;
+    const cc_j1 det = j1_sub(j1_mul(n00, n11), j1_mul(n10, n01));
+    const double dgi = 1.0 / det.a, dfg = 1.0 * dgi;
+    const cc_j1 invdet{dfg, (0.0 - dfg * det.t) * dgi};
+    const cc_j1 i00 = j1_mul(n11, invdet), i01 = j1_mul(j1_neg(n01), invdet);
+    const cc_j1 i10 = j1_mul(j1_neg(n10), invdet), i11 = j1_mul(n00, invdet);
+    const double h0a = -0.5 * m0a, h0t = -0.5 * m0t, h1a = -0.5 * m1a, h1t = -0.5 * m1t;  // d/dx h0 = d/dy h1 = -0.5
+    const double r0a = h0a * i00.a + h1a * i10.a, r0x = -0.5 * i00.a, r0y = -0.5 * i10.a;
+    const double r0t = (h0a * i00.t + h0t * i00.a) + (h1a * i10.t + h1t * i10.a);
+    const double r1a = h0a * i01.a + h1a * i11.a, r1x = -0.5 * i01.a, r1y = -0.5 * i11.a;
+    const double r1t = (h0a * i01.t + h0t * i01.a) + (h1a * i11.t + h1t * i11.a);
+    const double qa = r0a * m0a + r1a * m1a;
+    const double qx = (r0a + r0x * m0a) + r1x * m1a;
+    const double qy = r0y * m0a + (r1a + r1y * m1a);
+    const double qt = (r0a * m0t + r0t * m0a) + (r1a * m1t + r1t * m1a);
+    const double sq = sqrt(det.a), sqh = 1.0 / (2.0 * sq), sqt = sqh * det.t;
+    const double B = (-(double)et.w) * (double)es.w * 1.0;
+    const double cgi = 1.0 / sq, Ca = B * cgi, Ct = (0.0 - Ca * sqt) * cgi;
+    const double e = exp(qa);
+    acc_a = acc_a + Ca * e;
+    acc_x = acc_x + Ca * (e * qx);
+    acc_y = acc_y + Ca * (e * qy);
+    acc_t = acc_t + (Ca * (e * qt) + Ct * e);
   }
-  *cost = cc_group_sum_d(acc.a, G);
+  *cost = cc_group_sum_d(acc_a, G);
   if (want_grad) {
-    grad[0] = cc_group_sum_d(acc.v0, G);
-    grad[1] = cc_group_sum_d(acc.v1, G);
-    grad[2] = cc_group_sum_d(acc.v2, G);
+    grad[0] = cc_group_sum_d(acc_x, G);
+    grad[1] = cc_group_sum_d(acc_y, G);
+    grad[2] = cc_group_sum_d(acc_t, G);
   }
 }
 
 // ---- Ceres 2.x line search pieces (see oracle/orc_gmm.h for the provenance notes) ----
-struct cc_fs {  // FunctionSample
+struct cc_fs {  // FunctionSample; vector_x is not kept (it is pos + x * dir, recomputed where needed)
   double x, value, gradient;
-  double vx[3], vg[3];
+  double vg[3];
   bool value_ok, grad_ok;
 };
-
-__device__ __forceinline__ double cc_polyval(const double *p, int n, double x) {
-  double v = 0.0;
-  for (int i = 0; i < n; i++) v = v * x + p[i];
-  return v;
+__device__ __forceinline__ cc_fs cc_fs_sel(bool c, const cc_fs &a, const cc_fs &b) {  // c ? a : b, field by field (keeps both in registers)
+  cc_fs r;
+  r.x = c ? a.x : b.x;
+  r.value = c ? a.value : b.value;
+  r.gradient = c ? a.gradient : b.gradient;
+  r.vg[0] = c ? a.vg[0] : b.vg[0];
+  r.vg[1] = c ? a.vg[1] : b.vg[1];
+  r.vg[2] = c ? a.vg[2] : b.vg[2];
+  r.value_ok = c ? a.value_ok : b.value_ok;
+  r.grad_ok = c ? a.grad_ok : b.grad_ok;
+  return r;
 }
 
-__device__ void cc_solve_fullpiv(double A[4][4], double b[4], int n, double x[4]) {
-  int colperm[4] = {0, 1, 2, 3};
-  for (int k = 0; k < n; k++) {
+__device__ __forceinline__ double cc_ipow(double x, int k) {  // the Vandermonde entries: k in 0..3
+  return k == 0 ? 1.0 : (k == 1 ? x : (k == 2 ? x * x : x * x * x));
+}
+
+// FullPivLU solve of the n x n Vandermonde system (what Eigen's fullPivLu().solve() does in
+// FindInterpolatingPolynomial), n <= 4.  Every array index is a compile-time constant after unrolling and the
+// permutations are conditional register swaps, so nothing spills to scratch.
+__device__ __forceinline__ void cc_solve_fullpiv(double (&A)[4][4], double (&b)[4], int n, double (&x)[4]) {
+  int cp[4] = {0, 1, 2, 3};
+  bool done = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
     int pr = k, pc = k;
     double best = -1;
-    for (int i = k; i < n; i++)
-      for (int j = k; j < n; j++)
-        if (fabs(A[i][j]) > best) {
-          best = fabs(A[i][j]);
+#pragma unroll
+    for (int i = k; i < 4; i++) {
+#pragma unroll
+      for (int j = k; j < 4; j++) {
+        const double v = fabs(A[i][j]);
+        if (i < n && j < n && v > best) {
+          best = v;
           pr = i;
           pc = j;
         }
-    if (best == 0.0) break;
-    for (int j = 0; j < n; j++) {
-      double t = A[k][j];
-      A[k][j] = A[pr][j];
-      A[pr][j] = t;
-    }
-    {
-      double t = b[k];
-      b[k] = b[pr];
-      b[pr] = t;
-    }
-    if (pc != k) {
-      for (int i = 0; i < n; i++) {
-        double t = A[i][k];
-        A[i][k] = A[i][pc];
-        A[i][pc] = t;
       }
-      int t = colperm[k];
-      colperm[k] = colperm[pc];
-      colperm[pc] = t;
     }
-    for (int i = k + 1; i < n; i++) {
-      const double f = A[i][k] / A[k][k];
-      A[i][k] = 0;
-      for (int j = k + 1; j < n; j++) A[i][j] -= f * A[k][j];
-      b[i] -= f * b[k];
+    if (k >= n || best == 0.0) done = true;
+    if (!done) {
+#pragma unroll
+      for (int r = k + 1; r < 4; r++) {
+        if (pr == r) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const double t = A[k][j];
+            A[k][j] = A[r][j];
+            A[r][j] = t;
+          }
+          const double t = b[k];
+          b[k] = b[r];
+          b[r] = t;
+        }
+      }
+#pragma unroll
+      for (int c = k + 1; c < 4; c++) {
+        if (pc == c) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const double t = A[i][k];
+            A[i][k] = A[i][c];
+            A[i][c] = t;
+          }
+          const int t = cp[k];
+          cp[k] = cp[c];
+          cp[c] = t;
+        }
+      }
+#pragma unroll
+      for (int i = k + 1; i < 4; i++) {
+        if (i < n) {
+          const double f = A[i][k] / A[k][k];
+          A[i][k] = 0;
+#pragma unroll
+          for (int j = k + 1; j < 4; j++) A[i][j] -= f * A[k][j];
+          b[i] -= f * b[k];
+        }
+      }
     }
   }
   double yv[4] = {0, 0, 0, 0};
-  for (int i = n - 1; i >= 0; i--) {
-    double s = b[i];
-    for (int j = i + 1; j < n; j++) s -= A[i][j] * yv[j];
-    yv[i] = (A[i][i] != 0.0) ? s / A[i][i] : 0.0;
+#pragma unroll
+  for (int i = 3; i >= 0; i--) {
+    if (i < n) {
+      double sacc = b[i];
+#pragma unroll
+      for (int j = i + 1; j < 4; j++)
+        if (j < n) sacc -= A[i][j] * yv[j];
+      yv[i] = (A[i][i] != 0.0) ? sacc / A[i][i] : 0.0;
+    }
   }
-  for (int i = 0; i < n; i++) x[colperm[i]] = yv[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (i < n && cp[i] == c) x[c] = yv[i];
 }
 
-// InterpolatingPolynomialMinimizingStepSize for CUBIC with samples {lowerbound, current} (both with gradients)
+// polynomial with coefficients p[4 - np .. 3] (highest power first), Horner
+__device__ __forceinline__ double cc_polyval(const double (&p)[4], int np, double x) {
+  double v = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i >= 4 - np) v = v * x + p[i];
+  return v;
+}
+
+// InterpolatingPolynomialMinimizingStepSize for CUBIC with samples {lowerbound, current}
 __device__ double cc_interp_step(const cc_fs &lo, const cc_fs &cur, double x_min, double x_max) {
   if (!cur.value_ok) {
     double s = cur.x * 0.5;
     s = s < x_min ? x_min : s;
     return s < x_max ? s : x_max;
   }
-  const cc_fs *smp[2] = {&lo, &cur};
-  int nc = 0;
-  for (int i = 0; i < 2; i++) {
-    if (smp[i]->value_ok) nc++;
-    if (smp[i]->grad_ok) nc++;
-  }
+  const int nc = (lo.value_ok ? 1 : 0) + (lo.grad_ok ? 1 : 0) + (cur.value_ok ? 1 : 0) + (cur.grad_ok ? 1 : 0);
   const int degree = nc - 1;
+  // rows in the reference's order (sample 0 value, sample 0 gradient, sample 1 value, sample 1 gradient), absent rows
+  // skipped; built as 4 candidates that are compacted with conditional moves
   double A[4][4], b[4], poly[4];
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     b[i] = 0;
+#pragma unroll
     for (int j = 0; j < 4; j++) A[i][j] = 0;
   }
   int row = 0;
-  for (int i = 0; i < 2; i++) {
-    if (smp[i]->value_ok) {
-      for (int j = 0; j <= degree; j++) A[row][j] = pow(smp[i]->x, (double)(degree - j));
-      b[row] = smp[i]->value;
-      row++;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const bool is_grad = (c & 1) != 0;
+    const bool present = c == 0 ? lo.value_ok : (c == 1 ? lo.grad_ok : (c == 2 ? cur.value_ok : cur.grad_ok));
+    const double sx = c < 2 ? lo.x : cur.x;
+    double rv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!is_grad)
+        rv[j] = j <= degree ? cc_ipow(sx, degree - j) : 0.0;
+      else
+        rv[j] = j < degree ? (double)(degree - j) * cc_ipow(sx, degree - j - 1) : 0.0;
     }
-    if (smp[i]->grad_ok) {
-      for (int j = 0; j < degree; j++) A[row][j] = (degree - j) * pow(smp[i]->x, (double)(degree - j - 1));
-      b[row] = smp[i]->gradient;
+    const double rb = c == 0 ? lo.value : (c == 1 ? lo.gradient : (c == 2 ? cur.value : cur.gradient));
+    if (present) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (row == r) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) A[r][j] = rv[j];
+          b[r] = rb;
+        }
+      }
       row++;
     }
   }
-  cc_solve_fullpiv(A, b, nc, poly);
+  double sol[4] = {0, 0, 0, 0};
+  cc_solve_fullpiv(A, b, nc, sol);
+  // poly[] right-aligned: coefficient of x^(np-1-i) at index 4 - np + i
   const int np = nc;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    poly[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (i - (4 - np) == j) poly[i] = sol[j];
+  }
   double opt_x = (x_min + x_max) / 2.0;
   double opt_v = cc_polyval(poly, np, opt_x);
   const double vmin = cc_polyval(poly, np, x_min);
@@ -1350,59 +1439,76 @@ __device__ double cc_interp_step(const cc_fs &lo, const cc_fs &cur, double x_min
     opt_x = x_max;
   }
   if (np > 2) {
+    // derivative coefficients, right-aligned in d[0..2] (d[2] = constant term); leading zeros are skipped
     double d[3];
-    const int deg = np - 1;
-    for (int i = 0; i < deg; i++) d[i] = (deg - i) * poly[i];
-    int lead = 0;
-    while (lead + 1 < deg && d[lead] == 0.0) lead++;
-    const int dd = deg - lead - 1;  // degree of the derivative after removing leading zeros
-    double roots[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = (double)(3 - i) * poly[i];  // exponent of poly[i] is 3 - i
+    // `while (lead + 1 < deg && d[lead] == 0) lead++`: quadratic, linear or constant derivative (for np == 3, d[0] is 0)
+    double a = 0, bb = 0, c = 0;
+    int dd = 0;
+    if (d[0] != 0.0) {
+      dd = 2;
+      a = d[0];
+      bb = d[1];
+      c = d[2];
+    } else if (d[1] != 0.0) {
+      dd = 1;
+      a = d[1];
+      bb = d[2];
+    }
+    double roots[2] = {0, 0};
     int nr = 0;
     if (dd == 1) {
-      roots[nr++] = -d[lead + 1] / d[lead];
+      roots[0] = -bb / a;
+      nr = 1;
     } else if (dd == 2) {
-      const double a = d[lead], bb = d[lead + 1], c = d[lead + 2];
       const double D = bb * bb - 4 * a * c;
       const double sq = sqrt(fabs(D));
+      nr = 2;
       if (D >= 0) {
         if (bb >= 0) {
-          roots[nr++] = (-bb - sq) / (2.0 * a);
-          roots[nr++] = (2.0 * c) / (-bb - sq);
+          roots[0] = (-bb - sq) / (2.0 * a);
+          roots[1] = (2.0 * c) / (-bb - sq);
         } else {
-          roots[nr++] = (2.0 * c) / (-bb + sq);
-          roots[nr++] = (-bb + sq) / (2.0 * a);
+          roots[0] = (2.0 * c) / (-bb + sq);
+          roots[1] = (-bb + sq) / (2.0 * a);
         }
       } else {
-        roots[nr++] = -bb / (2.0 * a);
-        roots[nr++] = -bb / (2.0 * a);
+        roots[0] = -bb / (2.0 * a);
+        roots[1] = -bb / (2.0 * a);
       }
     }
-    for (int i = 0; i < nr; i++) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
       const double r = roots[i];
-      if (r < x_min || r > x_max) continue;
-      const double v = cc_polyval(poly, np, r);
-      if (v < opt_v) {
-        opt_v = v;
-        opt_x = r;
+      if (i < nr && !(r < x_min || r > x_max)) {
+        const double v = cc_polyval(poly, np, r);
+        if (v < opt_v) {
+          opt_v = v;
+          opt_x = r;
+        }
       }
     }
   }
+#pragma unroll
   for (int i = 0; i < 2; i++) {
-    const double sx = smp[i]->x;
-    if (sx < x_min || sx > x_max) continue;
-    const double v = cc_polyval(poly, np, sx);
-    if (v < opt_v) {
-      opt_x = sx;
-      opt_v = v;
+    const double sx = i == 0 ? lo.x : cur.x;
+    if (!(sx < x_min || sx > x_max)) {
+      const double v = cc_polyval(poly, np, sx);
+      if (v < opt_v) {
+        opt_x = sx;
+        opt_v = v;
+      }
     }
   }
   return opt_x;
 }
 
-__device__ void cc_ls_eval(const cc_gmm_lds *S, const double pos[3], const double dir[3], double x, cc_fs *o) {
+__device__ __forceinline__ void cc_ls_eval(const cc_gmm_lds *S, const double pos[3], const double dir[3], double x, cc_fs *o) {
   o->x = x;
-  for (int i = 0; i < 3; i++) o->vx[i] = pos[i] + x * dir[i];
-  cc_gmm_eval(S, o->vx, true, &o->value, o->vg);
+  double vx[3];
+  for (int i = 0; i < 3; i++) vx[i] = pos[i] + x * dir[i];
+  cc_gmm_eval(S, vx, true, &o->value, o->vg);
   o->value_ok = isfinite(o->value);
   o->grad_ok = o->value_ok && isfinite(o->vg[0]) && isfinite(o->vg[1]) && isfinite(o->vg[2]);
   o->gradient = dir[0] * o->vg[0] + dir[1] * o->vg[1] + dir[2] * o->vg[2];
@@ -1419,10 +1525,7 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
   init.value = cost0;
   init.gradient = dgrad0;
   init.value_ok = init.grad_ok = true;
-  for (int i = 0; i < 3; i++) {
-    init.vx[i] = pos[i];
-    init.vg[i] = g0[i];
-  }
+  for (int i = 0; i < 3; i++) init.vg[i] = g0[i];
   int nit = 0;
   cc_fs prev = init, cur, lo = init, hi = init;
   bool zoom = false;
@@ -1480,8 +1583,8 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
       }
       ++nit;
       const bool lo_first = blo.x < bhi.x;
-      const cc_fs &lb = lo_first ? blo : bhi;
-      const cc_fs &ub = lo_first ? bhi : blo;
+      const cc_fs lb = cc_fs_sel(lo_first, blo, bhi);
+      const cc_fs ub = cc_fs_sel(lo_first, bhi, blo);
       const double step = cc_interp_step(lb, ub, lb.x, ub.x);
       cc_ls_eval(S, pos, dir, step, &sol);
       if (!sol.value_ok || !sol.grad_ok) {
@@ -1518,7 +1621,8 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   char *base_lds = smem + (size_t)sub * CC_GMM_LDS_BYTES(ecap, pcap);
   cc_gmm_lds Sv;
   Sv.ell = (cc_ell *)base_lds;
-  Sv.pairs = (unsigned *)(base_lds + 2 * CC_GMM_LEVELS * (size_t)ecap * sizeof(cc_ell));
+  Sv.hist = (double *)(base_lds + 2 * CC_GMM_LEVELS * (size_t)ecap * sizeof(cc_ell));
+  Sv.pairs = (unsigned *)(Sv.hist + 80);
   Sv.n_ell = (int *)(Sv.pairs + pcap);
   Sv.n_pairs = Sv.n_ell + 2 * CC_GMM_LEVELS;
   Sv.flags = Sv.n_pairs + 1;
@@ -1532,7 +1636,8 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   for (int pbase = blockIdx.x * ppw; pbase < n_prob; pbase += gridDim.x * ppw) {
   const int pidx = pbase + sub;
   if (pidx >= n_prob) continue;
-  if (redo_only && !(results[pidx].flags & 3)) continue;
+  if ((redo_only & 1) && !(results[pidx].flags & 3)) continue;
+  const int dbg = redo_only >> 8;  // tuning aid (env CC_GMM_CUT): stop after a phase, results are then meaningless
   const cc_gmm_problem pb = probs[pidx];
   const cc_scan_desc_t *src = db_desc + pb.gidx;
   const cc_scan_desc_t *tgt = qdesc + pb.q;
@@ -1615,6 +1720,13 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   }
   if (np > pcap) np = pcap;
   if (sl == 0) *S->n_pairs = np;
+  if (dbg == 1) {
+    if (sl == 0) {
+      cc_gmm_result Z = {};
+      results[pidx] = Z;
+    }
+    continue;
+  }
   // ---- auto-correlation (correlation.h:102-119)
   double ac[2] = {0, 0};
   for (int side = 0; side < 2; side++) {
@@ -1637,6 +1749,13 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
     ac[side] = cc_group_sum_d(acc, G);
   }
   cc_group_sync(G);
+  if (dbg == 2) {
+    if (sl == 0) {
+      cc_gmm_result Z = {};
+      results[pidx] = Z;
+    }
+    continue;
+  }
   // ---- initial correlation (tryProblem, correlation.h:196-202)
   double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
   double cost, g[3];
@@ -1651,13 +1770,20 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   R.optimized = 0;
   R.iterations = 0;
   R.termination = 0;
+  if (dbg == 3) {
+    if (sl == 0) {
+      cc_gmm_result Z = {};
+      results[pidx] = Z;
+    }
+    continue;
+  }
   if (!((float)R.corr_init < corr_lb)) {
     // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations
     R.optimized = 1;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     double cur_cost = cost, cur_g[3] = {g[0], g[1], g[2]};
     double prev_cost = 0, prev_g[3] = {0, 0, 0}, prev_dir[3] = {0, 0, 0}, prev_step = 0;
-    double dxh[10][3], dgh[10][3], dxdg[10];
+    double *dxh = S->hist, *dgh = S->hist + 30, *dxdg = S->hist + 60, *alpha = S->hist + 70;  // [k * 3 + i]
     int ncorr = 0;
     int restarts = 0;
     int term = 0, iter = 0;
@@ -1667,7 +1793,7 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
       term = 1;
     } else {
       while (true) {
-        if (iter >= 10) {
+        if (iter >= (dbg >= 4 ? dbg - 3 : 10)) {
           term = 0;
           break;
         }
@@ -1685,21 +1811,21 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
           const double dd = ddx[0] * ddg[0] + ddx[1] * ddg[1] + ddx[2] * ddg[2];
           if (dd > 1e-14 && ncorr < 10) {
             for (int i = 0; i < 3; i++) {
-              dxh[ncorr][i] = ddx[i];
-              dgh[ncorr][i] = ddg[i];
+              dxh[ncorr * 3 + i] = ddx[i];
+              dgh[ncorr * 3 + i] = ddg[i];
             }
             dxdg[ncorr] = dd;
             ncorr++;
           }
-          double sd[3] = {cur_g[0], cur_g[1], cur_g[2]}, alpha[10];
+          double sd[3] = {cur_g[0], cur_g[1], cur_g[2]};
           for (int k = ncorr - 1; k >= 0; k--) {
-            const double al = (dxh[k][0] * sd[0] + dxh[k][1] * sd[1] + dxh[k][2] * sd[2]) / dxdg[k];
-            for (int i = 0; i < 3; i++) sd[i] -= al * dgh[k][i];
+            const double al = (dxh[k * 3 + 0] * sd[0] + dxh[k * 3 + 1] * sd[1] + dxh[k * 3 + 2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] -= al * dgh[k * 3 + i];
             alpha[k] = al;
           }
           for (int k = 0; k < ncorr; k++) {
-            const double beta = (dgh[k][0] * sd[0] + dgh[k][1] * sd[1] + dgh[k][2] * sd[2]) / dxdg[k];
-            for (int i = 0; i < 3; i++) sd[i] += dxh[k][i] * (alpha[k] - beta);
+            const double beta = (dgh[k * 3 + 0] * sd[0] + dgh[k * 3 + 1] * sd[1] + dgh[k * 3 + 2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] += dxh[k * 3 + i] * (alpha[k] - beta);
           }
           for (int i = 0; i < 3; i++) dir[i] = -1.0 * sd[i];
           if (dir[0] * cur_g[0] + dir[1] * cur_g[1] + dir[2] * cur_g[2] >= 0.0) ls_status = false;
@@ -1734,9 +1860,11 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
         gmax = fmax(fabs(cur_g[0]), fmax(fabs(cur_g[1]), fabs(cur_g[2])));
         const double xnorm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         double sn = 0;
-        for (int i = 0; i < 3; i++) sn += (opt.vx[i] - x[i]) * (opt.vx[i] - x[i]);
+        double nx[3];
+        for (int i = 0; i < 3; i++) nx[i] = x[i] + opt.x * dir[i];  // optimal_point.vector_x
+        for (int i = 0; i < 3; i++) sn += (nx[i] - x[i]) * (nx[i] - x[i]);
         sn = sqrt(sn);
-        for (int i = 0; i < 3; i++) x[i] = opt.vx[i];
+        for (int i = 0; i < 3; i++) x[i] = nx[i];
         final_cost = cur_cost;
         if (sn <= parameter_tolerance * (xnorm + parameter_tolerance)) {
           term = 3;
