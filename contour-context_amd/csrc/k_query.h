@@ -20,7 +20,7 @@ __device__ __forceinline__ void cc_group_sync(int G) {
 // ------------------------------------------------------------------------------------------------
 // K3: exhaustive top-k over the layer's key matrix with the reference's visibility rules.
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_CAP 2048  // LDS candidate buffer (entries of 8 B)
+#define CC_KNN_CAP 1024  // LDS candidate buffer per anchor key (entries of 8 B)
 
 struct cc_knn_params {
   const float *keys[CC_NQLEV];        // SoA [CC_KEY_DIM][cap_k]
@@ -58,128 +58,151 @@ __device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n
   }
 }
 
-// grid = nq * CC_NQLEV * CC_NPIV, block = 256
+// One workgroup per (query scan, layer): the layer's key matrix is streamed ONCE for the 6 anchor keys of the scan
+// (the stream is the cost: 10 f32 per key from L2/HBM), every lane scores its key against all six.
+// grid = nq * CC_NQLEV, block = 256
+struct cc_knn_lds {
+  unsigned long long buf[CC_NPIV][CC_KNN_CAP];  // (dist bits << 32 | key id) candidates below the anchor's current radius
+  float k[CC_NPIV][CC_KEY_DIM];
+  float ub[CC_NPIV];
+  unsigned vis[CC_NPIV];
+  int cnt[CC_NPIV];
+  int valid[CC_NPIV];
+};
+
 __global__ void __launch_bounds__(256)
 cc_k_knn(cc_knn_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_query_meta *__restrict__ qmeta,
          cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
-  __shared__ unsigned long long buf[CC_KNN_CAP];
-  __shared__ int s_cnt;
-  __shared__ float s_ub;
+  __shared__ cc_knn_lds L;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int slot = blockIdx.x % (CC_NQLEV * CC_NPIV);
-  const int q = blockIdx.x / (CC_NQLEV * CC_NPIV);
-  const int ll = slot / CC_NPIV, seq = slot - ll * CC_NPIV;
-  cc_knn_hit_t *out = hits + (size_t)blockIdx.x * CC_KNN_MAX;
+  const int ll = blockIdx.x % CC_NQLEV;
+  const int q = blockIdx.x / CC_NQLEV;
+  const int slot0 = (q * CC_NQLEV + ll) * CC_NPIV;
   if (ll >= P.n_q_levels) {
-    if (tid == 0) hit_cnt[blockIdx.x] = 0;
+    if (tid < CC_NPIV) hit_cnt[slot0 + tid] = 0;
     return;
   }
   const int level = P.q_levels[ll];
-  const float *qk = &qdesc[q].keys[level][seq][0];
-  float k[CC_KEY_DIM];
-  float sum = 0.f;
-  for (int d = 0; d < CC_KEY_DIM; d++) {
-    k[d] = qk[d];
-    sum += k[d];
-  }
-  if (!(sum != 0.f)) {  // q_keys[seq].sum() != 0 (contour_db.h:726)
-    if (tid == 0) hit_cnt[blockIdx.x] = 0;
-    return;
-  }
   const cc_query_meta qm = qmeta[q];
-  // dist_ub (contour_db.h:733-749), f32 results of f64 products exactly as written there
-  const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
-  const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
-  const float b20 = (float)((double)k[2] * 0.8 * 0.75), b21 = (float)((double)k[2] / (0.8 * 0.75));
-  const float t0a = (k[0] - b00) * (k[0] - b00), t0b = (k[0] - b01) * (k[0] - b01);
-  const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
-  const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
-  const float dist_ub = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
-  // mid bucket and the buckets layerKNNSearch actually visits (src/cont2/contour_db.cpp:322-369):
-  // {0..mid} and {mid+i : i > mid, mid+i < 6}
   float rg[7];
   for (int i = 0; i < 7; i++) rg[i] = qm.ranges[ll][i];
-  int mid = 0;
-  for (int i = 0; i < 6; i++)
-    if (rg[i] <= k[0] && rg[i + 1] > k[0]) {
-      mid = i;
-      break;
+  if (tid < CC_NPIV) {
+    const int seq = tid;
+    const float *qk = &qdesc[q].keys[level][seq][0];
+    float k[CC_KEY_DIM];
+    float sum = 0.f;
+    for (int d = 0; d < CC_KEY_DIM; d++) {
+      k[d] = qk[d];
+      sum += k[d];
+      L.k[seq][d] = k[d];
     }
-  unsigned vis = 0;
-  for (int b = 0; b < 6; b++)
-    if (b <= mid || b >= 2 * mid + 1) vis |= 1u << b;
-  if (tid == 0) {
-    s_cnt = 0;
-    s_ub = dist_ub;
+    L.valid[seq] = (sum != 0.f) ? 1 : 0;  // q_keys[seq].sum() != 0 (contour_db.h:726)
+    // dist_ub (contour_db.h:733-749), f32 results of f64 products exactly as written there
+    const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
+    const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
+    const float b20 = (float)((double)k[2] * 0.8 * 0.75), b21 = (float)((double)k[2] / (0.8 * 0.75));
+    const float t0a = (k[0] - b00) * (k[0] - b00), t0b = (k[0] - b01) * (k[0] - b01);
+    const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
+    const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
+    L.ub[seq] = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
+    // mid bucket and the buckets layerKNNSearch actually visits (src/cont2/contour_db.cpp:322-369):
+    // {0..mid} and {mid+i : i > mid, mid+i < 6}
+    int mid = 0;
+    for (int i = 0; i < 6; i++)
+      if (rg[i] <= k[0] && rg[i + 1] > k[0]) {
+        mid = i;
+        break;
+      }
+    unsigned vis = 0;
+    for (int b = 0; b < 6; b++)
+      if (b <= mid || b >= 2 * mid + 1) vis |= 1u << b;
+    L.vis[seq] = vis;
+    L.cnt[seq] = 0;
   }
   __syncthreads();
+  unsigned any_vis = 0;
+  for (int p = 0; p < CC_NPIV; p++)
+    if (L.valid[p]) any_vis |= L.vis[p];
   const int nk = qm.n_keys[ll];
   const float *K = P.keys[ll];
   const int *act = P.kactive[ll];
   const int cap = P.cap_k;
   const int epoch = qm.epoch;
   const int nnk = P.nnk;
-  for (int base = 0; base < nk; base += nt) {
-    const int id = base + tid;
-    if (id < nk && act[id] <= epoch) {
-      const float c0 = K[id];
-      int bk = -1;
-      for (int b = 0; b < 6; b++)
-        if (rg[b] <= c0 && c0 < rg[b + 1]) {
-          bk = b;
-          break;
-        }
-      if (bk >= 0 && ((vis >> bk) & 1u)) {
-        // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-        float d0 = k[0] - c0, d1 = k[1] - K[cap + id], d2 = k[2] - K[2 * cap + id], d3 = k[3] - K[3 * cap + id];
-        float res = 0.f;
-        res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        d0 = k[4] - K[4 * cap + id];
-        d1 = k[5] - K[5 * cap + id];
-        d2 = k[6] - K[6 * cap + id];
-        d3 = k[7] - K[7 * cap + id];
-        res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        d0 = k[8] - K[8 * cap + id];
-        res += d0 * d0;
-        d0 = k[9] - K[9 * cap + id];
-        res += d0 * d0;
-        if (res < s_ub) {
-          int p = atomicAdd(&s_cnt, 1);
-          buf[p] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)id;
+  if (any_vis) {
+    for (int base = 0; base < nk; base += nt) {
+      const int id = base + tid;
+      if (id < nk && act[id] <= epoch) {
+        const float c0 = K[id];
+        int bk = -1;
+        for (int b = 0; b < 6; b++)
+          if (rg[b] <= c0 && c0 < rg[b + 1]) {
+            bk = b;
+            break;
+          }
+        if (bk >= 0 && ((any_vis >> bk) & 1u)) {
+          const float c1 = K[cap + id], c2 = K[2 * cap + id], c3 = K[3 * cap + id], c4 = K[4 * cap + id];
+          const float c5 = K[5 * cap + id], c6 = K[6 * cap + id], c7 = K[7 * cap + id], c8 = K[8 * cap + id], c9 = K[9 * cap + id];
+#pragma unroll
+          for (int p = 0; p < CC_NPIV; p++) {
+            if (L.valid[p] && ((L.vis[p] >> bk) & 1u)) {
+              // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+              float d0 = L.k[p][0] - c0, d1 = L.k[p][1] - c1, d2 = L.k[p][2] - c2, d3 = L.k[p][3] - c3;
+              float res = 0.f;
+              res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+              d0 = L.k[p][4] - c4;
+              d1 = L.k[p][5] - c5;
+              d2 = L.k[p][6] - c6;
+              d3 = L.k[p][7] - c7;
+              res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+              d0 = L.k[p][8] - c8;
+              res += d0 * d0;
+              d0 = L.k[p][9] - c9;
+              res += d0 * d0;
+              if (res < L.ub[p]) {
+                const int pos = atomicAdd(&L.cnt[p], 1);
+                L.buf[p][pos] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)id;
+              }
+            }
+          }
         }
       }
-    }
-    __syncthreads();
-    if (s_cnt > CC_KNN_CAP - nt) {  // uniform: shrink to the best nnk and tighten the radius
-      const int n = s_cnt;
-      for (int i = n + tid; i < CC_KNN_CAP; i += nt) buf[i] = ~0ull;
       __syncthreads();
-      cc_bitonic_sort_u64(buf, CC_KNN_CAP, tid, nt);
-      if (tid == 0) {
-        s_cnt = n < nnk ? n : nnk;
-        if (n >= nnk) s_ub = __uint_as_float((unsigned)(buf[nnk - 1] >> 32));
+      for (int p = 0; p < CC_NPIV; p++) {
+        if (L.cnt[p] > CC_KNN_CAP - nt) {  // uniform: shrink to the best nnk and tighten the radius
+          const int n = L.cnt[p];
+          for (int i = n + tid; i < CC_KNN_CAP; i += nt) L.buf[p][i] = ~0ull;
+          __syncthreads();
+          cc_bitonic_sort_u64(L.buf[p], CC_KNN_CAP, tid, nt);
+          if (tid == 0) {
+            L.cnt[p] = n < nnk ? n : nnk;
+            if (n >= nnk) L.ub[p] = __uint_as_float((unsigned)(L.buf[p][nnk - 1] >> 32));
+          }
+          __syncthreads();
+        }
       }
-      __syncthreads();
     }
   }
-  {
-    const int n = s_cnt;
+  for (int p = 0; p < CC_NPIV; p++) {
+    cc_knn_hit_t *out = hits + (size_t)(slot0 + p) * CC_KNN_MAX;
+    const int n = L.valid[p] ? L.cnt[p] : 0;
     int np2 = 64;
     while (np2 < n) np2 <<= 1;
-    for (int i = n + tid; i < np2; i += nt) buf[i] = ~0ull;
+    for (int i = n + tid; i < np2; i += nt) L.buf[p][i] = ~0ull;
     __syncthreads();
-    cc_bitonic_sort_u64(buf, np2, tid, nt);
+    cc_bitonic_sort_u64(L.buf[p], np2, tid, nt);
     const int m = n < nnk ? n : nnk;
     for (int i = tid; i < m; i += nt) {
-      const unsigned id = (unsigned)(buf[i] & 0xFFFFFFFFu);
+      const unsigned id = (unsigned)(L.buf[p][i] & 0xFFFFFFFFu);
       cc_knn_hit_t h;
       h.gidx = P.kgidx[ll][id];
       h.level = (int16_t)level;
       h.seq = (int16_t)P.kseq[ll][id];
-      h.dist_sq = __uint_as_float((unsigned)(buf[i] >> 32));
+      h.dist_sq = __uint_as_float((unsigned)(L.buf[p][i] >> 32));
       out[i] = h;
     }
-    if (tid == 0) hit_cnt[blockIdx.x] = m;
+    if (tid == 0) hit_cnt[slot0 + p] = m;
+    __syncthreads();
   }
 }
 
