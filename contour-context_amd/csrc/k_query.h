@@ -20,7 +20,7 @@ __device__ __forceinline__ void cc_group_sync(int G) {
 // ------------------------------------------------------------------------------------------------
 // K3: exhaustive top-k over the layer's key matrix with the reference's visibility rules.
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_CAP 1024  // LDS candidate buffer per anchor key (entries of 8 B)
+#define CC_KNN_CAP 512   // LDS candidate buffer per anchor key (entries of 8 B); shrunk to the best nnk when > CAP - 256
 
 struct cc_knn_params {
   const float *keys[CC_NQLEV];        // SoA [CC_KEY_DIM][cap_k]
@@ -31,6 +31,7 @@ struct cc_knn_params {
   int nnk;
   int n_q_levels;
   int q_levels[CC_NQLEV];
+  int dbg_cut;  // tuning aid (env CC_KNN_CUT)
 };
 
 struct cc_query_meta {  // per query scan, host-built
@@ -120,64 +121,89 @@ cc_k_knn(cc_knn_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_que
     L.cnt[seq] = 0;
   }
   __syncthreads();
+  // anchor keys, radii and bucket masks in registers (mask 0 = anchor not searched)
+  float pk[CC_NPIV][CC_KEY_DIM], ub[CC_NPIV];
+  unsigned pvis[CC_NPIV];
   unsigned any_vis = 0;
-  for (int p = 0; p < CC_NPIV; p++)
-    if (L.valid[p]) any_vis |= L.vis[p];
+#pragma unroll
+  for (int p = 0; p < CC_NPIV; p++) {
+#pragma unroll
+    for (int d = 0; d < CC_KEY_DIM; d++) pk[p][d] = L.k[p][d];
+    ub[p] = L.ub[p];
+    pvis[p] = L.valid[p] ? L.vis[p] : 0u;
+    any_vis |= pvis[p];
+  }
   const int nk = qm.n_keys[ll];
   const float *K = P.keys[ll];
   const int *act = P.kactive[ll];
   const int cap = P.cap_k;
   const int epoch = qm.epoch;
   const int nnk = P.nnk;
-  if (any_vis) {
+  if (any_vis && P.dbg_cut != 1) {
+    // software pipeline: the 11 loads of the next key are in flight while the current one is scored
+    float c[CC_KEY_DIM], cn[CC_KEY_DIM];
+    int a_cur = 0x7fffffff, a_nxt = 0x7fffffff;
+#pragma unroll
+    for (int d = 0; d < CC_KEY_DIM; d++) c[d] = cn[d] = 0.f;
+    if (tid < nk) {
+      a_cur = act[tid];
+#pragma unroll
+      for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + tid];
+    }
     for (int base = 0; base < nk; base += nt) {
       const int id = base + tid;
-      if (id < nk && act[id] <= epoch) {
-        const float c0 = K[id];
+      const int idn = id + nt;
+      a_nxt = 0x7fffffff;
+      if (idn < nk) {
+        a_nxt = act[idn];
+#pragma unroll
+        for (int d = 0; d < CC_KEY_DIM; d++) cn[d] = K[(size_t)d * cap + idn];
+      }
+      if (id < nk && a_cur <= epoch) {
+        const float c0 = c[0];
         int bk = -1;
+#pragma unroll
         for (int b = 0; b < 6; b++)
-          if (rg[b] <= c0 && c0 < rg[b + 1]) {
-            bk = b;
-            break;
-          }
+          if (bk < 0 && rg[b] <= c0 && c0 < rg[b + 1]) bk = b;
         if (bk >= 0 && ((any_vis >> bk) & 1u)) {
-          const float c1 = K[cap + id], c2 = K[2 * cap + id], c3 = K[3 * cap + id], c4 = K[4 * cap + id];
-          const float c5 = K[5 * cap + id], c6 = K[6 * cap + id], c7 = K[7 * cap + id], c8 = K[8 * cap + id], c9 = K[9 * cap + id];
 #pragma unroll
           for (int p = 0; p < CC_NPIV; p++) {
-            if (L.valid[p] && ((L.vis[p] >> bk) & 1u)) {
-              // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-              float d0 = L.k[p][0] - c0, d1 = L.k[p][1] - c1, d2 = L.k[p][2] - c2, d3 = L.k[p][3] - c3;
-              float res = 0.f;
-              res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-              d0 = L.k[p][4] - c4;
-              d1 = L.k[p][5] - c5;
-              d2 = L.k[p][6] - c6;
-              d3 = L.k[p][7] - c7;
-              res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-              d0 = L.k[p][8] - c8;
-              res += d0 * d0;
-              d0 = L.k[p][9] - c9;
-              res += d0 * d0;
-              if (res < L.ub[p]) {
-                const int pos = atomicAdd(&L.cnt[p], 1);
-                L.buf[p][pos] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)id;
-              }
+            // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+            float d0 = pk[p][0] - c0, d1 = pk[p][1] - c[1], d2 = pk[p][2] - c[2], d3 = pk[p][3] - c[3];
+            float res = 0.f;
+            res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            d0 = pk[p][4] - c[4];
+            d1 = pk[p][5] - c[5];
+            d2 = pk[p][6] - c[6];
+            d3 = pk[p][7] - c[7];
+            res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            d0 = pk[p][8] - c[8];
+            res += d0 * d0;
+            d0 = pk[p][9] - c[9];
+            res += d0 * d0;
+            if (res < ub[p] && ((pvis[p] >> bk) & 1u) && P.dbg_cut != 2) {
+              const int pos = atomicAdd(&L.cnt[p], 1);
+              L.buf[p][pos] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)id;
             }
           }
         }
       }
+      a_cur = a_nxt;
+#pragma unroll
+      for (int d = 0; d < CC_KEY_DIM; d++) c[d] = cn[d];
       __syncthreads();
+#pragma unroll
       for (int p = 0; p < CC_NPIV; p++) {
-        if (L.cnt[p] > CC_KNN_CAP - nt) {  // uniform: shrink to the best nnk and tighten the radius
-          const int n = L.cnt[p];
-          for (int i = n + tid; i < CC_KNN_CAP; i += nt) L.buf[p][i] = ~0ull;
+        const int n = L.cnt[p];
+        if (n > CC_KNN_CAP - nt) {  // uniform: shrink to the best nnk and tighten the radius
+          int np2 = 64;
+          while (np2 < n) np2 <<= 1;
+          for (int i = n + tid; i < np2; i += nt) L.buf[p][i] = ~0ull;
           __syncthreads();
-          cc_bitonic_sort_u64(L.buf[p], CC_KNN_CAP, tid, nt);
-          if (tid == 0) {
-            L.cnt[p] = n < nnk ? n : nnk;
-            if (n >= nnk) L.ub[p] = __uint_as_float((unsigned)(L.buf[p][nnk - 1] >> 32));
-          }
+          cc_bitonic_sort_u64(L.buf[p], np2, tid, nt);
+          if (n >= nnk) ub[p] = __uint_as_float((unsigned)(L.buf[p][nnk - 1] >> 32));
+          __syncthreads();
+          if (tid == 0) L.cnt[p] = n < nnk ? n : nnk;
           __syncthreads();
         }
       }
