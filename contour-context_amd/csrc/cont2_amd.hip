@@ -149,7 +149,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
   if (getenv("CC_K2_PHASES")) HIPCHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
-  c->lds2 = ((nc * 4 + 15) & ~(size_t)15) + CC_K2_R_BYTES;
+  c->lds2 = CC_K2_LDS_BYTES(nc);
   HIPCHK(hipFuncSetAttribute((const void *)cc_k_rasterize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   HIPCHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
   *out = c;

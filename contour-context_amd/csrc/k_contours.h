@@ -41,7 +41,49 @@ struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
 };
 
 #define CC_K2_R_BYTES 65536
-// dynamic LDS = n_cell*4 (H) + CC_K2_R_BYTES
+// dynamic LDS: LV u8[n_cell] | IDX u16[n_cell] | R
+#define CC_K2_LV_BYTES(nc) (((size_t)(nc) + 15) & ~(size_t)15)
+#define CC_K2_IDX_BYTES(nc) (((size_t)(nc) * 2 + 15) & ~(size_t)15)
+#define CC_K2_LDS_BYTES(nc) (CC_K2_LV_BYTES(nc) + CC_K2_IDX_BYTES(nc) + CC_K2_R_BYTES)
+
+// ---- union-find on the u16 label image (labels = cell indices, a root points to itself, parents always point to a
+// smaller index so the root of a component is its smallest cell: the label min-propagation would converge to).
+// Links are 32-bit CAS on the word holding the u16; no plain stores happen while unions run.
+__device__ __forceinline__ unsigned cc_uf_find(const uint16_t *LAB, unsigned x) {
+  const volatile uint16_t *V = LAB;
+  unsigned p;
+  while ((p = V[x]) != x) x = p;
+  return x;
+}
+__device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned b) {
+  a = cc_uf_find(LAB, a);
+  b = cc_uf_find(LAB, b);
+  while (a != b) {
+    if (a < b) {
+      const unsigned t = a;
+      a = b;
+      b = t;
+    }
+    // a > b: hang root a under b, provided a is still a root
+    unsigned *w = (unsigned *)LAB + (a >> 1);
+    const int shf = (a & 1) * 16;
+    unsigned old = *(volatile unsigned *)w;
+    unsigned cur;
+    while (true) {
+      cur = (old >> shf) & 0xFFFFu;
+      if (cur != a) break;
+      const unsigned got = atomicCAS(w, old, (old & ~(0xFFFFu << shf)) | (b << shf));
+      if (got == old) {
+        cur = b;
+        break;
+      }
+      old = got;
+    }
+    if (cur == b) break;
+    a = cc_uf_find(LAB, cur);
+    b = cc_uf_find(LAB, b);
+  }
+}
 
 __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
 
@@ -60,8 +102,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   const int tid = threadIdx.x, nt = blockDim.x;
   const int scan = blockIdx.x;
 
-  float *H = (float *)smem;
-  char *R = smem + (((size_t)n_cell * 4 + 15) & ~(size_t)15);
+  unsigned char *LV = (unsigned char *)smem;                       // #levels the cell's height exceeds: bev > lv_grads[l] <=> LV > l
+  uint16_t *IDX = (uint16_t *)(smem + CC_K2_LV_BYTES(n_cell));     // root cell -> component index of the current level (0xFFFF: not kept)
+  char *R = smem + CC_K2_LV_BYTES(n_cell) + CC_K2_IDX_BYTES(n_cell);
   // ---- region R, phase "levels" ----
   uint16_t *LAB = (uint16_t *)R;                                   // n_cell u16 (45000)
   unsigned *W = (unsigned *)(R + 45056);                           // 7 * CC_NC u32 working arrays / CNT2 alias (8960)
@@ -77,7 +120,12 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   cc_k2_scratch *scr = scratch_all + scan;
   cc_scan_desc_t *desc = desc_out + scan;
 
-  for (int c = tid; c < n_cell; c += nt) H[c] = bev[c];
+  for (int c = tid; c < n_cell; c += nt) {
+    const float h = bev[c];
+    int lv = 0;
+    for (int e = 0; e < CC_NLEV; e++) lv += (h > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+    LV[c] = (unsigned char)lv;
+  }
   if (tid < 32) sh[tid] = 0;
   __syncthreads();
 
@@ -93,57 +141,48 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   } while (0)
   const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
   for (int l = CC_NLEV - 1; l >= 0; --l) {
-    const float g = cfg.lv_grads[l];
-    // (a) init labels: cv::threshold BINARY is strict `>` (contour_mng.cpp:283).  LAB still holds the converged
-    //     root labels of level l+1 (a subset of this level's cells): keeping them seeds the propagation with the
-    //     already-merged structure, new cells start as their own root.
+    // (a) init labels.  LAB still holds the root labels of level l+1 (a subset of this level's cells, lv_grads ascending):
+    //     those components stay merged; cells new at this level (LV == l + 1) start as their own root.
     if (l == CC_NLEV - 1) {
-      for (int c = tid; c < n_cell; c += nt) LAB[c] = (H[c] > g) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
+      for (int c = tid; c < n_cell; c += nt) LAB[c] = (LV[c] > l) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
     } else {
       for (int c = tid; c < n_cell; c += nt)
-        if (LAB[c] == CC_LAB_NONE && H[c] > g) LAB[c] = (uint16_t)c;
+        if (LV[c] == l + 1) LAB[c] = (uint16_t)c;
     }
     __syncthreads();
-    // (b) 8-connected labelling: min-propagation with pointer jumping until stable
-    while (true) {
-      if (tid == 0) sh[0] = 0;
-      __syncthreads();
-      int changed = 0;
-      for (int c = tid; c < n_cell; c += nt) {
-        unsigned lab = LAB[c];
-        if (lab == CC_LAB_NONE) continue;
-        const int r = c / n_col, cc = c - r * n_col;
-        unsigned m = lab;
-        const bool up = r > 0, dn = r < n_row - 1, lf = cc > 0, rt = cc < n_col - 1;
-        unsigned v;
-        if (up) {
-          if (lf) { v = LAB[c - n_col - 1]; m = v < m ? v : m; }
-          v = LAB[c - n_col]; m = v < m ? v : m;
-          if (rt) { v = LAB[c - n_col + 1]; m = v < m ? v : m; }
+    // (b) 8-connected labelling: one union per adjacent pair (W, NW, N, NE of every cell) that involves a new cell --
+    //     two old neighbours already share a root -- then every cell is pointed at its root.
+    for (int c = tid; c < n_cell; c += nt) {
+      const int lvc = LV[c];
+      if (lvc <= l) continue;
+      const bool newc = lvc == l + 1;
+      const int r = c / n_col, cc = c - r * n_col;
+      if (cc > 0) {
+        const int lvn = LV[c - 1];
+        if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - 1);
+      }
+      if (r > 0) {
+        if (cc > 0) {
+          const int lvn = LV[c - n_col - 1];
+          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col - 1);
         }
-        if (lf) { v = LAB[c - 1]; m = v < m ? v : m; }
-        if (rt) { v = LAB[c + 1]; m = v < m ? v : m; }
-        if (dn) {
-          if (lf) { v = LAB[c + n_col - 1]; m = v < m ? v : m; }
-          v = LAB[c + n_col]; m = v < m ? v : m;
-          if (rt) { v = LAB[c + n_col + 1]; m = v < m ? v : m; }
+        {
+          const int lvn = LV[c - n_col];
+          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col);
         }
-        while (true) {
-          unsigned m2 = LAB[m];
-          if (m2 >= m) break;
-          m = m2;
-        }
-        if (m < lab) {
-          LAB[c] = (uint16_t)m;
-          changed = 1;
+        if (cc < n_col - 1) {
+          const int lvn = LV[c - n_col + 1];
+          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col + 1);
         }
       }
-      if (changed) sh[0] = 1;
-      __syncthreads();
-      const int any = sh[0];
-      __syncthreads();
-      if (!any) break;
     }
+    __syncthreads();
+    for (int c = tid; c < n_cell; c += nt) {
+      if (LV[c] <= l) continue;
+      const unsigned rt = cc_uf_find(LAB, c);
+      LAB[c] = (uint16_t)rt;
+    }
+    __syncthreads();
     CC_K2_LAP(acc_ccl);
     // (c) which roots own >= min_cont_cell_cnt_ (3) cells: 2-bit saturating counters
     const int n_w = (n_cell + 15) >> 4;
@@ -165,9 +204,12 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     __syncthreads();
     // (d) enumerate kept roots, sorted by cell index
     for (int c = tid; c < n_cell; c += nt) {
-      if (LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
-        int k = atomicAdd(&sh[1], 1);
-        if (k < CC_NC) cand[k] = (uint16_t)c;
+      if (LAB[c] == (unsigned)c) {
+        IDX[c] = 0xFFFFu;
+        if (cc_cnt2_get(CNT2, c) >= need) {
+          int k = atomicAdd(&sh[1], 1);
+          if (k < CC_NC) cand[k] = (uint16_t)c;
+        }
       }
     }
     __syncthreads();
@@ -181,6 +223,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int rk = 0;
       for (int j = 0; j < n_kept; j++) rk += (cand[j] < me) ? 1 : 0;
       roots[rk] = (uint16_t)me;
+      IDX[me] = (uint16_t)rk;
     }
     __syncthreads();
     // (f) bbox / area via LDS atomics (W aliases CNT2; the kept test is done before W is re-initialised).
@@ -201,19 +244,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     for (int c = tid; c < n_cell; c += nt) {
       const unsigned r = LAB[c];
       if (r == CC_LAB_NONE) continue;
-      int lo = 0, hi = n_kept - 1, j = -1;
-      while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const unsigned v = roots[mid];
-        if (v == r) {
-          j = mid;
-          break;
-        }
-        if (v < r)
-          lo = mid + 1;
-        else
-          hi = mid - 1;
-      }
+      const int j = IDX[r] == 0xFFFFu ? -1 : (int)IDX[r];
       if (j < 0) continue;  // component with < 3 cells (or beyond the capacity)
       const int rr = c / n_col, cc = c - rr * n_col;
       atomicMin(&w_minr[j], (unsigned)rr);
@@ -242,20 +273,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     CC_K2_LAP(acc_enum);
     // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
     for (int k = tid; k < prev_n; k += nt) {
-      const unsigned r = LAB[prev_root[k]];
-      int lo = 0, hi = n_kept - 1, j = 0xFFFF;
-      while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const unsigned v = roots[mid];
-        if (v == r) {
-          j = mid;
-          break;
-        }
-        if (v < r)
-          lo = mid + 1;
-        else
-          hi = mid - 1;
-      }
+      const unsigned j = IDX[LAB[prev_root[k]]];
       scr->comp[l + 1][k].parent = (uint16_t)j;
     }
     __syncthreads();
@@ -279,7 +297,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           if (!mask) continue;
           float h = 0.f, px = 0.f, py = 0.f;
           if (mem) {
-            h = H[base + col];
+            h = bev[base + col];
             const float2 rc = pix[base + col];
             px = rc.x;
             py = rc.y;
@@ -327,22 +345,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
       for (int c = tid; c < n_cell; c += nt) {
         const unsigned r = LAB[c];
-        int j = -1;
-        if (r != CC_LAB_NONE) {
-          int lo = 0, hi = n_kept - 1;
-          while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const unsigned v = roots[mid];
-            if (v == r) {
-              j = mid;
-              break;
-            }
-            if (v < r)
-              lo = mid + 1;
-            else
-              hi = mid - 1;
-          }
-        }
+        const int j = (r != CC_LAB_NONE && IDX[r] != 0xFFFFu) ? (int)IDX[r] : -1;
         ld[c] = (int16_t)j;
       }
     }
@@ -497,7 +500,6 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   const int roi_pad = (int)ceilf(cfg.roi_radius + 1.f);
   const float div_len = cfg.roi_radius / (float)(7 * 5);
   const float bin_len = cfg.roi_radius / (float)7;
-  const float g1 = cfg.lv_grads[1];  // DIST_BIN_LAYERS[0] == 1
   const double r_lim = (double)cfg.roi_radius - 1e-2;
   for (int t = tid; t < NA * 35; t += nt) {
     const int a = t / 35, d = t - a * 35;
@@ -516,14 +518,15 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       const double norm = sqrt(2 * 3.14159265358979323846 * 1.0 * 1.0);
       for (int rr = r_min; rr <= r_max; rr++) {
         for (int cc = c_min; cc <= c_max; cc++) {
-          const float h = H[rr * n_col + cc];
-          if (h < g1) continue;
+          // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
+          // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
+          const int lv = LV[rr * n_col + cc];
+          if (lv < 2) continue;
           const float2 rc = pix[rr * n_col + cc];
           const float dx = rc.x - vcx, dy = rc.y - vcy;
           const float dist = sqrtf(dx * dx + dy * dy);
-          if ((double)dist < r_lim && h > g1) {
-            int higher = 0;
-            for (int e = 1; e < CC_NLEV; e++) higher += (h > cfg.lv_grads[e]) ? 1 : 0;
+          if ((double)dist < r_lim) {
+            const int higher = lv - 1;
             cp++;
             const float u = (xg - dist) / 1.0f;
             const float pdf = (float)(exp(-0.5 * (double)u * (double)u) / norm);

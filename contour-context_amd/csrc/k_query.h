@@ -1209,6 +1209,94 @@ struct cc_ell {  // values are f32 in the reference too (getManualCov, pos_mean_
   float c00, c01, c10, c11, mx, my, w, maj;
 };
 
+// Per-scan inputs of the correlation, computed once per scan instead of once per (query, candidate) pair: the ellipses
+// GMMPair's ctor selects (correlation.h:49-82) and the scan's auto-correlation term (correlation.h:102-119).
+struct cc_gmm_feat {
+  int n_ell[CC_GMM_LEVELS];
+  int flags;  // bit0: more than CC_GMM_ECAP_L ellipses on a level, bit2: a needed contour was not stored in the descriptor
+  int pad[3];
+  double ac;  // sum over levels and ordered ellipse pairs (i, j) of the self term
+  cc_ell ell[CC_GMM_LEVELS][CC_GMM_ECAP_L];
+};
+
+// grid = n scans, block = 64
+__global__ void __launch_bounds__(64)
+cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__restrict__ feat) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const cc_scan_desc_t *d = desc + blockIdx.x;
+  cc_gmm_feat *F = feat + blockIdx.x;
+  __shared__ cc_ell E[CC_GMM_ECAP_L];
+  int flags = 0;
+  double acc = 0;
+  for (int li = 0; li < CC_GMM_LEVELS; li++) {
+    const int lev = li + 1;  // GMMOptConfig::levels_ = {1,2,3,4}
+    const int full = d->layer_cell_cnt[lev];
+    const int ncont = d->n_cont[lev], nst = d->n_stored[lev];
+    // contours in sorted order until >= 95 % of the level's cells: contour j is used iff the cells before it are < 95 %
+    int n_use = 0, run = 0;
+    for (int j0 = 0; j0 < ncont; j0 += 64) {
+      const int j = j0 + lane;
+      const int cnt = (j < ncont && j < nst) ? d->cont[lev][j].cell_cnt : 0;
+      int incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const int before = run + incl - cnt;
+      const bool use = j < ncont && !((double)before * 1.0 / (double)full >= 0.95);
+      const unsigned long long m = __ballot(use);
+      if (__ballot(use && j >= nst)) flags |= 4;
+      n_use += __popcll(m);
+      run += __shfl(incl, 63);
+      if (m != ~0ull) break;  // the used contours are a prefix
+    }
+    if (n_use > nst) n_use = nst;
+    if (n_use > CC_GMM_ECAP_L) {
+      n_use = CC_GMM_ECAP_L;
+      flags |= 1;
+    }
+    __syncthreads();
+    for (int j = lane; j < n_use; j += 64) {
+      const cc_contour_t &cv = d->cont[lev][j];
+      // getManualCov (contour.h:376-378) in f32; the reference then casts to double
+      const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
+      const float e0 = cv.eig_vals[0], e1 = cv.eig_vals[1];
+      const float a00 = v00 * e0, a01 = v01 * e1, a10 = v10 * e0, a11 = v11 * e1;
+      cc_ell e;
+      e.c00 = a00 * v00 + a01 * v01;
+      e.c01 = a00 * v10 + a01 * v11;
+      e.c10 = a10 * v00 + a11 * v01;
+      e.c11 = a10 * v10 + a11 * v11;
+      e.mx = cv.pos_mean[0];
+      e.my = cv.pos_mean[1];
+      e.w = (float)cv.cell_cnt;
+      e.maj = sqrtf(e1);
+      E[j] = e;
+      F->ell[li][j] = e;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < n_use * n_use; idx += 64) {
+      const int i = idx / n_use, j = idx - i * n_use;
+      const cc_ell a = E[i], b = E[j];
+      const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
+      const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
+      const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
+      const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
+      const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
+      const double h0 = -0.5 * mx, h1 = -0.5 * my;
+      const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
+      acc += (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+    }
+    if (lane == 0) F->n_ell[li] = n_use;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    F->ac = acc;
+    F->flags = flags;
+  }
+}
+
 // LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance).  A wave handles 64/G
 // problems at once, G lanes each (G = 16 for the common instance, 64 for the large-cap instance); every cross-lane
 // operation below is G-wide, so problems in the same wave may diverge freely.
@@ -1662,7 +1750,7 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
 // redo_only: process only problems whose previous result overflowed an LDS cap (flags & 3) -- the large-cap instance.
 __global__ void __launch_bounds__(64)
 cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap, int redo_only,
-         const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc, float corr_lb, int ecap, int pcap,
+         const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb, int ecap, int pcap,
          int ppw, cc_gmm_result *__restrict__ results) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int lane = threadIdx.x;
@@ -1688,50 +1776,33 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   if ((redo_only & 1) && !(results[pidx].flags & 3)) continue;
   const int dbg = redo_only >> 8;  // tuning aid (env CC_GMM_CUT): stop after a phase, results are then meaningless
   const cc_gmm_problem pb = probs[pidx];
-  const cc_scan_desc_t *src = db_desc + pb.gidx;
-  const cc_scan_desc_t *tgt = qdesc + pb.q;
+  const cc_gmm_feat *fsrc = db_feat + pb.gidx;
+  const cc_gmm_feat *ftgt = qfeat + pb.q;
   cc_group_sync(G);
   if (sl == 0) {
     *S->n_pairs = 0;
     *S->flags = 0;
   }
   cc_group_sync(G);
-  // ---- ellipses (GMMPair ctor, correlation.h:49-82): contours in sorted order until >= 95 % of the level's cells
+  // ---- ellipses of both scans (GMMPair ctor, correlation.h:49-82; selected per scan by cc_k_gmm_prep)
   if (sl < 2 * CC_GMM_LEVELS) {
     const int side = sl / CC_GMM_LEVELS, li = sl % CC_GMM_LEVELS;
-    const int lev = li + 1;  // GMMOptConfig::levels_ = {1,2,3,4}
-    const cc_scan_desc_t *d = side == 0 ? src : tgt;
-    const int full = d->layer_cell_cnt[lev];
-    int run = 0, n = 0;
-    const int nst = d->n_stored[lev];
-    for (int j = 0; j < d->n_cont[lev]; j++) {
-      if ((double)run * 1.0 / (double)full >= 0.95) break;
-      if (j >= nst) {
-        atomicOr((unsigned *)S->flags, 4u);
-        break;
-      }
-      if (n >= ecap) {
-        atomicOr((unsigned *)S->flags, 1u);
-        break;
-      }
-      const cc_contour_t &cv = d->cont[lev][j];
-      // getManualCov (contour.h:376-378) in f32; the reference then casts to double
-      const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
-      const float e0 = cv.eig_vals[0], e1 = cv.eig_vals[1];
-      const float a00 = v00 * e0, a01 = v01 * e1, a10 = v10 * e0, a11 = v11 * e1;
-      cc_ell e;
-      e.c00 = a00 * v00 + a01 * v01;
-      e.c01 = a00 * v10 + a01 * v11;
-      e.c10 = a10 * v00 + a11 * v01;
-      e.c11 = a10 * v10 + a11 * v11;
-      e.mx = cv.pos_mean[0];
-      e.my = cv.pos_mean[1];
-      e.w = (float)cv.cell_cnt;
-      e.maj = sqrtf(e1);
-      S->E(side, li, n++) = e;
-      run += cv.cell_cnt;
+    const cc_gmm_feat *f = side == 0 ? fsrc : ftgt;
+    int n = f->n_ell[li];
+    if (n > ecap) {
+      n = ecap;
+      atomicOr((unsigned *)S->flags, 1u);
     }
     S->n_ell[side * CC_GMM_LEVELS + li] = n;
+    if (li == 0 && (f->flags & 5)) atomicOr((unsigned *)S->flags, (unsigned)(f->flags & 5));
+  }
+  cc_group_sync(G);
+  for (int side = 0; side < 2; side++) {
+    const cc_gmm_feat *f = side == 0 ? fsrc : ftgt;
+    for (int li = 0; li < CC_GMM_LEVELS; li++) {
+      const int n = S->n_ell[side * CC_GMM_LEVELS + li];
+      for (int i = sl; i < n; i += G) S->E(side, li, i) = f->ell[li][i];
+    }
   }
   cc_group_sync(G);
   // ---- pair pre-selection (correlation.h:85-96), ordered compaction by a G-wide prefix sum
@@ -1776,27 +1847,8 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
     }
     continue;
   }
-  // ---- auto-correlation (correlation.h:102-119)
-  double ac[2] = {0, 0};
-  for (int side = 0; side < 2; side++) {
-    double acc = 0;
-    for (int li = 0; li < CC_GMM_LEVELS; li++) {
-      const int n = S->n_ell[side * CC_GMM_LEVELS + li];
-      for (int idx = sl; idx < n * n; idx += G) {
-        const int i = idx / n, j = idx - i * n;
-        const cc_ell &a = S->E(side, li, i), &b = S->E(side, li, j);
-        const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
-        const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
-        const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
-        const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
-        const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
-        const double h0 = -0.5 * mx, h1 = -0.5 * my;
-        const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
-        acc += (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
-      }
-    }
-    ac[side] = cc_group_sum_d(acc, G);
-  }
+  // ---- auto-correlation (correlation.h:102-119): per-scan terms
+  const double ac[2] = {fsrc->ac, ftgt->ac};
   cc_group_sync(G);
   if (dbg == 2) {
     if (sl == 0) {
