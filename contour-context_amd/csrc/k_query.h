@@ -399,7 +399,8 @@ __device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * 
 __global__ void __launch_bounds__(256)
 cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, unsigned short *__restrict__ surv,
-             int *__restrict__ surv_cnt, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt /*[nq][4]*/) {
+             cc_knn_hit_t *__restrict__ surv_hit, int *__restrict__ surv_cnt, unsigned char *__restrict__ pass_ok,
+             int *__restrict__ pass_cnt /*[nq][4]*/) {
   __shared__ int wcnt[4];
   __shared__ int s_base, s_chk1;
   const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -414,10 +415,14 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
   for (int t0 = 0; t0 < CC_CHK_STRIDE; t0 += nt) {
     const int t = t0 + tid;
     bool anchor_ok = false, keep = false;
+    cc_knn_hit_t h;
+    h.gidx = 0;
+    h.level = h.seq = 0;
+    h.dist_sq = 0.f;
     if (t < CC_CHK_STRIDE) {
       const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
       if (j < hit_cnt[q * NS + slot]) {
-        const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+        h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
         const int seq_tgt = slot % CC_NPIV;
         const cc_scan_desc_t *src = db_desc + h.gidx;
         anchor_ok = cc_check_sim(src->cont[h.level][h.seq], tgt->cont[h.level][seq_tgt], P.sim);
@@ -454,7 +459,10 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     int off = s_base;
     for (int w = 0; w < wave; w++) off += wcnt[w];
     off += __popcll(mk & ((1ull << lane) - 1ull));
-    if (keep) surv[(size_t)q * CC_CHK_STRIDE + off] = (unsigned short)t;
+    if (keep) {
+      surv[(size_t)q * CC_CHK_STRIDE + off] = (unsigned short)t;
+      surv_hit[(size_t)q * CC_CHK_STRIDE + off] = h;  // stage B reads the hit next to the slot instead of chasing it
+    }
     __syncthreads();
     if (tid == 0) s_base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     __syncthreads();
@@ -504,6 +512,7 @@ struct cc_chkb_lds {  // per group; the unions hold data of phases that never ov
   short seg[3][20];                        // sort: pending quicksort segments (first, last, depth left)
 };
 static_assert(CC_PP_MAX <= 256, "pair indices are bytes");
+static_assert(CC_BCI_MAXPTS <= 3 * CC_CHKB_G && sizeof(cc_relpt_t) == 12, "three 12-byte point loads per lane cover a BCI");
 
 __device__ __forceinline__ unsigned cc_group_ballot(bool pred, int sl) {  // bit i = pred of group lane i
   int v = pred ? (1 << sl) : 0;
@@ -655,6 +664,20 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int 
     cc_group_sync(G);
     return;
   }
+  if (npp <= G) {  // one pair per lane: stable rank through 16-wide shuffles, no LDS traffic
+    const float f = sl < npp ? CC_CHKB_KEY(L.pp[sl]) : 0.f;
+    int rank = 0;
+    for (int j = 0; j < npp; j++) {
+      const float fj = __shfl(f, j, G);
+      rank += (fj < f || (fj == f && j < sl)) ? 1 : 0;
+    }
+    if (sl < npp) {
+      L.sidx[rank] = (unsigned char)sl;
+      L.skey[rank] = f;
+    }
+    cc_group_sync(G);
+    return;
+  }
   if (npp <= 48) {
     for (int p = sl; p < npp; p += G) {
       const float f = CC_CHKB_KEY(L.pp[p]);
@@ -718,28 +741,65 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int 
 // grid = nq * CC_CHKB_PER_Q, block = 64
 __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
-             const cc_knn_hit_t *__restrict__ hits, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
+             const cc_knn_hit_t *__restrict__ surv_hit, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt) {
   __shared__ cc_chkb_lds LG[CC_CHKB_GPW];
   const int G = CC_CHKB_G;
   const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q;
   const int sub = threadIdx.x / CC_CHKB_G, sl = threadIdx.x % CC_CHKB_G;
   cc_chkb_lds &L = LG[sub];
-  const int NS = CC_NQLEV * CC_NPIV;
   const cc_scan_desc_t *tgt = qdesc + q;
   const int ns = surv_cnt[q];
-  for (int si = part * CC_CHKB_GPW + sub; si < ns; si += CC_CHKB_PER_Q * CC_CHKB_GPW) {
-    const int t = surv[(size_t)q * CC_CHK_STRIDE + si];
-    const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
-    const cc_knn_hit_t h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
+  // the (slot, hit) of the next check is fetched while the current one is worked on
+  const int si0 = part * CC_CHKB_GPW + sub;
+  int t_nxt = 0;
+  cc_knn_hit_t h_nxt;
+  h_nxt.gidx = 0;
+  h_nxt.level = h_nxt.seq = 0;
+  h_nxt.dist_sq = 0.f;
+  if (si0 < ns) {
+    t_nxt = surv[(size_t)q * CC_CHK_STRIDE + si0];
+    h_nxt = surv_hit[(size_t)q * CC_CHK_STRIDE + si0];
+  }
+  for (int si = si0; si < ns; si += CC_CHKB_PER_Q * CC_CHKB_GPW) {
+    const int t = t_nxt;
+    const cc_knn_hit_t h = h_nxt;
+    {
+      const int sn = si + CC_CHKB_PER_Q * CC_CHKB_GPW;
+      if (sn < ns) {
+        t_nxt = surv[(size_t)q * CC_CHK_STRIDE + sn];
+        h_nxt = surv_hit[(size_t)q * CC_CHK_STRIDE + sn];
+      }
+    }
+    const int slot = t / CC_KNN_MAX;
     const int level = h.level, seq_src = h.seq, seq_tgt = slot % CC_NPIV;
     const cc_scan_desc_t *src = db_desc + h.gidx;
     const cc_bci_t *bs = &src->bcis[level][seq_src];
     const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
+    // point tables and their sizes are fetched together (no dependent round trip): CC_BCI_MAXPTS <= 3 * G
+    // (moved as raw dwords: a cc_relpt_t is 3 of them)
+    unsigned ps[3][3], pt[3][3];
+    const unsigned *gs = (const unsigned *)bs->pts, *gt = (const unsigned *)bt->pts;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int i = sl + u * G;
+#pragma unroll
+      for (int w = 0; w < 3; w++) {
+        ps[u][w] = i < CC_BCI_MAXPTS ? gs[i * 3 + w] : 0u;
+        pt[u][w] = i < CC_BCI_MAXPTS ? gt[i * 3 + w] : 0u;
+      }
+    }
     const int nsp = bs->n_pts, ntp = bt->n_pts;
     cc_group_sync(G);
-    for (int i = sl; i < nsp; i += G) L.g.sp[i] = bs->pts[i];
-    for (int i = sl; i < ntp; i += G) L.g.tp[i] = bt->pts[i];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int i = sl + u * G;
+#pragma unroll
+      for (int w = 0; w < 3; w++) {
+        if (i < nsp) ((unsigned *)L.g.sp)[i * 3 + w] = ps[u][w];
+        if (i < ntp) ((unsigned *)L.g.tp)[i * 3 + w] = pt[u][w];
+      }
+    }
     if (P.dbg_cut == 1) continue;
     cc_group_sync(G);
     // src points are sorted by bit_pos: the partners of a tgt point are the contiguous range [lo, hi)
