@@ -247,7 +247,7 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
                        c->d_bev, c->d_pix, c->d_k1);
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
-    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
+    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
                        (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab, c->d_phase_clk);
     if (pe) HIPCHK(hipEventRecord(pe[2], stream));
     HIPCHK(hipGetLastError());

@@ -40,11 +40,22 @@ struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
   int cnt;
 };
 
-#define CC_K2_R_BYTES 65536
-// dynamic LDS: LV u8[n_cell] | IDX u16[n_cell] | R
+#define CC_K2_R_BYTES 57344
+// dynamic LDS: LV u8[n_cell] | R  -- 78 KB for the 150x150 grid, so that two workgroups (scans) share a CU and the
+// lane-serial stretches of one (sort replays, raster-order sums) overlap with the parallel phases of the other
 #define CC_K2_LV_BYTES(nc) (((size_t)(nc) + 15) & ~(size_t)15)
-#define CC_K2_IDX_BYTES(nc) (((size_t)(nc) * 2 + 15) & ~(size_t)15)
-#define CC_K2_LDS_BYTES(nc) (CC_K2_LV_BYTES(nc) + CC_K2_IDX_BYTES(nc) + CC_K2_R_BYTES)
+#define CC_K2_LDS_BYTES(nc) (CC_K2_LV_BYTES(nc) + CC_K2_R_BYTES)
+#define CC_K2_BLOCK 512
+
+// Label image conventions (u16 per cell): 0xFFFF = not in the level set; a non-root cell holds its root's cell index
+// (< 0x8000); a root holds its own index while the labelling runs and, once the kept components are numbered,
+// 0x8000 | component index.  cc_lab_comp: component index of a cell, CC_COMP_NONE if it has none.
+#define CC_COMP_NONE 0x7FFFu
+__device__ __forceinline__ unsigned cc_lab_comp(const uint16_t *LAB, int c) {
+  unsigned v = LAB[c];
+  if (!(v & 0x8000u)) v = LAB[v];            // cell -> its root
+  return (v & 0x8000u) ? (v & 0x7FFFu) : CC_COMP_NONE;  // unmarked root: component not kept
+}
 
 // ---- union-find on the u16 label image (labels = cell indices, a root points to itself, parents always point to a
 // smaller index so the root of a component is its smallest cell: the label min-propagation would converge to).
@@ -87,7 +98,7 @@ __device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned 
 
 __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(CC_K2_BLOCK)
 cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
               cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk) {
@@ -103,8 +114,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   const int scan = blockIdx.x;
 
   unsigned char *LV = (unsigned char *)smem;                       // #levels the cell's height exceeds: bev > lv_grads[l] <=> LV > l
-  uint16_t *IDX = (uint16_t *)(smem + CC_K2_LV_BYTES(n_cell));     // root cell -> component index of the current level (0xFFFF: not kept)
-  char *R = smem + CC_K2_LV_BYTES(n_cell) + CC_K2_IDX_BYTES(n_cell);
+  char *R = smem + CC_K2_LV_BYTES(n_cell);
   // ---- region R, phase "levels" ----
   uint16_t *LAB = (uint16_t *)R;                                   // n_cell u16 (45000)
   unsigned *W = (unsigned *)(R + 45056);                           // 7 * CC_NC u32 working arrays / CNT2 alias (8960)
@@ -204,12 +214,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     __syncthreads();
     // (d) enumerate kept roots, sorted by cell index
     for (int c = tid; c < n_cell; c += nt) {
-      if (LAB[c] == (unsigned)c) {
-        IDX[c] = 0xFFFFu;
-        if (cc_cnt2_get(CNT2, c) >= need) {
-          int k = atomicAdd(&sh[1], 1);
-          if (k < CC_NC) cand[k] = (uint16_t)c;
-        }
+      if (LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
+        int k = atomicAdd(&sh[1], 1);
+        if (k < CC_NC) cand[k] = (uint16_t)c;
       }
     }
     __syncthreads();
@@ -223,7 +230,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int rk = 0;
       for (int j = 0; j < n_kept; j++) rk += (cand[j] < me) ? 1 : 0;
       roots[rk] = (uint16_t)me;
-      IDX[me] = (uint16_t)rk;
+      LAB[me] = (uint16_t)(0x8000u | (unsigned)rk);  // nothing reads LAB in this loop
     }
     __syncthreads();
     // (f) bbox / area via LDS atomics (W aliases CNT2; the kept test is done before W is re-initialised).
@@ -242,10 +249,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
     __syncthreads();
     for (int c = tid; c < n_cell; c += nt) {
-      const unsigned r = LAB[c];
-      if (r == CC_LAB_NONE) continue;
-      const int j = IDX[r] == 0xFFFFu ? -1 : (int)IDX[r];
-      if (j < 0) continue;  // component with < 3 cells (or beyond the capacity)
+      const unsigned j = cc_lab_comp(LAB, c);
+      if (j == CC_COMP_NONE) continue;  // empty, or a component with < 3 cells (or beyond the capacity)
       const int rr = c / n_col, cc = c - rr * n_col;
       atomicMin(&w_minr[j], (unsigned)rr);
       atomicMax(&w_maxr[j], (unsigned)rr);
@@ -256,16 +261,15 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     __syncthreads();
     // first member column in the component's first row (cA) and in the row below (cB): first-2x2-block key
     for (int k = tid; k < n_kept; k += nt) {
-      const unsigned root = roots[k];
       const int r0 = (int)w_minr[k], c0 = (int)w_minc[k], c1 = (int)w_maxc[k];
       for (int c = c0; c <= c1; c++)
-        if (LAB[r0 * n_col + c] == root) {
+        if (cc_lab_comp(LAB, r0 * n_col + c) == (unsigned)k) {
           w_cA[k] = (unsigned)c;
           break;
         }
       if (r0 + 1 <= (int)w_maxr[k])
         for (int c = c0; c <= c1; c++)
-          if (LAB[(r0 + 1) * n_col + c] == root) {
+          if (cc_lab_comp(LAB, (r0 + 1) * n_col + c) == (unsigned)k) {
             w_cB[k] = (unsigned)c;
             break;
           }
@@ -273,7 +277,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     CC_K2_LAP(acc_enum);
     // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
     for (int k = tid; k < prev_n; k += nt) {
-      const unsigned j = IDX[LAB[prev_root[k]]];
+      unsigned j = cc_lab_comp(LAB, prev_root[k]);
+      if (j == CC_COMP_NONE) j = 0xFFFF;
       scr->comp[l + 1][k].parent = (uint16_t)j;
     }
     __syncthreads();
@@ -292,7 +297,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
         const int base = r * n_col;
         for (int cb = c0; cb <= c1; cb += 64) {
           const int col = cb + lane;
-          const bool mem = col <= c1 && LAB[base + col] == root;
+          const bool mem = col <= c1 && cc_lab_comp(LAB, base + col) == (unsigned)k;
           unsigned long long mask = __ballot(mem);
           if (!mask) continue;
           float h = 0.f, px = 0.f, py = 0.f;
@@ -344,13 +349,15 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     if (labels_dbg) {
       int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
       for (int c = tid; c < n_cell; c += nt) {
-        const unsigned r = LAB[c];
-        const int j = (r != CC_LAB_NONE && IDX[r] != 0xFFFFu) ? (int)IDX[r] : -1;
-        ld[c] = (int16_t)j;
+        const unsigned jj = cc_lab_comp(LAB, c);
+        ld[c] = (int16_t)(jj == CC_COMP_NONE ? -1 : (int)jj);
       }
     }
     __syncthreads();
-    for (int k = tid; k < n_kept; k += nt) prev_root[k] = roots[k];
+    for (int k = tid; k < n_kept; k += nt) {
+      prev_root[k] = roots[k];
+      LAB[roots[k]] = roots[k];  // roots point at themselves again: the next level's labelling continues from here
+    }
     if (tid == 0) sh[8 + l] = n_kept;
     prev_n = n_kept;
     __syncthreads();
