@@ -332,7 +332,8 @@ cc_k_knn(cc_knn_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_que
 // ------------------------------------------------------------------------------------------------
 // K4: the four-stage gate per (candidate scan, anchor pair).  One lane per check.
 // ------------------------------------------------------------------------------------------------
-#define CC_PP_MAX 256      // potential (src,tgt) neighbour pairs per check
+#define CC_PP_MAX 256      // potential (src,tgt) neighbour pairs per check (large instance of stage B)
+#define CC_PP_SMALL 64     // ... handled by the common, high-occupancy instance
 #define CC_CSTL_MAX 64     // pairs kept in a constellation
 #define CC_PASS_CAP 1024   // >= nnk * 18: every check of a query may pass
 
@@ -484,11 +485,12 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
 #define CC_CHKB_GPW (64 / CC_CHKB_G)
 #define CC_CHKB_PER_Q 8  // stage-B workgroups (waves) per query
 
+template <int PPM>
 struct cc_chkb_lds {  // per group; the unions hold data of phases that never overlap in time
   unsigned long long bitsw[8];             // pair bitmap staging (first member: 8-byte aligned for the 64-bit LDS atomics)
-  unsigned long long pp[CC_PP_MAX];        // potential pairs in generation order: fkey(orie) << 32 | l | s << 8 | t << 16
+  unsigned long long pp[PPM];              // potential pairs in generation order: fkey(orie) << 32 | l | s << 8 | t << 16
   union {
-    int hist[256];                         // sort: orientation bins (count -> start -> end)
+    int hist[PPM > 64 ? 256 : 2];          // sort: orientation bins (count -> start -> end), large instance only
     struct {
       float spm[CC_CSTL_MAX][2], tpm[CC_CSTL_MAX][2];  // pos_mean of the constellation's contours
     } m;
@@ -499,7 +501,7 @@ struct cc_chkb_lds {  // per group; the unions hold data of phases that never ov
       unsigned short off[CC_BCI_MAXPTS + 2];  // first potential pair of each tgt point
       unsigned char lo[CC_BCI_MAXPTS], hi[CC_BCI_MAXPTS];
     } g;
-    float skey[CC_PP_MAX];                 // sort result -> window search: orie in sorted order
+    float skey[PPM];                       // sort result -> window search: orie in sorted order
     struct {                               // constellation checks
       signed char cs[CC_CSTL_MAX][3];
       unsigned char keepf[CC_CSTL_MAX];
@@ -507,8 +509,8 @@ struct cc_chkb_lds {  // per group; the unions hold data of phases that never ov
       int misc[4];
     } c;
   };
-  unsigned char binidx[CC_PP_MAX];         // pair indices grouped by bin
-  unsigned char sidx[CC_PP_MAX];           // pair indices in sorted order
+  unsigned char binidx[PPM];               // pair indices grouped by bin
+  unsigned char sidx[PPM];                 // pair indices in sorted order
   short seg[3][20];                        // sort: pending quicksort segments (first, last, depth left)
 };
 static_assert(CC_PP_MAX <= 256, "pair indices are bytes");
@@ -522,12 +524,13 @@ __device__ __forceinline__ unsigned cc_group_ballot(bool pred, int sl) {  // bit
 
 // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1, in
 // src order.
-__device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds &L, int ntp, int sl) {
+template <int PPM>
+__device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds<PPM> &L, int ntp, int sl) {
   for (int i = sl; i < ntp; i += CC_CHKB_G) {
     const cc_relpt_t r2 = L.g.tp[i];
     int o = L.g.off[i];
     for (int sj = L.g.lo[i]; sj < L.g.hi[i]; sj++, o++) {
-      if (o >= CC_PP_MAX) break;
+      if (o >= PPM) break;
       const cc_relpt_t r1 = L.g.sp[sj];
       float od = r2.theta - r1.theta;
       od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
@@ -556,7 +559,8 @@ __device__ __forceinline__ int cc_chkb_bin(float od) {
 //   (2) the final insertion sort is a STABLE sort of what (1) left: rank = #smaller + #equal-and-earlier.
 // The heapsort branch (depth limit 2*floor(log2 n) exhausted) is replayed serially by one lane on regenerated input.
 // Result: L.sidx[k] = index into L.pp of the k-th pair, L.skey[k] = its orie_diff.
-__device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int sl) {
+template <int PPM>
+__device__ __noinline__ void cc_chkb_sort(cc_chkb_lds<PPM> &L, int npp, int ntp, int sl) {
   const int G = CC_CHKB_G;
   unsigned char *lpos = L.binidx, *rasc = L.sidx;  // stopper lists (both arrays are free until step 2)
   bool deep = false;
@@ -678,7 +682,7 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int 
     cc_group_sync(G);
     return;
   }
-  if (npp <= 48) {
+  if (npp <= 48 || PPM <= 64) {
     for (int p = sl; p < npp; p += G) {
       const float f = CC_CHKB_KEY(L.pp[p]);
       int rank = 0;
@@ -692,6 +696,7 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int 
     cc_group_sync(G);
     return;
   }
+  if constexpr (PPM > 64) {
   // counting sort on orientation bins + exact rank inside a bin
   for (int i = sl; i < 256; i += G) L.hist[i] = 0;
   cc_group_sync(G);
@@ -736,18 +741,22 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds &L, int npp, int ntp, int 
     L.skey[start + rank] = f;
   }
   cc_group_sync(G);
+  }
 }
 
+// Two instances: <CC_PP_SMALL, false> handles every check with <= 64 potential pairs (12 KB of LDS per workgroup) and
+// marks the others (pass_ok = 2); <CC_PP_MAX, true> then runs only those.
 // grid = nq * CC_CHKB_PER_Q, block = 64
+template <int PPM, bool REDO>
 __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ surv_hit, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt) {
-  __shared__ cc_chkb_lds LG[CC_CHKB_GPW];
+  __shared__ cc_chkb_lds<PPM> LG[CC_CHKB_GPW];
   const int G = CC_CHKB_G;
   const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q;
   const int sub = threadIdx.x / CC_CHKB_G, sl = threadIdx.x % CC_CHKB_G;
-  cc_chkb_lds &L = LG[sub];
+  cc_chkb_lds<PPM> &L = LG[sub];
   const cc_scan_desc_t *tgt = qdesc + q;
   const int ns = surv_cnt[q];
   // the (slot, hit) of the next check is fetched while the current one is worked on
@@ -770,6 +779,10 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
         t_nxt = surv[(size_t)q * CC_CHK_STRIDE + sn];
         h_nxt = surv_hit[(size_t)q * CC_CHK_STRIDE + sn];
       }
+    }
+    if (REDO) {
+      if (pass_ok[(size_t)q * CC_CHK_STRIDE + t] != 2) continue;
+      if (sl == 0) pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 0;
     }
     const int slot = t / CC_KNN_MAX;
     const int level = h.level, seq_src = h.seq, seq_tgt = slot % CC_NPIV;
@@ -841,8 +854,12 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     if (P.dbg_cut == 2) continue;
     int flags = 0;
     int npp = npp_all;
-    if (npp > CC_PP_MAX) {
-      npp = CC_PP_MAX;
+    if (npp > PPM) {
+      if (!REDO) {  // left to the large instance
+        if (sl == 0) pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 2;
+        continue;
+      }
+      npp = PPM;
       flags |= 1;
     }
     cc_group_sync(G);
@@ -1099,18 +1116,35 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       rec->n_pairs = ncs;
       rec->flags = flags;
       rec->pad = 0;
-      const double th = atan2(r10, r00);
-      const double c_ = cos(th), s_2 = sin(th);
       rec->tf[0] = dmx - (r00 * smx + (-r10) * smy);
       rec->tf[1] = dmy - (r10 * smx + r00 * smy);
-      rec->tf[2] = th;
-      rec->cs[0] = c_;
-      rec->cs[1] = s_2;
-      rec->cs[2] = atan2(s_2, c_);
+      // the rotation's angle and the entries of Isometry2d::rotate(angle) are filled in by cc_k_check_c, one lane per
+      // passing check (here they would be evaluated by a mostly idle wave)
+      rec->tf[2] = 0.0;
+      rec->cs[0] = r00;
+      rec->cs[1] = r10;
+      rec->cs[2] = 0.0;
       pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 1;
     }
     if (sl < 7) pass[(size_t)q * CC_CHK_STRIDE + t].bits[sl] = L.bitsw[sl];
   }
+}
+
+// Stage C (one lane per check slot): T_pass's angle atan2(R10, R00) and the rotation rebuilt from it, as the reference
+// does (getTFFromConstell returns Isometry2d; addProposal and the pose output go through rotate(angle)).
+// grid = ceil(nq * CC_CHK_STRIDE / 256), block = 256
+__global__ void __launch_bounds__(256)
+cc_k_check_c(int n_slots, cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots || !pass_ok[i]) return;
+  cc_pass_rec *rec = &pass[i];
+  const double r00 = rec->cs[0], r10 = rec->cs[1];
+  const double th = atan2(r10, r00);
+  const double c_ = cos(th), s_2 = sin(th);
+  rec->tf[2] = th;
+  rec->cs[0] = c_;
+  rec->cs[1] = s_2;
+  rec->cs[2] = atan2(s_2, c_);
 }
 
 // ------------------------------------------------------------------------------------------------
