@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--db-scans", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=512, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
@@ -154,29 +154,52 @@ def main():
         elapsed = float(t.item())
 
     import ctypes as C
-    ms2 = (C.c_double * 2)()
-    nl = C.c_int()
-    cc.lib().cc_profile_read(ctx.h, ms2, C.byref(nl))
-    ms4 = (C.c_double * 5)()
-    nl2 = C.c_int()
-    cc.lib().cc_db_profile_read(db.h, ms4, C.byref(nl2))
+
+    def read_kernel_ms():
+        ms2 = (C.c_double * 2)()
+        nl = C.c_int()
+        cc.lib().cc_profile_read(ctx.h, ms2, C.byref(nl))
+        ms5 = (C.c_double * 5)()
+        nl2 = C.c_int()
+        cc.lib().cc_db_profile_read(db.h, ms5, C.byref(nl2))
+        a, b = max(nl.value, 1), max(nl2.value, 1)
+        return {"cc_k_rasterize": ms2[0] / a, "cc_k_contours": ms2[1] / a, "cc_k_knn": ms5[0] / b, "cc_k_check": ms5[1] / b,
+                "cc_k_merge": ms5[2] / b, "cc_k_gmm": ms5[3] / b, "cc_k_final": ms5[4] / b}
+
+    kms = read_kernel_ms()          # HIP events over the timed region (kernels of the two streams overlap each other)
+    kms_iso = None
+    if not args.no_overlap:         # the same kernels one after the other (2 extra, untimed steps): isolated durations
+        args.no_overlap = True
+        run_steps(W, min(2, K))
+        torch.cuda.synchronize()
+        kms_iso = read_kernel_ms()
 
     if rank == 0:
         total_scans = K * B * world
         value = total_scans / elapsed
-        # ---- roofline of the dominant ingest kernel (HIP-event timed on the launch stream) ----
-        launches = max(nl.value, 1)
-        k1_ms, k2_ms = ms2[0] / launches, ms2[1] / launches
+        # ---- roofline of the dominant kernel (HIP-event timed on its launch stream inside the timed region) ----
         d = cc.desc_to_numpy(qdesc2[(K - 1) & 1][:64])
-        # algorithmic bytes per scan: K1 streams the xyzi records once (16 B/point) and emits the dense BEV
-        # + per-cell continuous positions; K2 reads those and emits the descriptor actually used downstream.
+        n_pix = float(d["n_pix"].mean())
+        # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"): what the step has to move, independent of how.
+        #  K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions;
+        #  K2 reads those and emits the descriptor used downstream;
+        #  K3 reads the layers' key matrices once and, per anchor key, the 40 B key and <= nnk 12-B hits;
+        #  K4 reads, per KNN hit, the hit and two contour records, per anchor-similar pair the two 256-bit rings, per
+        #     check that reaches the pairing the two 600-B BCIs, and writes a 104-B record per pass;
+        #  merge reads those records; K5 reads two ellipse tables (32 B/ellipse) per problem and writes 64 B.
         desc_emit = float(np.mean(72 + 16 + 1440 + 36 * 600 + d["n_stored"].sum(1) * 76))
-        k1_bytes = B * (P * 16 + 22500 * 4 + float(d["n_pix"].mean()) * 8)
-        k2_bytes = B * (22500 * 4 + float(d["n_pix"].mean()) * 8 + desc_emit)
-        if k2_ms >= k1_ms:
-            dom, dom_ms, dom_bytes = "cc_k_contours", k2_ms, k2_bytes
-        else:
-            dom, dom_ms, dom_bytes = "cc_k_rasterize", k1_ms, k1_bytes
+        f = {k: float(res[k].mean()) for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check3", "n_cand_tidy")}
+        n_keys_db = 3 * 6 * n_db
+        alg = {"cc_k_rasterize": B * (P * 16 + 22500 * 4 + n_pix * 8),
+               "cc_k_contours": B * (22500 * 4 + n_pix * 8 + desc_emit),
+               "cc_k_knn": n_keys_db * 44 + B * 18 * 40 + B * f["n_knn_hits"] * 12,
+               "cc_k_check": B * (f["n_knn_hits"] * (12 + 2 * 76) + f["cand_aft_check1"] * (64 + 2 * 600) + f["cand_aft_check3"] * 104),
+               "cc_k_merge": B * f["cand_aft_check3"] * 104,
+               "cc_k_gmm": B * f["n_cand_tidy"] * (2 * 45 * 32 + 64),
+               "cc_k_final": B * 64}
+        dom = max(kms, key=lambda k: kms[k])
+        dom_ms, dom_bytes = kms[dom], alg[dom]
+        k1_ms, k1_bytes = kms["cc_k_rasterize"], alg["cc_k_rasterize"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
@@ -188,11 +211,10 @@ def main():
                        "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B)[0], "traffic_source": pmc_traffic(dom, B)[1],
-                         "kernels_ms_per_launch": {"cc_k_rasterize": k1_ms, "cc_k_contours": k2_ms,
-                                                   "cc_k_knn": ms4[0] / max(nl2.value, 1), "cc_k_check": ms4[1] / max(nl2.value, 1),
-                                                   "cc_k_merge": ms4[2] / max(nl2.value, 1), "cc_k_gmm": ms4[3] / max(nl2.value, 1),
-                                                   "cc_k_final": ms4[4] / max(nl2.value, 1)},
-                         "rasterize_GBs": k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else None},
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "kernels_ms_per_launch": kms, "kernels_ms_per_launch_isolated": kms_iso,
+                         "streams": 1 if kms_iso is None else 2,
+                         "rasterize_GBs": k1_bytes / ((kms_iso or kms)["cc_k_rasterize"] * 1e-3) / 1e9 if k1_ms > 0 else None},
             "setup_s": setup_s,
         }
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:

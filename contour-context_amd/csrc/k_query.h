@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256)
 cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, unsigned short *__restrict__ surv,
              cc_knn_hit_t *__restrict__ surv_hit, int *__restrict__ surv_cnt, unsigned char *__restrict__ pass_ok,
-             int *__restrict__ pass_cnt /*[nq][4]*/) {
+             int *__restrict__ pass_cnt /*[nq][4]*/, int *__restrict__ redo_cnt /*[nq]*/) {
   __shared__ int wcnt[4];
   __shared__ int s_base, s_chk1;
   const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -470,6 +470,7 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
   }
   if (tid == 0) {
     surv_cnt[q] = s_base;
+    redo_cnt[q] = 0;
     pass_cnt[q * 4 + 0] = 0;
     pass_cnt[q * 4 + 1] = s_chk1;
     pass_cnt[q * 4 + 2] = 0;
@@ -751,8 +752,10 @@ template <int PPM, bool REDO>
 __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ surv_hit, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
-             cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt) {
+             cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt,
+             int *__restrict__ redo_cnt) {
   __shared__ cc_chkb_lds<PPM> LG[CC_CHKB_GPW];
+  if (REDO && redo_cnt[blockIdx.x / CC_CHKB_PER_Q] == 0) return;  // nothing was left over for this query
   const int G = CC_CHKB_G;
   const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q;
   const int sub = threadIdx.x / CC_CHKB_G, sl = threadIdx.x % CC_CHKB_G;
@@ -856,7 +859,10 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     int npp = npp_all;
     if (npp > PPM) {
       if (!REDO) {  // left to the large instance
-        if (sl == 0) pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 2;
+        if (sl == 0) {
+          pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 2;
+          atomicAdd(&redo_cnt[q], 1);
+        }
         continue;
       }
       npp = PPM;
