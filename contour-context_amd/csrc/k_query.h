@@ -3,8 +3,9 @@
 //   K4  CandidateManager::checkCandWithHint: ContourView::checkSim,           contour_db.h:374-488
 //       BCI::checkConstellSim, checkConstellCorrespSim, getTFFromConstell     contour.h:278-329, contour_mng.h:288-388,1124-1277
 //   K5  GMMPair / ConstellCorrelation::initProblem + calcCorrelation          correlation.h:42-238
-// The sequential bookkeeping between them (CandidatePoseData::addProposal, tidyUpCandidates'
-// selection, fineOptimize's ordering) runs on the host in cc_db_api.inc.
+//   K4b CandidatePoseData::addProposal, tidyUpCandidates (selection part)         contour_db.h:286-338,494-546
+//   K6  tidyUpCandidates (compaction), fineOptimize ordering                       contour_db.h:560-648
+// A query batch is one launch chain (knn -> check a/b/c -> merge -> gmm prep/small/large -> final) and one D2H copy.
 #pragma once
 #include "cc_dev.h"
 #include "cc_sort.h"
