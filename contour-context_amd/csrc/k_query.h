@@ -535,7 +535,12 @@ __device__ __forceinline__ void cc_chkb_gen_pairs(cc_chkb_lds<PPM> &L, int ntp, 
       if (o >= PPM) break;
       const cc_relpt_t r1 = L.g.sp[sj];
       float od = r2.theta - r1.theta;
-      od = (float)((double)od - floor(((double)od + 3.14159265358979323846) / (2 * 3.14159265358979323846)) * 2 * 3.14159265358979323846);
+      // clampAng (tools/algos.h:49-51): ang - floor((ang + pi) / (2 pi)) * 2 * pi in double.  |theta| <= float(pi), so the
+      // quotient lies in (-0.51, 1.51) and its floor is -1 (x < 0), 1 (x >= 2 pi; the quotient of two doubles cannot round
+      // up to 1 from below) or 0 -- two compares instead of an f64 division
+      const double xw = (double)od + 3.14159265358979323846;
+      const double kw = xw < 0.0 ? -1.0 : (xw >= 2 * 3.14159265358979323846 ? 1.0 : 0.0);
+      od = (float)((double)od - kw * 2 * 3.14159265358979323846);
       L.pp[o] = ((unsigned long long)cc_fkey(od) << 32) |
                 (unsigned long long)((unsigned)(r1.level & 0xFF) | ((unsigned)(r1.seq & 0xFF) << 8) | ((unsigned)(r2.seq & 0xFF) << 16));
     }
@@ -888,7 +893,8 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       int a = p1, b = p1 + npp - 1;  // window [p1, p2], p2 in [p1, p1+npp)
       while (a < b) {                // largest p2 with valid(p2); valid is monotone in p2
         const int mid = (a + b + 1) >> 1;
-        const double v = (double)(L.skey[mid % npp] - v1) + 2 * 3.14159265358979323846 * (double)(mid / npp);
+        const int wr = mid >= npp ? 1 : 0;  // mid < 2 * npp: mid % npp and mid / npp without a division
+        const double v = (double)(L.skey[mid - (wr ? npp : 0)] - v1) + 2 * 3.14159265358979323846 * (double)wr;
         if (v > (double)angular_range)
           b = mid - 1;
         else
@@ -928,7 +934,8 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       bool sim = false;
       if (e < n_in) {
         if (e < longest && e < n_in - 1) {
-          const unsigned w = (unsigned)L.pp[L.sidx[(beg + e) % npp]];
+          const int pe = beg + e;  // < 2 * npp
+          const unsigned w = (unsigned)L.pp[L.sidx[pe >= npp ? pe - npp : pe]];
           l = (int)(signed char)(w & 0xFF);
           s_ = (int)(signed char)((w >> 8) & 0xFF);
           t_ = (int)(signed char)((w >> 16) & 0xFF);

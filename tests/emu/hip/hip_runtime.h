@@ -150,6 +150,7 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
 }
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl_any(v, lane); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl_any(v, 0); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
