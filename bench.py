@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="ingest and query strictly one after the other (one stream)")
+    ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
     args = ap.parse_args()
 
@@ -80,6 +80,8 @@ def main():
     else:
         desc_db = desc_local[:n_db]
     db = cc.Database(ctx, capacity=n_db + 16)
+    if args.no_overlap:
+        db.set_lanes(1)
     ts_db = np.arange(n_db, dtype=np.float64) / 10.0
     db.add_scans(desc_db.contiguous(), ts_db, np.arange(n_db, dtype=np.int32))
     del desc_db
@@ -166,10 +168,14 @@ def main():
         return {"cc_k_rasterize": ms2[0] / a, "cc_k_contours": ms2[1] / a, "cc_k_knn": ms5[0] / b, "cc_k_check": ms5[1] / b,
                 "cc_k_merge": ms5[2] / b, "cc_k_gmm": ms5[3] / b, "cc_k_final": ms5[4] / b}
 
-    kms = read_kernel_ms()          # HIP events over the timed region (kernels of the two streams overlap each other)
+    # HIP events over the timed region: per 512-scan step, the summed durations of the kernel's launches (one per
+    # 256-query chunk on the query side).  Launches of different streams overlap each other, so these are durations of
+    # kernels SHARING the GPU, and a chunk pair's durations add up although they ran side by side.
+    kms = read_kernel_ms()
     kms_iso = None
-    if not args.no_overlap:         # the same kernels one after the other (2 extra, untimed steps): isolated durations
+    if not args.no_overlap:         # the same kernels strictly one after the other (2 extra, untimed steps): isolated durations
         args.no_overlap = True
+        db.set_lanes(1)
         run_steps(W, min(2, K))
         torch.cuda.synchronize()
         kms_iso = read_kernel_ms()
@@ -213,7 +219,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B)[0], "traffic_source": pmc_traffic(dom, B)[1],
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "kernels_ms_per_launch": kms, "kernels_ms_per_launch_isolated": kms_iso,
-                         "streams": 1 if kms_iso is None else 2,
+                         "streams": 1 if kms_iso is None else 3,
                          "rasterize_GBs": k1_bytes / ((kms_iso or kms)["cc_k_rasterize"] * 1e-3) / 1e9 if k1_ms > 0 else None},
             "setup_s": setup_s,
         }

@@ -45,7 +45,7 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
            "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
-           "cc_db_add_scan_host", "cc_db_query_host"]
+           "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes"]
 
 
 def lib():
@@ -208,6 +208,10 @@ class Database:
         if want_knn:
             return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
         return res
+
+    def set_lanes(self, n):
+        """1 = query chunks one after the other, 2 (default) = two 256-query chunks in flight on internal streams."""
+        _chk(lib().cc_db_set_lanes(self.h, int(n)), "cc_db_set_lanes")
 
     def bucket_state(self):
         sizes = np.zeros((3, 6), np.int32)

@@ -260,6 +260,11 @@ const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
 int cc_db_profile_enable(cc_db *db, int on);
 int cc_db_profile_read(cc_db *db, double ms_out[5], int *n_launches);
 
+/* cc_db_query_batch cuts a batch into chunks of 256 queries and keeps up to two of them in flight on internal streams
+ * (the f64-bound correlation of one chunk overlaps the latency-bound retrieval/checks of the next).  n = 1 runs the
+ * chunks one after the other (per-kernel timing, debugging); default 2.  No reference counterpart. */
+int cc_db_set_lanes(cc_db *db, int n);
+
 /* Host-side introspection of the K0 bookkeeping for parity tests:
  * tree sizes per (layer, bucket) and bucket ranges at the current epoch. */
 int cc_db_bucket_state(const cc_db *db, int32_t *tree_sizes /*[3][6]*/, float *ranges /*[3][7]*/);
