@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--db-scans", type=int, default=5000)
-    ap.add_argument("--batch", type=int, default=512, help="query scans per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
@@ -164,12 +164,12 @@ def main():
         ms5 = (C.c_double * 5)()
         nl2 = C.c_int()
         cc.lib().cc_db_profile_read(db.h, ms5, C.byref(nl2))
-        a, b = max(nl.value, 1), max(nl2.value, 1)
+        a, b = max(nl.value, 1), max(nl2.value, 1) / float(B)   # ingest launches (one per step) | queries -> steps
         return {"cc_k_rasterize": ms2[0] / a, "cc_k_contours": ms2[1] / a, "cc_k_knn": ms5[0] / b, "cc_k_check": ms5[1] / b,
                 "cc_k_merge": ms5[2] / b, "cc_k_gmm": ms5[3] / b, "cc_k_final": ms5[4] / b}
 
-    # HIP events over the timed region: per 512-scan step, the summed durations of the kernel's launches (one per
-    # 256-query chunk on the query side).  Launches of different streams overlap each other, so these are durations of
+    # HIP events over the timed region: per step, the summed durations of the kernel's launches (one per
+    # chunk of <= 512 queries on the query side).  Launches of different streams overlap each other, so these are durations of
     # kernels SHARING the GPU, and a chunk pair's durations add up although they ran side by side.
     kms = read_kernel_ms()
     kms_iso = None

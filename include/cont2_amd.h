@@ -256,11 +256,13 @@ int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t 
  * device buffer, then cc_db_add_scans consumes it). */
 const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
 
-/* Same for the query kernels: accumulated ms {K3 knn, K4 check, K4b merge, K5 gmm, K6 final} + launch count. */
+/* Same for the query kernels: accumulated ms {K3 knn, K4 check, K4b merge, K5 gmm, K6 final} summed over the chunk
+ * launches (chunks in flight together overlap in time), and the number of QUERIES the sums cover (*n_launches). */
 int cc_db_profile_enable(cc_db *db, int on);
 int cc_db_profile_read(cc_db *db, double ms_out[5], int *n_launches);
 
-/* cc_db_query_batch cuts a batch into chunks of 256 queries and keeps up to two of them in flight on internal streams
+/* cc_db_query_batch cuts a batch into chunks of <= 512 queries (two per batch when it is smaller than 1024) and keeps
+ * up to two of them in flight on internal streams
  * (the f64-bound correlation of one chunk overlaps the latency-bound retrieval/checks of the next).  n = 1 runs the
  * chunks one after the other (per-kernel timing, debugging); default 2.  No reference counterpart. */
 int cc_db_set_lanes(cc_db *db, int n);

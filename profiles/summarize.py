@@ -25,12 +25,25 @@ def short(name):
     return n.split("<")[0]
 
 
-# grid size (threads) of the launch that belongs to a <batch>-scan step, per kernel
-def step_grid(k):
-    return {"cc_k_rasterize": batch * 1024, "cc_k_contours": batch * 512, "cc_k_knn": batch * 18 * 64, "cc_k_check_a": batch * 256,
-            "cc_k_check_b": batch * 8 * 64, "cc_k_check_c": batch * 1152, "cc_k_merge": batch * 128, "cc_k_gmm_prep": batch * 64,
-            "cc_k_final": batch * 64}.get(k)
+# The launches of a timed step are the LARGEST launches of each kernel (the DB build ingests 128-scan chunks; a step
+# ingests <batch> scans at once and queries them in chunks of <= 512): they are picked by grid size.
+_max_grid = {}
 
+
+def note_grid(k, g):
+    _max_grid[k] = max(_max_grid.get(k, 0), g)
+
+
+def step_grid(k):
+    return _max_grid.get(k)
+
+
+for fn in (f_trace, f_fetch, f_write):
+    if os.path.exists(fn):
+        for r in csv.DictReader(open(fn)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("cc_k_"):
+                note_grid(k, int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]))
 
 if os.path.exists(f_stats):
     rows = [r for r in csv.DictReader(open(f_stats)) if short(r["Name"]).startswith("cc_k_")]
@@ -49,7 +62,7 @@ if os.path.exists(f_trace):
             continue
         g = step_grid(k)
         gs = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
-        if g is None or gs == g or k == "cc_k_gmm":
+        if g is None or gs == g or k in ("cc_k_gmm", "cc_k_ksort_new", "cc_k_ksort_merge", "cc_k_ksort_act", "cc_k_extract"):
             acc[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(os.path.join(out, tag + "_kernel_trace_timed_launches.csv"), "w") as f:
         f.write("kernel,launches,mean_us,min_us,max_us\n")
