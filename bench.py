@@ -233,16 +233,20 @@ def main():
 
 
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r*_pmc_summary.json; FETCH_SIZE/WRITE_SIZE, gfx950 x2 correction applied where it is calibrated)."""
+    """HBM bytes per STEP of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_pmc_summary.json: FETCH_SIZE/WRITE_SIZE per launch, gfx950 x2 correction applied where it is calibrated).
+    Query kernels are launched once per chunk (two chunks per step up to 1024 scans, 512-query chunks above)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    if d.get("batch_scans") != batch or kernel not in d.get("kernels", {}):
+    ks = d.get("kernels", {})
+    parts = ["cc_k_check_a", "cc_k_check_b", "cc_k_check_c"] if kernel == "cc_k_check" else [kernel]
+    if d.get("batch_scans") != batch or any(p not in ks or "hbm_bytes_per_launch" not in ks[p] for p in parts):
         return None, None
-    return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    per_step = 1 if kernel in ("cc_k_rasterize", "cc_k_contours") else max(2, (batch + 511) // 512)
+    return sum(ks[p]["hbm_bytes_per_launch"] for p in parts) * per_step, os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(cc, wld, n_db, batch0, P, n_q, max_db_seconds=150.0):
