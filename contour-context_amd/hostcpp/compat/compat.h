@@ -1,6 +1,7 @@
 // Minimal stand-ins for the third-party types the reference's public API mentions, so a driver written
 // against include/cont2/*.h of the reference compiles against this mirror without Eigen / PCL / glog:
-//   pcl::PointXYZ, pcl::PointCloud<PointT>(::Ptr/::ConstPtr), Eigen::Isometry2d (the subset the driver uses),
+//   pcl::PointXYZ, pcl::PointCloud<PointT>(::Ptr/::ConstPtr), Eigen::Isometry2d / Isometry3d (the subset the driver and the
+//   evaluator use),
 //   CHECK / CHECK_GT (abort like glog).
 #pragma once
 #include <cmath>
@@ -65,5 +66,95 @@ struct Isometry2d {
     double norm() const { return std::sqrt(x_ * x_ + y_ * y_); }
   };
   Vec2 translation() const { return {m[0][2], m[1][2]}; }
+  Isometry2d inverse() const {
+    Isometry2d o;
+    o.m[0][0] = m[0][0];
+    o.m[0][1] = m[1][0];
+    o.m[1][0] = m[0][1];
+    o.m[1][1] = m[1][1];
+    o.m[0][2] = -(o.m[0][0] * m[0][2] + o.m[0][1] * m[1][2]);
+    o.m[1][2] = -(o.m[1][0] * m[0][2] + o.m[1][1] * m[1][2]);
+    return o;
+  }
+  Isometry2d operator*(const Isometry2d &b) const {
+    Isometry2d o;
+    for (int i = 0; i < 2; i++) {
+      o.m[i][0] = m[i][0] * b.m[0][0] + m[i][1] * b.m[1][0];
+      o.m[i][1] = m[i][0] * b.m[0][1] + m[i][1] * b.m[1][1];
+      o.m[i][2] = m[i][0] * b.m[0][2] + m[i][1] * b.m[1][2] + m[i][2];
+    }
+    return o;
+  }
+};
+
+// 3-D rigid transform: what the evaluator keeps per scan (ground-truth sensor pose) and evalMetricEst consumes
+struct Isometry3d {
+  double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  double t[3] = {0, 0, 0};
+  struct Vec3 {
+    double v[3];
+    double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+    Vec3 operator-(const Vec3 &o) const { return {{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
+    double operator()(int i) const { return v[i]; }
+  };
+  static Isometry3d Identity() { return Isometry3d(); }
+  Vec3 translation() const { return {{t[0], t[1], t[2]}}; }
+  double operator()(int r, int c) const { return c < 3 ? R[r][c] : t[r]; }
+  Isometry3d inverse() const {  // [R^T, -R^T t]
+    Isometry3d o;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) o.R[i][j] = R[j][i];
+    for (int i = 0; i < 3; i++) o.t[i] = -(o.R[i][0] * t[0] + o.R[i][1] * t[1] + o.R[i][2] * t[2]);
+    return o;
+  }
+  Isometry3d operator*(const Isometry3d &b) const {
+    Isometry3d o;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) o.R[i][j] = R[i][0] * b.R[0][j] + R[i][1] * b.R[1][j] + R[i][2] * b.R[2][j];
+      o.t[i] = R[i][0] * b.t[0] + R[i][1] * b.t[1] + R[i][2] * b.t[2] + t[i];
+    }
+    return o;
+  }
+  // Quaterniond(rotation matrix) followed by rotate(q) on an identity transform: the matrix is re-orthonormalised
+  // through a unit quaternion, which is what the reference's pose loader does (eval/evaluator.h:118-121)
+  void setRotationViaQuaternion(const double M[3][3]) {
+    double w, x, y, z;
+    const double tr = M[0][0] + M[1][1] + M[2][2];
+    if (tr > 0) {
+      double s = std::sqrt(tr + 1.0);
+      w = 0.5 * s;
+      s = 0.5 / s;
+      x = (M[2][1] - M[1][2]) * s;
+      y = (M[0][2] - M[2][0]) * s;
+      z = (M[1][0] - M[0][1]) * s;
+    } else {
+      int i = 0;
+      if (M[1][1] > M[0][0]) i = 1;
+      if (M[2][2] > M[i][i]) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      double s = std::sqrt(M[i][i] - M[j][j] - M[k][k] + 1.0);
+      double q[3];
+      q[i] = 0.5 * s;
+      s = 0.5 / s;
+      w = (M[k][j] - M[j][k]) * s;
+      q[j] = (M[j][i] + M[i][j]) * s;
+      q[k] = (M[k][i] + M[i][k]) * s;
+      x = q[0];
+      y = q[1];
+      z = q[2];
+    }
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+                 tzz = tz * z;
+    R[0][0] = 1 - (tyy + tzz);
+    R[0][1] = txy - twz;
+    R[0][2] = txz + twy;
+    R[1][0] = txy + twz;
+    R[1][1] = 1 - (txx + tzz);
+    R[1][2] = tyz - twx;
+    R[2][0] = txz - twy;
+    R[2][1] = tyz + twx;
+    R[2][2] = 1 - (txx + tyy);
+  }
 };
 }  // namespace Eigen

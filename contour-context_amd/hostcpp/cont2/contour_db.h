@@ -127,4 +127,35 @@ struct ConstellCorrelation {
     T.pretranslate(out[0], out[1]);
     return T;
   }
+
+  // correlation.h:241-280: error of the estimated sensor-to-sensor transform (metres, radians) against the 3-D ground
+  // truth projected to 2-D (xy offset; yaw after rotating the relative z axis back onto z).  Returns T_gt^-1 * T_est.
+  static Eigen::Isometry2d evalMetricEst(const Eigen::Isometry2d &T_delta, const Eigen::Isometry3d &gt_src_3d,
+                                         const Eigen::Isometry3d &gt_tgt_3d, const ContourManagerConfig &bev_config) {
+    CC_CHECK(bev_config.reso_row_ == bev_config.reso_col_);
+    Eigen::Isometry2d T_est = getEstSensTF(T_delta, bev_config);
+    T_est.m[0][2] *= bev_config.reso_row_;
+    T_est.m[1][2] *= bev_config.reso_row_;
+    const Eigen::Isometry3d rel = gt_tgt_3d.inverse() * gt_src_3d;  // src sensor in the tgt sensor frame
+    // axis-angle that takes the relative z axis back to (0,0,1): axis = z0 x z1 normalised, angle = -acos(z0 . z1)
+    const double z1[3] = {rel.R[0][2], rel.R[1][2], rel.R[2][2]};
+    double ax[3] = {-z1[1], z1[0], 0.0};
+    const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1]);
+    if (an > 0) {
+      ax[0] /= an;
+      ax[1] /= an;
+    }
+    const double ang = -std::acos(z1[2]);
+    const double c = std::cos(ang), s = std::sin(ang), C = 1 - c;
+    const double D[3][3] = {{c + ax[0] * ax[0] * C, ax[0] * ax[1] * C - ax[2] * s, ax[0] * ax[2] * C + ax[1] * s},
+                            {ax[1] * ax[0] * C + ax[2] * s, c + ax[1] * ax[1] * C, ax[1] * ax[2] * C - ax[0] * s},
+                            {ax[2] * ax[0] * C - ax[1] * s, ax[2] * ax[1] * C + ax[0] * s, c + ax[2] * ax[2] * C}};
+    double Rr[2][2];  // top-left 2x2 of D * rel.R
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) Rr[i][j] = D[i][0] * rel.R[0][j] + D[i][1] * rel.R[1][j] + D[i][2] * rel.R[2][j];
+    Eigen::Isometry2d T_gt;
+    T_gt.rotate(std::atan2(Rr[1][0], Rr[0][0]));
+    T_gt.pretranslate(rel.t[0], rel.t[1]);
+    return T_gt.inverse() * T_est;
+  }
 };

@@ -1,0 +1,276 @@
+// Mirror of the reference's loop-closure evaluator (include/eval/evaluator.h:13-431): same class, method names and
+// file formats, no Eigen/glog.  It feeds scans to the detector in order, judges every prediction against the ground
+// truth (TP/FP/TN/FN), accumulates pose errors and writes the 8-column outcome file scripts/pr_mpe.py consumes.
+//
+//   pose file : `ts r00 r01 r02 tx r10 r11 r12 ty r20 r21 r22 tz` per line (sensor pose, z up), any order
+//   scan list : `ts seq path` per line, ordered by ts and seq
+//   outcome   : `tfpn \t tgt-src \t correlation \t err_x \t err_y \t err_theta \t tgt_path \t src_path` (`x` = no candidate)
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+#include <type_traits>
+
+#include "../cont2/contour_db.h"
+
+// nearest element of a sorted vector within `tol`, or -1 (tools/algos.h:77-90)
+template <typename T>
+int lookupNN(const T &q_val, const std::vector<T> &sorted_vec, const T &tol) {
+  if (sorted_vec.empty()) return -1;
+  auto lo = std::lower_bound(sorted_vec.begin(), sorted_vec.end(), q_val);
+  auto it = lo;
+  if (lo == sorted_vec.end())
+    it = lo - 1;
+  else if (lo != sorted_vec.begin())
+    it = std::abs(q_val - *lo) < std::abs(q_val - *(lo - 1)) ? lo : lo - 1;
+  if (std::abs(*it - q_val) > tol) return -1;
+  return (int)(it - sorted_vec.begin());
+}
+
+template <int dim>
+struct SimpleRMSE {  // evaluator.h:13-33
+  double sum_sqs = 0, sum_abs = 0;
+  int cnt_sqs = 0;
+  void addOneErr(const double *d) {
+    double sq = 0;
+    for (int i = 0; i < dim; i++) sq += d[i] * d[i];
+    cnt_sqs++;
+    sum_sqs += sq;
+    sum_abs += std::sqrt(sq);
+  }
+  double getRMSE() const { return cnt_sqs ? std::sqrt(sum_sqs / cnt_sqs) : -1; }
+  double getMean() const { return cnt_sqs ? sum_abs / cnt_sqs : -1; }
+};
+
+struct PredictionOutcome {  // evaluator.h:35-45
+  enum Res { TP, FP, TN, FN };
+  int id_src = -1;
+  int id_tgt = -1;
+  Res tfpn = Res::TN;
+  double est_err[3]{};  // error on SE(2) when a candidate was proposed, else zero
+  double correlation{};
+};
+
+class ContLCDEvaluator {
+ public:
+  struct LaserScanInfo {
+    bool has_gt_positive_lc = false;
+    Eigen::Isometry3d sens_pose;
+    int seq = 0;
+    double ts = 0;
+    std::string fpath;
+  };
+
+ private:
+  std::vector<LaserScanInfo> laser_info_;
+  std::vector<int> assigned_seqs_;
+  const double ts_diff_tol = 10e-3;   // a scan is used only if a gt pose lies within 10 ms
+  const double min_time_excl = 15.0;  // revisits younger than 15 s are not loops
+  const double sim_thres;             // similarity at or above which a prediction counts as positive
+  int p_lidar_curr = -1;
+  SimpleRMSE<2> tp_trans_rmse, all_trans_rmse;
+  SimpleRMSE<1> tp_rot_rmse, all_rot_rmse;
+  std::vector<PredictionOutcome> pred_records;
+
+ public:
+  ContLCDEvaluator(const std::string &fpath_pose, const std::string &fpath_laser, const double &bar) : sim_thres(bar) {
+    // 1. stamped ground-truth poses, sorted by time
+    std::ifstream f_pose(fpath_pose);
+    if (!f_pose.good()) {
+      std::cerr << "Error opening gt pose file: " << fpath_pose << std::endl;
+      return;
+    }
+    std::vector<double> gt_tss;
+    std::vector<Eigen::Isometry3d> gt_poses;
+    std::string line;
+    while (std::getline(f_pose, line)) {
+      std::istringstream iss(line);
+      double v[13];
+      for (double &x : v) CC_CHECK(iss >> x);
+      double M[3][3];
+      Eigen::Isometry3d T;
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) M[r][c] = v[1 + 4 * r + c];
+        T.t[r] = v[1 + 4 * r + 3];
+      }
+      T.setRotationViaQuaternion(M);
+      gt_tss.push_back(v[0]);
+      gt_poses.push_back(T);
+    }
+    printf("Added %lu stamped gt poses.\n", gt_poses.size());
+    std::vector<int> order(gt_poses.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return gt_tss[a] < gt_tss[b]; });
+    {
+      std::vector<double> ts2(order.size());
+      std::vector<Eigen::Isometry3d> p2(order.size());
+      for (size_t i = 0; i < order.size(); i++) {
+        ts2[i] = gt_tss[order[i]];
+        p2[i] = gt_poses[order[i]];
+      }
+      gt_tss.swap(ts2);
+      gt_poses.swap(p2);
+    }
+    // 2. scans that have a ground-truth pose
+    std::ifstream f_laser(fpath_laser);
+    if (!f_laser.good()) {
+      std::cerr << "Error opening laser info file: " << fpath_laser << std::endl;
+      return;
+    }
+    size_t n_listed = 0;
+    while (std::getline(f_laser, line)) {
+      std::istringstream iss(line);
+      LaserScanInfo info;
+      if (!(iss >> info.ts)) continue;
+      iss >> info.seq >> info.fpath;
+      n_listed++;
+      const int gi = lookupNN<double>(info.ts, gt_tss, ts_diff_tol);
+      if (gi < 0) continue;
+      info.sens_pose = gt_poses[gi];
+      laser_info_.push_back(info);
+      assigned_seqs_.push_back(info.seq);
+    }
+    printf("Added %lu laser bin paths.\n", n_listed);
+    printf("Found %d laser scans with gt poses.\n", (int)laser_info_.size());
+    for (size_t i = 1; i < laser_info_.size(); i++) {
+      CC_CHECK(laser_info_[i - 1].seq < laser_info_[i].seq);
+      CC_CHECK(laser_info_[i - 1].ts < laser_info_[i].ts);
+    }
+    printf("Ordering check passed\n");
+    // 3. ground-truth loops: an earlier scan (by at least min_time_excl) within 5 m
+    int cnt_gt_lc_p = 0, cnt_gt_lc = 0;
+    for (auto &fast : laser_info_) {
+      for (const auto &slow : laser_info_) {
+        if (fast.ts < slow.ts + min_time_excl) break;
+        if ((fast.sens_pose.translation() - slow.sens_pose.translation()).norm() < 5.0) {
+          if (!fast.has_gt_positive_lc) {
+            fast.has_gt_positive_lc = true;
+            cnt_gt_lc_p++;
+          }
+          cnt_gt_lc++;
+        }
+      }
+    }
+    printf("Found %d poses with %d gt loops.\n", cnt_gt_lc_p, cnt_gt_lc);
+  }
+
+  bool loadNewScan() {
+    p_lidar_curr++;
+    CC_CHECK(p_lidar_curr >= 0);
+    if (p_lidar_curr >= (int)laser_info_.size()) {
+      printf("\n===\ncurrent addr %d exceeds boundary\n", p_lidar_curr);
+      return false;
+    }
+    printf("\n===\nloaded scan addr %d, seq: %d, fpath: %s\n", p_lidar_curr, laser_info_[p_lidar_curr].seq,
+           laser_info_[p_lidar_curr].fpath.c_str());
+    return true;
+  }
+
+  const LaserScanInfo &getCurrScanInfo() const {
+    CC_CHECK(p_lidar_curr >= 0 && p_lidar_curr < (int)laser_info_.size());
+    return laser_info_[p_lidar_curr];
+  }
+
+  // read the current scan's .bin (x,y,z,i f32; tools/pointcloud_util.h:9-47) and build its descriptor on the device
+  std::shared_ptr<ContourManager> getCurrContourManager(const ContourManagerConfig &config) const {
+    const LaserScanInfo &info = getCurrScanInfo();
+    std::shared_ptr<ContourManager> cm(new ContourManager(config, info.seq));
+    auto cloud = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    FILE *f = fopen(info.fpath.c_str(), "rb");
+    if (!f) {
+      printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
+      exit(-1);
+    }
+    std::vector<float> buf(1000000);
+    const size_t n = fread(buf.data(), sizeof(float), buf.size(), f) / 4;
+    fclose(f);
+    cloud->reserve(n);
+    for (size_t i = 0; i < n; i++) cloud->push_back(pcl::PointXYZ{buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], 0.f});
+    std::string str_id = std::to_string(info.seq);
+    str_id = "assigned_id_" + std::string(8 - str_id.length(), '0') + str_id;
+    pcl::PointCloud<pcl::PointXYZ>::ConstPtr cptr = cloud;
+    cm->makeBEV<pcl::PointXYZ>(cptr, str_id);
+    cm->makeContoursRecurs();
+    return cm;
+  }
+
+  // judge one query: `cand_mng` is the proposed loop candidate (nullptr: none), T_est_delta_2d its BEV-frame transform
+  PredictionOutcome addPrediction(const std::shared_ptr<const ContourManager> &q_mng, double est_corr,
+                                  const std::shared_ptr<const ContourManager> &cand_mng = nullptr,
+                                  const Eigen::Isometry2d &T_est_delta_2d = Eigen::Isometry2d::Identity()) {
+    PredictionOutcome res;
+    res.id_tgt = q_mng->getIntID();
+    res.correlation = est_corr;
+    const int addr_tgt = lookupNN<int>(res.id_tgt, assigned_seqs_, 0);
+    CC_CHECK(addr_tgt >= 0);
+    const bool gt_pos = laser_info_[addr_tgt].has_gt_positive_lc;
+    if (cand_mng) {
+      res.id_src = cand_mng->getIntID();
+      const int addr_src = lookupNN<int>(res.id_src, assigned_seqs_, 0);
+      CC_CHECK(addr_src >= 0);
+      const ContourManagerConfig bev_cfg = q_mng->getConfig();
+      const Eigen::Isometry2d tf_err = ConstellCorrelation::evalMetricEst(T_est_delta_2d, laser_info_[addr_src].sens_pose,
+                                                                          laser_info_[addr_tgt].sens_pose, bev_cfg);
+      const double est_trans_norm2d = ConstellCorrelation::getEstSensTF(T_est_delta_2d, bev_cfg).translation().norm();
+      const double gt_trans_norm3d = (laser_info_[addr_src].sens_pose.translation() - laser_info_[addr_tgt].sens_pose.translation()).norm();
+      printf(" Dist: Est2d: %.2f; GT3d: %.2f\n", est_trans_norm2d, gt_trans_norm3d);
+      const double err_vec[3] = {tf_err.translation().x(), tf_err.translation().y(), std::atan2(tf_err(1, 0), tf_err(0, 0))};
+      printf(" Error: dx=%f, dy=%f, dtheta=%f\n", err_vec[0], err_vec[1], err_vec[2]);
+      std::memcpy(res.est_err, err_vec, sizeof(err_vec));
+      if (est_corr >= sim_thres) {
+        if (gt_pos && gt_trans_norm3d < 5.0) {
+          res.tfpn = PredictionOutcome::TP;
+          tp_trans_rmse.addOneErr(err_vec);
+          tp_rot_rmse.addOneErr(err_vec + 2);
+        } else {
+          res.tfpn = PredictionOutcome::FP;
+        }
+      } else {
+        res.tfpn = gt_pos ? PredictionOutcome::FN : PredictionOutcome::TN;
+      }
+      all_trans_rmse.addOneErr(err_vec);
+      all_rot_rmse.addOneErr(err_vec + 2);
+    } else {
+      res.tfpn = gt_pos ? PredictionOutcome::FN : PredictionOutcome::TN;
+    }
+    pred_records.push_back(res);
+    return res;
+  }
+
+  void savePredictionResults(const std::string &sav_path) const {
+    std::fstream out(sav_path, std::ios::out);
+    if (!out.good()) {
+      std::cerr << "Error opening " << sav_path << std::endl;
+      return;
+    }
+    auto tail32 = [](const std::string &s) { return s.substr(s.length() > 32 ? s.length() - 32 : 0); };
+    for (const auto &rec : pred_records) {
+      const int addr_tgt = lookupNN<int>(rec.id_tgt, assigned_seqs_, 0);
+      CC_CHECK(addr_tgt >= 0);
+      std::string rep_src = "x";
+      out << rec.tfpn << "\t" << rec.id_tgt << "-";
+      if (rec.id_src < 0) {
+        out << "x";
+      } else {
+        const int addr_src = lookupNN<int>(rec.id_src, assigned_seqs_, 0);
+        CC_CHECK(addr_src >= 0);
+        out << rec.id_src;
+        rep_src = laser_info_[addr_src].fpath;
+      }
+      out << "\t" << rec.correlation << "\t" << rec.est_err[0] << "\t" << rec.est_err[1] << "\t" << rec.est_err[2] << "\t"
+          << tail32(laser_info_[addr_tgt].fpath) << "\t" << tail32(rep_src) << "\n";
+    }
+    printf("In outcome file:\nTP is %d\nFP is %d\nTN is %d\nFN is %d\n", (int)PredictionOutcome::TP, (int)PredictionOutcome::FP,
+           (int)PredictionOutcome::TN, (int)PredictionOutcome::FN);
+    out.close();
+    printf("Outcome saved successfully.\n");
+  }
+
+  double getTPMeanTrans() const { return tp_trans_rmse.getMean(); }
+  double getTPMeanRot() const { return tp_rot_rmse.getMean(); }
+  double getTPRMSETrans() const { return tp_trans_rmse.getRMSE(); }
+  double getTPRMSERot() const { return tp_rot_rmse.getRMSE(); }
+};
