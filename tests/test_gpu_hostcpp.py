@@ -41,3 +41,61 @@ def test_batch_bin_demo_matches_oracle(cc, oracle, tmp_path):
         if ores["n_res"][i]:
             assert abs(float(r[2]) - ores["correlation"][i]) < 1e-4
             assert np.abs(np.array([float(v) for v in r[3:6]]) - ores["tf"][i]).max() < 1e-4
+
+
+def test_batch_bin_test_driver_end_to_end(cc, oracle, tmp_path):
+    """The drop-in offline driver (hostcpp/examples/batch_bin_test.cpp = the reference's test/batch_bin_test.cpp without
+    ROS): YAML config -> ContLCDEvaluator -> ContourManager/ContourDB on the device -> outcome file.  Candidates and
+    scores must equal the oracle's replay; TFPN labels must follow the ground truth; pr_eval reads the file back."""
+    pkg = os.path.join(ROOT, "contour-context_amd")
+    exe = str(tmp_path / "batch_bin_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(pkg, "hostcpp", "examples", "batch_bin_test.cpp"),
+                           "-I", os.path.join(pkg, "hostcpp"), "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcont2_amd",
+                           "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    w = cc.synth.World(loop_len=40.0)
+    n = 96
+    x, poses, ts = cc.synth.make_sequence(n, world=w, beams=32, azim=900, device="cuda")
+    ts = ts * 4.0  # 0.4 s per scan: a 40-scan lap takes 16 s, past the evaluator's 15 s exclusion window
+    xs = x.cpu().numpy()
+    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
+    with open(lst, "w") as f, open(pos, "w") as g:
+        for i in range(n):
+            p = tmp_path / ("%06d.bin" % i)
+            xs[i].astype(np.float32).tofile(p)
+            f.write("%.6f %d %s\n" % (ts[i], i, p))
+            c, s_ = np.cos(poses[i, 2]), np.sin(poses[i, 2])
+            g.write("%.6f %.9f %.9f 0 %.9f %.9f %.9f 0 %.9f 0 0 1 0\n" % (ts[i], c, -s_, poses[i, 0], s_, c, poses[i, 1]))
+    cfg = open(os.path.join(pkg, "hostcpp", "examples", "batch_bin_test_config.yaml")).read()
+    cfg = cfg.replace("/path/to/ts-sens_pose-kitti08.txt", str(pos)).replace("/path/to/ts-lidar_bins-kitti08.txt", str(lst))
+    cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
+    cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 10.0").replace("min_elapse_: 15.0", "min_elapse_: 6.0")
+    (tmp_path / "cfg.yaml").write_text(cfg)
+    subprocess.check_output([exe, str(tmp_path / "cfg.yaml")], text=True)
+    rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "outcome.txt")]
+    assert len(rows) == n
+    dcfg = cc.L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 10.0, 6.0
+    P = xs.shape[1]
+    ores, _, _ = oracle.run_sequence(xs.reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * P, ts, np.arange(n, dtype=np.int32), dcfg=dcfg)
+    assert (ores["n_res"] > 0).sum() > 10
+    xy = poses[:, :2]
+    for i, r in enumerate(rows):
+        a, b = r[1].split("-")
+        assert int(a) == i
+        assert (b == "x") == (ores["n_res"][i] == 0)
+        earlier = [j for j in range(n) if ts[i] >= ts[j] + 15.0 and np.hypot(*(xy[i] - xy[j])) < 5.0]
+        if b != "x":
+            assert int(b) == ores["cand_gidx"][i]
+            assert abs(float(r[2]) - ores["correlation"][i]) < 1e-4 * max(1.0, abs(ores["correlation"][i]))
+            positive = float(r[2]) >= 0.64928
+            near = np.hypot(*(xy[i] - xy[int(b)])) < 5.0
+            want = (0 if (earlier and near) else 1) if positive else (3 if earlier else 2)
+        else:
+            want = 3 if earlier else 2
+        assert int(r[0]) == want, (i, r, want)
+    assert sum(int(r[0]) == 0 for r in rows) > 5, "the sequence should contain true positives"
+    import sys
+    sys.path.insert(0, pkg)
+    import pr_eval
+    res = pr_eval.evaluate(pr_eval.load_gt_poses(str(pos)), pr_eval.load_outcome(str(tmp_path / "outcome.txt")))
+    assert 0.0 <= res["max_f1"] <= 1.0
