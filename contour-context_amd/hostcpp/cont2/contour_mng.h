@@ -2,6 +2,8 @@
 // (include/cont2_amd.h).  Same names, argument meaning and error behaviour (CHECK -> abort) as used by
 // test/batch_bin_test.cpp and include/eval/evaluator.h; the work itself runs in the HIP kernels.
 #pragma once
+#include <fstream>
+#include <iostream>
 #include <array>
 #include <cstring>
 #include <map>
@@ -204,6 +206,33 @@ class ContourManager {
   const cc_bci_t &getBCI(int level, int seq) const { return desc().bcis[level][seq]; }
   float getAreaPerc(const int8_t &lev, const int8_t &seq) const {
     return desc().cont[lev][seq].cell_cnt * 1.0f / desc().layer_cell_cnt[lev];
+  }
+  // contour_mng.cpp:7-47 (saveContours) / contour_mng.h:915-918: the 20-column text dump scripts/plot_contours.py reads --
+  // level, cell_cnt, pos_mean(2), pos_cov(4, column-major), eig_vals(2), eig_vecs(4), eccen, vol3_mean, com(2), ecc_feat,
+  // com_feat; one row per stored contour, levels in order, between "DATA_START" and "DATA_END"
+  void saveContours(const std::string &fpath) const {
+    std::fstream out(fpath, std::ios::out);
+    if (!out.good()) {
+      std::cerr << "Error opening " << fpath << std::endl;
+      return;
+    }
+    printf("Writing results to file \"%s\" ...", fpath.c_str());
+    const cc_scan_desc_t &d = desc();
+    out << "\nDATA_START\n";
+    for (int l = 0; l < CC_NLEV; l++) {
+      for (int j = 0; j < d.n_stored[l]; j++) {
+        const cc_contour_t &c = d.cont[l][j];
+        out << c.level << '\t' << c.cell_cnt << '\t' << c.pos_mean[0] << '\t' << c.pos_mean[1] << '\t';
+        for (int i = 0; i < 4; i++) out << c.pos_cov[i] << '\t';
+        out << c.eig_vals[0] << '\t' << c.eig_vals[1] << '\t';
+        for (int i = 0; i < 4; i++) out << c.eig_vecs[i] << '\t';
+        out << c.eccen << '\t' << c.vol3_mean << '\t' << c.com[0] << '\t' << c.com[1] << '\t' << int(c.ecc_feat) << '\t'
+            << int(c.com_feat) << '\t' << '\n';
+      }
+    }
+    out << "DATA_END\n";
+    out.close();
+    printf("Writing results finished.\n");
   }
   std::string getStrID() const { return str_id_; }
   int getIntID() const { return int_id_; }

@@ -27,7 +27,7 @@ typename pcl::PointCloud<PointType>::ConstPtr readKITTIPointCloudBin(const std::
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s <ts-lidar_bins list> [min_elapse max_elapse]\n", argv[0]);
+    fprintf(stderr, "usage: %s <ts-lidar_bins list> [min_elapse max_elapse [dump_seq dump_path]]\n", argv[0]);
     return 2;
   }
   ContourManagerConfig cm_config;
@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
     cm->makeBEV<pcl::PointXYZ>(cloud, std::to_string(seq));
     cm->makeContoursRecurs();
     cm->clearImage();
+    if (argc >= 6 && seq == atoi(argv[4])) cm->saveContours(argv[5]);  // contour dump of one scan (parity / plotting)
     std::vector<std::shared_ptr<const ContourManager>> cands;
     std::vector<double> corr;
     std::vector<Eigen::Isometry2d> tfs;

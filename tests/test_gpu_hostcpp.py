@@ -26,9 +26,28 @@ def test_batch_bin_demo_matches_oracle(cc, oracle, tmp_path):
             p = tmp_path / ("%06d.bin" % i)
             xs[i].astype(np.float32).tofile(p)
             f.write("%.6f %d %s\n" % (ts[i], i, p))
-    out = subprocess.check_output([exe, str(lst), "1.5", "2.5"], text=True)
-    rows = [l.split() for l in out.strip().split("\n")]
+    dump = tmp_path / "contours_17.txt"
+    out = subprocess.check_output([exe, str(lst), "1.5", "2.5", "17", str(dump)], text=True)
+    rows = [l.split() for l in out.strip().split("\n") if l and l[0].isdigit()]
     assert len(rows) == n
+    # the 20-column contour dump (ContourManager::saveContours) against the oracle's descriptor of the same scan
+    od = oracle.Scan(xs[17], int_id=17, keep_cells=False).desc()
+    lines = open(dump).read().split("\n")
+    assert lines[1] == "DATA_START" and lines[-2] == "DATA_END"
+    body = [l.rstrip("\t").split("\t") for l in lines[2:-2]]
+    ocont = np.array(od["cont"]).reshape(6, -1)
+    nst = np.array(od["n_stored"]).reshape(-1)
+    assert len(body) == int(nst.sum())
+    k = 0
+    for l in range(6):
+        for j in range(int(nst[l])):
+            c, r = ocont[l, j], body[k]
+            k += 1
+            assert len(r) == 20 and int(r[0]) == l and int(r[1]) == c["cell_cnt"]
+            want = list(c["pos_mean"]) + list(c["pos_cov"]) + list(c["eig_vals"]) + list(c["eig_vecs"]) + [c["eccen"], c["vol3_mean"]] + list(c["com"])
+            got = [float(v) for v in r[2:18]]
+            assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (l, j, got, want)
+            assert int(r[18]) == c["ecc_feat"] and int(r[19]) == c["com_feat"]
     dcfg = cc.L.default_db_cfg()
     dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
     P = xs.shape[1]
