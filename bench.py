@@ -6,9 +6,11 @@ Contract (see the task statement):  python bench.py --gpus N --steps K --warmup 
     resident in HBM: cc_ingest_batch (BEV rasterise -> contours -> keys/BCI) + cc_db_query_batch
     (KNN preselect -> constellation checks -> GMM-L2 + L-BFGS) against a prebuilt 5 000-scan DB;
   * N > 1: launched by torch.distributed.run, one rank per GPU.  The DB build is scan-sharded
-    (each rank ingests n_db/N scans) followed by ONE all-gather of the descriptors over RCCL; in the
-    timed step every rank ingests + queries its own batch (weak scaling) and the batch's descriptors
-    are all-gathered so every replica could append them (the path's only exchange);
+    (each rank ingests n_db/N scans) followed by ONE all-gather of the descriptors over RCCL (the path's only
+    exchange: every replica needs every DB scan); in the timed step every rank ingests + queries its own
+    batch against its replica (weak scaling, no data-path collective: queries never need another rank's scans).
+    `--share-descriptors` additionally all-gathers each batch's raw descriptor blocks (169 KB/scan), which an
+    online deployment that appends the queried scans to every replica would do;
   * rank 0 prints ONE JSON line.  `value` is whole-job scans/s.
 Extra objects: `roofline` (dominant kernel, HIP-event timed inside the library) and `cpu_baseline`
 (the CPU restatement of the reference under oracle/, single thread, bounded sample, rank 0, N=1 only).
@@ -36,6 +38,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--share-descriptors", action="store_true",
+                    help="N > 1: all-gather every batch's descriptors in the timed step (what appending them to all replicas needs)")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
     args = ap.parse_args()
@@ -95,7 +99,8 @@ def main():
     offs = np.arange(B + 1, dtype=np.int64) * P
     epochs = np.full(B, n_db, np.int32)
     qdesc = torch.empty((B, cc.DESC_BYTES), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * B, cc.DESC_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    share = world > 1 and args.share_descriptors
+    gathered = torch.empty((world * B, cc.DESC_BYTES), dtype=torch.uint8, device=dev) if share else None
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -126,7 +131,7 @@ def main():
                 if k + 1 < count:
                     ev = ingest_async(batches[first + k + 1], slot ^ 1)
             q = qdesc2[slot]
-            if world > 1:
+            if share:
                 dist.all_gather_into_tensor(gathered, q)
             res = db.query(q, epochs)
             found += int((res["n_res"] > 0).sum())
@@ -214,7 +219,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic Velodyne-64 scans (64x1875=120000 pts), %d-scan DB, %d query scans/step/GPU, "
                                    "queries revisit DB places (loop closures found: %d of %d on rank 0)" % (n_db, B, n_found, K * B),
-                       "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d" % world},
+                       "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B)[0], "traffic_source": pmc_traffic(dom, B)[1],
                          "algorithmic_bytes_per_launch": dom_bytes,
