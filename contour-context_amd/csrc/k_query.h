@@ -485,7 +485,7 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
 // the groups of a wave diverge freely, so every hand-off goes through cc_group_sync / 16-wide shuffles.
 #define CC_CHKB_G 16
 #define CC_CHKB_GPW (64 / CC_CHKB_G)
-#define CC_CHKB_PER_Q 8  // stage-B workgroups (waves) per query
+#define CC_CHKB_PER_Q 8  // stage-B workgroups (waves) per query (default; a launch parameter)
 
 template <int PPM>
 struct cc_chkb_lds {  // per group; the unions hold data of phases that never overlap in time
@@ -753,17 +753,17 @@ __device__ __noinline__ void cc_chkb_sort(cc_chkb_lds<PPM> &L, int npp, int ntp,
 
 // Two instances: <CC_PP_SMALL, false> handles every check with <= 64 potential pairs (12 KB of LDS per workgroup) and
 // marks the others (pass_ok = 2); <CC_PP_MAX, true> then runs only those.
-// grid = nq * CC_CHKB_PER_Q, block = 64
+// grid = nq * per_q, block = 64
 template <int PPM, bool REDO>
 __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ surv_hit, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt,
-             int *__restrict__ redo_cnt) {
+             int *__restrict__ redo_cnt, int per_q) {
   __shared__ cc_chkb_lds<PPM> LG[CC_CHKB_GPW];
-  if (REDO && redo_cnt[blockIdx.x / CC_CHKB_PER_Q] == 0) return;  // nothing was left over for this query
+  if (REDO && redo_cnt[blockIdx.x / per_q] == 0) return;  // nothing was left over for this query
   const int G = CC_CHKB_G;
-  const int q = blockIdx.x / CC_CHKB_PER_Q, part = blockIdx.x % CC_CHKB_PER_Q;
+  const int q = blockIdx.x / per_q, part = blockIdx.x % per_q;
   const int sub = threadIdx.x / CC_CHKB_G, sl = threadIdx.x % CC_CHKB_G;
   cc_chkb_lds<PPM> &L = LG[sub];
   const cc_scan_desc_t *tgt = qdesc + q;
@@ -779,11 +779,11 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
     t_nxt = surv[(size_t)q * CC_CHK_STRIDE + si0];
     h_nxt = surv_hit[(size_t)q * CC_CHK_STRIDE + si0];
   }
-  for (int si = si0; si < ns; si += CC_CHKB_PER_Q * CC_CHKB_GPW) {
+  for (int si = si0; si < ns; si += per_q * CC_CHKB_GPW) {
     const int t = t_nxt;
     const cc_knn_hit_t h = h_nxt;
     {
-      const int sn = si + CC_CHKB_PER_Q * CC_CHKB_GPW;
+      const int sn = si + per_q * CC_CHKB_GPW;
       if (sn < ns) {
         t_nxt = surv[(size_t)q * CC_CHK_STRIDE + sn];
         h_nxt = surv_hit[(size_t)q * CC_CHK_STRIDE + sn];
