@@ -790,7 +790,9 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       }
     }
     if (REDO) {
-      if (pass_ok[(size_t)q * CC_CHK_STRIDE + t] != 2) continue;
+      const bool left_over = pass_ok[(size_t)q * CC_CHK_STRIDE + t] == 2;
+      cc_group_sync(G);  // every lane of the group has read the mark before lane 0 clears it
+      if (!left_over) continue;
       if (sl == 0) pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 0;
     }
     const int slot = t / CC_KNN_MAX;
