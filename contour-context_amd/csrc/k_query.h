@@ -1955,10 +1955,14 @@ __device__ bool cc_wolfe(const cc_gmm_lds *S, const double pos[3], const double 
 // grid = any (grid-stride over the device-side problem count), block = 64, `ppw` problems per wave (G = 64/ppw lanes
 // each), dynamic LDS = ppw * CC_GMM_LDS_BYTES(ecap, pcap).
 // redo_only: process only problems whose previous result overflowed an LDS cap (flags & 3) -- the large-cap instance.
+// Two passes over the problems (the reference refines only the first max_fine_opt_ candidates of a query,
+// contour_db.h:604-648, but needs the initial correlation of all of them, :548-592):
+//   sel_list == nullptr : every problem, initial correlation only (tryProblem)
+//   sel_list != nullptr : the problems cc_k_select listed (n_prob_p = their count), initial correlation + L-BFGS
 __global__ void __launch_bounds__(64)
 cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap, int redo_only,
          const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb, int ecap, int pcap,
-         int ppw, cc_gmm_result *__restrict__ results) {
+         int ppw, const int *__restrict__ sel_list, cc_gmm_result *__restrict__ results) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int lane = threadIdx.x;
   const int G = 64 / ppw, sub = lane / G, sl = lane - sub * G;
@@ -1978,8 +1982,8 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   int n_prob = *n_prob_p;
   if (n_prob > prob_cap) n_prob = prob_cap;
   for (int pbase = blockIdx.x * ppw; pbase < n_prob; pbase += gridDim.x * ppw) {
-  const int pidx = pbase + sub;
-  if (pidx >= n_prob) continue;
+  if (pbase + sub >= n_prob) continue;
+  const int pidx = sel_list ? sel_list[pbase + sub] : pbase + sub;
   if ((redo_only & 1) && !(results[pidx].flags & 3)) continue;
   const int dbg = redo_only >> 8;  // tuning aid (env CC_GMM_CUT): stop after a phase, results are then meaningless
   const cc_gmm_problem pb = probs[pidx];
@@ -2085,7 +2089,7 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
     }
     continue;
   }
-  if (!((float)R.corr_init < corr_lb)) {
+  if (sel_list && !((float)R.corr_init < corr_lb)) {
     // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations
     R.optimized = 1;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
@@ -2199,6 +2203,50 @@ cc_k_gmm(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_pro
   R.flags = *S->flags;
   if (sl == 0) results[pidx] = R;
   }  // problem loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5s: which candidates of a query get refined -- the first max_fine_opt_ of candidates_ after tidyUpCandidates'
+// compaction and fineOptimize's sort on the still-all-zero correlation_ (the same replay as in K6; contour_db.h:560-616).
+// Their GMM problems are appended to sel_list.  One wave per query.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
+            const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list, int *__restrict__ n_sel) {
+  __shared__ unsigned short idx[CC_MAXCAND];
+  __shared__ unsigned char has[CC_MAXCAND];
+  __shared__ int gm[CC_MAXCAND];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= nq) return;
+  const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
+  const int nc = qstate[q].n_cand;
+  for (int k = lane; k < nc; k += 64) {
+    const int g = cands[k].gmm_idx;
+    idx[k] = (unsigned short)k;
+    gm[k] = g;
+    has[k] = (g >= 0 && !((float)gres[g].corr_init < corr_lb)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  int p1 = 0, p2 = nc - 1;
+  while (p1 <= p2) {
+    if (!has[idx[p1]] && has[idx[p2]]) {
+      const unsigned short t = idx[p1];
+      idx[p1] = idx[p2];
+      idx[p2] = t;
+      p1++;
+      p2--;
+    } else {
+      if (has[idx[p1]]) p1++;
+      if (!has[idx[p2]]) p2--;
+    }
+  }
+  const int n = p2 + 1;
+  if (n <= 0) return;
+  ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; });
+  const int pre = max_fine_opt < n ? max_fine_opt : n;
+  const int base = atomicAdd(n_sel, pre);
+  for (int i = 0; i < pre; i++) sel_list[base + i] = gm[idx[i]];
 }
 
 // ------------------------------------------------------------------------------------------------
