@@ -248,32 +248,29 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       w_cB[k] = 255;
     }
     __syncthreads();
+    // The root of a component is its first cell in raster order, i.e. (first row, first member column of that row): cA
+    // needs no search, and a cell knows its component's first row from its label alone, so the first member column of the
+    // second row (cB) is one more atomicMin in the same pass.
     for (int c = tid; c < n_cell; c += nt) {
-      const unsigned j = cc_lab_comp(LAB, c);
-      if (j == CC_COMP_NONE) continue;  // empty, or a component with < 3 cells (or beyond the capacity)
+      unsigned v = LAB[c];
+      unsigned root_cell = (unsigned)c;
+      if (!(v & 0x8000u)) {  // a non-root cell holds its root's cell index
+        root_cell = v;
+        v = LAB[v];
+      }
+      if (!(v & 0x8000u)) continue;  // unmarked root: component with < 3 cells (or beyond the capacity)
+      const unsigned j = v & 0x7FFFu;
+      if (j == CC_COMP_NONE) continue;  // empty cell
       const int rr = c / n_col, cc = c - rr * n_col;
       atomicMin(&w_minr[j], (unsigned)rr);
       atomicMax(&w_maxr[j], (unsigned)rr);
       atomicMin(&w_minc[j], (unsigned)cc);
       atomicMax(&w_maxc[j], (unsigned)cc);
       atomicAdd(&w_area[j], 1u);
+      if (rr == (int)(root_cell / (unsigned)n_col) + 1) atomicMin(&w_cB[j], (unsigned)cc);
     }
     __syncthreads();
-    // first member column in the component's first row (cA) and in the row below (cB): first-2x2-block key
-    for (int k = tid; k < n_kept; k += nt) {
-      const int r0 = (int)w_minr[k], c0 = (int)w_minc[k], c1 = (int)w_maxc[k];
-      for (int c = c0; c <= c1; c++)
-        if (cc_lab_comp(LAB, r0 * n_col + c) == (unsigned)k) {
-          w_cA[k] = (unsigned)c;
-          break;
-        }
-      if (r0 + 1 <= (int)w_maxr[k])
-        for (int c = c0; c <= c1; c++)
-          if (cc_lab_comp(LAB, (r0 + 1) * n_col + c) == (unsigned)k) {
-            w_cB[k] = (unsigned)c;
-            break;
-          }
-    }
+    for (int k = tid; k < n_kept; k += nt) w_cA[k] = (unsigned)roots[k] % (unsigned)n_col;
     CC_K2_LAP(acc_enum);
     // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
     for (int k = tid; k < prev_n; k += nt) {
