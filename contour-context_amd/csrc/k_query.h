@@ -331,12 +331,12 @@ cc_k_knn(cc_knn_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_que
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: the four-stage gate per (candidate scan, anchor pair).  One lane per check.
+// K4: the four-stage gate per (candidate scan, anchor pair): stage A one lane per KNN hit, stage B 16 lanes per survivor,
+// stage C one lane per passing check.
 // ------------------------------------------------------------------------------------------------
 #define CC_PP_MAX 256      // potential (src,tgt) neighbour pairs per check (large instance of stage B)
 #define CC_PP_SMALL 64     // ... handled by the common, high-occupancy instance
 #define CC_CSTL_MAX 64     // pairs kept in a constellation
-#define CC_PASS_CAP 1024   // >= nnk * 18: every check of a query may pass
 
 struct cc_pass_rec {
   int q;           // query index within the launch
@@ -359,10 +359,6 @@ struct cc_check_params {
   int dbg_cut;  // tuning aid (env CC_CHKB_CUT): stage B stops after phase dbg_cut, 0 = run everything
 };
 
-struct cc_dsp {  // BCI::DistSimPair
-  float orie;
-  signed char l, s, t, pad;
-};
 
 __device__ __forceinline__ bool cc_check_sim(const cc_contour_t &a, const cc_contour_t &b, const cc_sim_cfg_t &th) {
   const float ca = (float)a.cell_cnt, cb = (float)b.cell_cnt;
