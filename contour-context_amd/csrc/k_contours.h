@@ -46,6 +46,8 @@ struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
 #define CC_K2_LV_BYTES(nc) (((size_t)(nc) + 15) & ~(size_t)15)
 #define CC_K2_LDS_BYTES(nc) (CC_K2_LV_BYTES(nc) + CC_K2_R_BYTES)
 #define CC_K2_BLOCK 512
+#define CC_KEYS_GRP 12   // anchors whose RoI cell lists are in LDS at a time
+#define CC_KEYS_CAP 416  // cells per list: a disc of radius 10 touches < 400 unit cells
 
 // Label image conventions (u16 per cell): 0xFFFF = not in the level set; a non-root cell holds its root's cell index
 // (< 0x8000); a root holds its own index while the labelling runs and, once the kept components are numbered,
@@ -505,44 +507,82 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   const float div_len = cfg.roi_radius / (float)(7 * 5);
   const float bin_len = cfg.roi_radius / (float)7;
   const double r_lim = (double)cfg.roi_radius - 1e-2;
-  for (int t = tid; t < NA * 35; t += nt) {
-    const int a = t / 35, d = t - a * 35;
-    float acc = 0.f;
-    int cp = 0;
-    if (valid[a]) {
-      const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-      const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
-      const int r_cen = (int)vcx, c_cen = (int)vcy;
-      const int r_min = r_cen - roi_pad > 0 ? r_cen - roi_pad : 0;
-      const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
-      const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
-      const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
-      // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56)
-      const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
-      const double norm = sqrt(2 * 3.14159265358979323846 * 1.0 * 1.0);
-      for (int rr = r_min; rr <= r_max; rr++) {
-        for (int cc = c_min; cc <= c_max; cc++) {
-          // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
-          // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
-          const int lv = LV[rr * n_col + cc];
-          if (lv < 2) continue;
-          const float2 rc = pix[rr * n_col + cc];
-          const float dx = rc.x - vcx, dy = rc.y - vcy;
-          const float dist = sqrtf(dx * dx + dy * dy);
-          if ((double)dist < r_lim) {
-            const int higher = lv - 1;
-            cp++;
+  // The 35 divisions of an anchor accumulate over the same cells (RoI cells above level 1 within the radius, in raster
+  // order; contour_mng.h:735-770): the cell list -- distance to the anchor, number of levels above -- is built once per
+  // anchor by a wave (ballot-ordered, so raster order is kept), then one lane per (anchor, division) walks it in LDS with
+  // the reference's f32 accumulation order.  Anchors are handled CC_KEYS_GRP at a time; the lists live where the
+  // ordering tables were.
+  {
+    const int CAP = CC_KEYS_CAP;
+    float *ldist = (float *)R;
+    unsigned char *lhi = (unsigned char *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 4);
+    int *lcnt = (int *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 5);
+    for (int g0 = 0; g0 < NA; g0 += CC_KEYS_GRP) {
+      for (int a = g0 + wave_id; a < g0 + CC_KEYS_GRP && a < NA; a += n_waves) {
+        int n = 0;
+        if (valid[a]) {
+          const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+          const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
+          const int r_cen = (int)vcx, c_cen = (int)vcy;
+          const int r_min = r_cen - roi_pad > 0 ? r_cen - roi_pad : 0;
+          const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
+          const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
+          const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
+          const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
+          for (int base = 0; base < tot; base += 64) {
+            const int idx = base + lane;
+            bool q = false;
+            float dist = 0.f;
+            int lv = 0;
+            if (idx < tot) {
+              const int ro = idx / W;
+              const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
+              // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
+              // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
+              lv = LV[cell];
+              if (lv >= 2) {
+                const float2 rc = pix[cell];
+                const float dx = rc.x - vcx, dy = rc.y - vcy;
+                dist = sqrtf(dx * dx + dy * dy);
+                q = (double)dist < r_lim;
+              }
+            }
+            const unsigned long long m = __ballot(q);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (q && pos < CAP) {
+              ldist[(a - g0) * CAP + pos] = dist;
+              lhi[(a - g0) * CAP + pos] = (unsigned char)(lv - 1);
+            }
+            n += __popcll(m);
+          }
+          if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
+        }
+        if (lane == 0) lcnt[a - g0] = n;
+      }
+      __syncthreads();
+      for (int t = tid; t < CC_KEYS_GRP * 35; t += nt) {
+        const int al = t / 35, d = t - al * 35, a = g0 + al;
+        if (a >= NA) continue;
+        float acc = 0.f;
+        const int n = lcnt[al] < CAP ? lcnt[al] : CAP;
+        if (valid[a]) {
+          // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56)
+          const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
+          const double norm = sqrt(2 * 3.14159265358979323846 * 1.0 * 1.0);
+          for (int i = 0; i < n; i++) {
+            const float dist = ldist[al * CAP + i];
+            const int higher = lhi[al * CAP + i];
             const float u = (xg - dist) / 1.0f;
             const float pdf = (float)(exp(-0.5 * (double)u * (double)u) / norm);
             acc += (float)higher * pdf;
           }
         }
+        divs[a * 35 + d] = acc;
+        if (d == 0) cntp[a] = valid[a] ? lcnt[al] : 0;
       }
+      __syncthreads();
     }
-    divs[t] = acc;
-    if (d == 0) cntp[a] = cp;
   }
-  __syncthreads();
   for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {
     const int a = t / CC_KEY_DIM, kd = t - a * CC_KEY_DIM;
     const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
