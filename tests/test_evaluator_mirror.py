@@ -94,3 +94,38 @@ def test_replay_reproduces_shipped_outcome(cc, tmp_path):
             assert g[3:6] == ["0", "0", "0"]
     assert "Found 4071 laser scans with gt poses." in log
     assert {r[0] for r in got} == {"0", "1", "2", "3"}
+
+
+def test_python_evaluator_reproduces_shipped_outcome(cc, tmp_path):
+    """the numpy twin (contour-context_amd/evaluator.py) on the same replay: same labels, same rows"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "contour-context_amd"))
+    import evaluator as E
+    poses = tmp_path / "poses.txt"
+    with gzip.open(os.path.join(GOLD, "ts-sens_pose-kitti08.txt.gz"), "rt") as f:
+        pose_lines = [l for l in f.read().split("\n") if l.strip()]
+    poses.write_text("\n".join(pose_lines) + "\n")
+    with gzip.open(os.path.join(GOLD, "outcome-kitti08.txt.gz"), "rt") as f:
+        rows = [l.rstrip("\n").split("\t") for l in f if l.strip()]
+    scans = tmp_path / "scans.txt"
+    with open(scans, "w") as f:
+        for i, l in enumerate(pose_lines):
+            f.write("%s %d /data/kitti/2_dataset/08/velodyne/%06d.bin\n" % (l.split()[0], i, i))
+    ev = E.ContLCDEvaluator(str(poses), str(scans), SIM_THRES)
+    assert len(ev.scans) == 4071
+    P = np.array([[float(v) for v in l.split()[1:]] for l in pose_lines]).reshape(-1, 3, 4)
+    rng = np.random.default_rng(1)
+    for k, r in enumerate(rows):
+        a, b = r[1].split("-")
+        T = (rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-0.5, 0.5))
+        rec = ev.add_prediction(int(a), float(r[2]), None if b == "x" else int(b), T)
+        assert rec["tfpn"] == int(r[0]), (k, r[:3], rec)
+        if b != "x" and k % 7 == 0:
+            # the evaluator re-orthonormalises the 6-digit pose matrices through a quaternion, the check does not
+            assert np.allclose(rec["err"], _yaw_only_err(T, P[int(b)], P[int(a)]), rtol=2e-5, atol=3e-4)
+    out = tmp_path / "outcome_py.txt"
+    ev.save_prediction_results(str(out))
+    got = [l.rstrip("\n").split("\t") for l in open(out)]
+    for g, r in zip(got, rows):
+        assert g[0] == r[0] and g[1] == r[1] and g[6] == r[6] and g[7] == r[7]
+        assert abs(float(g[2]) - float(r[2])) <= 1e-6 * max(1.0, abs(float(r[2])))
