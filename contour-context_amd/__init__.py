@@ -45,7 +45,8 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
            "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
-           "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes"]
+           "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
+           "cc_db_add_scans_host", "cc_db_query_batch_host"]
 
 
 def lib():

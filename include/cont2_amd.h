@@ -251,6 +251,12 @@ int cc_db_add_scan_host(cc_db *db, const cc_scan_desc_t *h_desc, double ts, int3
 int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t *thres_lb, const cc_score_t *thres_ub,
                      cc_query_result_t *h_res);
 
+/* The two batched calls with host descriptor buffers (one H2D copy each): for drivers that keep descriptors on the host,
+ * e.g. an offline replay of a whole sequence (all scans added, then scan i queried against epoch i). */
+int cc_db_add_scans_host(cc_db *db, const cc_scan_desc_t *h_desc, int n, const double *h_ts, const int32_t *h_seed);
+int cc_db_query_batch_host(cc_db *db, const cc_scan_desc_t *h_qdesc, int nq, const int32_t *h_epoch,
+                           const cc_score_t *thres_lb, const cc_score_t *thres_ub, cc_query_result_t *h_res);
+
 /* Device pointer of the DB's descriptor array ([cc_db_size()] cc_scan_desc_t) and raw
  * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
  * device buffer, then cc_db_add_scans consumes it). */

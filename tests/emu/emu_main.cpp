@@ -3,6 +3,7 @@
 // and host bookkeeping -- can be exercised against the oracle without a GPU.  Built by
 // tests/emu/build.sh into tests/emu/libcc_emu.so.  Never loaded by the product.
 #define CC_INGEST_BLOCK 256
+#define CC_GMM_GRID 16  // grid-stride kernel: fewer workgroups = fewer OS threads to create, same results
 #include "../../contour-context_amd/csrc/cont2_amd.hip"
 
 namespace emu {

@@ -1,0 +1,61 @@
+"""The offline batch evaluator (contour-context_amd/tools/batch_eval.py) end to end on the CPU build of the C-ABI:
+KITTI-format .bin files + pose/list files + a config with the reference's keys -> outcome file.  Candidates and scores
+must equal the oracle's replay of the online loop (query, then insert), the labels must follow the ground truth."""
+import os
+import sys
+
+import numpy as np
+
+import emu_api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batch_eval_matches_online_loop(cc, oracle, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "contour-context_amd", "tools"))
+    import batch_eval
+    w = cc.synth.World(loop_len=40.0)
+    n = 52
+    x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+    ts = ts * 4.0   # a 40-scan lap takes 16 s: past the evaluator's 15 s exclusion window
+    xs = x.numpy()
+    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
+    with open(lst, "w") as f, open(pos, "w") as g:
+        for i in range(n):
+            p = tmp_path / ("%06d.bin" % i)
+            xs[i].astype(np.float32).tofile(p)
+            f.write("%.6f %d %s\n" % (ts[i], i, p))
+            c, s_ = np.cos(poses[i, 2]), np.sin(poses[i, 2])
+            g.write("%.6f %.9f %.9f 0 %.9f %.9f %.9f 0 %.9f 0 0 1 0\n" % (ts[i], c, -s_, poses[i, 0], s_, c, poses[i, 1]))
+    cfg = open(os.path.join(ROOT, "contour-context_amd", "hostcpp", "examples", "batch_bin_test_config.yaml")).read()
+    cfg = cfg.replace("/path/to/ts-sens_pose-kitti08.txt", str(pos)).replace("/path/to/ts-lidar_bins-kitti08.txt", str(lst))
+    cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
+    cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 10.0").replace("min_elapse_: 15.0", "min_elapse_: 6.0")
+    (tmp_path / "cfg.yaml").write_text(cfg)
+    ev, res, summary = batch_eval.run(str(tmp_path / "cfg.yaml"), lib_path=emu_api.build(), chunk=8, verbose=False)
+    dcfg = cc.L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 10.0, 6.0
+    P = xs.shape[1]
+    ores, _, _ = oracle.run_sequence(xs.reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * P, ts, np.arange(n, dtype=np.int32), dcfg=dcfg)
+    assert (ores["n_res"] > 0).sum() >= 3
+    for f in ("n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy", "n_knn_hits"):
+        assert np.array_equal(ores[f], res[f]), f
+    hit = ores["n_res"] > 0
+    assert np.abs(ores["correlation"][hit] - res["correlation"][hit]).max() < 1e-6
+    rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "outcome.txt")]
+    assert len(rows) == n
+    xy = poses[:, :2]
+    for i, r in enumerate(rows):
+        a, b = r[1].split("-")
+        assert int(a) == i and (b == "x") == (not hit[i])
+        earlier = any(ts[i] >= ts[j] + 15.0 and np.hypot(*(xy[i] - xy[j])) < 5.0 for j in range(n))
+        if b != "x":
+            assert int(b) == ores["cand_gidx"][i]
+            if float(r[2]) >= 0.64928:
+                want = 0 if (earlier and np.hypot(*(xy[i] - xy[int(b)])) < 5.0) else 1
+            else:
+                want = 3 if earlier else 2
+        else:
+            want = 3 if earlier else 2
+        assert int(r[0]) == want, (i, r, want)
+    assert 0.0 <= summary["max_f1"] <= 1.0

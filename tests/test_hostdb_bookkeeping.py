@@ -25,7 +25,7 @@ def _fake_desc(L, rng, n, key0_lo=3.0, key0_hi=90.0):
 def test_bucket_timeline_matches_oracle(oracle):
     L = oracle.L
     rng = np.random.default_rng(11)
-    n = 1500
+    n = 1000
     desc = _fake_desc(L, rng, n)
     ts = np.cumsum(rng.uniform(0.05, 0.15, n))
     seeds = np.arange(n, dtype=np.int32)
@@ -53,7 +53,7 @@ def test_knn_with_buckets_matches_oracle(oracle):
     layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
     L = oracle.L
     rng = np.random.default_rng(5)
-    n = 900
+    n = 600
     desc = _fake_desc(L, rng, n, 3.0, 40.0)
     ts = np.arange(n) * 0.1
     seeds = np.arange(n, dtype=np.int32)
