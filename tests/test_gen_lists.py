@@ -1,0 +1,77 @@
+"""tools/gen_lists.py: the evaluator's two input files from KITTI-odometry / MulRan layouts.  When the reference tree is
+present its own generator (scripts/gen_batch_bin_configs.py) is imported and must produce the same files."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/scripts/gen_batch_bin_configs.py"
+
+
+def _mod(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _fake_kitti(tmp_path, n=12):
+    rng = np.random.default_rng(3)
+    bins = tmp_path / "velodyne"
+    bins.mkdir()
+    for i in range(n + 2):
+        (bins / ("%06d.bin" % i)).write_bytes(b"\0" * 16)
+    poses = []
+    for i in range(n):
+        a = 0.05 * i
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        poses.append(np.hstack([R, rng.uniform(-1, 1, (3, 1)) + [[0.0], [0.0], [1.0 * i]]]).reshape(-1))
+    np.savetxt(tmp_path / "poses.txt", np.array(poses), "%.9e")
+    np.savetxt(tmp_path / "times.txt", np.arange(n) * 0.1037, "%.6e")
+    (tmp_path / "calib.txt").write_text("P0: 1 0 0 0 0 1 0 0 0 0 1 0\nTr: 4.2e-04 -9.99e-01 -7.2e-03 -1.2e-02 -7.2e-03 7.2e-03 -9.99e-01 -5.4e-02 9.99e-01 4.8e-04 -7.2e-03 -2.9e-01\n")
+    return str(bins), str(tmp_path / "poses.txt"), str(tmp_path / "times.txt"), str(tmp_path / "calib.txt")
+
+
+def test_kitti_lists(tmp_path):
+    g = _mod(os.path.join(ROOT, "contour-context_amd", "tools", "gen_lists.py"), "gen_lists")
+    args = _fake_kitti(tmp_path)
+    n = g.gen_kitti(*args, str(tmp_path / "pose_a.txt"), str(tmp_path / "list_a.txt"))
+    assert n == 12
+    P = np.loadtxt(tmp_path / "pose_a.txt")
+    assert P.shape == (12, 13)
+    rows = [l.split() for l in open(tmp_path / "list_a.txt")]
+    assert [int(r[1]) for r in rows] == list(range(12)) and rows[3][2].endswith("000003.bin")
+    # a pure forward motion along the camera's z is a motion along the LiDAR's x (Tr maps x_velo -> z_cam)
+    assert P[-1, 4] - P[0, 4] > 5.0
+    if os.path.exists(REF):
+        r = _mod(REF, "ref_gen")
+        r.gen_kitti(*args, str(tmp_path / "pose_b.txt"), str(tmp_path / "list_b.txt"))
+        assert np.allclose(np.loadtxt(tmp_path / "pose_b.txt"), P, atol=2e-6)
+        assert open(tmp_path / "list_b.txt").read().split() == open(tmp_path / "list_a.txt").read().split()
+
+
+def test_mulran_lists(tmp_path):
+    g = _mod(os.path.join(ROOT, "contour-context_amd", "tools", "gen_lists.py"), "gen_lists")
+    bins = tmp_path / "Ouster"
+    bins.mkdir()
+    stamps = [1561000000000000000 + i * 100000000 for i in range(6)]
+    for s in stamps:
+        (bins / ("%d.bin" % s)).write_bytes(b"\0" * 16)
+    with open(tmp_path / "global_pose.csv", "w") as f:
+        for i, s in enumerate(stamps):
+            a = 0.1 * i
+            row = [s, np.cos(a), -np.sin(a), 0, 10.0 + i, np.sin(a), np.cos(a), 0, 20.0 - i, 0, 0, 1, 5.0]
+            f.write(",".join([str(int(row[0]))] + ["%.9f" % float(v) for v in row[1:]]) + "\n")
+        f.write("garbage,line\n")
+    n, nb = g.gen_mulran(str(bins), str(tmp_path / "global_pose.csv"), str(tmp_path / "pose_a.txt"), str(tmp_path / "list_a.txt"))
+    assert (n, nb) == (6, 6)
+    P = np.loadtxt(tmp_path / "pose_a.txt")
+    assert np.allclose(P[0, 1:].reshape(3, 4), np.eye(4)[:3], atol=1e-9)          # first LiDAR frame is the origin
+    assert abs(P[1, 0] - P[0, 0] - 0.1) < 1e-6
+    if os.path.exists(REF):
+        r = _mod(REF, "ref_gen")
+        r.gen_mulran(str(bins), str(tmp_path / "global_pose.csv"), str(tmp_path / "pose_b.txt"), str(tmp_path / "list_b.txt"))
+        assert np.allclose(np.loadtxt(tmp_path / "pose_b.txt"), P, atol=2e-6)
+        assert open(tmp_path / "list_b.txt").read().split() == open(tmp_path / "list_a.txt").read().split()
