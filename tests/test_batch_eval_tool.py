@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_batch_eval_matches_online_loop(cc, oracle, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "contour-context_amd", "tools"))
     import batch_eval
-    w = cc.synth.World(loop_len=40.0)
-    n = 52
+    w = cc.synth.World(loop_len=32.0)
+    n = 42
     x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
-    ts = ts * 4.0   # a 40-scan lap takes 16 s: past the evaluator's 15 s exclusion window
+    ts = ts * 5.0   # a 32-scan lap takes 16 s: past the evaluator's 15 s exclusion window
     xs = x.numpy()
     lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
     with open(lst, "w") as f, open(pos, "w") as g:
@@ -30,11 +30,11 @@ def test_batch_eval_matches_online_loop(cc, oracle, tmp_path):
     cfg = open(os.path.join(ROOT, "contour-context_amd", "hostcpp", "examples", "batch_bin_test_config.yaml")).read()
     cfg = cfg.replace("/path/to/ts-sens_pose-kitti08.txt", str(pos)).replace("/path/to/ts-lidar_bins-kitti08.txt", str(lst))
     cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
-    cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 10.0").replace("min_elapse_: 15.0", "min_elapse_: 6.0")
+    cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 12.5").replace("min_elapse_: 15.0", "min_elapse_: 7.5")
     (tmp_path / "cfg.yaml").write_text(cfg)
     ev, res, summary = batch_eval.run(str(tmp_path / "cfg.yaml"), lib_path=emu_api.build(), chunk=8, verbose=False)
     dcfg = cc.L.default_db_cfg()
-    dcfg.max_elapse, dcfg.min_elapse = 10.0, 6.0
+    dcfg.max_elapse, dcfg.min_elapse = 12.5, 7.5
     P = xs.shape[1]
     ores, _, _ = oracle.run_sequence(xs.reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * P, ts, np.arange(n, dtype=np.int32), dcfg=dcfg)
     assert (ores["n_res"] > 0).sum() >= 3
