@@ -237,6 +237,16 @@ def main():
         dist.destroy_process_group()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def pmc_traffic(kernel, batch):
     """HBM bytes per STEP of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/r*_pmc_summary.json: FETCH_SIZE/WRITE_SIZE per launch, gfx950 x2 correction applied where it is calibrated).
@@ -298,7 +308,7 @@ def cpu_baseline(cc, wld, n_db, batch0, P, n_q, max_db_seconds=150.0):
                       % (n_q, n_db, t_build, "reference nanoflann (oracle/_ref)" if kd else "exact scan", found),
             "seconds_per_scan": {"ingest (make bev)": t_ing / n_q, "query (KNN+Constell+L2 opt)": t_qry / n_q,
                                  "ingest while building the DB": t_ingest_db / n_db},
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
 
 
 if __name__ == "__main__":
