@@ -51,3 +51,20 @@ def test_golden_fixture(oracle):
     d = _check(oracle, scans)
     for i in range(2):
         assert not compare_desc(exp[i], d[i], float_exact=True)
+
+
+def test_height_ties_in_crowded_cells(oracle):
+    """A few cells, hundreds of points each, heights on a 6-value lattice: the cell maximum is attained many times
+    all over the file, and the FIRST such point must supply the cell's continuous (row, col) (contour_mng.h:517)."""
+    scans = []
+    for seed, n in ((5, 6000), (6, 2500)):
+        rng = np.random.default_rng(seed)
+        s = np.zeros((n, 4), np.float32)
+        s[:, 0] = rng.uniform(10.0, 16.0, n)
+        s[:, 1] = rng.uniform(-3.0, 3.0, n)
+        s[:, 2] = rng.integers(0, 6, n) * 0.5 - 1.0
+        # the maximum appears late for some cells, early for others
+        late = rng.random(n) < 0.5
+        s[: n // 2, 2] = np.where(late[: n // 2], np.minimum(s[: n // 2, 2], 0.5), s[: n // 2, 2])
+        scans.append(s)
+    _check(oracle, scans)
