@@ -61,7 +61,7 @@ struct cc_ctx {
 };
 
 static int prof_flush(cc_ctx *c) {
-  for (size_t i = 0; i + 2 < c->ev_used + 1 && i + 2 < c->ev.size() + 1 && i < c->ev_used; i += 3) {
+  for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
     float a = 0, b = 0;
     if (hipEventSynchronize(c->ev[i + 2]) != hipSuccess) return CC_EHIP;
     hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]);
@@ -133,21 +133,30 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   if (ndev <= 0 || device < 0 || device >= ndev) return set_err(CC_EHIP, "cc_create: no such HIP device (this library has no CPU path)");
   HIPCHK(hipSetDevice(device));
   cc_ctx *c = new cc_ctx();
+#define CREATE_CHK(call)                      \
+  do {                                        \
+    hipError_t e_ = (call);                   \
+    if (e_ != hipSuccess) {                   \
+      cc_destroy(c);                          \
+      return set_err(CC_EHIP, #call, e_);     \
+    }                                         \
+  } while (0)
   c->device = device;
   c->mcfg = *cfg;
   c->dcfg = dc;
   c->max_batch = max_batch_scans;
   const size_t nc = (size_t)dc.n_cell;
-  HIPCHK(hipMalloc(&c->d_bev, sizeof(float) * nc * max_batch_scans));
-  HIPCHK(hipMalloc(&c->d_pix, sizeof(float2) * nc * max_batch_scans));
-  HIPCHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
-  HIPCHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
-  HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
-  if (getenv("CC_K2_PHASES")) HIPCHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
+  CREATE_CHK(hipMalloc(&c->d_bev, sizeof(float) * nc * max_batch_scans));
+  CREATE_CHK(hipMalloc(&c->d_pix, sizeof(float2) * nc * max_batch_scans));
+  CREATE_CHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
+  CREATE_CHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
+  CREATE_CHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
+  if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
-  HIPCHK(hipFuncSetAttribute((const void *)cc_k_rasterize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
-  HIPCHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
+#undef CREATE_CHK
   *out = c;
   return CC_OK;
 }
@@ -262,11 +271,15 @@ int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int
   float *d_x = nullptr;
   cc_scan_desc_t *d_o = nullptr;
   HIPCHK(hipMalloc(&d_x, sizeof(float) * 4 * (size_t)total));
-  HIPCHK(hipMalloc(&d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans));
+  hipError_t e = hipMalloc(&d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans);
+  if (e != hipSuccess) {
+    hipFree(d_x);
+    return set_err(CC_EHIP, "cc_ingest_host: hipMalloc", e);
+  }
   int rc = CC_OK;
   std::vector<int64_t> off(n_scans + 1);
   for (int i = 0; i <= n_scans; i++) off[i] = h_offsets[i] - base;
-  hipError_t e = hipMemcpy(d_x, h_xyzi + 4 * base, sizeof(float) * 4 * (size_t)total, hipMemcpyHostToDevice);
+  e = hipMemcpy(d_x, h_xyzi + 4 * base, sizeof(float) * 4 * (size_t)total, hipMemcpyHostToDevice);
   if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: H2D", e);
   if (rc == CC_OK) rc = cc_ingest_batch(c, d_x, off.data(), n_scans, d_o, nullptr, nullptr);
   if (rc == CC_OK) {

@@ -36,6 +36,11 @@ extern "C" {
 #define CC_KNN_MAX 64      /* nnk_ upper bound (shipped 50)                                     */
 #define CC_GMM_LEVELS 4    /* GMMOptConfig::levels_ = {1,2,3,4}, correlation.h:18               */
 
+/* Status codes.  Every entry point returns one; cc_last_error() (thread-local text) explains a non-zero one.
+ * CC_EINVAL / CC_ECAPACITY leave the handle's state unchanged: it stays usable.  CC_EHIP means a HIP runtime
+ * call failed part-way: destroy the handle (cc_db_destroy / cc_destroy release everything that was allocated).
+ * Threading follows the reference (none): a cc_ctx and the cc_db objects created from it are to be
+ * driven by one host thread at a time; different contexts (one per GPU / process) are independent. */
 enum {
   CC_OK = 0,
   CC_EINVAL = -1,   /* bad argument / unsupported configuration            */
