@@ -286,6 +286,13 @@ int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int
     e = hipMemcpy(h_out, d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: D2H", e);
   }
+  if (rc == CC_OK)
+    for (int i = 0; i < n_scans; i++)
+      if (h_out[i].flags & (CC_DESC_INEXACT_COMPONENTS | CC_DESC_INEXACT_KEYS)) {
+        rc = set_err(CC_ECAPACITY, "cc_ingest_host: a scan exceeds a fixed capacity of the contour kernel (more than CC_MAXC components on "
+                                   "a level, or an over-full key RoI): its descriptor is not exact");
+        break;
+      }
   hipFree(d_x);
   hipFree(d_o);
   return rc;

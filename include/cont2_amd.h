@@ -139,13 +139,25 @@ typedef struct {
  * (contour_mng.h:426-436): sorted contour tables, per-level totals, 36 keys, 36 BCIs.
  * cont_perc_[l][j] is not stored: it is cell_cnt * 1.0f / layer_cell_cnt[l]
  * (contour_mng.h:607) and is recomputed bit-identically where needed. */
+/* Descriptor flags.  The reference has no capacities; this build stores at most CC_MAXC contours per level (only the
+ * first piv_firsts_/dist_firsts_ and the largest ~95 % of the area are ever read downstream).
+ *   CC_DESC_TRUNCATED          : a level has more than CC_MAXC contours, the CC_MAXC largest are stored (exact otherwise;
+ *                                set by the CPU restatement only -- the device reports the next bit instead)
+ *   CC_DESC_INEXACT_COMPONENTS : the device met more than CC_MAXC components (>= min_cont_cell_cnt_ cells) on a level:
+ *                                the descriptor is NOT exact and must not be used
+ *   CC_DESC_INEXACT_KEYS       : a retrieval-key RoI held more cells than the kernel's list: the keys are NOT exact
+ * cc_ingest_host returns CC_ECAPACITY for the last two; callers of cc_ingest_batch (device output) check `flags`
+ * themselves.  KITTI/MulRan-like scans have tens to ~100 contours per level. */
+#define CC_DESC_TRUNCATED 1
+#define CC_DESC_INEXACT_COMPONENTS 2
+#define CC_DESC_INEXACT_KEYS 4
 typedef struct {
   int32_t n_cont[CC_NLEV];         /* cont_views_[l].size() (true count)                  */
   int32_t n_stored[CC_NLEV];       /* min(n_cont, CC_MAXC)                                */
   int32_t layer_cell_cnt[CC_NLEV]; /* layer_cell_cnt_                                     */
   float max_bin_val, min_bin_val;  /* contour_mng.h:436,524-525                           */
   int32_t n_pix;                   /* bev_pixfs_.size()                                   */
-  int32_t flags;                   /* bit0: some level overflowed CC_MAXC                 */
+  int32_t flags;                   /* CC_DESC_* bits below; 0 = exact                     */
   float keys[CC_NLEV][CC_NPIV][CC_KEY_DIM];
   cc_bci_t bcis[CC_NLEV][CC_NPIV];
   cc_contour_t cont[CC_NLEV][CC_MAXC];

@@ -59,6 +59,15 @@ class EmuApi:
                                           C.c_void_p(desc.ctypes.data), dbg_p, None), "cc_ingest_batch")
         return (desc, dbg) if debug else desc
 
+    def ingest_host(self, ctx, xyzi, offsets):
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        desc = np.zeros(n, self.L.scan_desc_dt)
+        self.chk(self.lib.cc_ingest_host(ctx, C.c_void_p(xyzi.ctypes.data), C.c_void_p(offsets.ctypes.data), n,
+                                         C.c_void_p(desc.ctypes.data)), "cc_ingest_host")
+        return desc
+
     def db_create(self, ctx, cfg=None, cap=1024):
         cfg = cfg or self.L.default_db_cfg()
         h = C.c_void_p()

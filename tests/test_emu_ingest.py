@@ -11,13 +11,13 @@ from parity import compare_desc, terrain_scan
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _check(oracle, scans):
+def _check(oracle, scans, cfg=None):
     api = emu_api.EmuApi(oracle.L)
-    ctx = api.create(max_batch=len(scans))
+    ctx = api.create(cfg=cfg, max_batch=len(scans))
     offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
     desc, dbg = api.ingest(ctx, np.concatenate(scans, 0), offs, debug=True)
     for i, s in enumerate(scans):
-        o = oracle.Scan(s)
+        o = oracle.Scan(s, cfg=cfg)
         ob, opix = o.bev()
         assert np.array_equal(ob, dbg["bev"][i])
         assert np.array_equal(opix, dbg["pix_rc"][i])
@@ -68,3 +68,30 @@ def test_height_ties_in_crowded_cells(oracle):
         s[: n // 2, 2] = np.where(late[: n // 2], np.minimum(s[: n // 2, 2], 0.5), s[: n // 2, 2])
         scans.append(s)
     _check(oracle, scans)
+
+
+def test_mulran_level_set(oracle):
+    """The other shipped level set (config/batch_bin_test_config.yaml:31, MulRan: wider, taller steps) on tall terrain
+    with 200-290 contours on every level (close to the CC_MAXC capacity)."""
+    cfg = oracle.L.default_manager_cfg()
+    for i, v in enumerate([1.0, 2.5, 4.0, 5.5, 7.0, 8.5]):
+        cfg.lv_grads[i] = v
+    d = _check(oracle, [terrain_scan(12, n=6000, scale=5.0, quant=0.5)], cfg=cfg)
+    assert (d["n_cont"][:, 5] > 0).all() and (d["flags"] == 0).all() and d["n_cont"].max() > 200
+
+
+def test_component_capacity_is_reported(oracle):
+    """More than CC_MAXC components on a level: the device marks the descriptor as not exact and cc_ingest_host refuses
+    it (the reference has no such capacity; real scans stay far below it)."""
+    L = oracle.L
+    s = terrain_scan(13, n=7000, scale=4.0)
+    assert oracle.Scan(s).desc()[0]["n_cont"].max() > L.MAXC
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=1)
+    offs = np.array([0, len(s)], np.int64)
+    try:
+        api.ingest_host(ctx, s, offs)
+    except RuntimeError as e:
+        assert "(-4)" in str(e) and "not exact" in str(e)
+    else:
+        raise AssertionError("expected CC_ECAPACITY")
