@@ -34,3 +34,51 @@ def test_short_loop_sequence(cc, oracle):
         if ores["n_res"][qi]:
             assert abs(ores["correlation"][qi] - res["correlation"][k]) < 1e-6
             assert np.abs(ores["tf"][qi] - res["tf"][k]).max() < 1e-6
+
+
+def _variant(cc, oracle, nnk, qlv, mfo, thr, sim):
+    L = oracle.L
+    d = L.default_db_cfg()
+    d.max_elapse, d.min_elapse = 2.5, 1.5
+    d.nnk, d.max_fine_opt, d.n_q_levels = nnk, mfo, len(qlv)
+    for i, v in enumerate(qlv):
+        d.q_levels[i] = v
+    for k, v in sim.items():
+        setattr(d.cont_sim, k, v)
+    lb, ub = L.default_thresholds()
+    for k, v in thr.items():
+        setattr(lb, k, v)
+    w = cc.synth.World(loop_len=40.0)
+    n = 64
+    x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+    xs = x.numpy().reshape(-1, 4)
+    offs = np.arange(n + 1, dtype=np.int64) * x.shape[1]
+    seeds = np.arange(n, dtype=np.int32)
+    ores, _, odesc = oracle.run_sequence(xs, offs, ts, seeds, dcfg=d, lb=lb, ub=ub, want_desc=True)
+    hit = np.nonzero(ores["n_res"] > 0)[0]
+    assert len(hit) >= 3
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, d, cap=n)
+    api.db_add(db, odesc, ts, seeds)
+    qs = np.unique(np.concatenate([hit[:3], [20, n - 1]])).astype(np.int32)
+    res = api.db_query(db, odesc[qs], qs, lb=lb, ub=ub)
+    for k, qi in enumerate(qs):
+        for f in INT_FIELDS:
+            assert ores[f][qi] == res[f][k], (qi, f, ores[f][qi], res[f][k])
+        if ores["n_res"][qi]:
+            assert abs(ores["correlation"][qi] - res["correlation"][k]) < 1e-6
+            assert np.abs(ores["tf"][qi] - res["tf"][k]).max() < 1e-6
+
+
+def test_non_default_db_config_small_k_two_levels(cc, oracle):
+    """nnk_ = 10, q_levels_ = [2, 3], max_fine_opt_ = 2, stricter gates."""
+    _variant(cc, oracle, 10, (2, 3), 2, dict(i_ovlp_sum=5, i_ovlp_max_one=4, i_in_ang_rng=4, i_indiv_sim=4, i_orie_sim=5,
+                                             correlation=0.5, area_perc=0.05), {})
+
+
+def test_non_default_db_config_full_k_relaxed(cc, oracle):
+    """nnk_ = 64 (the build's upper bound), q_levels_ = [2, 3, 4], relaxed gates and looser contour similarity."""
+    _variant(cc, oracle, 64, (2, 3, 4), 10, dict(i_ovlp_sum=2, i_ovlp_max_one=2, i_in_ang_rng=2, i_indiv_sim=2, i_orie_sim=3,
+                                                 correlation=0.1, area_perc=0.01, neg_est_dist=-8.0),
+             dict(ta_cell_cnt=12.0, tp_cell_cnt=0.4, tp_eigval=0.4, ta_h_bar=0.6, ta_rcom=0.8, tp_rcom=0.5))
