@@ -82,3 +82,45 @@ def test_non_default_db_config_full_k_relaxed(cc, oracle):
     _variant(cc, oracle, 64, (2, 3, 4), 10, dict(i_ovlp_sum=2, i_ovlp_max_one=2, i_in_ang_rng=2, i_indiv_sim=2, i_orie_sim=3,
                                                  correlation=0.1, area_perc=0.01, neg_est_dist=-8.0),
              dict(ta_cell_cnt=12.0, tp_cell_cnt=0.4, tp_eigval=0.4, ta_h_bar=0.6, ta_rcom=0.8, tp_rcom=0.5))
+
+
+def _load_query_fixture(L):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "query_fixture.npz"))
+    desc = np.frombuffer(z["desc"].tobytes(), dtype=L.scan_desc_dt)
+    res = np.frombuffer(z["res"].tobytes(), dtype=L.query_result_dt)
+    d = L.default_db_cfg()
+    d.min_elapse, d.max_elapse = float(z["elapse"][0]), float(z["elapse"][1])
+    return desc, z["ts"], res, d
+
+
+def _same_result(exp, got, tol):
+    for f in INT_FIELDS:
+        assert exp[f] == got[f], (f, exp[f], got[f])
+    if exp["n_res"]:
+        assert abs(exp["correlation"] - got["correlation"]) < tol and np.abs(exp["tf"] - got["tf"]).max() < tol
+
+
+def test_golden_query_fixture(oracle):
+    """Committed descriptors + expected results (tests/golden/make_query_golden.py): the oracle, replaying the driver loop
+    from the descriptors, still reproduces them, and the emulated query kernels match them."""
+    L = oracle.L
+    desc, ts, exp, d = _load_query_fixture(L)
+    n = len(desc)
+    assert n == 64 and (exp["n_res"] > 0).sum() == 31
+    odb = oracle.DB(d)
+    for i in range(n):
+        s = oracle.Scan.from_desc(desc[i], int_id=i)
+        _same_result(exp[i], odb.query(s), 1e-12)
+        odb.add_scan(s, ts[i])
+        odb.push_and_balance(i, ts[i])
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, d, cap=n)
+    seeds = np.arange(n, dtype=np.int32)
+    api.db_add(db, desc, ts, seeds)
+    hit = np.nonzero(exp["n_res"] > 0)[0]
+    qs = np.concatenate([hit[[0, 10, 20, 30]], [3, 40]]).astype(np.int32)
+    got = api.db_query(db, desc[qs], qs)
+    for k, qi in enumerate(qs):
+        _same_result(exp[qi], got[k], 1e-6)

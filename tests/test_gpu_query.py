@@ -95,3 +95,22 @@ def test_knn_matches_oracle_db(cc, oracle, loop_sequence):
                 assert np.allclose(a["dist_sq"], b["dist_sq"], rtol=1e-5, atol=1e-6)
     db.close()
     ctx.close()
+
+
+def test_golden_query_fixture(cc):
+    """Committed descriptors of a 64-scan looping sequence + the expected result of every query (tests/golden/
+    make_query_golden.py; checked against the oracle by the CPU suite): scan i queries the DB as it was after i scans."""
+    import torch
+    from test_emu_query import _load_query_fixture, _same_result
+    L = cc.L
+    desc, ts, exp, d = _load_query_fixture(L)
+    n = len(desc)
+    ddesc = torch.from_numpy(np.frombuffer(desc.tobytes(), np.uint8).reshape(n, cc.DESC_BYTES).copy()).cuda()
+    ctx = cc.Context(0, max_batch=8)
+    db = cc.Database(ctx, cfg=d, capacity=n)
+    seeds = np.arange(n, dtype=np.int32)
+    db.add_scans(ddesc, ts, seeds)
+    got = db.query(ddesc, seeds)
+    assert (exp["n_res"] > 0).sum() == 31
+    for i in range(n):
+        _same_result(exp[i], got[i], 1e-4)
