@@ -309,7 +309,10 @@ def cpu_baseline(cc, wld, n_db, batch0, P, n_q, max_db_seconds=150.0):
                       % (n_q, n_db, t_build, "reference nanoflann (oracle/_ref)" if kd else "exact scan", found),
             "seconds_per_scan": {"ingest (make bev)": t_ing / n_q, "query (KNN+Constell+L2 opt)": t_qry / n_q,
                                  "ingest while building the DB": t_ingest_db / n_db},
-            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
+            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
+            # not a measurement: the reference is single-threaded; this is what host_cpus independent copies of it on
+            # disjoint scans could reach at best (perfect scaling, no memory-bandwidth loss)
+            "ideal_all_cores_upper_bound": n_q / dt * (os.cpu_count() or 1)}
 
 
 if __name__ == "__main__":
