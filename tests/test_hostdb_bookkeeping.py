@@ -53,7 +53,7 @@ def test_knn_with_buckets_matches_oracle(oracle):
     layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
     L = oracle.L
     rng = np.random.default_rng(5)
-    n = 600
+    n = 480
     desc = _fake_desc(L, rng, n, 3.0, 40.0)
     ts = np.arange(n) * 0.1
     seeds = np.arange(n, dtype=np.int32)
