@@ -46,7 +46,7 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
-           "cc_db_add_scans_host", "cc_db_query_batch_host"]
+           "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host"]
 
 
 def lib():
@@ -209,6 +209,23 @@ class Database:
         if want_knn:
             return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
         return res
+
+    def check_hints(self, qdesc, hints, lb=None, ub=None, max_fine_opt=10):
+        """CandidateManager driven by explicit hints (checkCandWithHint in the given order, tidyUpCandidates, fineOptimize).
+        qdesc: torch uint8 CUDA [DESC_BYTES] of the query scan; hints: array of L.hint_dt (cand_gidx = DB index).
+        Returns (cc_query_result_t record, per-hint L.hint_score_dt array)."""
+        import torch
+        if lb is None:
+            lb, ub = L.default_thresholds()
+        hints = np.ascontiguousarray(hints, L.hint_dt)
+        qdesc = qdesc.reshape(-1)
+        assert qdesc.is_cuda and qdesc.is_contiguous() and qdesc.numel() == DESC_BYTES
+        res = np.zeros(1, L.query_result_dt)
+        sc = np.zeros(len(hints), L.hint_score_dt)
+        stream = torch.cuda.current_stream(qdesc.device).cuda_stream
+        _chk(lib().cc_db_check_hints(self.h, qdesc.data_ptr(), hints.ctypes.data, len(hints), C.addressof(lb), C.addressof(ub),
+                                     int(max_fine_opt), res.ctypes.data, sc.ctypes.data, stream), "cc_db_check_hints")
+        return res[0], sc
 
     def set_lanes(self, n):
         """1 = query chunks one after the other, 2 (default) = two 256-query chunks in flight on internal streams."""

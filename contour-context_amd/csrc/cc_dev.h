@@ -35,7 +35,9 @@ __device__ __forceinline__ float cc_funkey(unsigned k) {
 // hashPointToImage (contour_mng.h:448-463).  Returns cell index or -1 (rejected or row 0:
 // makeBEV only uses points with rc.first > 0, contour_mng.h:515).
 __device__ __forceinline__ int cc_point_cell(const cc_dev_cfg &c, float x, float y) {
-  if (x < c.x_lo || x > c.x_hi || y < c.y_lo || y > c.y_hi || (y * y + x * x) < c.blind_sq) return -1;
+  // written so that a NaN coordinate is rejected (the reference's int(floor(NaN)) is undefined behaviour); identical to
+  // `x < lo || x > hi || ...` for every other value
+  if (!(x >= c.x_lo && x <= c.x_hi && y >= c.y_lo && y <= c.y_hi) || (y * y + x * x) < c.blind_sq) return -1;
   int row = (int)floorf(x / c.reso_row) + c.half_row;
   int col = (int)floorf(y / c.reso_col) + c.half_col;
   if (row <= 0) return -1;

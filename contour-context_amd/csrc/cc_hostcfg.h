@@ -12,6 +12,7 @@ static inline int cc_make_dev_cfg(const cc_manager_cfg_t *m, cc_dev_cfg *c) {
     if (!(m->lv_grads[i] > m->lv_grads[i - 1])) return -1;                   // nested level sets
   if (m->piv_firsts < 1 || m->piv_firsts > CC_NPIV || m->dist_firsts < 1 || m->dist_firsts > CC_NDIST) return -1;
   if (m->min_cont_cell_cnt < 1) return -1;
+  if (!(m->reso_row > 0.f) || !(m->reso_col > 0.f)) return -1;              // also rejects NaN
   const float padding = 1e-2f;
   const float x_min = -(float)(m->n_row / 2) * m->reso_row, x_max = -x_min;
   const float y_min = -(float)(m->n_col / 2) * m->reso_col, y_max = -y_min;

@@ -50,6 +50,17 @@ struct cc_ctx {
   cc_k1_scan_out *d_k1 = nullptr;
   cc_k2_scratch *d_scr = nullptr;
   long long *d_offsets = nullptr;
+  // pinned staging ring for the per-chunk point offsets: a slot is reused only after the copy that read it has finished
+  static const int NSLOT = 4;
+  long long *h_off[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t off_ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  bool off_busy[NSLOT] = {false, false, false, false};
+  int off_next = 0;
+  // the ingest scratch (d_bev, d_pix, d_k1, d_scr, d_offsets) is shared by all calls: the previous call's last kernel
+  // is waited for (on the device) when the next call comes in on a different stream
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   size_t lds1 = 0, lds2 = 0;
   // optional per-kernel timing (cc_profile_*)
@@ -151,6 +162,11 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   CREATE_CHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
   CREATE_CHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
   CREATE_CHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
+  for (int i = 0; i < cc_ctx::NSLOT; i++) {
+    CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * (max_batch_scans + 1), hipHostMallocDefault));
+    CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
+  }
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
   if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
@@ -211,6 +227,11 @@ int cc_destroy(cc_ctx *c) {
   hipFree(c->d_k1);
   hipFree(c->d_scr);
   hipFree(c->d_offsets);
+  for (int i = 0; i < cc_ctx::NSLOT; i++) {
+    if (c->h_off[i]) hipHostFree(c->h_off[i]);
+    if (c->off_ev[i]) hipEventDestroy(c->off_ev[i]);
+  }
+  if (c->ev_last) hipEventDestroy(c->ev_last);
   hipFree(c->d_phase_clk);
   delete c;
   return CC_OK;
@@ -231,13 +252,18 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     if (n >= (1 << CC_K1_IDX_BITS)) return set_err(CC_EINVAL, "cc_ingest_batch: scan with >= 2^21 points");
   }
   const size_t nc = (size_t)c->dcfg.n_cell;
+  if (c->has_last && c->last_stream != stream) HIPCHK(hipStreamWaitEvent(stream, c->ev_last, 0));
   for (int b0 = 0; b0 < n_scans; b0 += c->max_batch) {
     const int nb = (n_scans - b0 < c->max_batch) ? n_scans - b0 : c->max_batch;
-    // offsets relative to the chunk's first point
-    std::vector<long long> off(nb + 1);
+    // offsets relative to the chunk's first point, staged in pinned memory: the call only queues work
+    const int slot = c->off_next;
+    c->off_next = (slot + 1) % cc_ctx::NSLOT;
+    if (c->off_busy[slot]) HIPCHK(hipEventSynchronize(c->off_ev[slot]));
+    long long *off = c->h_off[slot];
     for (int i = 0; i <= nb; i++) off[i] = (long long)(h_offsets[b0 + i] - h_offsets[b0]);
-    HIPCHK(hipMemcpyAsync(c->d_offsets, off.data(), sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));  // `off` is a stack-lifetime staging buffer
+    HIPCHK(hipMemcpyAsync(c->d_offsets, off, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(c->off_ev[slot], stream));
+    c->off_busy[slot] = true;
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
     if (dbg && dbg->d_pix_rc)
       hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)c->d_pix, -1.f, nc * 2 * nb);
@@ -260,6 +286,11 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
       HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, c->d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));
     if (dbg && dbg->d_pix_rc)
       HIPCHK(hipMemcpyAsync(dbg->d_pix_rc + (size_t)b0 * nc * 2, c->d_pix, sizeof(float2) * nc * nb, hipMemcpyDeviceToDevice, stream));
+  }
+  if (n_scans > 0) {
+    HIPCHK(hipEventRecord(c->ev_last, stream));
+    c->last_stream = stream;
+    c->has_last = true;
   }
   return CC_OK;
 }

@@ -272,6 +272,44 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       if (rr == (int)(root_cell / (unsigned)n_col) + 1) atomicMin(&w_cB[j], (unsigned)cc);
     }
     __syncthreads();
+    // min_cont_cell_cnt_ > 3: the saturating counters only prove ">= 3 cells"; with the exact areas known, drop the
+    // components below the bar (stats(n,4) < cfg_.min_cont_cell_cnt_, contour_mng.cpp:303) and renumber the rest.
+    // Compaction moves entries to lower indices only, so chunks of nt components are handled front to back.
+    if (cfg.min_cont_cell_cnt > 3) {
+      int n_new = 0;
+      for (int k0 = 0; k0 < n_kept; k0 += nt) {
+        const int k = k0 + tid;
+        unsigned v[7] = {0, 0, 0, 0, 0, 0, 0};
+        unsigned rt = 0;
+        bool keep = false;
+        if (k < n_kept) {
+          for (int a = 0; a < 7; a++) v[a] = W[a * CC_NC + k];
+          rt = roots[k];
+          keep = (int)v[4] >= cfg.min_cont_cell_cnt;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) sh[24 + wave_id] = __popcll(m);
+        __syncthreads();
+        int off = n_new + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+        for (int w = 0; w < n_waves; w++) {
+          if (w < wave_id) off += sh[24 + w];
+          tot += sh[24 + w];
+        }
+        if (k < n_kept) {
+          if (keep) {
+            for (int a = 0; a < 7; a++) W[a * CC_NC + off] = v[a];
+            roots[off] = (uint16_t)rt;
+            LAB[rt] = (uint16_t)(0x8000u | (unsigned)off);
+          } else {
+            LAB[rt] = (uint16_t)rt;  // unmarked root: component not kept
+          }
+        }
+        n_new += tot;
+        __syncthreads();
+      }
+      n_kept = n_new;
+    }
     for (int k = tid; k < n_kept; k += nt) w_cA[k] = (unsigned)roots[k] % (unsigned)n_col;
     CC_K2_LAP(acc_enum);
     // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell

@@ -29,7 +29,11 @@ __device__ __forceinline__ void cc_group_sync(int G) {
 // starts at dist_ub and drops to the nnk-th best distance as soon as nnk candidates are known, so a search typically
 // touches a few hundred keys of tens of thousands.
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_CAP 192  // LDS candidate buffer per search (entries of 8 B): < 2 * nnk (nnk <= 64) kept candidates + one 64-key step
+// LDS candidate buffer per search (entries of 8 B).  Between two tightenings at most 2 * nnk - 1 kept candidates + one
+// 64-key step are pending (191 at nnk = CC_KNN_MAX = 64), and the bitonic sort pads that to the next power of two.
+#define CC_KNN_CAP 256
+static_assert(2 * CC_KNN_MAX - 1 + 64 <= CC_KNN_CAP && (CC_KNN_CAP & (CC_KNN_CAP - 1)) == 0,
+              "cc_k_knn: the padded sort width must fit the LDS buffer");
 
 struct cc_knn_params {
   const float *skeys[CC_NQLEV];       // SoA [CC_KEY_DIM][cap_k], sorted by dim 0 (ties: insertion order)
@@ -388,6 +392,13 @@ __device__ __forceinline__ bool cc_check_sim(const cc_contour_t &a, const cc_con
 __device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * x + y * y); }
 
 #define CC_CHK_STRIDE (CC_NQLEV * CC_NPIV * CC_KNN_MAX)  // dense check slots per query: slot * CC_KNN_MAX + j
+#define CC_NSCORE 5  // per-check gate scores (hint flow): ovlp_sum, max_one, in_ang_rng, indiv_sim, orie_sim
+// A KNN hit names the candidate's anchor (level, seq); the query's anchor is implied by the slot.  In the hint flow
+// (cc_db_check_hints) the checks sit in caller order instead, and the query's anchor rides in the high byte of `level`
+// (0 = none: derive it from the slot).
+#define CC_HIT_LEVEL(h) ((int)((h).level & 0xFF))
+#define CC_HIT_SEQ_TGT(h, slot) (((h).level >> 8) ? (int)((h).level >> 8) - 1 : (slot) % CC_NPIV)
+#define CC_HIT_PACK_LEVEL(level, seq_tgt) ((int16_t)((level) | (((seq_tgt) + 1) << 8)))
 
 // Stage A (one lane per check slot): (1/4) anchor ContourView::checkSim and the popcount part of (2/4)
 // BCI::checkConstellSim (ovlp_sum / max_one bars).  Survivors are written as an ORDERED list per query; the slot
@@ -398,7 +409,8 @@ __global__ void __launch_bounds__(256)
 cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, unsigned short *__restrict__ surv,
              cc_knn_hit_t *__restrict__ surv_hit, int *__restrict__ surv_cnt, unsigned char *__restrict__ pass_ok,
-             int *__restrict__ pass_cnt /*[nq][4]*/, int *__restrict__ redo_cnt /*[nq]*/) {
+             int *__restrict__ pass_cnt /*[nq][4]*/, int *__restrict__ redo_cnt /*[nq]*/,
+             int *__restrict__ scores /*[nq][CC_CHK_STRIDE][CC_NSCORE] or nullptr: per-check gate scores (hint flow)*/) {
   __shared__ int wcnt[4];
   __shared__ int s_base, s_chk1;
   const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -413,6 +425,7 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
   for (int t0 = 0; t0 < CC_CHK_STRIDE; t0 += nt) {
     const int t = t0 + tid;
     bool anchor_ok = false, keep = false;
+    int sc_sum = 0, sc_max = 0;
     cc_knn_hit_t h;
     h.gidx = 0;
     h.level = h.seq = 0;
@@ -421,12 +434,12 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
       if (j < hit_cnt[q * NS + slot]) {
         h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
-        const int seq_tgt = slot % CC_NPIV;
+        const int seq_tgt = CC_HIT_SEQ_TGT(h, slot), lev = CC_HIT_LEVEL(h);
         const cc_scan_desc_t *src = db_desc + h.gidx;
-        anchor_ok = cc_check_sim(src->cont[h.level][h.seq], tgt->cont[h.level][seq_tgt], P.sim);
+        anchor_ok = cc_check_sim(src->cont[lev][h.seq], tgt->cont[lev][seq_tgt], P.sim);
         if (anchor_ok) {
-          const cc_bci_t *bs = &src->bcis[h.level][h.seq];
-          const cc_bci_t *bt = &tgt->bcis[h.level][seq_tgt];
+          const cc_bci_t *bs = &src->bcis[lev][h.seq];
+          const cc_bci_t *bt = &tgt->bcis[lev][seq_tgt];
           unsigned long long S[4], T[4];
           for (int w = 0; w < 4; w++) {
             S[w] = bs->dist_bin[w];
@@ -444,9 +457,17 @@ cc_k_check_a(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
           int max_one = ov2 < ov3 ? ov3 : ov2;
           max_one = ov1 < max_one ? max_one : ov1;
           keep = (ovlp_sum >= P.lb.i_ovlp_sum && max_one >= P.lb.i_ovlp_max_one);
+          sc_sum = ovlp_sum;
+          sc_max = max_one;
         }
       }
       pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 0;
+      if (scores) {
+        int *sc = scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE;
+        sc[0] = sc_sum;
+        sc[1] = sc_max;
+        sc[2] = sc[3] = sc[4] = 0;
+      }
     }
     const unsigned long long mk = __ballot(keep), ma = __ballot(anchor_ok);
     if (lane == 0) {
@@ -755,7 +776,7 @@ __global__ void __launch_bounds__(64)
 cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const cc_scan_desc_t *__restrict__ db_desc,
              const cc_knn_hit_t *__restrict__ surv_hit, const unsigned short *__restrict__ surv, const int *__restrict__ surv_cnt,
              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt,
-             int *__restrict__ redo_cnt, int per_q) {
+             int *__restrict__ redo_cnt, int per_q, int *__restrict__ scores /*see cc_k_check_a; or nullptr*/) {
   __shared__ cc_chkb_lds<PPM> LG[CC_CHKB_GPW];
   if (REDO && redo_cnt[blockIdx.x / per_q] == 0) return;  // nothing was left over for this query
   const int G = CC_CHKB_G;
@@ -792,7 +813,8 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       if (sl == 0) pass_ok[(size_t)q * CC_CHK_STRIDE + t] = 0;
     }
     const int slot = t / CC_KNN_MAX;
-    const int level = h.level, seq_src = h.seq, seq_tgt = slot % CC_NPIV;
+    const int level = CC_HIT_LEVEL(h), seq_src = h.seq, seq_tgt = CC_HIT_SEQ_TGT(h, slot);
+    int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
     const cc_scan_desc_t *src = db_desc + h.gidx;
     const cc_bci_t *bs = &src->bcis[level][seq_src];
     const cc_bci_t *bt = &tgt->bcis[level][seq_tgt];
@@ -873,7 +895,10 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       flags |= 1;
     }
     cc_group_sync(G);
-    if (npp == 0) continue;
+    if (npp == 0) {
+      if (sc && sl == 0) sc[2] = 1;  // the window search starts from longest_in_range = 1 (contour_mng.h:345)
+      continue;
+    }
     cc_chkb_gen_pairs(L, ntp, sl);
     if (P.dbg_cut == 3) continue;
     if (P.dbg_cut >= 10) {  // tuning aid: per-query sums reported through cand_aft_check2
@@ -917,6 +942,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       longest = 1;
       beg = 0;
     }
+    if (sc && sl == 0) sc[2] = longest;
     if (longest < P.lb.i_in_ang_rng) continue;
     if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
     // (3/4) individual similarity of the window pairs + the anchors, in cstl_in order
@@ -966,6 +992,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       ncs = CC_CSTL_MAX;
       flags |= 1;
     }
+    if (sc && sl == 0) sc[3] = ncs;
     if (ncs < P.lb.i_indiv_sim) continue;
     cc_group_sync(G);
     // part 2: the "shaft" (contour_mng.h:1173-1184).  The reference scans the (i, j<i) pairs of the first <=10 entries in
@@ -1074,6 +1101,7 @@ cc_k_check_b(cc_check_params P, const cc_scan_desc_t *__restrict__ qdesc, const 
       ncs = L.c.misc[0];
     }
     if (P.dbg_cut == 8) continue;
+    if (sc && sl == 0) sc[4] = ncs;
     if (ncs < P.lb.i_orie_sim) continue;
     // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form; sums in list order (uniform loops on LDS)
     if (sl < 8) L.bitsw[sl] = 0ull;

@@ -1,22 +1,24 @@
 // K1 -- BEV rasterisation.  Replaces ContourManager::makeBEV (contour_mng.h:505-556) for a batch
 // of scans: one workgroup per scan, the 150x150 max-height grid lives in LDS.
 //
-//   pass 1: stream the scan's (x,y,z,i) records with coalesced 16-B loads, LDS atomicMax of the
-//           order-preserving height key per cell                                    (90 KB LDS)
-//   pass 2: re-stream; among the points whose height equals the cell maximum keep the smallest
-//           point index -- the reference updates a cell only on `bev < height` (strict), so the
-//           FIRST point in file order wins ties (contour_mng.h:517).  Indices are 21-bit fields,
-//           three per 64-bit LDS word, updated with a CAS loop                       (60 KB LDS)
+//   sweep : stream the scan's (x,y,z,i) records ONCE with coalesced 16-B loads, a register-held chunk at a time:
+//           LDS atomicMax of the order-preserving height key per cell               (90 KB LDS), then, among the
+//           chunk's points whose height equals the cell maximum, keep the smallest point index -- the reference
+//           updates a cell only on `bev < height` (strict), so the FIRST point in file order wins ties
+//           (contour_mng.h:517).  Indices are 21-bit fields, three per 64-bit LDS word, erased with an atomicOr when
+//           the cell's maximum rises and min-updated with a CAS loop                 (60 KB LDS)
 //   out   : dense bev image + continuous (row_f,col_f) of the winning point per occupied cell
 //           (pointToContRowCol, contour_mng.h:468-472), max/min accepted height, #occupied cells.
 //
-// Roofline: HBM.  Algorithmic bytes = 16 B x points; this two-pass form reads the
-// stream twice (second pass partly from L2/MALL).
+// Roofline: HBM.  Algorithmic bytes = 16 B x points = what the sweep reads.
 #pragma once
 #include "cc_dev.h"
 
 #define CC_K1_IDX_BITS 21
 #define CC_K1_IDX_MASK 0x1FFFFFull
+#ifndef CC_K1_U
+#define CC_K1_U 4  // points per lane and chunk
+#endif
 
 struct cc_k1_scan_out {
   float max_bin_val, min_bin_val;
@@ -70,64 +72,77 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   }
   __syncthreads();
 
-  // ---- pass 1: per-cell max height ----
+  // ---- one sweep over the stream, in chunks of CC_K1_U * blockDim points held in registers ----
+  // step A (all lanes): atomicMax of the chunk's heights; a point that RAISES a cell's maximum erases the cell's
+  //                     index field (the index recorded so far belongs to a lower height)
+  // step B (after a barrier): the chunk's points that equal the cell maximum min-reduce their index into the field.
+  // A cell whose maximum dates from an earlier chunk keeps that (smaller) index: later equal heights never replace
+  // it, which is the strict `bev < height` update of contour_mng.h:517.  The barrier after step B keeps the next
+  // chunk's erasures behind this chunk's index updates.
   float vmax = CC_BEV_EMPTY, vmin = -CC_BEV_EMPTY;
-  for (int i = tid; i < n_pts; i += 4 * nt) {
-    float4 q[4];
-    int cell[4];
+  const int chunk = CC_K1_U * nt;
+  float4 q[CC_K1_U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int j = i + u * nt;
-      q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
-    }
+  for (int u = 0; u < CC_K1_U; u++) {
+    int j = tid + u * nt;
+    q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
+  }
+  for (int base = 0; base < n_pts; base += chunk) {
+    int cell[CC_K1_U];
+    unsigned key[CC_K1_U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < CC_K1_U; u++) {
       cell[u] = cc_point_cell(cfg, q[u].x, q[u].y);
+      float h = cfg.lidar_height + q[u].z;
+      key[u] = cc_fkey(h);
+      // a NaN height never updates a cell or the max/min in the reference (`bev < NaN`, `max < NaN`, `min > NaN` are
+      // all false, contour_mng.h:517-524): such a point is dropped here
+      if (!(h == h)) cell[u] = -1;
       if (cell[u] >= 0) {
-        float h = cfg.lidar_height + q[u].z;
-        atomicMax(&hmax[cell[u]], cc_fkey(h));
         vmax = vmax < h ? h : vmax;
         vmin = vmin > h ? h : vmin;
       }
     }
+    // the next chunk's records travel while this chunk is resolved in LDS
+#pragma unroll
+    for (int u = 0; u < CC_K1_U; u++) {
+      int j = base + chunk + tid + u * nt;
+      q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < CC_K1_U; u++) {
+      if (cell[u] >= 0) {
+        unsigned old = atomicMax(&hmax[cell[u]], key[u]);
+        if (old < key[u]) {
+          const int w = cell[u] / 3, sh = (cell[u] - 3 * w) * CC_K1_IDX_BITS;
+          atomicOr(&idx3[w], CC_K1_IDX_MASK << sh);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CC_K1_U; u++) {
+      if (cell[u] >= 0 && key[u] == hmax[cell[u]] && key[u] != KEY_EMPTY) {
+        const unsigned long long j = (unsigned long long)(base + tid + u * nt);
+        const int w = cell[u] / 3, sh = (cell[u] - 3 * w) * CC_K1_IDX_BITS;
+        unsigned long long old = idx3[w];
+        while (true) {
+          unsigned long long cur = (old >> sh) & CC_K1_IDX_MASK;
+          if (j >= cur) break;
+          unsigned long long nw = (old & ~(CC_K1_IDX_MASK << sh)) | (j << sh);
+          unsigned long long got = atomicCAS(&idx3[w], old, nw);
+          if (got == old) break;
+          old = got;
+        }
+      }
+    }
+    __syncthreads();
   }
   vmax = cc_wave_max(vmax);
   vmin = cc_wave_min(vmin);
   if ((tid & 63) == 0) {
     atomicMax(&red[0], cc_fkey(vmax));
     atomicMin(&red[1], cc_fkey(vmin));
-  }
-  __syncthreads();
-
-  // ---- pass 2: first point (smallest index) attaining the maximum ----
-  for (int i = tid; i < n_pts; i += 4 * nt) {
-    float4 q[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int j = i + u * nt;
-      q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int j = i + u * nt;
-      int cell = cc_point_cell(cfg, q[u].x, q[u].y);
-      if (cell >= 0) {
-        float h = cfg.lidar_height + q[u].z;
-        unsigned k = cc_fkey(h);
-        if (k == hmax[cell] && k != KEY_EMPTY) {
-          const int w = cell / 3, sh = (cell - 3 * w) * CC_K1_IDX_BITS;
-          unsigned long long old = idx3[w];
-          while (true) {
-            unsigned long long cur = (old >> sh) & CC_K1_IDX_MASK;
-            if ((unsigned long long)j >= cur) break;
-            unsigned long long nw = (old & ~(CC_K1_IDX_MASK << sh)) | ((unsigned long long)j << sh);
-            unsigned long long got = atomicCAS(&idx3[w], old, nw);
-            if (got == old) break;
-            old = got;
-          }
-        }
-      }
-    }
   }
   __syncthreads();
 

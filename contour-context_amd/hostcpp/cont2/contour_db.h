@@ -115,6 +115,138 @@ class ContourDB {
   double pending_ts_ = 0;
 };
 
+// contour_db.h:264-656, the hint-driven use of CandidateManager (the single-pair flow of test/kitti_read_bin_test.cpp:226-291):
+//   CandidateManager m(cm_query, lb, ub);  m.checkCandWithHint(cm_cand, {level, seq_src, seq_tgt}, cont_sim); ...
+//   m.tidyUpCandidates();  m.fineOptimize(max_fine_opt, cands, corr, tfs);
+// All three stages run on the device (cc_db_check_hints): checkCandWithHint evaluates its hint at once for the returned
+// scores and records it; fineOptimize replays the recorded hints in call order through checks, proposal merge, tidy-up
+// and refinement.  Candidate scans live in a process-wide device store (one per cont_sim setting).  Hint levels: 1..4.
+class CandidateManager {
+  struct Store {
+    cc_db *db = nullptr;
+    std::map<const ContourManager *, int> pos;
+    std::vector<std::shared_ptr<const ContourManager>> keep;  // as ContourDB::all_bevs_: scans stay alive
+  };
+  static Store &store(const ContourManager &cm, const ContourSimThresConfig &cs) {
+    static std::map<std::string, Store> pool;
+    std::string key((const char *)&cm.ccfg(), sizeof(cc_manager_cfg_t));
+    key.append((const char *)&cs, sizeof(cs));
+    Store &st = pool[key];
+    if (!st.db) {
+      cc_db_cfg_t d;
+      cc_default_db_cfg(&d);
+      d.cont_sim.ta_cell_cnt = cs.ta_cell_cnt;
+      d.cont_sim.tp_cell_cnt = cs.tp_cell_cnt;
+      d.cont_sim.tp_eigval = cs.tp_eigval;
+      d.cont_sim.ta_h_bar = cs.ta_h_bar;
+      d.cont_sim.ta_rcom = cs.ta_rcom;
+      d.cont_sim.tp_rcom = cs.tp_rcom;
+      if (cc_db_create(cc_host::context(cm.ccfg()), &d, 4096, &st.db) != CC_OK) die();
+    }
+    return st;
+  }
+  static void die() {
+    fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+    abort();
+  }
+  static cc_score_t to_c(const CandidateScoreEnsemble &e) {
+    cc_score_t s;
+    s.i_ovlp_sum = e.sim_constell.i_ovlp_sum;
+    s.i_ovlp_max_one = e.sim_constell.i_ovlp_max_one;
+    s.i_in_ang_rng = e.sim_constell.i_in_ang_rng;
+    s.i_indiv_sim = e.sim_pair.i_indiv_sim;
+    s.i_orie_sim = e.sim_pair.i_orie_sim;
+    s.correlation = e.sim_post.correlation;
+    s.area_perc = e.sim_post.area_perc;
+    s.neg_est_dist = e.sim_post.neg_est_dist;
+    return s;
+  }
+
+  std::shared_ptr<const ContourManager> cm_tgt_;
+  const CandidateScoreEnsemble sim_ub_;
+  CandidateScoreEnsemble sim_var_;
+  Store *st_ = nullptr;
+  std::vector<cc_hint_t> hints_;
+  int flow_valve = 0;
+
+ public:
+  int cand_aft_check1 = 0, cand_aft_check2 = 0, cand_aft_check3 = 0;
+
+  CandidateManager(std::shared_ptr<const ContourManager> cm_q, const CandidateScoreEnsemble sim_lb, const CandidateScoreEnsemble sim_ub)
+      : cm_tgt_(std::move(cm_q)), sim_ub_(sim_ub), sim_var_(sim_lb) {
+    CC_CHECK(sim_lb.sim_constell.strictSmaller(sim_ub.sim_constell));
+    CC_CHECK(sim_lb.sim_pair.strictSmaller(sim_ub.sim_pair));
+    CC_CHECK(sim_lb.sim_post.strictSmaller(sim_ub.sim_post));
+  }
+
+  // contour_db.h:374-488
+  CandidateScoreEnsemble checkCandWithHint(const std::shared_ptr<const ContourManager> &cm_cand, const ConstellationPair &anchor_pair,
+                                           const ContourSimThresConfig &cont_sim = ContourSimThresConfig()) {
+    CC_CHECK(flow_valve == 0);
+    Store &st = store(*cm_tgt_, cont_sim);
+    CC_CHECK(st_ == nullptr || st_ == &st);  // one cont_sim setting per manager
+    st_ = &st;
+    auto it = st.pos.find(cm_cand.get());
+    if (it == st.pos.end()) {
+      const int g = cc_db_size(st.db);
+      if (cc_db_add_scan_host(st.db, &cm_cand->desc(), (double)g, g) != CC_OK) die();
+      it = st.pos.insert({cm_cand.get(), g}).first;
+      st.keep.push_back(cm_cand);
+    }
+    cc_hint_t h;
+    h.cand_gidx = it->second;
+    h.level = anchor_pair.level;
+    h.seq_src = anchor_pair.seq_src;
+    h.seq_tgt = anchor_pair.seq_tgt;
+    h.pad = 0;
+    const cc_score_t lb = to_c(sim_var_), ub = to_c(sim_ub_);
+    cc_query_result_t r;
+    cc_hint_score_t sc;
+    if (cc_db_check_hints_host(st.db, &cm_tgt_->desc(), &h, 1, &lb, &ub, 1, &r, &sc) != CC_OK) die();
+    hints_.push_back(h);
+    cand_aft_check1 += r.cand_aft_check1;
+    cand_aft_check2 += r.cand_aft_check2;
+    cand_aft_check3 += r.cand_aft_check3;
+    CandidateScoreEnsemble ret;
+    ret.sim_constell.i_ovlp_sum = sc.i_ovlp_sum;
+    ret.sim_constell.i_ovlp_max_one = sc.i_ovlp_max_one;
+    ret.sim_constell.i_in_ang_rng = sc.i_in_ang_rng;
+    ret.sim_pair.i_indiv_sim = sc.i_indiv_sim;
+    ret.sim_pair.i_orie_sim = sc.i_orie_sim;
+    return ret;
+  }
+
+  // contour_db.h:494-596.  The work happens in fineOptimize (one device pass over the recorded hints).
+  void tidyUpCandidates() {
+    CC_CHECK(flow_valve < 1);
+    flow_valve++;
+  }
+
+  // contour_db.h:604-648: returns the number of results (0 or 1)
+  int fineOptimize(int max_fine_opt, std::vector<std::shared_ptr<const ContourManager>> &res_cand, std::vector<double> &res_corr,
+                   std::vector<Eigen::Isometry2d> &res_T) {
+    CC_CHECK(flow_valve == 1);
+    flow_valve++;
+    res_cand.clear();
+    res_corr.clear();
+    res_T.clear();
+    if (hints_.empty() || !st_) return 0;
+    const cc_score_t lb = to_c(sim_var_), ub = to_c(sim_ub_);
+    cc_query_result_t r;
+    if (cc_db_check_hints_host(st_->db, &cm_tgt_->desc(), hints_.data(), (int)hints_.size(), &lb, &ub, max_fine_opt, &r, nullptr) != CC_OK)
+      die();
+    if (r.n_res > 0) {
+      res_cand.push_back(st_->keep[r.cand_gidx]);
+      res_corr.push_back(r.correlation);
+      Eigen::Isometry2d T;
+      T.rotate(r.tf[2]);
+      T.pretranslate(r.tf[0], r.tf[1]);
+      res_T.push_back(T);
+    }
+    return r.n_res;
+  }
+};
+
 // correlation.h:287-296
 struct ConstellCorrelation {
   static Eigen::Isometry2d getEstSensTF(const Eigen::Isometry2d &T_delta, const ContourManagerConfig &bev_config) {

@@ -5,6 +5,7 @@
 #include <fstream>
 #include <iostream>
 #include <array>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -65,6 +66,14 @@ union ScoreConstellSim {
   struct {
     int i_ovlp_sum, i_ovlp_max_one, i_in_ang_rng;
   };
+  const int &overall() const { return i_in_ang_rng; }  // the value the stage is judged by
+  int cnt() const { return i_in_ang_rng; }
+  void print() const { printf("%d, %d, %d;", i_ovlp_sum, i_ovlp_max_one, i_in_ang_rng); }
+  bool strictSmaller(const ScoreConstellSim &b) const {
+    for (int i = 0; i < SizeAtCompileTime; i++)
+      if (!(data[i] < b.data[i])) return false;
+    return true;
+  }
 };
 union ScorePairwiseSim {
   enum { SizeAtCompileTime = 2 };
@@ -72,6 +81,14 @@ union ScorePairwiseSim {
   struct {
     int i_indiv_sim, i_orie_sim;
   };
+  const int &overall() const { return i_orie_sim; }
+  int cnt() const { return i_orie_sim; }
+  void print() const { printf("%d, %d;", i_indiv_sim, i_orie_sim); }
+  bool strictSmaller(const ScorePairwiseSim &b) const {
+    for (int i = 0; i < SizeAtCompileTime; i++)
+      if (!(data[i] < b.data[i])) return false;
+    return true;
+  }
 };
 union ScorePostProc {
   enum { SizeAtCompileTime = 3 };
@@ -79,6 +96,25 @@ union ScorePostProc {
   struct {
     float correlation, area_perc, neg_est_dist;
   };
+  const float &overall() const { return correlation; }
+  void print() const { printf("%6f, %6f%%, %6fm;", correlation, 100 * area_perc, neg_est_dist); }
+  bool strictSmaller(const ScorePostProc &b) const {
+    for (int i = 0; i < SizeAtCompileTime; i++)
+      if (!(data[i] < b.data[i])) return false;
+    return true;
+  }
+};
+
+// contour_mng.h:221-240: one matched contour pair (the "hint" of CandidateManager::checkCandWithHint when it is an anchor)
+struct ConstellationPair {
+  int8_t level, seq_src, seq_tgt;
+  ConstellationPair(int8_t l, int8_t s, int8_t t) : level(l), seq_src(s), seq_tgt(t) {}
+  bool operator<(const ConstellationPair &a) const {
+    if (level != a.level) return level < a.level;
+    if (seq_src != a.seq_src) return seq_src < a.seq_src;
+    return seq_tgt < a.seq_tgt;
+  }
+  bool operator==(const ConstellationPair &a) const { return level == a.level && seq_src == a.seq_src && seq_tgt == a.seq_tgt; }
 };
 
 // contour.h:97-119, read-only view over one cc_contour_t

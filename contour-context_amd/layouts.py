@@ -32,6 +32,11 @@ query_result_dt = np.dtype([
 assert contour_dt.itemsize == 76 and relpt_dt.itemsize == 12 and bci_dt.itemsize == 600
 assert scan_desc_dt.itemsize == 169048, scan_desc_dt.itemsize
 assert knn_hit_dt.itemsize == 12 and query_result_dt.itemsize == 64, query_result_dt.itemsize
+# cc_hint_t / cc_hint_score_t (cc_db_check_hints)
+hint_dt = np.dtype([("cand_gidx", "<i4"), ("level", "i1"), ("seq_src", "i1"), ("seq_tgt", "i1"), ("pad", "i1")], align=True)
+hint_score_dt = np.dtype([("i_ovlp_sum", "<i4"), ("i_ovlp_max_one", "<i4"), ("i_in_ang_rng", "<i4"), ("i_indiv_sim", "<i4"),
+                          ("i_orie_sim", "<i4"), ("passed", "<i4")], align=True)
+assert hint_dt.itemsize == 8 and hint_score_dt.itemsize == 24
 
 
 class ManagerCfg(C.Structure):

@@ -274,6 +274,31 @@ int cc_db_add_scans_host(cc_db *db, const cc_scan_desc_t *h_desc, int n, const d
 int cc_db_query_batch_host(cc_db *db, const cc_scan_desc_t *h_qdesc, int nq, const int32_t *h_epoch,
                            const cc_score_t *thres_lb, const cc_score_t *thres_ub, cc_query_result_t *h_res);
 
+/* CandidateManager driven by explicit anchor hints instead of the KNN search (the single-pair flow of
+ * test/kitti_read_bin_test.cpp:226-291): for one query scan, CandidateManager::checkCandWithHint (contour_db.h:374-488)
+ * for every hint IN THE GIVEN ORDER, then tidyUpCandidates (:494-596) and fineOptimize (:604-648).  Candidate scans are
+ * scans of `db` (any scan added so far, searchable or not).  Hint levels must be within 1..4 (DIST_BIN_LAYERS), at most
+ * CC_HINT_MAX hints.  h_scores (optional, [n_hints]) receives what checkCandWithHint returns per hint. */
+#define CC_HINT_MAX (CC_NQLEV * CC_NPIV * CC_KNN_MAX)
+typedef struct {
+  int32_t cand_gidx; /* candidate scan = cm_cand (DB index)                    */
+  int8_t level;      /* ConstellationPair{level, seq_src, seq_tgt}, contour_mng.h:221-240 */
+  int8_t seq_src;    /* anchor contour of the candidate scan                   */
+  int8_t seq_tgt;    /* anchor contour of the query scan                       */
+  int8_t pad;
+} cc_hint_t;
+typedef struct {
+  int32_t i_ovlp_sum, i_ovlp_max_one, i_in_ang_rng; /* ScoreConstellSim  */
+  int32_t i_indiv_sim, i_orie_sim;                  /* ScorePairwiseSim  */
+  int32_t passed;                                   /* 1: a proposal was added for this hint */
+} cc_hint_score_t;
+int cc_db_check_hints(cc_db *db, const cc_scan_desc_t *d_qdesc, const cc_hint_t *h_hints, int n_hints,
+                      const cc_score_t *thres_lb, const cc_score_t *thres_ub, int max_fine_opt,
+                      cc_query_result_t *h_res, cc_hint_score_t *h_scores, void *stream);
+int cc_db_check_hints_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_hint_t *h_hints, int n_hints,
+                           const cc_score_t *thres_lb, const cc_score_t *thres_ub, int max_fine_opt,
+                           cc_query_result_t *h_res, cc_hint_score_t *h_scores);
+
 /* Device pointer of the DB's descriptor array ([cc_db_size()] cc_scan_desc_t) and raw
  * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
  * device buffer, then cc_db_add_scans consumes it). */

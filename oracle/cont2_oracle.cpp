@@ -352,6 +352,59 @@ void orc_check_pair(void *cand, void *tgt, int level, int seq_src, int seq_tgt, 
     out_i[6] = k;
   }
 }
+// The single-pair flow of test/kitti_read_bin_test.cpp:226-291: one CandidateManager for the query `tgt`,
+// checkCandWithHint for every hint in the given order, tidyUpCandidates, fineOptimize(max_fine_opt).
+// hints[i] = {index into cands[], level, seq_src, seq_tgt}; scores[i] = {ovlp_sum, max_one, in_ang_rng, indiv_sim,
+// orie_sim, passed}; res->cand_gidx = index into cands[].
+void orc_check_hints(void *tgt, void **cands, int n_cands, const int32_t *hints /*[n][4]*/, int n_hints, const cc_sim_cfg_t *sim,
+                     const cc_score_t *lb, const cc_score_t *ub, int max_fine_opt, cc_query_result_t *res, int32_t *scores /*[n][6]*/) {
+  ContourSimThresConfig cs;
+  cs.ta_cell_cnt = sim->ta_cell_cnt;
+  cs.tp_cell_cnt = sim->tp_cell_cnt;
+  cs.tp_eigval = sim->tp_eigval;
+  cs.ta_h_bar = sim->ta_h_bar;
+  cs.ta_rcom = sim->ta_rcom;
+  cs.tp_rcom = sim->tp_rcom;
+  CandidateManager mng(((ScanH *)tgt)->cm, toScore(lb), toScore(ub));
+  for (int i = 0; i < n_hints; i++) {
+    const int32_t *h = hints + 4 * i;
+    const int before = mng.cand_aft_check3;
+    CandidateScoreEnsemble s = mng.checkCandWithHint(((ScanH *)cands[h[0]])->cm, ConstellationPair(h[1], h[2], h[3]), cs);
+    if (scores) {
+      int32_t *o = scores + 6 * i;
+      o[0] = s.sim_constell.i_ovlp_sum;
+      o[1] = s.sim_constell.i_ovlp_max_one;
+      o[2] = s.sim_constell.i_in_ang_rng;
+      o[3] = s.sim_pair.i_indiv_sim;
+      o[4] = s.sim_pair.i_orie_sim;
+      o[5] = mng.cand_aft_check3 > before ? 1 : 0;
+    }
+  }
+  std::memset(res, 0, sizeof(*res));
+  res->cand_gidx = -1;
+  res->cand_aft_check1 = mng.cand_aft_check1;
+  res->cand_aft_check2 = mng.cand_aft_check2;
+  res->cand_aft_check3 = mng.cand_aft_check3;
+  mng.tidyUpCandidates();
+  res->n_cand_pose = mng.n_cand_pose;
+  res->n_cand_tidy = (int)mng.candidates_.size();
+  res->n_knn_hits = n_hints;
+  std::vector<std::shared_ptr<const ContourManager>> rc;
+  std::vector<double> corr;
+  std::vector<Iso2d> tfs;
+  res->n_res = mng.fineOptimize(max_fine_opt, rc, corr, tfs);
+  if (res->n_res) {
+    for (int i = 0; i < n_cands; i++)
+      if (((ScanH *)cands[i])->cm.get() == rc[0].get()) {
+        res->cand_gidx = i;
+        break;
+      }
+    res->correlation = corr[0];
+    res->tf[0] = tfs[0](0, 2);
+    res->tf[1] = tfs[0](1, 2);
+    res->tf[2] = std::atan2(tfs[0](1, 0), tfs[0](0, 0));
+  }
+}
 // GMM: init correlation at T_init and the refined (correlation, x, y, theta) after <=10 L-BFGS iterations
 void orc_gmm(void *src, void *tgt, const double tf_init[3], double *corr_init, double *corr_opt, double tf_opt[3],
              int32_t *iters) {

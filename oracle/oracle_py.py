@@ -61,6 +61,8 @@ def lib():
         _lib.orc_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.orc_ingest_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.orc_check_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+        _lib.orc_check_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p]
         _lib.orc_gmm.argtypes = [C.c_void_p] * 7
         _lib.orc_gmm_eval.argtypes = [C.c_void_p] * 7
         _lib.orc_umeyama.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -202,6 +204,21 @@ def check_pair(cand, tgt, level, seq_src, seq_tgt, sim=None, lb=None, ub=None):
     lib().orc_check_pair(cand.h, tgt.h, level, seq_src, seq_tgt, C.addressof(sim), C.addressof(lb), C.addressof(ub),
                          _p(oi), _p(tf), _p(pairs))
     return oi, tf, pairs[:oi[6]]
+
+
+def check_hints(tgt, cands, hints, sim=None, lb=None, ub=None, max_fine_opt=10):
+    """single-pair flow (kitti_read_bin_test.cpp:226-291): hints = int array [n][4] of (index into cands, level, seq_src, seq_tgt)
+    -> (cc_query_result_t record with cand_gidx = index into cands, scores [n][6])"""
+    sim = sim or L.default_db_cfg().cont_sim
+    if lb is None:
+        lb, ub = L.default_thresholds()
+    hints = np.ascontiguousarray(hints, np.int32).reshape(-1, 4)
+    hs = (C.c_void_p * len(cands))(*[c.h for c in cands])
+    res = np.zeros(1, L.query_result_dt)
+    sc = np.zeros((len(hints), 6), np.int32)
+    lib().orc_check_hints(tgt.h, hs, len(cands), _p(hints), len(hints), C.addressof(sim), C.addressof(lb), C.addressof(ub),
+                          int(max_fine_opt), _p(res), _p(sc))
+    return res[0], sc
 
 
 def gmm(src, tgt, tf_init):

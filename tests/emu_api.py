@@ -27,7 +27,7 @@ class EmuApi:
         self.lib.cc_last_error.restype = C.c_char_p
         self.lib.cc_db_desc_ptr.restype = C.c_void_p
         for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state"):
+                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state", "cc_db_check_hints"):
             getattr(self.lib, f).restype = C.c_int
 
     def chk(self, rc, what):
@@ -96,6 +96,19 @@ class EmuApi:
                                             C.c_void_p(knn.ctypes.data) if want_knn else None,
                                             C.c_void_p(cnt.ctypes.data) if want_knn else None, None), "cc_db_query_batch")
         return (res, knn, cnt) if want_knn else res
+
+    def check_hints(self, db, qdesc, hints, lb=None, ub=None, max_fine_opt=10):
+        L = self.L
+        if lb is None:
+            lb, ub = L.default_thresholds()
+        qdesc = np.ascontiguousarray(qdesc)
+        hints = np.ascontiguousarray(hints, L.hint_dt)
+        res = np.zeros(1, L.query_result_dt)
+        sc = np.zeros(len(hints), L.hint_score_dt)
+        self.chk(self.lib.cc_db_check_hints(db, C.c_void_p(qdesc.ctypes.data), C.c_void_p(hints.ctypes.data), len(hints), C.byref(lb),
+                                            C.byref(ub), int(max_fine_opt), C.c_void_p(res.ctypes.data), C.c_void_p(sc.ctypes.data),
+                                            None), "cc_db_check_hints")
+        return res[0], sc
 
     def bucket_state(self, db):
         sizes = np.zeros((3, 6), np.int32)

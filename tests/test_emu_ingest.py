@@ -95,3 +95,27 @@ def test_component_capacity_is_reported(oracle):
         assert "(-4)" in str(e) and "not exact" in str(e)
     else:
         raise AssertionError("expected CC_ECAPACITY")
+
+
+def test_min_cont_cell_cnt_above_three(oracle):
+    """min_cont_cell_cnt_ = 6: components of 3..5 cells must be dropped too (stats(n,4) < min_cont_cell_cnt_,
+    contour_mng.cpp:303); the kernel's saturating counters only prove >= 3, the exact areas decide."""
+    cfg = oracle.L.default_manager_cfg()
+    cfg.min_cont_cell_cnt = 6
+    s = terrain_scan(2, n=20000, scale=1.2)
+    d3 = _check(oracle, [s])
+    d6 = _check(oracle, [s], cfg=cfg)
+    assert d6["n_cont"].sum() < d3["n_cont"].sum()
+    for l in range(oracle.L.NLEV):
+        ns = int(d6["n_stored"][0, l])
+        assert ns == 0 or d6["cont"][0, l]["cell_cnt"][:ns].min() >= 6
+
+
+def test_nan_heights_are_ignored(oracle):
+    """z = NaN never wins a cell nor the max/min (`bev < NaN` is false, contour_mng.h:517-524)."""
+    s = terrain_scan(7, n=20000, scale=1.2)
+    s[::7, 2] = np.nan
+    clean = s[~np.isnan(s[:, 2])]
+    d = _check(oracle, [s])
+    d2 = _check(oracle, [clean])
+    assert np.isfinite(d["max_bin_val"]).all() and d["n_pix"][0] == d2["n_pix"][0]

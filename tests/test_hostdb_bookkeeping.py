@@ -78,3 +78,42 @@ def test_knn_with_buckets_matches_oracle(oracle):
                 a, b = oknn[ll, seq, :m], knn[k, ll, seq, :m]
                 assert np.array_equal(a["dist_sq"], b["dist_sq"])
                 assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
+
+
+def test_knn_crowded_layer_matches_oracle(oracle):
+    """Thousands of near-identical keys: every 64-key step of a search passes the radius test, so the pending candidate
+    list grows to 2 * nnk - 1 + 64 entries before it is tightened and the bitonic sort pads it to 256 (the LDS buffer
+    must hold the padded width; found by an ASAN run of this harness in round 1's review)."""
+    L = oracle.L
+    rng = np.random.default_rng(21)
+    n = 700
+    desc = _fake_desc(L, rng, n)
+    base = rng.uniform(8.0, 12.0, L.KEY_DIM).astype(np.float32)
+    k = (base[None, None, None, :] + rng.normal(0, 0.05, (n, L.NLEV, L.NPIV, L.KEY_DIM))).astype(np.float32)
+    desc["keys"] = k
+    ts = np.arange(n) * 0.1
+    seeds = np.arange(n, dtype=np.int32)
+    cfg = L.default_manager_cfg()
+    for nnk in (50, 64):
+        dcfg = L.default_db_cfg()
+        dcfg.nnk = nnk
+        api = emu_api.EmuApi(L)
+        ctx = api.create(max_batch=4)
+        db = api.db_create(ctx, dcfg, cap=n)
+        api.db_add(db, desc, ts, seeds)
+        odb = oracle.DB(dcfg)
+        for i in range(n):
+            odb.add_scan(oracle.Scan.from_desc(desc[i], cfg, int_id=i), ts[i])
+            odb.push_and_balance(i, ts[i])
+        q = desc[[3, 650]].copy()
+        q["keys"] += np.float32(0.01)
+        res, knn, cnt = api.db_query(db, q, np.full(2, n, np.int32), want_knn=True)
+        for kq in range(2):
+            ores, oknn, ocnt = odb.query(oracle.Scan.from_desc(q[kq], cfg, int_id=10000 + kq), want_knn=True)
+            assert np.array_equal(ocnt, cnt[kq]) and ocnt.min() == nnk
+            for ll in range(3):
+                for seq in range(6):
+                    m = ocnt[ll, seq]
+                    a, b = oknn[ll, seq, :m], knn[kq, ll, seq, :m]
+                    assert np.array_equal(a["dist_sq"], b["dist_sq"])
+                    assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
