@@ -43,7 +43,25 @@ def main():
                     help="N > 1: all-gather every batch's descriptors in the timed step (what appending them to all replicas needs)")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
+    ap.add_argument("--workload", choices=("sparse", "dense"), default="sparse",
+                    help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
+                         "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level")
+    ap.add_argument("--tune-sweep", default="",
+                    help="tuning aid (library built with -DCC_TUNE): 'VAR=v1,v2;VAR2=...': after the timed run, rebuild the DB "
+                         "handle under each setting and print the isolated per-kernel ms of two steps to stderr")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run
+    # (one process per GPU, RCCL over xGMI) and let rank 0's JSON line through.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import cc_amd
@@ -53,18 +71,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CC_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # n_gpus in the JSON line = the ranks the process group really has
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     n_db, B, K, W = args.db_scans, args.batch, args.steps, args.warmup
     P = 64 * 1875
-    wld = cc.synth.World()
+    wld = cc.synth.World(dense=(args.workload == "dense"))
     ctx = cc.Context(local_rank, max_batch=max(B, 256))
 
     # ---------------- DB build (untimed): scan-sharded ingest + one all-gather of descriptors ----------------
@@ -89,7 +111,8 @@ def main():
         db.set_lanes(1)
     ts_db = np.arange(n_db, dtype=np.float64) / 10.0
     db.add_scans(desc_db.contiguous(), ts_db, np.arange(n_db, dtype=np.int32))
-    del desc_db
+    if not args.tune_sweep:
+        del desc_db
     # ---------------- query batches (resident in HBM before the timed region) ----------------
     n_steps_total = W + K
     batches = []
@@ -186,12 +209,38 @@ def main():
         torch.cuda.synchronize()
         kms_iso = read_kernel_ms()
 
+    if args.tune_sweep and rank == 0:  # tuning aid: isolated kernel times under each setting of a -DCC_TUNE build's knobs
+        print("tune-sweep base: " + json.dumps({k: round(v, 4) for k, v in (kms_iso or kms).items()}), file=sys.stderr)
+        for spec in args.tune_sweep.split(";"):
+            var, vals = spec.split("=")
+            for v in vals.split(","):
+                os.environ[var] = v
+                db2 = cc.Database(ctx, capacity=n_db + 16)
+                db2.set_lanes(1)
+                db2.add_scans(desc_db.contiguous(), ts_db, np.arange(n_db, dtype=np.int32))
+                cc.lib().cc_db_profile_enable(db2.h, 1)
+                db_saved, db = db, db2
+                run_steps(W, min(2, K))
+                torch.cuda.synchronize()
+                ms5 = (C.c_double * 5)()
+                nl2 = C.c_int()
+                cc.lib().cc_db_profile_read(db2.h, ms5, C.byref(nl2))
+                bq = max(nl2.value, 1) / float(B)
+                print("tune-sweep %s=%s: knn %.4f check %.4f merge %.4f gmm %.4f final %.4f (ms per %d queries, isolated)"
+                      % (var, v, ms5[0] / bq, ms5[1] / bq, ms5[2] / bq, ms5[3] / bq, ms5[4] / bq, B), file=sys.stderr)
+                db = db_saved
+                db2.close()
+            os.environ.pop(var, None)
+
     if rank == 0:
         total_scans = K * B * world
         value = total_scans / elapsed
         # ---- roofline of the dominant kernel (HIP-event timed on its launch stream inside the timed region) ----
         d = cc.desc_to_numpy(qdesc2[(K - 1) & 1][:64])
         n_pix = float(d["n_pix"].mean())
+        wl_stats = {"occupied_cells_mean": round(n_pix, 1), "contours_per_level_mean": [round(float(v), 1) for v in d["n_cont"].mean(0)],
+                    "cells_above_level_mean": [round(float(v), 1) for v in d["layer_cell_cnt"].mean(0)],
+                    "inexact_descriptors": int((d["flags"] & 6).astype(bool).sum())}
         # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"): what the step has to move, independent of how.
         #  K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions;
         #  K2 reads those and emits the descriptor used downstream;
@@ -218,8 +267,12 @@ def main():
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic Velodyne-64 scans (64x1875=120000 pts), %d-scan DB, %d query scans/step/GPU, "
-                                   "queries revisit DB places (loop closures found: %d of %d on rank 0)" % (n_db, B, n_found, K * B),
+            "config": {"workload": "synthetic Velodyne-64 scans (64x1875=120000 pts), %s world, %d-scan DB, %d query scans/step/GPU, "
+                                   "queries revisit DB places (loop closures found: %d of %d on rank 0); a step = ingest + query of "
+                                   "the batch, the DB update (addScan/pushAndBalance) is outside the timed step"
+                                   % (args.workload, n_db, B, n_found, K * B),
+                       "world": args.workload, "workload_stats": wl_stats,
+                       "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10, <= 320 contours/level (flagged otherwise)",
                        "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B)[0], "traffic_source": pmc_traffic(dom, B)[1],

@@ -73,6 +73,11 @@ def lib():
         _lib.cc_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_db_profile_enable.argtypes = [C.c_void_p, C.c_int]
         _lib.cc_db_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_check_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_check_hints_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+        _lib.cc_db_set_lanes.argtypes = [C.c_void_p, C.c_int]
     return _lib
 
 

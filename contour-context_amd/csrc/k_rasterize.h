@@ -16,9 +16,7 @@
 
 #define CC_K1_IDX_BITS 21
 #define CC_K1_IDX_MASK 0x1FFFFFull
-#ifndef CC_K1_U
-#define CC_K1_U 4  // points per lane and chunk
-#endif
+#define CC_K1_U_DEFAULT 4  // points per lane and chunk (instances: 4 and 8)
 
 struct cc_k1_scan_out {
   float max_bin_val, min_bin_val;
@@ -46,6 +44,7 @@ __device__ __forceinline__ int cc_wave_sum(int v) {
 }
 
 // grid = n_scans, block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
+template <int CC_K1_U>
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
                float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {

@@ -18,8 +18,17 @@ MAX_RANGE = 80.0
 
 
 class World:
-    def __init__(self, seed=20260926, tile=1000.0, density=1.0 / 150.0, loop_len=1500.0, clearance=5.0):
+    """`dense=True` is the second bench workload (SURVEY.md 8(d) density figures: 4-9 k occupied cells, tens to hundreds
+    of contours per level): ~6x the object density, most of it vegetation-like clutter (thin trunks, bushes) that rays
+    thread through to varied depths, low raised patches (embankments, kerbed lawns) whose tops the downward beams see,
+    and walls/fences; the default world keeps SURVEY's sparse 1 object / 150 m2."""
+
+    def __init__(self, seed=20260926, tile=1000.0, density=1.0 / 150.0, loop_len=1500.0, clearance=5.0, dense=False):
         rng = np.random.Generator(np.random.PCG64(seed))
+        self.dense = bool(dense)
+        if dense:
+            self._init_dense(rng, tile, loop_len, clearance)
+            return
         # road corridor: the sensor path must not run through objects
         rx, ry, _ = trajectory(int(loop_len), step=1.0, loop_len=loop_len, tile=tile, jitter=False)
         n_obj = int(tile * tile * density)
@@ -55,6 +64,88 @@ class World:
         self.loop_len = loop_len
 
 
+def _world_init_dense(self, rng, tile, loop_len, clearance, density=1.0 / 22.0):
+    rx, ry, _ = trajectory(int(loop_len), step=1.0, loop_len=loop_len, tile=tile, jitter=False)
+    # objects only matter within sensor range of the path: a coarse occupancy mask of the corridor keeps the count down
+    g = 20.0
+    ng = int(tile / g) + 1
+    near = np.zeros((ng, ng), bool)
+    gi = np.clip(((rx + tile / 2) / g).astype(int), 0, ng - 1)
+    gj = np.clip(((ry + tile / 2) / g).astype(int), 0, ng - 1)
+    R = int(np.ceil(MAX_RANGE / g)) + 1
+    for di in range(-R, R + 1):
+        for dj in range(-R, R + 1):
+            near[np.clip(gi + di, 0, ng - 1), np.clip(gj + dj, 0, ng - 1)] = True
+    n_obj = int(tile * tile * density)
+    kind = rng.random(n_obj)
+    cx = rng.uniform(-tile / 2, tile / 2, n_obj)
+    cy = rng.uniform(-tile / 2, tile / 2, n_obj)
+    par = rng.random((n_obj, 4))
+    ok = near[np.clip(((cx + tile / 2) / g).astype(int), 0, ng - 1), np.clip(((cy + tile / 2) / g).astype(int), 0, ng - 1)]
+    boxes, cyls = [], []
+    c2 = clearance * clearance
+
+    def clear_of_road(x0, y0, x1, y1):
+        ddx = np.maximum(np.maximum(x0 - rx, rx - x1), 0.0)
+        ddy = np.maximum(np.maximum(y0 - ry, ry - y1), 0.0)
+        return np.min(ddx * ddx + ddy * ddy) > c2
+
+    for i in np.nonzero(ok)[0]:
+        k, x, y = kind[i], cx[i], cy[i]
+        a, b, c, d = par[i]
+        if k < 0.06:  # building
+            sx, sy, h = 5 + 30 * a, 5 + 30 * b, 3 + 17 * c
+            bb = (x - sx / 2, y - sy / 2, 0.0, x + sx / 2, y + sy / 2, h)
+        elif k < 0.14:  # car
+            sx, sy = (4.0, 1.8) if a < 0.5 else (1.8, 4.0)
+            bb = (x - sx / 2, y - sy / 2, 0.0, x + sx / 2, y + sy / 2, 1.5)
+        elif k < 0.22:  # wall / fence / hedge: long and thin
+            ln, th, h = 4 + 16 * a, 0.3 + 0.5 * b, 1.0 + 2.0 * c
+            sx, sy = (ln, th) if d < 0.5 else (th, ln)
+            bb = (x - sx / 2, y - sy / 2, 0.0, x + sx / 2, y + sy / 2, h)
+        elif k < 0.30:  # raised patch: embankment, kerbed lawn
+            sx, sy, h = 4 + 14 * a, 4 + 14 * b, 0.3 + 1.4 * c
+            bb = (x - sx / 2, y - sy / 2, 0.0, x + sx / 2, y + sy / 2, h)
+        else:  # trunk, pole, bush
+            bb = None
+            r = 0.15 + 0.9 * a * a
+            h = 1.0 + 7.0 * b
+            if clear_of_road(x - r, y - r, x + r, y + r):
+                cyls.append((x, y, r, h))
+        if bb is not None and clear_of_road(bb[0], bb[1], bb[3], bb[4]):
+            boxes.append(bb)
+    self.boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 6)
+    self.cyls = np.asarray(cyls, dtype=np.float32).reshape(-1, 4)
+    self.tile = tile
+    self.loop_len = loop_len
+    # terrain relief: a few long waves, +-2.5 m; objects stand on it (bases sunk 1.5 m so nothing floats)
+    nw = 6
+    self.relief = np.stack([rng.uniform(0.25, 0.6, nw), 2 * np.pi / rng.uniform(45.0, 140.0, nw), rng.uniform(0, 2 * np.pi, nw),
+                            2 * np.pi / rng.uniform(45.0, 140.0, nw), rng.uniform(0, 2 * np.pi, nw)], axis=1).astype(np.float32)
+    gb = self.ground(self.boxes[:, [0, 3]].mean(1), self.boxes[:, [1, 4]].mean(1)) if len(self.boxes) else np.zeros(0, np.float32)
+    self.boxes[:, 2] = gb - 1.5
+    self.boxes[:, 5] += gb
+    self.cyl_base = self.ground(self.cyls[:, 0], self.cyls[:, 1]).astype(np.float32) if len(self.cyls) else np.zeros(0, np.float32)
+
+
+def _world_ground(self, x, y):
+    """terrain height at (x, y): numpy or torch arrays"""
+    if self.relief is None:
+        return x * 0
+    is_t = torch.is_tensor(x)
+    sin = torch.sin if is_t else np.sin
+    z = x * 0
+    for a, fx, px_, fy, py_ in self.relief.tolist():
+        z = z + a * sin(fx * x + px_) * sin(fy * y + py_)
+    return z
+
+
+World._init_dense = _world_init_dense
+World.ground = _world_ground
+World.relief = None
+World.cyl_base = None
+
+
 def trajectory(n_scans, step=1.0, loop_len=1500.0, tile=1000.0, seed=7, jitter=True):
     """Closed figure-eight traversed repeatedly at `step` m/scan; each lap is shifted sideways by a
     small seeded offset so revisits are near (not exact) repeats, with crossings at other headings.
@@ -88,8 +179,18 @@ def trajectory(n_scans, step=1.0, loop_len=1500.0, tile=1000.0, seed=7, jitter=T
     return x, y, yaw
 
 
-def _ray_dirs(beams, azim, device):
-    elev = torch.linspace(math.radians(2.0), math.radians(-24.8), beams, device=device, dtype=torch.float32)
+def _ray_dirs(beams, azim, device, hdl64=False, elev_deg=None):
+    if elev_deg is not None:  # another sensor, e.g. MulRan's Ouster OS1-64: (+16.6, -16.6) deg
+        elev = torch.linspace(math.radians(elev_deg[0]), math.radians(elev_deg[1]), beams, device=device, dtype=torch.float32)
+    elif hdl64 and beams % 2 == 0:
+        # the HDL-64E's two laser blocks: upper half 1/3 deg apart from +2 deg, lower half 1/2 deg apart down to -24.33 deg
+        # (more beams reach beyond the first 15 m of ground than with a uniform fan)
+        h = beams // 2
+        up = torch.linspace(2.0, 2.0 - (h - 1) * (10.33 / 31.0) * (32.0 / h), h)
+        lo = torch.linspace(-8.83, -24.33, h)
+        elev = torch.deg2rad(torch.cat([up, lo])).to(device=device, dtype=torch.float32)
+    else:
+        elev = torch.linspace(math.radians(2.0), math.radians(-24.8), beams, device=device, dtype=torch.float32)
     az = torch.arange(azim, device=device, dtype=torch.float32) * (2 * math.pi / azim)
     ce, se = torch.cos(elev)[:, None], torch.sin(elev)[:, None]
     d = torch.stack([ce * torch.cos(az)[None, :], ce * torch.sin(az)[None, :], se.expand(beams, azim)], dim=-1)
@@ -97,15 +198,17 @@ def _ray_dirs(beams, azim, device):
 
 
 @torch.no_grad()
-def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, gen=None, chunk=32768):
+def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, gen=None, chunk=32768, elev_deg=None):
     """One scan at pose=(x, y, yaw). Returns float32 [beams*azim, 4] (x,y,z,intensity) in the sensor frame."""
     px, py, yaw = float(pose[0]), float(pose[1]), float(pose[2])
     dev = torch.device(device)
-    d_s = _ray_dirs(beams, azim, dev)
+    d_s = _ray_dirs(beams, azim, dev, hdl64=getattr(world, "dense", False), elev_deg=elev_deg)
     c, s = math.cos(yaw), math.sin(yaw)
     # world-frame directions
     dw = torch.stack([c * d_s[:, 0] - s * d_s[:, 1], s * d_s[:, 0] + c * d_s[:, 1], d_s[:, 2]], dim=-1)
-    o = torch.tensor([px, py, SENSOR_H], device=dev, dtype=torch.float32)
+    relief = getattr(world, "relief", None) is not None
+    gz = float(world.ground(np.float64(px), np.float64(py))) if relief else 0.0
+    o = torch.tensor([px, py, gz + SENSOR_H], device=dev, dtype=torch.float32)
     # cull objects
     bx = world.boxes
     keep = (bx[:, 3] > px - MAX_RANGE) & (bx[:, 0] < px + MAX_RANGE) & (bx[:, 4] > py - MAX_RANGE) & (bx[:, 1] < py + MAX_RANGE)
@@ -113,13 +216,40 @@ def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, 
     cy = world.cyls
     keepc = (np.abs(cy[:, 0] - px) < MAX_RANGE) & (np.abs(cy[:, 1] - py) < MAX_RANGE)
     cyls = torch.from_numpy(cy[keepc]).to(dev)
+    cbase = torch.from_numpy(world.cyl_base[keepc]).to(dev) if relief else None
+    cid = torch.from_numpy(np.nonzero(keepc)[0]).to(dev) if relief else None
     N = dw.shape[0]
     t_best = torch.full((N,), float("inf"), device=dev)
     for i0 in range(0, N, chunk):
         d = dw[i0:i0 + chunk]
         tb = torch.full((d.shape[0],), float("inf"), device=dev)
-        # ground plane z = 0
-        tg = torch.where(d[:, 2] < -1e-6, -SENSOR_H / d[:, 2], torch.full_like(d[:, 2], float("inf")))
+        if not relief:
+            # ground plane z = 0
+            tg = torch.where(d[:, 2] < -1e-6, -SENSOR_H / d[:, 2], torch.full_like(d[:, 2], float("inf")))
+        else:
+            # terrain: all 0.5 m march samples of a ray at once, first sample below ground, linear interpolation, then
+            # two secant refinements
+            ns = int(MAX_RANGE / 0.5)
+            tt = torch.arange(1, ns + 1, device=dev, dtype=torch.float32) * 0.5                       # [ns]
+            fx = o[0] + d[:, 0:1] * tt[None, :]
+            fy = o[1] + d[:, 1:2] * tt[None, :]
+            f = o[2] + d[:, 2:3] * tt[None, :] - world.ground(fx, fy)                                  # [n, ns]
+            below = f <= 0
+            anyb = below.any(dim=1)
+            first = torch.argmax(below.to(torch.uint8), dim=1)                                         # first sample below ground
+            f1 = torch.gather(f, 1, first[:, None])[:, 0]
+            f0 = torch.where(first > 0, torch.gather(f, 1, (first - 1).clamp(min=0)[:, None])[:, 0], torch.full_like(f1, SENSOR_H))
+            t1 = tt[first]
+            t0 = t1 - 0.5
+            ts_ = t0 + 0.5 * f0 / (f0 - f1).clamp(min=1e-6)
+            del f, fx, fy, below
+            for _ in range(2):
+                fa = o[2] + ts_ * d[:, 2] - world.ground(o[0] + ts_ * d[:, 0], o[1] + ts_ * d[:, 1])
+                e = 0.05
+                fb = o[2] + (ts_ + e) * d[:, 2] - world.ground(o[0] + (ts_ + e) * d[:, 0], o[1] + (ts_ + e) * d[:, 1])
+                df = (fb - fa) / e
+                ts_ = ts_ - fa / torch.where(df.abs() < 1e-4, torch.full_like(df, -1e-4), df)
+            tg = torch.where(anyb, ts_.clamp(min=0.0), torch.full_like(ts_, float("inf")))
         tb = torch.minimum(tb, tg)
         if boxes.shape[0]:
             inv = 1.0 / torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)  # [n,3]
@@ -141,7 +271,15 @@ def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, 
             sq = torch.sqrt(torch.clamp(disc, min=0))
             tc = (-b - sq) / (2 * a + 1e-12)
             z = o[2] + tc * d[:, 2:3]
-            ok = (disc > 0) & (tc > 0) & (z >= 0) & (z <= cyls[None, :, 3])
+            if relief:
+                ok = (disc > 0) & (tc > 0) & (z >= cbase[None, :] - 1.5) & (z <= cbase[None, :] + cyls[None, :, 3])
+                # foliage is porous: a ray is stopped by a bush / crown (r > 0.45 m) with probability 0.3, decided by an
+                # integer hash of (ray, object) so that a scan is reproducible
+                ridx = torch.arange(i0, i0 + d.shape[0], device=dev, dtype=torch.int64)[:, None]
+                hsh = ((ridx * 2654435761 + cid[None, :] * 40503 + 12345) >> 7) & 1023
+                ok = ok & ((cyls[None, :, 2] <= 0.45) | (hsh < 307))
+            else:
+                ok = (disc > 0) & (tc > 0) & (z >= 0) & (z <= cyls[None, :, 3])
             tc = torch.where(ok, tc, torch.full_like(tc, float("inf")))
             tb = torch.minimum(tb, tc.amin(dim=1))
         t_best[i0:i0 + chunk] = tb
@@ -162,7 +300,7 @@ def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, 
 
 
 def make_sequence(n_scans, beams=64, azim=1875, device="cpu", seed=20260926, step=1.0, loop_len=1500.0,
-                  start=0, world=None, noise_sigma=0.02):
+                  start=0, world=None, noise_sigma=0.02, elev_deg=None):
     """Scans `start .. start+n_scans-1` of the seeded trajectory: returns (xyzi [n, P, 4] f32, poses [n,3], ts [n])."""
     world = world or World(seed, loop_len=loop_len)
     total = start + n_scans
@@ -171,7 +309,7 @@ def make_sequence(n_scans, beams=64, azim=1875, device="cpu", seed=20260926, ste
     out = []
     for i in range(start, total):
         gen.manual_seed(seed * 1000003 + i)
-        out.append(cast_scan(world, (x[i], y[i], yaw[i]), beams, azim, device, noise_sigma, gen))
+        out.append(cast_scan(world, (x[i], y[i], yaw[i]), beams, azim, device, noise_sigma, gen, elev_deg=elev_deg))
     xyzi = torch.stack(out, dim=0)
     poses = np.stack([x[start:total], y[start:total], yaw[start:total]], axis=1)
     ts = np.arange(start, total, dtype=np.float64) / 10.0

@@ -76,3 +76,42 @@ def test_ingest_host_matches_device(cc, oracle):
     o = oracle.Scan(scans[0])
     assert not compare_desc(o.desc()[0], out[0], float_exact=False)
     ctx.close()
+
+
+def _mulran_cfg(L):
+    """config/batch_bin_test_config.yaml:31 (MulRan, Ouster-64): the alternative level set."""
+    cfg = L.default_manager_cfg()
+    for i, v in enumerate([1.0, 2.5, 4.0, 5.5, 7.0, 8.5]):
+        cfg.lv_grads[i] = v
+    return cfg
+
+
+def test_ingest_mulran_level_set(cc, oracle):
+    """BASELINE config 4's manager configuration on full-size synthetic scans and on tall terrain."""
+    cfg = _mulran_cfg(cc.L)
+    w = cc.synth.World(loop_len=200.0)
+    xyzi, _, _ = cc.synth.make_sequence(2, world=w, device="cuda", start=40, beams=64, azim=1024, elev_deg=(16.6, -16.6))
+    scans = [xyzi[i].cpu().numpy() for i in range(2)] + [terrain_scan(12, n=6000, scale=5.0, quant=0.5), terrain_scan(3, n=40000, scale=4.0)]
+    report, d = _run(cc, oracle, scans, cfg=cfg)
+    assert not report, "\n".join(report[:40])
+    assert (d["n_cont"][2:, 5] > 0).all()
+
+
+def test_ingest_dense_world(cc, oracle):
+    """The cluttered bench world (bench.py --workload dense): tens of contours on every level."""
+    w = cc.synth.World(dense=True)
+    xyzi, _, _ = cc.synth.make_sequence(3, world=w, device="cuda", start=5000)
+    scans = [xyzi[i].cpu().numpy() for i in range(3)]
+    report, d = _run(cc, oracle, scans)
+    assert not report, "\n".join(report[:40])
+    assert (d["flags"] == 0).all() and d["n_cont"][:, :3].min() >= 20
+
+
+def test_ingest_min_cont_cell_cnt_and_nan(cc, oracle):
+    cfg = cc.L.default_manager_cfg()
+    cfg.min_cont_cell_cnt = 6
+    s = terrain_scan(2, n=20000, scale=1.2)
+    s2 = s.copy()
+    s2[::7, 2] = np.nan
+    report, _ = _run(cc, oracle, [s, s2], cfg=cfg)
+    assert not report, "\n".join(report[:40])

@@ -114,3 +114,57 @@ def test_golden_query_fixture(cc):
     assert (exp["n_res"] > 0).sum() == 31
     for i in range(n):
         _same_result(exp[i], got[i], 1e-4)
+
+
+def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10):
+    import torch
+    n, P = xyzi.shape[0], xyzi.shape[1]
+    offs = np.arange(n + 1, dtype=np.int64) * P
+    seeds = np.arange(n, dtype=np.int32)
+    ctx = cc.Context(0, mcfg, max_batch=128)
+    desc = ctx.ingest(xyzi.reshape(-1, 4), offs)
+    db = cc.Database(ctx, cfg=dcfg, capacity=n)
+    db.add_scans(desc, ts, seeds)
+    res = db.query(desc, seeds)
+    torch.cuda.synchronize()
+    d = cc.desc_to_numpy(desc)
+    assert (d["flags"] == 0).all()
+    ores, _, odesc = oracle.run_sequence(xyzi.cpu().numpy().reshape(-1, 4), offs, ts, seeds, mcfg=mcfg, dcfg=dcfg, want_desc=True)
+    assert (ores["n_res"] > 0).sum() >= min_hits, "sequence should contain loop closures (%d)" % (ores["n_res"] > 0).sum()
+    bad = []
+    for i in range(n):
+        for f in INT_FIELDS:
+            if ores[f][i] != res[f][i]:
+                bad.append("query %d: %s oracle=%d got=%d" % (i, f, ores[f][i], res[f][i]))
+        if ores["n_res"][i]:
+            if abs(ores["correlation"][i] - res["correlation"][i]) > 1e-4:
+                bad.append("query %d: correlation %g vs %g" % (i, ores["correlation"][i], res["correlation"][i]))
+            if np.abs(ores["tf"][i] - res["tf"][i]).max() > 1e-4:
+                bad.append("query %d: tf %s vs %s" % (i, ores["tf"][i], res["tf"][i]))
+    assert not bad, "%d mismatches\n" % len(bad) + "\n".join(bad[:40])
+    db.close()
+    ctx.close()
+    return ores, res
+
+
+def test_sequence_mulran_config(cc, oracle):
+    """BASELINE config 4's parameters (config/batch_bin_test_config.yaml:30-31, the MulRan variant): lv_grads_ =
+    [1.0, 2.5, 4.0, 5.5, 7.0, 8.5] and ta_h_bar = 0.75, on a looping full-size sequence."""
+    L = cc.L
+    mcfg = L.default_manager_cfg()
+    for i, v in enumerate([1.0, 2.5, 4.0, 5.5, 7.0, 8.5]):
+        mcfg.lv_grads[i] = v
+    dcfg = L.default_db_cfg()
+    dcfg.cont_sim.ta_h_bar = 0.75
+    w = cc.synth.World(loop_len=200.0)
+    # MulRan's sensor: Ouster OS1-64, 64 x 1024 rays, +-16.6 deg (a Velodyne's +2 deg never sees above 4.6 m inside the BEV,
+    # so the taller level set would stay empty)
+    xyzi, poses, ts = cc.synth.make_sequence(330, world=w, device="cuda", beams=64, azim=1024, elev_deg=(16.6, -16.6))
+    ores, _ = _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=mcfg, dcfg=dcfg)
+
+
+def test_sequence_dense_world(cc, oracle):
+    """The cluttered bench world (bench.py --workload dense, tens of contours per level) on a 150 m loop."""
+    w = cc.synth.World(dense=True, loop_len=150.0)
+    xyzi, poses, ts = cc.synth.make_sequence(330, world=w, device="cuda")
+    _seq_vs_oracle(cc, oracle, xyzi, ts)
