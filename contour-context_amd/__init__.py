@@ -21,8 +21,8 @@ import layouts as L  # noqa: E402
 import synth  # noqa: E402,F401
 
 LIB_PATH = os.path.join(_HERE, "libcont2_amd.so")
-_SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "k_rasterize.h", "k_contours.h",
-         "k_query.h", "cc_hostdb.h", "cc_db_api.inc"]
+_SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_group.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "k_rasterize.h", "k_contours.h",
+         "k_knn.h", "k_check.h", "k_merge.h", "k_gmm.h", "cc_hostdb.h", "cc_db_api.inc"]
 
 
 def build(force=False, verbose=False):
@@ -43,7 +43,8 @@ _lib = None
 # every symbol include/cont2_amd.h declares
 EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-           "cc_db_add_scans", "cc_db_query_batch", "cc_db_desc_ptr", "cc_db_bucket_state", "cc_est_sens_tf",
+           "cc_db_add_scans", "cc_db_query_batch", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
+           "cc_packed_sizes", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
            "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host"]
@@ -65,8 +66,13 @@ def lib():
         _lib.cc_db_size.argtypes = [C.c_void_p]
         _lib.cc_db_add_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_db_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
-        _lib.cc_db_desc_ptr.argtypes = [C.c_void_p]
-        _lib.cc_db_desc_ptr.restype = C.c_void_p
+        for f in ("cc_db_hot_ptr", "cc_db_feat_ptr"):
+            getattr(_lib, f).argtypes = [C.c_void_p]
+            getattr(_lib, f).restype = C.c_void_p
+        _lib.cc_packed_sizes.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.cc_packed_sizes.restype = None
+        _lib.cc_pack_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_db_bucket_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_est_sens_tf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.cc_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -95,6 +101,12 @@ class IngestDebug(C.Structure):
 
 
 DESC_BYTES = L.scan_desc_dt.itemsize
+
+
+def packed_sizes():
+    hb, fb = C.c_size_t(), C.c_size_t()
+    lib().cc_packed_sizes(C.byref(hb), C.byref(fb))
+    return int(hb.value), int(fb.value)
 
 
 class Context:
@@ -143,6 +155,18 @@ class Context:
         _chk(lib().cc_ingest_batch(self.h, xyzi.data_ptr(), offsets.ctypes.data, n, out.data_ptr(), dbg_p, stream),
              "cc_ingest_batch")
         return (out, dbg) if debug else out
+
+    def pack(self, desc):
+        """Full descriptors (torch uint8 CUDA [n, DESC_BYTES]) -> (hot [n, HOT_BYTES], feat [n, FEAT_BYTES]): the compact
+        per-scan records the database keeps and the ranks exchange (35 KB instead of 169 KB per scan)."""
+        import torch
+        n = desc.shape[0]
+        hb, fb = packed_sizes()
+        hot = torch.empty((n, hb), dtype=torch.uint8, device=desc.device)
+        feat = torch.empty((n, fb), dtype=torch.uint8, device=desc.device)
+        stream = torch.cuda.current_stream(desc.device).cuda_stream
+        _chk(lib().cc_pack_scans(self.h, desc.data_ptr(), n, hot.data_ptr(), feat.data_ptr(), stream), "cc_pack_scans")
+        return hot, feat
 
     def ingest_host(self, xyzi, offsets):
         xyzi = np.ascontiguousarray(xyzi, np.float32)
@@ -214,6 +238,19 @@ class Database:
         if want_knn:
             return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
         return res
+
+    def add_packed(self, hot, feat, ts, seeds):
+        """hot / feat: torch uint8 CUDA [n, HOT_BYTES] / [n, FEAT_BYTES] as produced by Context.pack (possibly gathered from
+        other ranks).  Same effect as add_scans on the full descriptors."""
+        import torch
+        ts = np.ascontiguousarray(ts, np.float64)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        n = hot.shape[0]
+        assert hot.is_cuda and feat.is_cuda and hot.is_contiguous() and feat.is_contiguous() and feat.shape[0] == n
+        assert len(ts) == n and len(seeds) == n
+        stream = torch.cuda.current_stream(hot.device).cuda_stream
+        _chk(lib().cc_db_add_packed(self.h, hot.data_ptr(), feat.data_ptr(), n, ts.ctypes.data, seeds.ctypes.data, stream),
+             "cc_db_add_packed")
 
     def check_hints(self, qdesc, hints, lb=None, ub=None, max_fine_opt=10):
         """CandidateManager driven by explicit hints (checkCandWithHint in the given order, tidyUpCandidates, fineOptimize).

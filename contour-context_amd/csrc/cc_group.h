@@ -1,0 +1,130 @@
+// 16-lane group collectives.  The query-side kernels give one candidate check / one correlation problem to a group of
+// 16 lanes (a DPP "row"), four groups per wave; the groups of a wave may sit in different branches, so every
+// collective below involves only the caller's own row:
+//   * ballots: the wave-wide v_cmp mask, shifted to the row's 16 bits (inactive rows contribute zeros to a mask nobody
+//     reads);
+//   * prefix sums / reductions: DPP row_shr, quad_perm and row_mirror moves (register-to-register, no LDS crossbar);
+//   * broadcast of one lane's value: ds_bpermute through __shfl(width 16).
+// CC_EMU (defined only by the CPU test harness' stand-in for <hip/hip_runtime.h>) selects plain width-16 shuffles, which
+// is what that harness can rendezvous on; the product build never sees it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CC_G 16
+
+#ifndef CC_EMU
+// LDS hand-off between the lanes of one group: a wave's lanes run in lockstep and its LDS operations complete in
+// order, so only the compiler has to be kept from reordering across the hand-off.
+__device__ __forceinline__ void cc_group_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+template <int CTRL>
+__device__ __forceinline__ int cc_dpp_i(int v) {  // out-of-row sources read as 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double cc_dpp_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = cc_dpp_i<CTRL>((int)(b & 0xFFFFFFFFll)), hi = cc_dpp_i<CTRL>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+#define CC_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define CC_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define CC_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i inside each half row
+#define CC_DPP_MIRROR 0x140       // lane i <-> 15 - i inside the row
+
+// bit i = pred of group lane i
+__device__ __forceinline__ unsigned cc_group_ballot(bool pred) {
+  const unsigned long long m = __ballot(pred);
+  return (unsigned)(m >> (threadIdx.x & 48u)) & 0xFFFFu;
+}
+// inclusive prefix sum over the group's lanes
+__device__ __forceinline__ int cc_group_scan_incl(int v) {
+  v += cc_dpp_i<0x111>(v);  // row_shr:1
+  v += cc_dpp_i<0x112>(v);
+  v += cc_dpp_i<0x114>(v);
+  v += cc_dpp_i<0x118>(v);
+  return v;
+}
+// sum over the group, result in every lane
+__device__ __forceinline__ int cc_group_sum_i(int v) {
+  v += cc_dpp_i<CC_DPP_XOR1>(v);
+  v += cc_dpp_i<CC_DPP_XOR2>(v);
+  v += cc_dpp_i<CC_DPP_HALF_MIRROR>(v);
+  v += cc_dpp_i<CC_DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ double cc_group_sum_d(double v) {
+  v += cc_dpp_d<CC_DPP_XOR1>(v);
+  v += cc_dpp_d<CC_DPP_XOR2>(v);
+  v += cc_dpp_d<CC_DPP_HALF_MIRROR>(v);
+  v += cc_dpp_d<CC_DPP_MIRROR>(v);
+  return v;
+}
+// lexicographic (larger a, then smaller b) over the group, result in every lane
+__device__ __forceinline__ void cc_group_best(int &a, int &b) {
+#define CC_GB_STEP(CTRL)                                   \
+  {                                                        \
+    const int oa = cc_dpp_i<CTRL>(a), ob = cc_dpp_i<CTRL>(b); \
+    if (oa > a || (oa == a && ob < b)) {                   \
+      a = oa;                                              \
+      b = ob;                                              \
+    }                                                      \
+  }
+  CC_GB_STEP(CC_DPP_XOR1)
+  CC_GB_STEP(CC_DPP_XOR2)
+  CC_GB_STEP(CC_DPP_HALF_MIRROR)
+  CC_GB_STEP(CC_DPP_MIRROR)
+#undef CC_GB_STEP
+}
+// value of group lane `src` (any lane-varying or uniform index 0..15)
+template <typename T>
+__device__ __forceinline__ T cc_group_bcast(T v, int src) {
+  return __shfl(v, src, CC_G);
+}
+#else  // ---------------------------------------------------------------- CPU test harness
+__device__ __forceinline__ void cc_group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  (void)__shfl(0, 0, CC_G);  // rendezvous of the group's 16 OS threads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ __forceinline__ unsigned cc_group_ballot(bool pred) {
+  const int sl = threadIdx.x & 15;
+  int v = pred ? (1 << sl) : 0;
+  for (int o = 1; o < CC_G; o <<= 1) v |= __shfl_xor(v, o, CC_G);
+  return (unsigned)v;
+}
+__device__ __forceinline__ int cc_group_scan_incl(int v) {
+  const int sl = threadIdx.x & 15;
+  for (int o = 1; o < CC_G; o <<= 1) {
+    const int t = __shfl_up(v, o, CC_G);
+    if (sl >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int cc_group_sum_i(int v) {
+  for (int o = 1; o < CC_G; o <<= 1) v += __shfl_xor(v, o, CC_G);
+  return v;
+}
+__device__ __forceinline__ double cc_group_sum_d(double v) {
+  // same association as the DPP form: xor 1, xor 2, then the two mirror steps pair up the same partial sums
+  v += __shfl_xor(v, 1, CC_G);
+  v += __shfl_xor(v, 2, CC_G);
+  const int sl = threadIdx.x & 15;
+  v += __shfl(v, (sl & 8) | (7 - (sl & 7)), CC_G);
+  v += __shfl(v, 15 - sl, CC_G);
+  return v;
+}
+__device__ __forceinline__ void cc_group_best(int &a, int &b) {
+  for (int o = 1; o < CC_G; o <<= 1) {
+    const int oa = __shfl_xor(a, o, CC_G), ob = __shfl_xor(b, o, CC_G);
+    if (oa > a || (oa == a && ob < b)) {
+      a = oa;
+      b = ob;
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ T cc_group_bcast(T v, int src) {
+  return __shfl(v, src, CC_G);
+}
+#endif

@@ -127,22 +127,22 @@ __device__ __forceinline__ int unguarded_partition_pivot(T *a, int first, int la
   }
 }
 
-// std::sort(a, a + n, less)
+// std::sort(a, a + n, less).  n < 4096.  `stk`: CC_SORT_STACK words of caller-provided storage (LDS; one per sorting
+// lane) for the pending (cut, last) halves of __introsort_loop -- at most 2*floor(log2 n) + 1 of them, packed as
+// first | last << 12 | depth << 24 -- so that no lane-indexed array ends up in scratch memory.
+#define CC_SORT_STACK 26
 template <typename T, typename Less>
-__device__ void std_sort(T *a, int n, Less less) {
+__device__ void std_sort(T *a, int n, Less less, unsigned *stk) {
   if (n <= 0) return;
-  // __introsort_loop with an explicit stack for the recursive (cut, last) halves
-  int stk_first[40], stk_last[40], stk_depth[40];
   int sp = 0;
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) lg++;
-  stk_first[0] = 0;
-  stk_last[0] = n;
-  stk_depth[0] = lg * 2;
+  stk[0] = 0u | ((unsigned)n << 12) | ((unsigned)(lg * 2) << 24);
   sp = 1;
   while (sp > 0) {
     --sp;
-    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    const unsigned w_ = stk[sp];
+    int first = (int)(w_ & 0xFFFu), last = (int)((w_ >> 12) & 0xFFFu), depth = (int)(w_ >> 24);
     // The reference recursion is: loop { cut = partition; introsort_loop(cut, last); last = cut; }
     // i.e. the RIGHT part is fully processed before the left part continues.  Disjoint ranges are
     // independent, so the order in which they are processed does not change the result.
@@ -153,9 +153,7 @@ __device__ void std_sort(T *a, int n, Less less) {
       }
       --depth;
       int cut = unguarded_partition_pivot(a, first, last, less);
-      stk_first[sp] = cut;
-      stk_last[sp] = last;
-      stk_depth[sp] = depth;
+      stk[sp] = (unsigned)cut | ((unsigned)last << 12) | ((unsigned)depth << 24);
       ++sp;
       last = cut;
     }
@@ -167,6 +165,13 @@ __device__ void std_sort(T *a, int n, Less less) {
   } else {
     insertion_sort(a, 0, n, less);
   }
+}
+
+// same, with the pending-halves stack in the lane's private memory (callers outside the hot kernels)
+template <typename T, typename Less>
+__device__ void std_sort(T *a, int n, Less less) {
+  unsigned stk[CC_SORT_STACK];
+  std_sort(a, n, less, stk);
 }
 
 }  // namespace ccsort

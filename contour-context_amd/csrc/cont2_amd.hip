@@ -18,7 +18,10 @@
 #include "cc_hostcfg.h"
 #include "k_rasterize.h"
 #include "k_contours.h"
-#include "k_query.h"
+#include "k_knn.h"
+#include "k_check.h"
+#include "k_merge.h"
+#include "k_gmm.h"
 #include "cc_hostdb.h"
 
 #ifndef CC_INGEST_BLOCK

@@ -1,0 +1,1003 @@
+// K5 / K6 -- GMM-L2 correlation (GMMPair / ConstellCorrelation, correlation.h:42-238), the candidates fineOptimize refines
+// and the final selection (contour_db.h:560-648).
+//
+//   cc_k_gmm_prep    per scan, once: the ellipses GMMPair's ctor selects and the scan's auto-correlation term
+//   cc_k_gmm_init    every (query, candidate) problem: pair pre-selection and the initial correlation in one sweep over
+//                    the ellipse grid -- nothing is stored but the correlation and the pair count
+//   cc_k_select      the <= max_fine_opt_ candidates per query the reference refines, split by pair count
+//   cc_k_gmm_refine  those problems: the selected pairs' constants are written to a pool (64 B per pair, streamed
+//                    coalesced by every evaluation), then Ceres' LineSearchMinimizer restated (L-BFGS + Wolfe / cubic).
+//                    Two instances: 16 lanes per problem (4 problems per wave) and 64 lanes for the long pair lists.
+//   cc_k_final       tidyUp compaction, fineOptimize ordering, result record
+// No capacity anywhere on this path: ellipse tables are read where they lie, pair lists take what they need of the pool.
+#pragma once
+#include "cc_dev.h"
+#include "cc_group.h"
+#include "cc_sort.h"
+#include "k_merge.h"
+
+#define CC_GMM_ECAP_L 128  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat)
+#define CC_GMM_G16_MAX_PAIRS 96  // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above
+
+struct cc_gmm_result {
+  double corr_init;
+  double corr_opt;
+  double tf_opt[3];
+  int optimized;   // 0: init correlation below the bar (no refinement)
+  int iterations;
+  int termination;
+  int flags;       // bit0: a scan kept only its first CC_GMM_ECAP_L ellipses of a level, bit1: the pair pool was full,
+                   // bit2: contour table truncated (CC_MAXC)
+  int n_pairs;     // selected (src, tgt) ellipse pairs
+  int pad;
+};
+
+struct cc_ell {  // values are f32 in the reference too (getManualCov, pos_mean_, cell_cnt_), widened to f64 at use
+  float c00, c01, c10, c11, mx, my, w, maj;
+};
+
+// Per-scan inputs of the correlation, computed once per scan instead of once per (query, candidate) pair: the ellipses
+// GMMPair's ctor selects (correlation.h:49-82) and the scan's auto-correlation term (correlation.h:102-119).
+struct cc_gmm_feat {
+  int n_ell[CC_GMM_LEVELS];
+  int flags;  // bit0: more than CC_GMM_ECAP_L ellipses on a level, bit2: a needed contour was not stored in the descriptor
+  int pad[3];
+  double ac;  // sum over levels and ordered ellipse pairs (i, j) of the self term
+  cc_ell ell[CC_GMM_LEVELS][CC_GMM_ECAP_L];
+};
+
+// grid = n scans, block = 64
+__global__ void __launch_bounds__(64)
+cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__restrict__ feat) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const cc_scan_desc_t *d = desc + blockIdx.x;
+  cc_gmm_feat *F = feat + blockIdx.x;
+  __shared__ cc_ell E[CC_GMM_ECAP_L];
+  int flags = 0;
+  double acc = 0;
+  for (int li = 0; li < CC_GMM_LEVELS; li++) {
+    const int lev = li + 1;  // GMMOptConfig::levels_ = {1,2,3,4}
+    const int full = d->layer_cell_cnt[lev];
+    const int ncont = d->n_cont[lev], nst = d->n_stored[lev];
+    // contours in sorted order until >= 95 % of the level's cells: contour j is used iff the cells before it are < 95 %
+    int n_use = 0, run = 0;
+    for (int j0 = 0; j0 < ncont; j0 += 64) {
+      const int j = j0 + lane;
+      const int cnt = (j < ncont && j < nst) ? d->cont[lev][j].cell_cnt : 0;
+      int incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const int before = run + incl - cnt;
+      const bool use = j < ncont && !((double)before * 1.0 / (double)full >= 0.95);
+      const unsigned long long m = __ballot(use);
+      if (__ballot(use && j >= nst)) flags |= 4;
+      n_use += __popcll(m);
+      run += __shfl(incl, 63);
+      if (m != ~0ull) break;  // the used contours are a prefix
+    }
+    if (n_use > nst) n_use = nst;
+    if (n_use > CC_GMM_ECAP_L) {
+      n_use = CC_GMM_ECAP_L;
+      flags |= 1;
+    }
+    __syncthreads();
+    for (int j = lane; j < n_use; j += 64) {
+      const cc_contour_t &cv = d->cont[lev][j];
+      // getManualCov (contour.h:376-378) in f32; the reference then casts to double
+      const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
+      const float e0 = cv.eig_vals[0], e1 = cv.eig_vals[1];
+      const float a00 = v00 * e0, a01 = v01 * e1, a10 = v10 * e0, a11 = v11 * e1;
+      cc_ell e;
+      e.c00 = a00 * v00 + a01 * v01;
+      e.c01 = a00 * v10 + a01 * v11;
+      e.c10 = a10 * v00 + a11 * v01;
+      e.c11 = a10 * v10 + a11 * v11;
+      e.mx = cv.pos_mean[0];
+      e.my = cv.pos_mean[1];
+      e.w = (float)cv.cell_cnt;
+      e.maj = sqrtf(e1);
+      E[j] = e;
+      F->ell[li][j] = e;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < n_use * n_use; idx += 64) {
+      const int i = idx / n_use, j = idx - i * n_use;
+      const cc_ell a = E[i], b = E[j];
+      const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
+      const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
+      const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
+      const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
+      const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
+      const double h0 = -0.5 * mx, h1 = -0.5 * my;
+      const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
+      acc += (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+    }
+    if (lane == 0) F->n_ell[li] = n_use;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    F->ac = acc;
+    F->flags = flags;
+  }
+}
+
+// LDS view of one problem (pointers into the dynamic LDS block, sized by the kernel instance).  A wave handles 64/G
+// problems at once, G lanes each (G = 16 for the common instance, 64 for the large-cap instance); every cross-lane
+// operation below is G-wide, so problems in the same wave may diverge freely.
+
+// One selected (src, tgt) ellipse pair as the evaluations read it: the f32 values of the two cc_ell records.
+struct cc_gpair {
+  float s00, s01, s10, s11, t00, t01, t10, t11;
+  float smx, smy, tmx, tmy, sw, tw, pad0, pad1;
+};  // 64 B
+static_assert(sizeof(cc_gpair) == 64, "four 16-byte loads per pair");
+
+// sum over the lanes of a problem, result in every lane
+template <int G>
+__device__ __forceinline__ double cc_gsum(double v) {
+  if (G == 64) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+  }
+  return cc_group_sum_d(v);
+}
+
+// One term of GMMPair::operator() (correlation.h:123-160) and its gradient, in closed form.  The reference builds the
+// same function from ceres::Jet arithmetic; here the rotation is applied analytically:
+//   R C R^T = m I + [p q; q -p] + a J     m = (c00+c11)/2, d = (c00-c11)/2, b = (c01+c10)/2, a = (c10-c01)/2,
+//                                         p = d cos2t - b sin2t, q = d sin2t + b cos2t,  dp/dt = -2q, dq/dt = 2p
+//   N = 2 (R C_s R^T + C_t),  mu = R m_s + t - m_t,  E = mu^T adj(N) mu,  Q = -E / (2 det N)
+//   term = -w_s w_t / sqrt(det N) * exp(Q)
+// Same value and derivatives as the Jet evaluation up to f64 rounding of the individual terms.
+struct cc_gterm {
+  double v, gx, gy, gt;
+};
+__device__ __forceinline__ cc_gterm cc_gmm_term(const cc_gpair &P, double px, double py, double c, double s, double c2, double s2) {
+  const double sm = 0.5 * ((double)P.s00 + (double)P.s11), sd = 0.5 * ((double)P.s00 - (double)P.s11);
+  const double sb = 0.5 * ((double)P.s01 + (double)P.s10), sa = 0.5 * ((double)P.s10 - (double)P.s01);
+  const double p = sd * c2 - sb * s2, q = sd * s2 + sb * c2;
+  const double n00 = 2.0 * (sm + p + (double)P.t00), n11 = 2.0 * (sm - p + (double)P.t11);
+  const double n01 = 2.0 * (q - sa + (double)P.t01), n10 = 2.0 * (q + sa + (double)P.t10);
+  const double nx = n01 + n10;
+  const double det = n00 * n11 - n01 * n10;
+  const double ddet = 4.0 * (q * (n00 - n11) - p * nx);
+  const double g0 = -s * (double)P.smx - c * (double)P.smy, g1 = c * (double)P.smx - s * (double)P.smy;  // d mu / d theta
+  const double m0 = g1 + px - (double)P.tmx, m1 = -g0 + py - (double)P.tmy;
+  const double E = m0 * m0 * n11 - m0 * m1 * nx + m1 * m1 * n00;
+  const double dE = 2.0 * m0 * g0 * n11 + m0 * m0 * (4.0 * q) - (g0 * m1 + m0 * g1) * nx - m0 * m1 * (8.0 * p) + 2.0 * m1 * g1 * n00 -
+                    m1 * m1 * (4.0 * q);
+  const double idet = 1.0 / det;
+  const double Q = -0.5 * E * idet;
+  const double v = -((double)P.tw * (double)P.sw) / sqrt(det) * exp(Q);
+  cc_gterm r;
+  r.v = v;
+  r.gx = v * (-0.5 * idet * (2.0 * m0 * n11 - m1 * nx));
+  r.gy = v * (-0.5 * idet * (2.0 * m1 * n00 - m0 * nx));
+  r.gt = v * (-0.5 * dE * idet - Q * ddet * idet - 0.5 * ddet * idet);
+  return r;
+}
+
+// the pair pre-selection test of GMMPair's ctor (correlation.h:85-96) at T_init = (tx, ty, rotation ct0/st0)
+__device__ __forceinline__ bool cc_gmm_pair_sel(const cc_ell &es, float tmx, float tmy, float tmaj, double ct0, double st0, double tx,
+                                                double ty) {
+  const double dx = (ct0 * (double)es.mx + (-st0) * (double)es.my + tx) - (double)tmx;
+  const double dy = (st0 * (double)es.mx + ct0 * (double)es.my + ty) - (double)tmy;
+  return sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + tmaj);
+}
+__device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_ell &et) {
+  cc_gpair P;
+  P.s00 = es.c00;
+  P.s01 = es.c01;
+  P.s10 = es.c10;
+  P.s11 = es.c11;
+  P.t00 = et.c00;
+  P.t01 = et.c01;
+  P.t10 = et.c10;
+  P.t11 = et.c11;
+  P.smx = es.mx;
+  P.smy = es.my;
+  P.tmx = et.mx;
+  P.tmy = et.my;
+  P.sw = es.w;
+  P.tw = et.w;
+  P.pad0 = P.pad1 = 0.f;
+  return P;
+}
+
+// K5a: initial correlation of every problem (tryProblem, correlation.h:196-202).  16 lanes per problem: a lane owns the
+// src ellipses sl, sl + 16, ... of a level and walks the level's tgt ellipses (the same address in all lanes: one
+// broadcast load); a selected pair's term is evaluated on the spot.
+// grid = any (grid-stride over the device-side problem count), block = 64
+__global__ void __launch_bounds__(64)
+cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap,
+              const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
+  const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
+  int n_prob = *n_prob_p;
+  if (n_prob > prob_cap) n_prob = prob_cap;
+  for (int pidx = blockIdx.x * (64 / CC_G) + sub; pidx < n_prob; pidx += gridDim.x * (64 / CC_G)) {
+    const cc_gmm_problem pb = probs[pidx];
+    const cc_gmm_feat *fsrc = db_feat + pb.gidx;
+    const cc_gmm_feat *ftgt = qfeat + pb.q;
+    const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
+    const double c2 = ct0 * ct0 - st0 * st0, s2 = 2.0 * st0 * ct0;
+    double acc = 0.0;
+    int np = 0;
+    for (int li = 0; li < CC_GMM_LEVELS; li++) {
+      const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
+      for (int si = sl; si < ns; si += CC_G) {
+        const cc_ell es = fsrc->ell[li][si];
+        for (int ti = 0; ti < ntg; ti++) {
+          const cc_ell *pt = &ftgt->ell[li][ti];
+          if (cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1])) {
+            const cc_gpair P = cc_gmm_make_pair(es, *pt);
+            acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
+            np++;
+          }
+        }
+      }
+    }
+    const double cost = cc_group_sum_d(acc);
+    np = cc_group_sum_i(np);
+    if (sl == 0) {
+      cc_gmm_result R;
+      R.corr_init = -cost / sqrt(fsrc->ac * ftgt->ac);
+      R.corr_opt = R.corr_init;
+      R.tf_opt[0] = pb.tf[0];
+      R.tf_opt[1] = pb.tf[1];
+      R.tf_opt[2] = pb.tf[2];
+      R.optimized = 0;
+      R.iterations = 0;
+      R.termination = 0;
+      R.flags = (fsrc->flags | ftgt->flags) & 5;
+      R.n_pairs = np;
+      R.pad = 0;
+      results[pidx] = R;
+    }
+  }
+}
+
+// hand-off between the G lanes of a problem through memory (lockstep on the GPU: a compiler fence; the CPU test harness
+// needs its threads to meet)
+template <int G>
+__device__ __forceinline__ void cc_gsync() {
+  if (G == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef CC_EMU
+    (void)__shfl(0, 0);
+#endif
+  } else {
+    cc_group_sync();
+  }
+}
+
+// cost and gradient at p over a problem's pair list, summed over its G lanes
+template <int G>
+__device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, int np, int sl, const double p[3], double *cost,
+                                            double grad[3]) {
+  const double c = cos(p[2]), s = sin(p[2]);
+  const double c2 = c * c - s * s, s2 = 2.0 * s * c;
+  double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
+  for (int i = sl; i < np; i += G) {
+    const float4 *g4 = (const float4 *)(pairs + i);
+    const float4 w0 = g4[0], w1 = g4[1], w2 = g4[2], w3 = g4[3];
+    cc_gpair P;
+    P.s00 = w0.x;
+    P.s01 = w0.y;
+    P.s10 = w0.z;
+    P.s11 = w0.w;
+    P.t00 = w1.x;
+    P.t01 = w1.y;
+    P.t10 = w1.z;
+    P.t11 = w1.w;
+    P.smx = w2.x;
+    P.smy = w2.y;
+    P.tmx = w2.z;
+    P.tmy = w2.w;
+    P.sw = w3.x;
+    P.tw = w3.y;
+    const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2);
+    a += t.v;
+    ax += t.gx;
+    ay += t.gy;
+    at += t.gt;
+  }
+  *cost = cc_gsum<G>(a);
+  grad[0] = cc_gsum<G>(ax);
+  grad[1] = cc_gsum<G>(ay);
+  grad[2] = cc_gsum<G>(at);
+}
+
+struct cc_gmm_ctx {  // what a line-search evaluation needs
+  const cc_gpair *pairs;
+  int np, sl;
+};
+// ---- Ceres 2.x line search pieces (see oracle/orc_gmm.h for the provenance notes) ----
+struct cc_fs {  // FunctionSample; vector_x is not kept (it is pos + x * dir, recomputed where needed)
+  double x, value, gradient;
+  double vg[3];
+  bool value_ok, grad_ok;
+};
+__device__ __forceinline__ cc_fs cc_fs_sel(bool c, const cc_fs &a, const cc_fs &b) {  // c ? a : b, field by field (keeps both in registers)
+  cc_fs r;
+  r.x = c ? a.x : b.x;
+  r.value = c ? a.value : b.value;
+  r.gradient = c ? a.gradient : b.gradient;
+  r.vg[0] = c ? a.vg[0] : b.vg[0];
+  r.vg[1] = c ? a.vg[1] : b.vg[1];
+  r.vg[2] = c ? a.vg[2] : b.vg[2];
+  r.value_ok = c ? a.value_ok : b.value_ok;
+  r.grad_ok = c ? a.grad_ok : b.grad_ok;
+  return r;
+}
+
+__device__ __forceinline__ double cc_ipow(double x, int k) {  // the Vandermonde entries: k in 0..3
+  return k == 0 ? 1.0 : (k == 1 ? x : (k == 2 ? x * x : x * x * x));
+}
+
+// FullPivLU solve of the n x n Vandermonde system (what Eigen's fullPivLu().solve() does in
+// FindInterpolatingPolynomial), n <= 4.  Every array index is a compile-time constant after unrolling and the
+// permutations are conditional register swaps, so nothing spills to scratch.
+__device__ __forceinline__ void cc_solve_fullpiv(double (&A)[4][4], double (&b)[4], int n, double (&x)[4]) {
+  int cp[4] = {0, 1, 2, 3};
+  bool done = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int pr = k, pc = k;
+    double best = -1;
+#pragma unroll
+    for (int i = k; i < 4; i++) {
+#pragma unroll
+      for (int j = k; j < 4; j++) {
+        const double v = fabs(A[i][j]);
+        if (i < n && j < n && v > best) {
+          best = v;
+          pr = i;
+          pc = j;
+        }
+      }
+    }
+    if (k >= n || best == 0.0) done = true;
+    if (!done) {
+#pragma unroll
+      for (int r = k + 1; r < 4; r++) {
+        if (pr == r) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const double t = A[k][j];
+            A[k][j] = A[r][j];
+            A[r][j] = t;
+          }
+          const double t = b[k];
+          b[k] = b[r];
+          b[r] = t;
+        }
+      }
+#pragma unroll
+      for (int c = k + 1; c < 4; c++) {
+        if (pc == c) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const double t = A[i][k];
+            A[i][k] = A[i][c];
+            A[i][c] = t;
+          }
+          const int t = cp[k];
+          cp[k] = cp[c];
+          cp[c] = t;
+        }
+      }
+#pragma unroll
+      for (int i = k + 1; i < 4; i++) {
+        if (i < n) {
+          const double f = A[i][k] / A[k][k];
+          A[i][k] = 0;
+#pragma unroll
+          for (int j = k + 1; j < 4; j++) A[i][j] -= f * A[k][j];
+          b[i] -= f * b[k];
+        }
+      }
+    }
+  }
+  double yv[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 3; i >= 0; i--) {
+    if (i < n) {
+      double sacc = b[i];
+#pragma unroll
+      for (int j = i + 1; j < 4; j++)
+        if (j < n) sacc -= A[i][j] * yv[j];
+      yv[i] = (A[i][i] != 0.0) ? sacc / A[i][i] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (i < n && cp[i] == c) x[c] = yv[i];
+}
+
+// polynomial with coefficients p[4 - np .. 3] (highest power first), Horner
+__device__ __forceinline__ double cc_polyval(const double (&p)[4], int np, double x) {
+  double v = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i >= 4 - np) v = v * x + p[i];
+  return v;
+}
+
+// InterpolatingPolynomialMinimizingStepSize for CUBIC with samples {lowerbound, current}
+__device__ double cc_interp_step(const cc_fs &lo, const cc_fs &cur, double x_min, double x_max) {
+  if (!cur.value_ok) {
+    double s = cur.x * 0.5;
+    s = s < x_min ? x_min : s;
+    return s < x_max ? s : x_max;
+  }
+  const int nc = (lo.value_ok ? 1 : 0) + (lo.grad_ok ? 1 : 0) + (cur.value_ok ? 1 : 0) + (cur.grad_ok ? 1 : 0);
+  const int degree = nc - 1;
+  // rows in the reference's order (sample 0 value, sample 0 gradient, sample 1 value, sample 1 gradient), absent rows
+  // skipped; built as 4 candidates that are compacted with conditional moves
+  double A[4][4], b[4], poly[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    b[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) A[i][j] = 0;
+  }
+  int row = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const bool is_grad = (c & 1) != 0;
+    const bool present = c == 0 ? lo.value_ok : (c == 1 ? lo.grad_ok : (c == 2 ? cur.value_ok : cur.grad_ok));
+    const double sx = c < 2 ? lo.x : cur.x;
+    double rv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!is_grad)
+        rv[j] = j <= degree ? cc_ipow(sx, degree - j) : 0.0;
+      else
+        rv[j] = j < degree ? (double)(degree - j) * cc_ipow(sx, degree - j - 1) : 0.0;
+    }
+    const double rb = c == 0 ? lo.value : (c == 1 ? lo.gradient : (c == 2 ? cur.value : cur.gradient));
+    if (present) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (row == r) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) A[r][j] = rv[j];
+          b[r] = rb;
+        }
+      }
+      row++;
+    }
+  }
+  double sol[4] = {0, 0, 0, 0};
+  cc_solve_fullpiv(A, b, nc, sol);
+  // poly[] right-aligned: coefficient of x^(np-1-i) at index 4 - np + i
+  const int np = nc;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    poly[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (i - (4 - np) == j) poly[i] = sol[j];
+  }
+  double opt_x = (x_min + x_max) / 2.0;
+  double opt_v = cc_polyval(poly, np, opt_x);
+  const double vmin = cc_polyval(poly, np, x_min);
+  if (vmin < opt_v) {
+    opt_v = vmin;
+    opt_x = x_min;
+  }
+  const double vmax = cc_polyval(poly, np, x_max);
+  if (vmax < opt_v) {
+    opt_v = vmax;
+    opt_x = x_max;
+  }
+  if (np > 2) {
+    // derivative coefficients, right-aligned in d[0..2] (d[2] = constant term); leading zeros are skipped
+    double d[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = (double)(3 - i) * poly[i];  // exponent of poly[i] is 3 - i
+    // `while (lead + 1 < deg && d[lead] == 0) lead++`: quadratic, linear or constant derivative (for np == 3, d[0] is 0)
+    double a = 0, bb = 0, c = 0;
+    int dd = 0;
+    if (d[0] != 0.0) {
+      dd = 2;
+      a = d[0];
+      bb = d[1];
+      c = d[2];
+    } else if (d[1] != 0.0) {
+      dd = 1;
+      a = d[1];
+      bb = d[2];
+    }
+    double roots[2] = {0, 0};
+    int nr = 0;
+    if (dd == 1) {
+      roots[0] = -bb / a;
+      nr = 1;
+    } else if (dd == 2) {
+      const double D = bb * bb - 4 * a * c;
+      const double sq = sqrt(fabs(D));
+      nr = 2;
+      if (D >= 0) {
+        if (bb >= 0) {
+          roots[0] = (-bb - sq) / (2.0 * a);
+          roots[1] = (2.0 * c) / (-bb - sq);
+        } else {
+          roots[0] = (2.0 * c) / (-bb + sq);
+          roots[1] = (-bb + sq) / (2.0 * a);
+        }
+      } else {
+        roots[0] = -bb / (2.0 * a);
+        roots[1] = -bb / (2.0 * a);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const double r = roots[i];
+      if (i < nr && !(r < x_min || r > x_max)) {
+        const double v = cc_polyval(poly, np, r);
+        if (v < opt_v) {
+          opt_v = v;
+          opt_x = r;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const double sx = i == 0 ? lo.x : cur.x;
+    if (!(sx < x_min || sx > x_max)) {
+      const double v = cc_polyval(poly, np, sx);
+      if (v < opt_v) {
+        opt_x = sx;
+        opt_v = v;
+      }
+    }
+  }
+  return opt_x;
+}
+
+
+template <int G>
+__device__ __forceinline__ void cc_ls_eval(const cc_gmm_ctx &S, const double pos[3], const double dir[3], double x, cc_fs *o) {
+  o->x = x;
+  double vx[3];
+  for (int i = 0; i < 3; i++) vx[i] = pos[i] + x * dir[i];
+  cc_gmm_eval<G>(S.pairs, S.np, S.sl, vx, &o->value, o->vg);
+  o->value_ok = isfinite(o->value);
+  o->grad_ok = o->value_ok && isfinite(o->vg[0]) && isfinite(o->vg[1]) && isfinite(o->vg[2]);
+  o->gradient = dir[0] * o->vg[0] + dir[1] * o->vg[1] + dir[2] * o->vg[2];
+}
+
+// WolfeLineSearch::DoSearch (bracketing + zoom).  Returns success; *opt is the accepted sample.
+template <int G>
+__device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double dir[3], double step0, double cost0,
+                         double dgrad0, const double g0[3], cc_fs *opt) {
+  const double min_step_size = 1e-9, suff_dec = 1e-4, suff_curv = 0.9, max_expand = 10.0;
+  const int max_it = 20;
+  const double dnorm = fmax(fabs(dir[0]), fmax(fabs(dir[1]), fabs(dir[2])));
+  cc_fs init;
+  init.x = 0;
+  init.value = cost0;
+  init.gradient = dgrad0;
+  init.value_ok = init.grad_ok = true;
+  for (int i = 0; i < 3; i++) init.vg[i] = g0[i];
+  int nit = 0;
+  cc_fs prev = init, cur, lo = init, hi = init;
+  bool zoom = false;
+  cc_ls_eval<G>(S, pos, dir, step0, &cur);
+  while (true) {
+    ++nit;
+    if (cur.value_ok && (cur.value > (init.value + suff_dec * init.gradient * cur.x) || (prev.value_ok && cur.value > prev.value))) {
+      zoom = true;
+      lo = prev;
+      hi = cur;
+      break;
+    }
+    if (cur.value_ok && fabs(cur.gradient) <= -suff_curv * init.gradient) {
+      lo = cur;
+      hi = cur;
+      break;
+    } else if (cur.value_ok && cur.gradient >= 0) {
+      zoom = true;
+      lo = cur;
+      hi = prev;
+      break;
+    } else if (nit >= max_it) {
+      if (cur.value_ok && cur.value < lo.value) lo = cur;
+      break;
+    }
+    const double mn = cur.value_ok ? cur.x : prev.x;
+    const double mx = cur.value_ok ? (cur.x * max_expand) : cur.x;
+    const double step = cc_interp_step(prev, cur, mn, mx);
+    if (step * dnorm < min_step_size) return false;
+    if (cur.value_ok) prev = cur;
+    cc_ls_eval<G>(S, pos, dir, step, &cur);
+  }
+  if (zoom && fabs(hi.x - lo.x) * dnorm < min_step_size) zoom = false;
+  if (!zoom) {
+    *opt = lo;
+    return true;
+  }
+  // zoom phase
+  cc_fs sol;
+  sol.value_ok = false;
+  bool zoom_ok = true;
+  cc_fs blo = lo, bhi = hi;
+  if (blo.gradient * (bhi.x - blo.x) >= 0) {
+    zoom_ok = false;
+  } else {
+    while (true) {
+      sol = blo;
+      if (nit >= max_it) {
+        zoom_ok = false;
+        break;
+      }
+      if (fabs(bhi.x - blo.x) * dnorm < min_step_size) {
+        zoom_ok = false;
+        break;
+      }
+      ++nit;
+      const bool lo_first = blo.x < bhi.x;
+      const cc_fs lb = cc_fs_sel(lo_first, blo, bhi);
+      const cc_fs ub = cc_fs_sel(lo_first, bhi, blo);
+      const double step = cc_interp_step(lb, ub, lb.x, ub.x);
+      cc_ls_eval<G>(S, pos, dir, step, &sol);
+      if (!sol.value_ok || !sol.grad_ok) {
+        zoom_ok = false;
+        break;
+      }
+      if ((sol.value > (init.value + suff_dec * init.gradient * sol.x)) || (sol.value >= blo.value)) {
+        bhi = sol;
+        continue;
+      }
+      if (fabs(sol.gradient) <= -suff_curv * init.gradient) break;
+      if (sol.gradient * (bhi.x - blo.x) >= 0) bhi = blo;
+      blo = sol;
+    }
+  }
+  if (!zoom_ok && !sol.value_ok) return false;
+  if (!sol.value_ok || sol.value > lo.value)
+    *opt = lo;
+  else
+    *opt = sol;
+  return true;
+}
+
+
+template <int G>
+__device__ __forceinline__ int cc_gscan_incl(int v, int *total) {  // inclusive prefix sum over the G lanes of a problem
+  int incl = cc_group_scan_incl(v);
+  int tot = cc_group_sum_i(v);
+  if (G == 64) {
+    const int row = (threadIdx.x & 63) >> 4;
+    const int t0 = __shfl(tot, 0), t1 = __shfl(tot, 16), t2 = __shfl(tot, 32), t3 = __shfl(tot, 48);
+    incl += (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+    tot = t0 + t1 + t2 + t3;
+  }
+  *total = tot;
+  return incl;
+}
+
+// K5b: calcCorrelation (correlation.h:206-238) for the problems cc_k_select listed: LineSearchMinimizer, LBFGS rank 20,
+// Wolfe / cubic interpolation, <= 10 iterations.  G lanes per problem.
+// grid = any (grid-stride over the device-side list), block = 64
+template <int G>
+__global__ void __launch_bounds__(64)
+cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
+                const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
+                cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
+  __shared__ double hist_all[64 / G][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
+  const int sub = threadIdx.x / G, sl = threadIdx.x % G;
+  double *hist = hist_all[sub];
+  const int n_sel = *n_sel_p;
+  for (int k = blockIdx.x * (64 / G) + sub; k < n_sel; k += gridDim.x * (64 / G)) {
+    const int pidx = sel_list[k];
+    cc_gmm_result R = results[pidx];
+    if ((float)R.corr_init < corr_lb) continue;
+    const cc_gmm_problem pb = probs[pidx];
+    const cc_gmm_feat *fsrc = db_feat + pb.gidx;
+    const cc_gmm_feat *ftgt = qfeat + pb.q;
+    // ---- the problem's pair list (GMMPair ctor order: level, src ellipse, tgt ellipse) into the pool
+    const int np = R.n_pairs;
+    int off = 0;
+    if (sl == 0) off = atomicAdd(pool_head, np);
+    off = G == 64 ? __shfl(off, 0) : cc_group_bcast(off, 0);
+    if (off + np > pool_cap) {
+      if (sl == 0) results[pidx].flags = R.flags | 2;
+      continue;
+    }
+    {
+      const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
+      int run = 0;
+      for (int li = 0; li < CC_GMM_LEVELS; li++) {
+        const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
+        for (int s0 = 0; s0 < ns; s0 += G) {
+          const int si = s0 + sl;
+          cc_ell es;
+          int c = 0;
+          if (si < ns) {
+            es = fsrc->ell[li][si];
+            for (int ti = 0; ti < ntg; ti++) {
+              const cc_ell *pt = &ftgt->ell[li][ti];
+              c += cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1]) ? 1 : 0;
+            }
+          }
+          int tot;
+          const int incl = cc_gscan_incl<G>(c, &tot);
+          if (c > 0) {
+            int o = off + run + incl - c;
+            for (int ti = 0; ti < ntg; ti++) {
+              const cc_ell *pt = &ftgt->ell[li][ti];
+              if (cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1])) pool[o++] = cc_gmm_make_pair(es, *pt);
+            }
+          }
+          run += tot;
+        }
+      }
+    }
+    __threadfence_block();  // the pairs are read back by all lanes of the problem
+    cc_gsync<G>();
+    cc_gmm_ctx S;
+    S.pairs = pool + off;
+    S.np = np;
+    S.sl = sl;
+    double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
+    double cost, g[3];
+    cc_gmm_eval<G>(S.pairs, S.np, S.sl, x, &cost, g);
+    const double denom = sqrt(fsrc->ac * ftgt->ac);
+    {
+    // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations
+    R.optimized = 1;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    double cur_cost = cost, cur_g[3] = {g[0], g[1], g[2]};
+    double prev_cost = 0, prev_g[3] = {0, 0, 0}, prev_dir[3] = {0, 0, 0}, prev_step = 0;
+    double *dxh = hist, *dgh = hist + 30, *dxdg = hist + 60, *alpha = hist + 70;  // [k * 3 + i]
+    int ncorr = 0;
+    int restarts = 0;
+    int term = 0, iter = 0;
+    double gmax = fmax(fabs(cur_g[0]), fmax(fabs(cur_g[1]), fabs(cur_g[2])));
+    double final_cost = cur_cost;
+    if (gmax <= gradient_tolerance) {
+      term = 1;
+    } else {
+      while (true) {
+        if (iter >= 10) {
+          term = 0;
+          break;
+        }
+        iter++;
+        double dir[3];
+        bool ls_status = true;
+        if (iter == 1) {
+          for (int i = 0; i < 3; i++) dir[i] = -cur_g[i];
+        } else {
+          double ddx[3], ddg[3];
+          for (int i = 0; i < 3; i++) {
+            ddx[i] = prev_dir[i] * prev_step;
+            ddg[i] = cur_g[i] - prev_g[i];
+          }
+          const double dd = ddx[0] * ddg[0] + ddx[1] * ddg[1] + ddx[2] * ddg[2];
+          if (dd > 1e-14 && ncorr < 10) {
+            for (int i = 0; i < 3; i++) {
+              dxh[ncorr * 3 + i] = ddx[i];
+              dgh[ncorr * 3 + i] = ddg[i];
+            }
+            dxdg[ncorr] = dd;
+            ncorr++;
+          }
+          double sd[3] = {cur_g[0], cur_g[1], cur_g[2]};
+          for (int k = ncorr - 1; k >= 0; k--) {
+            const double al = (dxh[k * 3 + 0] * sd[0] + dxh[k * 3 + 1] * sd[1] + dxh[k * 3 + 2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] -= al * dgh[k * 3 + i];
+            alpha[k] = al;
+          }
+          for (int k = 0; k < ncorr; k++) {
+            const double beta = (dgh[k * 3 + 0] * sd[0] + dgh[k * 3 + 1] * sd[1] + dgh[k * 3 + 2] * sd[2]) / dxdg[k];
+            for (int i = 0; i < 3; i++) sd[i] += dxh[k * 3 + i] * (alpha[k] - beta);
+          }
+          for (int i = 0; i < 3; i++) dir[i] = -1.0 * sd[i];
+          if (dir[0] * cur_g[0] + dir[1] * cur_g[1] + dir[2] * cur_g[2] >= 0.0) ls_status = false;
+        }
+        if (!ls_status && restarts >= 5) {
+          term = -1;
+          break;
+        } else if (!ls_status) {
+          restarts++;
+          ncorr = 0;
+          for (int i = 0; i < 3; i++) dir[i] = -cur_g[i];
+        }
+        const double dderiv = cur_g[0] * dir[0] + cur_g[1] * dir[1] + cur_g[2] * dir[2];
+        const double step0 = (iter == 1 || !ls_status) ? fmin(1.0, 1.0 / gmax) : fmin(1.0, 2.0 * (cur_cost - prev_cost) / dderiv);
+        if (step0 < 0.0) {
+          term = -1;
+          break;
+        }
+        cc_fs opt;
+        if (!cc_wolfe<G>(S, x, dir, step0, cur_cost, dderiv, cur_g, &opt)) {
+          term = -1;
+          break;
+        }
+        prev_cost = cur_cost;
+        for (int i = 0; i < 3; i++) {
+          prev_g[i] = cur_g[i];
+          prev_dir[i] = dir[i];
+        }
+        prev_step = opt.x;
+        cur_cost = opt.value;
+        for (int i = 0; i < 3; i++) cur_g[i] = opt.vg[i];
+        gmax = fmax(fabs(cur_g[0]), fmax(fabs(cur_g[1]), fabs(cur_g[2])));
+        const double xnorm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        double sn = 0;
+        double nx[3];
+        for (int i = 0; i < 3; i++) nx[i] = x[i] + opt.x * dir[i];  // optimal_point.vector_x
+        for (int i = 0; i < 3; i++) sn += (nx[i] - x[i]) * (nx[i] - x[i]);
+        sn = sqrt(sn);
+        for (int i = 0; i < 3; i++) x[i] = nx[i];
+        final_cost = cur_cost;
+        if (sn <= parameter_tolerance * (xnorm + parameter_tolerance)) {
+          term = 3;
+          break;
+        }
+        if (gmax <= gradient_tolerance) {
+          term = 1;
+          break;
+        }
+        if (fabs(prev_cost - cur_cost) <= function_tolerance * fabs(prev_cost)) {
+          term = 2;
+          break;
+        }
+      }
+    }
+    R.iterations = iter;
+    R.termination = term;
+    R.corr_opt = -final_cost / denom;
+    R.tf_opt[0] = x[0];
+    R.tf_opt[1] = x[1];
+    R.tf_opt[2] = x[2];
+    }
+    if (sl == 0) results[pidx] = R;
+  }
+}
+// ------------------------------------------------------------------------------------------------
+// K5s: which candidates of a query get refined -- the first max_fine_opt_ of candidates_ after tidyUpCandidates'
+// compaction and fineOptimize's sort on the still-all-zero correlation_ (the same replay as in K6; contour_db.h:560-616).
+// Their GMM problems are appended to sel_list.  One wave per query.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
+            const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[2][sel_stride]*/, int sel_stride,
+            int *__restrict__ n_sel /*[2]*/) {
+  __shared__ unsigned stk[CC_SORT_STACK];
+  __shared__ unsigned short idx[CC_MAXCAND];
+  __shared__ unsigned char has[CC_MAXCAND];
+  __shared__ int gm[CC_MAXCAND];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= nq) return;
+  const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
+  const int nc = qstate[q].n_cand;
+  for (int k = lane; k < nc; k += 64) {
+    const int g = cands[k].gmm_idx;
+    idx[k] = (unsigned short)k;
+    gm[k] = g;
+    has[k] = (g >= 0 && !((float)gres[g].corr_init < corr_lb)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  int p1 = 0, p2 = nc - 1;
+  while (p1 <= p2) {
+    if (!has[idx[p1]] && has[idx[p2]]) {
+      const unsigned short t = idx[p1];
+      idx[p1] = idx[p2];
+      idx[p2] = t;
+      p1++;
+      p2--;
+    } else {
+      if (has[idx[p1]]) p1++;
+      if (!has[idx[p2]]) p2--;
+    }
+  }
+  const int n = p2 + 1;
+  if (n <= 0) return;
+  ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; }, stk);
+  const int pre = max_fine_opt < n ? max_fine_opt : n;
+  // two lists: short pair lists go to the 16-lane refinement instance, long ones to the 64-lane instance
+  for (int i = 0; i < pre; i++) {
+    const int g = gm[idx[i]];
+    const int big = gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS ? 1 : 0;
+    sel_list[(size_t)big * sel_stride + atomicAdd(&n_sel[big], 1)] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: per query, the rest of tidyUpCandidates (correlation bar + order-changing compaction, contour_db.h:560-592) and
+// fineOptimize (contour_db.h:604-648): std::sort on the still-all-zero correlation_ (replayed), take the first
+// max_fine_opt_, adopt their refined score/pose, re-sort those, return the best.  One lane per query.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
+           const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
+           cc_query_result_t *__restrict__ out) {
+  // one wave per query: lanes fetch the per-candidate inputs in parallel, lane 0 replays the order-dependent part on LDS
+  __shared__ unsigned short idx[CC_MAXCAND];
+  __shared__ unsigned char has[CC_MAXCAND];
+  __shared__ float corr_o[CC_MAXCAND];
+  __shared__ int gm[CC_MAXCAND];
+  __shared__ int s_tot;
+  __shared__ unsigned stk[CC_SORT_STACK];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= nq) return;
+  const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
+  const int nc = qstate[q].n_cand;
+  for (int k = lane; k < nc; k += 64) {
+    const int g = cands[k].gmm_idx;
+    idx[k] = (unsigned short)k;
+    gm[k] = g;
+    bool h = false;
+    float co = 0.f;
+    if (g >= 0) {
+      h = !((float)gres[g].corr_init < corr_lb);
+      co = (float)gres[g].corr_opt;
+    }
+    has[k] = h ? 1 : 0;
+    corr_o[k] = co;
+  }
+  int tot = 0;
+  for (int s2 = lane; s2 < CC_NQLEV * CC_NPIV; s2 += 64) tot += hit_cnt[q * CC_NQLEV * CC_NPIV + s2];
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if (lane == 0) s_tot = tot;
+  __syncthreads();
+  if (lane != 0) return;
+  cc_query_result_t r;
+  r.n_res = 0;
+  r.cand_gidx = -1;
+  r.correlation = 0;
+  r.tf[0] = r.tf[1] = r.tf[2] = 0;
+  r.cand_aft_check1 = pass_cnt[q * 4 + 1];
+  r.cand_aft_check2 = pass_cnt[q * 4 + 2];
+  r.cand_aft_check3 = pass_cnt[q * 4 + 3];
+  r.n_cand_pose = nc;
+  r.n_knn_hits = s_tot;
+  // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592
+  int p1 = 0, p2 = nc - 1;
+  while (p1 <= p2) {
+    if (!has[idx[p1]] && has[idx[p2]]) {
+      const unsigned short t = idx[p1];
+      idx[p1] = idx[p2];
+      idx[p2] = t;
+      p1++;
+      p2--;
+    } else {
+      if (has[idx[p1]]) p1++;
+      if (!has[idx[p2]]) p2--;
+    }
+  }
+  const int n = p2 + 1;
+  r.n_cand_tidy = n;
+  if (n > 0) {
+    // first std::sort: every anch_props_[0].correlation_ is still 0 -> comparator is always false
+    ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; }, stk);
+    const int pre = max_fine_opt < n ? max_fine_opt : n;
+    // candidates beyond `pre` keep correlation_ = 0
+    ccsort::std_sort(idx, pre, [&](unsigned short a, unsigned short b) { return corr_o[a] > corr_o[b]; }, stk);
+    const int b = idx[0];
+    r.n_res = 1;
+    r.cand_gidx = cands[b].gidx;
+    r.correlation = pre > 0 ? (double)corr_o[b] : 0.0;
+    if (pre > 0) {
+      const cc_gmm_result *g = &gres[gm[b]];
+      // T_best_ = Identity.rotate(theta).pretranslate(x, y); reported as (x, y, atan2(T10, T00))
+      r.tf[0] = g->tf_opt[0];
+      r.tf[1] = g->tf_opt[1];
+      r.tf[2] = atan2(sin(g->tf_opt[2]), cos(g->tf_opt[2]));
+    }
+  }
+  out[q] = r;
+}
+
+

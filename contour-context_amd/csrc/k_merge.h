@@ -1,0 +1,233 @@
+// K4b -- CandidatePoseData::addProposal and the selection part of tidyUpCandidates (contour_db.h:286-338, 494-546).
+#pragma once
+#include "cc_dev.h"
+#include "k_check.h"
+
+// ------------------------------------------------------------------------------------------------
+// K4b: per query, replay the passing checks in order: CandidatePoseData::addProposal (contour_db.h:286-338) and the
+// part of tidyUpCandidates before the correlation (contour_db.h:503-546).  The greedy proposal merge is sequential
+// only among checks that name the SAME candidate scan, so the passing checks are threaded into one ordered list per
+// candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
+// ------------------------------------------------------------------------------------------------
+#define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
+#define CC_MERGE_BLOCK 128
+#define CC_MERGE_PER_T (CC_CHK_STRIDE / CC_MERGE_BLOCK)  // consecutive check slots scanned by one thread
+
+struct cc_gmm_problem {
+  int q;          // index into qdesc (tgt)
+  int gidx;       // index into db_desc (src)
+  double tf[3];   // T_init = (x, y, theta)
+};
+
+struct cc_dprop {  // CandidateAnchorProp (contour_db.h:267-274); constell_ kept as a 400-bit set in key order
+  unsigned long long bits[7];
+  double c, s, tx, ty;  // T_delta_ = [c -s tx; s c ty]
+  int vote_cnt;
+  float area_perc;
+};
+struct cc_dcand {  // CandidatePoseData (working state of one lane)
+  int gidx, nprops, gmm_idx, pad;
+  cc_dprop props[4];
+};
+struct cc_cand_out {  // what the final-selection kernel needs of a candidate
+  int gidx, nprops, gmm_idx, pad;
+};
+struct cc_qstate {
+  int n_cand;  // candidates_.size() before tidyUpCandidates
+  int flags;
+};
+struct cc_merge_lds {
+  cc_dcand st[CC_MERGE_BLOCK];             // lane-private candidate state
+  int gid[CC_CHK_STRIDE];                  // candidate scan of the i-th passing check
+  unsigned short ord[CC_CHK_STRIDE];       // its check slot
+  short next[CC_CHK_STRIDE];               // next passing check naming the same scan, -1 = none
+  unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
+  int wsum[CC_MERGE_BLOCK / 64];
+  int base;
+};
+
+static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
+
+// grid = nq, block = CC_MERGE_BLOCK
+__global__ void __launch_bounds__(CC_MERGE_BLOCK)
+cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__restrict__ qdesc,
+           const cc_hot_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
+           const int *__restrict__ pass_cnt, cc_cand_out *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
+           cc_gmm_problem *__restrict__ probs, int prob_cap, int *__restrict__ n_prob) {
+  __shared__ cc_merge_lds L;
+  const int q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (q >= nq) return;
+  const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
+  const cc_pass_rec *recs = pass + (size_t)q * CC_CHK_STRIDE;
+  // ---- ordered list of the passing checks (slot order = the reference's iteration order)
+  int n;
+  {
+    unsigned okm = 0;
+    int cnt = 0;
+    for (int u = 0; u < CC_MERGE_PER_T; u++) {
+      const int ok = okp[tid * CC_MERGE_PER_T + u] != 0;
+      okm |= (unsigned)ok << u;
+      cnt += ok;
+    }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) L.wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    n = 0;
+    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
+      if (w < wave) off += L.wsum[w];
+      n += L.wsum[w];
+    }
+    for (int u = 0; u < CC_MERGE_PER_T; u++) {
+      if ((okm >> u) & 1u) {
+        const int t = tid * CC_MERGE_PER_T + u;
+        L.ord[off] = (unsigned short)t;
+        L.gid[off] = recs[t].gidx;
+        L.next[off] = -1;
+        off++;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- thread the checks of one scan together; number the candidates in first-appearance order
+  int nc = 0;
+  for (int b0 = 0; b0 < n; b0 += CC_MERGE_BLOCK) {
+    const int i = b0 + tid;
+    bool first = false;
+    if (i < n) {
+      const int g = L.gid[i];
+      int j = i - 1;
+      while (j >= 0 && L.gid[j] != g) j--;
+      if (j >= 0)
+        L.next[j] = (short)i;  // j is the immediately preceding check of this scan: written by exactly one i
+      else
+        first = true;
+    }
+    const unsigned long long m = __ballot(first);
+    if (lane == 0) L.wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = nc + __popcll(m & ((1ull << lane) - 1ull));
+    int tot = 0;
+    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
+      if (w < wave) off += L.wsum[w];
+      tot += L.wsum[w];
+    }
+    if (first) L.firstrec[off] = (unsigned short)i;
+    nc += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    cc_qstate st;
+    st.n_cand = nc;
+    st.flags = 0;
+    qstate[q] = st;
+  }
+  // ---- one lane per candidate
+  const cc_hot_desc_t *tl = qdesc + q;
+  cc_dcand *c = &L.st[tid];
+  for (int k = tid; k < nc; k += CC_MERGE_BLOCK) {
+    int i = L.firstrec[k];
+    c->gidx = L.gid[i];
+    c->nprops = 0;
+    for (; i >= 0; i = L.next[i]) {
+      const cc_pass_rec *rec = &recs[L.ord[i]];
+      const int np = rec->n_pairs;
+      const double ptx = rec->tf[0], pty = rec->tf[1];
+      const double pc = rec->cs[0], ps = rec->cs[1];
+      const int nprops = c->nprops;
+      // CandidatePoseData::addProposal: first proposal within 2.0 (pixels) and 0.3 rad
+      int hit = -1;
+      for (int pi = 0; pi < nprops && hit < 0; pi++) {
+        const cc_dprop *p = &c->props[pi];
+        const double i00 = pc, i01 = ps, i10 = -ps, i11 = pc;
+        const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
+        const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
+        const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
+        if (sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3) hit = pi;
+      }
+      if (hit >= 0) {
+        cc_dprop *p = &c->props[hit];
+        for (int w = 0; w < 7; w++) p->bits[w] |= rec->bits[w];
+        p->vote_cnt += np;
+        const int w1 = p->vote_cnt, w2 = np;
+        const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
+        const double ang1 = atan2(p->s, p->c), ang2 = rec->cs[2];
+        double diff = ang2 - ang1;
+        if (diff < 0) diff += 2 * 3.14159265358979323846;
+        if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
+        const double ang_bl = diff * w2 / (w1 + w2) + ang1;
+        p->c = cos(ang_bl);
+        p->s = sin(ang_bl);
+        p->tx = bx;
+        p->ty = by;
+      } else if (nprops <= 3) {
+        cc_dprop *p = &c->props[nprops];
+        for (int w = 0; w < 7; w++) p->bits[w] = rec->bits[w];
+        p->c = pc;
+        p->s = ps;
+        p->tx = ptx;
+        p->ty = pty;
+        p->vote_cnt = np;
+        p->area_perc = 0.f;
+        c->nprops = nprops + 1;
+      }
+    }
+    // tidyUpCandidates before the correlation (contour_db.h:503-546)
+    const cc_hot_desc_t *sl = db_desc + c->gidx;
+    int idx_sel = 0;
+    for (int pi = 0; pi < c->nprops; pi++) {
+      float lev_perc[CC_NLEV] = {0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < 7; w++) {
+        unsigned long long m = c->props[pi].bits[w];
+        while (m) {
+          const int b = w * 64 + (__ffsll((unsigned long long)m) - 1);
+          m &= m - 1;
+          const int l = b / 100 + 1, s_ = (b % 100) / 10, t_ = b % 10;
+          const float psrc = (float)sl->cont[l - 1][s_].cell_cnt * 1.0f / (float)sl->layer_cell_cnt[l - 1];
+          const float ptgt = (float)tl->cont[l - 1][t_].cell_cnt * 1.0f / (float)tl->layer_cell_cnt[l - 1];
+          lev_perc[l] += 0.5f * (psrc + ptgt);
+        }
+      }
+      float perc = 0.f;
+      perc += 0.3f * lev_perc[1];
+      perc += 0.3f * lev_perc[2];
+      perc += 0.3f * lev_perc[3];
+      perc += 0.1f * lev_perc[4];
+      c->props[pi].area_perc = perc;
+      if (c->props[pi].vote_cnt > c->props[idx_sel].vote_cnt) idx_sel = pi;
+    }
+    const cc_dprop *p0 = &c->props[idx_sel];  // std::swap(anch_props_[0], anch_props_[idx_sel]): only [0] is used afterwards
+    int gi = -1;
+    if (!(p0->area_perc < lb.area_perc)) {
+      // getEstSensTF: T_so^-1 * T_delta * T_so with T_so = translate(n_row/2 - 0.5, n_col/2 - 0.5)
+      const double ox = n_row / 2 - 0.5, oy = n_col / 2 - 0.5;
+      const double mx = p0->c * ox + (-p0->s) * oy + p0->tx, my = p0->s * ox + p0->c * oy + p0->ty;
+      const double ex = 1.0 * mx + 0.0 * my + (-(1.0 * ox + 0.0 * oy)), ey = 0.0 * mx + 1.0 * my + (-(0.0 * ox + 1.0 * oy));
+      const double neg = -sqrt(ex * ex + ey * ey);
+      if (!(neg < (double)lb.neg_est_dist)) {
+        const int pi = atomicAdd(n_prob, 1);
+        if (pi < prob_cap) {
+          cc_gmm_problem pb;
+          pb.q = q;
+          pb.gidx = c->gidx;
+          pb.tf[0] = p0->tx;
+          pb.tf[1] = p0->ty;
+          pb.tf[2] = atan2(p0->s, p0->c);
+          probs[pi] = pb;
+          gi = pi;
+        }
+      }
+    }
+    cc_cand_out o;
+    o.gidx = c->gidx;
+    o.nprops = c->nprops;
+    o.gmm_idx = gi;
+    o.pad = 0;
+    cands_all[(size_t)q * CC_MAXCAND + k] = o;
+  }
+}
+

@@ -16,6 +16,7 @@
 #ifndef CONT2_AMD_H
 #define CONT2_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -163,6 +164,22 @@ typedef struct {
   cc_contour_t cont[CC_NLEV][CC_MAXC];
 } cc_scan_desc_t;
 
+/* The part of a scan's descriptor that the query path reads of a DATABASE scan (and of the query scan itself):
+ * retrieval keys, the first dist_firsts_ contours and the BCIs of levels 1..4 (DIST_BIN_LAYERS = q_levels_' range =
+ * GMMOptConfig::levels_, contour_mng.h:113, correlation.h:18).  18 KB instead of 169 KB: this is what the DB keeps
+ * resident per scan (next to the correlation inputs, cc_gmm_feat), and -- together with them -- the wire format of the
+ * multi-GPU exchange (cc_pack_scans / cc_db_add_packed).  hot.X[l] = desc.X[l + 1]. */
+#define CC_HOT_LEVELS 4
+typedef struct {
+  int32_t n_cont[CC_HOT_LEVELS];
+  int32_t layer_cell_cnt[CC_HOT_LEVELS];
+  int32_t flags;
+  int32_t pad_[3];
+  float keys[CC_HOT_LEVELS][CC_NPIV][CC_KEY_DIM];
+  cc_contour_t cont[CC_HOT_LEVELS][CC_NDIST]; /* rows >= n_stored are zero */
+  cc_bci_t bcis[CC_HOT_LEVELS][CC_NPIV];
+} cc_hot_desc_t; /* 48 + 960 + 3040 + 14400 = 18448 bytes */
+
 /* Optional parity/debug outputs of ingest (device pointers, any may be NULL):
  *   bev     [n_scans][n_row*n_col] f32  : bev_ image (contour_mng.h:432), -1000 = empty
  *   pix_rc  [n_scans][n_row*n_col][2] f32: continuous (row_f,col_f) of the arg-max point of
@@ -299,10 +316,20 @@ int cc_db_check_hints_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_hi
                            const cc_score_t *thres_lb, const cc_score_t *thres_ub, int max_fine_opt,
                            cc_query_result_t *h_res, cc_hint_score_t *h_scores);
 
-/* Device pointer of the DB's descriptor array ([cc_db_size()] cc_scan_desc_t) and raw
- * import of descriptors gathered from other ranks (multi-GPU: RCCL all-gather fills a
- * device buffer, then cc_db_add_scans consumes it). */
-const cc_scan_desc_t *cc_db_desc_ptr(const cc_db *db);
+/* ---- the compact per-scan records (multi-GPU exchange) ----
+ * cc_pack_scans turns full descriptors into the two records the database keeps per scan: the hot record
+ * (cc_hot_desc_t, 18 KB) and the correlation inputs (opaque, 16 KB; cc_packed_sizes gives both sizes).  A rank packs
+ * the scans it ingested, the ranks all-gather the two arrays over RCCL (35 KB per scan instead of the 169 KB
+ * descriptor), and every rank appends the gathered scans to its replica with cc_db_add_packed -- the same effect as
+ * cc_db_add_scans on the full descriptors (which is pack + add_packed).  d_hot_out / d_feat_out: device arrays of n
+ * records each. */
+void cc_packed_sizes(size_t *hot_bytes, size_t *feat_bytes);
+int cc_pack_scans(cc_ctx *ctx, const cc_scan_desc_t *d_desc, int n, void *d_hot_out, void *d_feat_out, void *stream);
+int cc_db_add_packed(cc_db *db, const void *d_hot, const void *d_feat, int n, const double *h_ts, const int32_t *h_seed,
+                     void *stream);
+/* Device pointers of the DB's own record arrays ([cc_db_size()] records each). */
+const void *cc_db_hot_ptr(const cc_db *db);
+const void *cc_db_feat_ptr(const cc_db *db);
 
 /* Same for the query kernels: accumulated ms {K3 knn, K4 check, K4b merge, K5 gmm, K6 final} summed over the chunk
  * launches (chunks in flight together overlap in time), and the number of QUERIES the sums cover (*n_launches). */

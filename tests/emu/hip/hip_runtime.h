@@ -7,6 +7,7 @@
 // for the 64-lane cross-lane ops, __atomic builtins for atomics.  It is never part of the product:
 // nothing under contour-context_amd/ includes or links it.
 #pragma once
+#define CC_EMU 1  // selects the shuffle-based forms of the 16-lane group collectives (csrc/cc_group.h)
 #include <pthread.h>
 #include <algorithm>
 #include <cmath>

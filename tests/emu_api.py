@@ -25,7 +25,6 @@ class EmuApi:
         self.L = L
         self.lib = C.CDLL(build())
         self.lib.cc_last_error.restype = C.c_char_p
-        self.lib.cc_db_desc_ptr.restype = C.c_void_p
         for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
                   "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state", "cc_db_check_hints"):
             getattr(self.lib, f).restype = C.c_int
@@ -69,6 +68,9 @@ class EmuApi:
         return desc
 
     def db_create(self, ctx, cfg=None, cap=1024):
+        # one OS thread per HIP thread: keep the grids of the list-driven kernels small here (read at cc_db_create)
+        for k in ("CC_B1_GRID", "CC_B2_GRID", "CC_GMM_GRID"):
+            os.environ.setdefault(k, "6")
         cfg = cfg or self.L.default_db_cfg()
         h = C.c_void_p()
         self.chk(self.lib.cc_db_create(ctx, C.byref(cfg), cap, C.byref(h)), "cc_db_create")

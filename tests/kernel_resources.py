@@ -11,14 +11,14 @@ for line in r.stderr.splitlines():
     m2 = re.search(r"remark: Function Name: (\S+)", line)
     if m2:
         cur = m2.group(1)
-        k = re.match(r"_Z\d+(cc_k_[a-z_]+?)(?:\d|P|i|f)", cur)
-        cur = k.group(1) if k else cur
+        dm = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip()
+        cur = re.sub(r"\(.*", "", dm).replace("void ", "") or cur
         rows[cur] = {}
         continue
     m3 = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
     if m3 and cur:
         rows[cur][m3.group(1).strip()] = int(m3.group(2))
 for k, v in rows.items():
-    print("%-18s VGPR %3d AGPR %3d SGPR %3d scratch %5d LDS %6d occupancy %d" % (
-        k[:18], v.get("VGPRs", -1), v.get("AGPRs", -1), v.get("TotalSGPRs", -1), v.get("ScratchSize", -1),
+    print("%-44s VGPR %3d AGPR %3d SGPR %3d scratch %5d LDS %6d occupancy %d" % (
+        k[:44], v.get("VGPRs", -1), v.get("AGPRs", -1), v.get("TotalSGPRs", -1), v.get("ScratchSize", -1),
         v.get("LDS Size", -1), v.get("Occupancy", -1)))
