@@ -13,8 +13,9 @@
 #define CC_G 16
 
 #ifndef CC_EMU
-// LDS hand-off between the lanes of one group: a wave's lanes run in lockstep and its LDS operations complete in
-// order, so only the compiler has to be kept from reordering across the hand-off.
+// LDS hand-off between the lanes of one group: a wave's lanes run in lockstep and its LDS operations are executed in
+// issue order, so only the compiler has to be kept from moving LDS accesses across the hand-off (a wavefront-scope fence
+// emits no wait by itself as long as the accesses are ds_* instructions).
 __device__ __forceinline__ void cc_group_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 template <int CTRL>
@@ -51,6 +52,14 @@ __device__ __forceinline__ int cc_group_sum_i(int v) {
   v += cc_dpp_i<CC_DPP_XOR2>(v);
   v += cc_dpp_i<CC_DPP_HALF_MIRROR>(v);
   v += cc_dpp_i<CC_DPP_MIRROR>(v);
+  return v;
+}
+// bitwise OR over the group, result in every lane
+__device__ __forceinline__ unsigned cc_group_or_u(unsigned v) {
+  v |= (unsigned)cc_dpp_i<CC_DPP_XOR1>((int)v);
+  v |= (unsigned)cc_dpp_i<CC_DPP_XOR2>((int)v);
+  v |= (unsigned)cc_dpp_i<CC_DPP_HALF_MIRROR>((int)v);
+  v |= (unsigned)cc_dpp_i<CC_DPP_MIRROR>((int)v);
   return v;
 }
 __device__ __forceinline__ double cc_group_sum_d(double v) {
@@ -103,6 +112,10 @@ __device__ __forceinline__ int cc_group_scan_incl(int v) {
 }
 __device__ __forceinline__ int cc_group_sum_i(int v) {
   for (int o = 1; o < CC_G; o <<= 1) v += __shfl_xor(v, o, CC_G);
+  return v;
+}
+__device__ __forceinline__ unsigned cc_group_or_u(unsigned v) {
+  for (int o = 1; o < CC_G; o <<= 1) v |= (unsigned)__shfl_xor((int)v, o, CC_G);
   return v;
 }
 __device__ __forceinline__ double cc_group_sum_d(double v) {

@@ -14,6 +14,8 @@
 // Results land in slot-indexed arrays (slot = the reference's candidate iteration order), so the order in which the lists
 // were filled never shows.  Both scans of a check are read through their 18 KB "hot" records (cc_hot_desc_t).
 #pragma once
+#include <cstddef>
+
 #include "cc_dev.h"
 #include "cc_group.h"
 #include "cc_sort.h"
@@ -115,15 +117,17 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
     h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
     const int seq_tgt = CC_HIT_SEQ_TGT(h, slot), li = CC_HIT_LEVEL(h) - 1;
     const cc_hot_desc_t *src = db_hot + h.gidx, *tgt = qhot + q;
+    // the rings are fetched next to the contour rows (both addresses follow from the hit alone): one dependent round trip
+    // instead of two, at the price of 64 unused bytes for the ~20 % of the hits that fail the anchor test
+    const cc_bci_t *bs = &src->bcis[li][h.seq];
+    const cc_bci_t *bt = &tgt->bcis[li][seq_tgt];
+    unsigned long long S[4], T[4];
+    for (int w = 0; w < 4; w++) {
+      S[w] = bs->dist_bin[w];
+      T[w] = bt->dist_bin[w];
+    }
     anchor_ok = cc_check_sim(src->cont[li][h.seq], tgt->cont[li][seq_tgt], P.sim);
     if (anchor_ok) {
-      const cc_bci_t *bs = &src->bcis[li][h.seq];
-      const cc_bci_t *bt = &tgt->bcis[li][seq_tgt];
-      unsigned long long S[4], T[4];
-      for (int w = 0; w < 4; w++) {
-        S[w] = bs->dist_bin[w];
-        T[w] = bt->dist_bin[w];
-      }
       int ov1 = 0, ov2 = 0, ov3 = 0;
       for (int w = 0; w < 4; w++) {
         const unsigned long long shl = (S[w] << 1) | (w > 0 ? (S[w - 1] >> 63) : 0ull);
@@ -183,12 +187,12 @@ struct cc_b1_lds {  // per group; the unions hold data of phases that never over
   short seg[3][20];                        // sort: pending quicksort segments (first, last, depth left); serial-sort stack
 };
 static_assert(CC_PP_MAX <= 256, "pair indices are bytes");
-static_assert(CC_BCI_MAXPTS <= 3 * CC_G && sizeof(cc_relpt_t) == 12, "three 12-byte point loads per lane cover a BCI");
+static_assert(CC_BCI_MAXPTS * sizeof(cc_relpt_t) == 60 * 8 && offsetof(cc_bci_t, pts) % 8 == 0, "a point table is 60 aligned 8-byte words");
 
 // potential pairs (contour_mng.h:311-334): for tgt point i (ascending bit_pos) all src points with bit_pos within +-1, in
 // src order.
-template <int PPM>
-__device__ __forceinline__ void cc_b1_gen_pairs(cc_b1_lds<PPM> &L, int ntp, int sl) {
+template <int PPM, typename LT>
+__device__ __forceinline__ void cc_b1_gen_pairs(LT &L, int ntp, int sl) {
   for (int i = sl; i < ntp; i += CC_G) {
     const cc_relpt_t r2 = L.g.tp[i];
     int o = L.g.off[i];
@@ -202,6 +206,7 @@ __device__ __forceinline__ void cc_b1_gen_pairs(cc_b1_lds<PPM> &L, int ntp, int 
       const double xw = (double)od + 3.14159265358979323846;
       const double kw = xw < 0.0 ? -1.0 : (xw >= 2 * 3.14159265358979323846 ? 1.0 : 0.0);
       od = (float)((double)od - kw * 2 * 3.14159265358979323846);
+      od += 0.0f;  // -0 -> +0: the order-preserving integer key below must not tell them apart (the float compare does not)
       L.pp[o] = ((unsigned long long)cc_fkey(od) << 32) |
                 (unsigned long long)((unsigned)(r1.level & 0xFF) | ((unsigned)(r1.seq & 0xFF) << 8) | ((unsigned)(r2.seq & 0xFF) << 16));
     }
@@ -216,6 +221,7 @@ __device__ __forceinline__ int cc_b1_bin(float od) {
 }
 
 #define CC_B1_KEY(w) cc_funkey((unsigned)((w) >> 32))
+#define CC_B1_UKEY(w) ((unsigned)((w) >> 32))
 
 // std::sort(potential_pairs, orie_diff <) (contour_mng.h:340).  Equal orie_diff are common (contour centres are means of
 // integer cell coordinates, so revisits reproduce them bit for bit) and the reference's order among them is whatever
@@ -228,11 +234,65 @@ __device__ __forceinline__ int cc_b1_bin(float od) {
 // The heapsort branch (depth limit 2*floor(log2 n) exhausted) is replayed serially by one lane on regenerated input.
 // Result: L.sidx[k] = index into L.pp of the k-th pair, L.skey[k] = its orie_diff.
 template <int PPM>
-__device__ __noinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, int sl) {
+__device__ __forceinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, int sl) {
   const int G = CC_G;
   unsigned char *lpos = L.binidx, *rasc = L.sidx;  // stopper lists (both arrays are free until step 2)
   bool deep = false;
   cc_group_sync();  // the pairs are in place
+  // Fast path (almost every check): when no two keys are equal the sorted order is unique, whatever algorithm produces
+  // it.  rank = number of smaller keys, compared as order-preserving integers; two equal keys get the same rank, which
+  // shows as a rank that nobody claims -- only then is libstdc++'s introsort replayed below.
+  if (PPM <= 64 || npp <= 64) {
+    const unsigned *kw = (const unsigned *)&L.pp[0];  // key of pair j: high word of pp[j]
+    unsigned kv[4];
+    int rk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = sl + u * G;
+      kv[u] = p < npp ? kw[2 * p + 1] : 0xFFFFFFFFu;
+      rk[u] = 0;
+    }
+    if (npp <= 32) {
+      for (int j = 0; j < npp; j++) {
+        const unsigned kj = kw[2 * j + 1];
+        rk[0] += kj < kv[0] ? 1 : 0;
+        rk[1] += kj < kv[1] ? 1 : 0;
+      }
+    } else {
+      for (int j = 0; j < npp; j++) {
+        const unsigned kj = kw[2 * j + 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rk[u] += kj < kv[u] ? 1 : 0;
+      }
+    }
+    // ranks claimed by this lane's pairs, as two 32-bit words; OR over the group: ranks of different lanes never collide
+    // unless keys are equal
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (sl + u * G < npp) {
+        const unsigned bit = 1u << (rk[u] & 31);
+        if (rk[u] < 32)
+          lo |= bit;
+        else
+          hi |= bit;
+      }
+    lo = cc_group_or_u(lo);
+    hi = cc_group_or_u(hi);
+    if (__popc(lo) + __popc(hi) == npp) {
+      cc_group_sync();  // all keys read before skey (shares storage with the point tables only) and sidx are written
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = sl + u * G;
+        if (p < npp) {
+          L.sidx[rk[u]] = (unsigned char)p;
+          L.skey[rk[u]] = cc_funkey(kv[u]);
+        }
+      }
+      cc_group_sync();
+      return;
+    }
+  }
   if (npp > 16) {
     int lg = 0;
     for (int t = npp; t > 1; t >>= 1) lg++;
@@ -252,7 +312,8 @@ __device__ __noinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, int
       depth--;
       const int mid = first + (last - first) / 2;
       const int ia = first + 1, ib = mid, ic = last - 1;
-      const float ka = CC_B1_KEY(L.pp[ia]), kb = CC_B1_KEY(L.pp[ib]), kc = CC_B1_KEY(L.pp[ic]);
+      // comparisons on the order-preserving integer keys (same outcome as on the floats: no NaN, no -0)
+      const unsigned ka = CC_B1_UKEY(L.pp[ia]), kb = CC_B1_UKEY(L.pp[ib]), kc = CC_B1_UKEY(L.pp[ic]);
       int sel;  // __move_median_to_first(first, first+1, mid, last-1)
       if (ka < kb) {
         if (kb < kc)
@@ -274,15 +335,15 @@ __device__ __noinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, int
         L.pp[sel] = t;
       }
       cc_group_sync();
-      const float piv = CC_B1_KEY(L.pp[first]);
+      const unsigned piv = CC_B1_UKEY(L.pp[first]);
       int nL = 0, nR = 0;
       for (int r0 = first + 1; r0 < last; r0 += G) {
         const int i = r0 + sl;
         bool ls = false, rs = false;
         if (i < last) {
-          const float k = CC_B1_KEY(L.pp[i]);
-          ls = !(k < piv);
-          rs = !(piv < k);
+          const unsigned k = CC_B1_UKEY(L.pp[i]);
+          ls = k >= piv;
+          rs = k <= piv;
         }
         const unsigned mL = cc_group_ballot(ls), mR = cc_group_ballot(rs);
         if (ls) lpos[nL + __popc(mL & ((1u << sl) - 1u))] = (unsigned char)i;
@@ -324,11 +385,12 @@ __device__ __noinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, int
   }
   if (deep) {
     cc_group_sync();
-    cc_b1_gen_pairs(L, ntp, sl);
+    cc_b1_gen_pairs<PPM>(L, ntp, sl);
     cc_group_sync();
     if (sl == 0)
-      ccsort::std_sort(L.pp, npp, [](const unsigned long long &x, const unsigned long long &y) { return CC_B1_KEY(x) < CC_B1_KEY(y); },
-                       (unsigned *)&L.seg[0][0]);
+      ccsort::std_sort(L.pp, npp,
+                       [](const unsigned long long &x, const unsigned long long &y) { return CC_B1_KEY(x) < CC_B1_KEY(y); },
+                       (unsigned *)&L.seg[0][0]);  // rare path: generic pointers are fine here
     cc_group_sync();
     for (int k = sl; k < npp; k += G) {
       L.sidx[k] = (unsigned char)k;
@@ -453,28 +515,24 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
     const cc_bci_t *bs = &db_hot[h.gidx].bcis[level - 1][seq_src];
     const cc_bci_t *bt = &qhot[q].bcis[level - 1][seq_tgt];
-    // point tables and their sizes are fetched together (no dependent round trip): CC_BCI_MAXPTS <= 3 * G
-    // (moved as raw dwords: a cc_relpt_t is 3 of them)
-    unsigned ps[3][3], pt[3][3];
-    const unsigned *gs = (const unsigned *)bs->pts, *gt = (const unsigned *)bt->pts;
+    // point tables and their sizes are fetched together (no dependent round trip), as 8-byte words: a table is
+    // 40 x 12 B = 60 words at an 8-byte aligned offset, four words per lane
+    uint2 ps[4], pt[4];
+    const uint2 *gs = (const uint2 *)bs->pts, *gt = (const uint2 *)bt->pts;
 #pragma unroll
-    for (int u = 0; u < 3; u++) {
+    for (int u = 0; u < 4; u++) {
       const int k = sl + u * G;
-#pragma unroll
-      for (int w = 0; w < 3; w++) {
-        ps[u][w] = k < CC_BCI_MAXPTS ? gs[k * 3 + w] : 0u;
-        pt[u][w] = k < CC_BCI_MAXPTS ? gt[k * 3 + w] : 0u;
-      }
+      ps[u] = k < 60 ? gs[k] : make_uint2(0u, 0u);
+      pt[u] = k < 60 ? gt[k] : make_uint2(0u, 0u);
     }
     const int nsp = bs->n_pts, ntp = bt->n_pts;
     cc_group_sync();  // the previous check's reads of the shared storage are done
 #pragma unroll
-    for (int u = 0; u < 3; u++) {
+    for (int u = 0; u < 4; u++) {
       const int k = sl + u * G;
-#pragma unroll
-      for (int w = 0; w < 3; w++) {
-        if (k < nsp) ((unsigned *)L.g.sp)[k * 3 + w] = ps[u][w];
-        if (k < ntp) ((unsigned *)L.g.tp)[k * 3 + w] = pt[u][w];
+      if (k < 60) {
+        ((uint2 *)L.g.sp)[k] = ps[u];
+        ((uint2 *)L.g.tp)[k] = pt[u];
       }
     }
     cc_group_sync();
@@ -525,8 +583,8 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       if (sc && sl == 0) sc[2] = 1;  // the window search starts from longest_in_range = 1 (contour_mng.h:345)
       continue;
     }
-    cc_b1_gen_pairs(L, ntp, sl);
-    cc_b1_sort(L, npp, ntp, sl);
+    cc_b1_gen_pairs<PPM>(L, ntp, sl);
+    cc_b1_sort<PPM>(L, npp, ntp, sl);
     // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
     // that attains the maximum length (what the two-pointer loop records)
     const float angular_range = (float)(3.14159265358979323846 / 16);

@@ -100,6 +100,58 @@ __device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned 
 
 __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
 
+// Rare configuration (min_cont_cell_cnt_ > 3), kept out of line so that its registers do not count against the kernel:
+// compaction of the kept-component tables W[7][CC_NC] / roots to the components with area >= min_cnt; dropped roots
+// become unmarked again.  Entries only move to lower indices, so chunks of blockDim components go front to back.
+// wsum: 8 ints of LDS.  Returns the new count (uniform).
+__device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *W, uint16_t *roots, uint16_t *LAB, int *wsum) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave_id = tid >> 6, n_waves = nt >> 6;
+  int n_new = 0;
+  for (int k0 = 0; k0 < n_kept; k0 += nt) {
+    const int k = k0 + tid;
+    unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, rt = 0;
+    bool keep = false;
+    if (k < n_kept) {
+      v0 = W[k];
+      v1 = W[CC_NC + k];
+      v2 = W[2 * CC_NC + k];
+      v3 = W[3 * CC_NC + k];
+      v4 = W[4 * CC_NC + k];
+      v5 = W[5 * CC_NC + k];
+      v6 = W[6 * CC_NC + k];
+      rt = roots[k];
+      keep = (int)v4 >= min_cnt;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wave_id] = __popcll(m);
+    __syncthreads();
+    int off = n_new + __popcll(m & ((1ull << lane) - 1ull));
+    int tot = 0;
+    for (int w = 0; w < n_waves; w++) {
+      if (w < wave_id) off += wsum[w];
+      tot += wsum[w];
+    }
+    if (k < n_kept) {
+      if (keep) {
+        W[off] = v0;
+        W[CC_NC + off] = v1;
+        W[2 * CC_NC + off] = v2;
+        W[3 * CC_NC + off] = v3;
+        W[4 * CC_NC + off] = v4;
+        W[5 * CC_NC + off] = v5;
+        W[6 * CC_NC + off] = v6;
+        roots[off] = (uint16_t)rt;
+        LAB[rt] = (uint16_t)(0x8000u | (unsigned)off);
+      } else {
+        LAB[rt] = (uint16_t)rt;  // unmarked root: component not kept
+      }
+    }
+    n_new += tot;
+    __syncthreads();
+  }
+  return n_new;
+}
+
 __global__ void __launch_bounds__(CC_K2_BLOCK)
 cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
@@ -273,43 +325,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
     __syncthreads();
     // min_cont_cell_cnt_ > 3: the saturating counters only prove ">= 3 cells"; with the exact areas known, drop the
-    // components below the bar (stats(n,4) < cfg_.min_cont_cell_cnt_, contour_mng.cpp:303) and renumber the rest.
-    // Compaction moves entries to lower indices only, so chunks of nt components are handled front to back.
-    if (cfg.min_cont_cell_cnt > 3) {
-      int n_new = 0;
-      for (int k0 = 0; k0 < n_kept; k0 += nt) {
-        const int k = k0 + tid;
-        unsigned v[7] = {0, 0, 0, 0, 0, 0, 0};
-        unsigned rt = 0;
-        bool keep = false;
-        if (k < n_kept) {
-          for (int a = 0; a < 7; a++) v[a] = W[a * CC_NC + k];
-          rt = roots[k];
-          keep = (int)v[4] >= cfg.min_cont_cell_cnt;
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) sh[24 + wave_id] = __popcll(m);
-        __syncthreads();
-        int off = n_new + __popcll(m & ((1ull << lane) - 1ull));
-        int tot = 0;
-        for (int w = 0; w < n_waves; w++) {
-          if (w < wave_id) off += sh[24 + w];
-          tot += sh[24 + w];
-        }
-        if (k < n_kept) {
-          if (keep) {
-            for (int a = 0; a < 7; a++) W[a * CC_NC + off] = v[a];
-            roots[off] = (uint16_t)rt;
-            LAB[rt] = (uint16_t)(0x8000u | (unsigned)off);
-          } else {
-            LAB[rt] = (uint16_t)rt;  // unmarked root: component not kept
-          }
-        }
-        n_new += tot;
-        __syncthreads();
-      }
-      n_kept = n_new;
-    }
+    // components below the bar (stats(n,4) < cfg_.min_cont_cell_cnt_, contour_mng.cpp:303) and renumber the rest
+    if (cfg.min_cont_cell_cnt > 3) n_kept = cc_k2_drop_small(cfg.min_cont_cell_cnt, n_kept, W, roots, LAB, sh + 24);
     for (int k = tid; k < n_kept; k += nt) w_cA[k] = (unsigned)roots[k] % (unsigned)n_col;
     CC_K2_LAP(acc_enum);
     // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
@@ -412,6 +429,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   __syncthreads();
   int n_lev[CC_NLEV];
   for (int l = 0; l < CC_NLEV; l++) n_lev[l] = sh[8 + l];
+  // lane-dependent level index: a select chain over the six registers (a lane-indexed array would live in scratch memory)
+#define CC_NLEV_AT(i) ((i) == 0 ? n_lev[0] : (i) == 1 ? n_lev[1] : (i) == 2 ? n_lev[2] : (i) == 3 ? n_lev[3] : (i) == 4 ? n_lev[4] : n_lev[5])
   const int flags0 = sh[2];
   __syncthreads();
   cc_comp_t *T = (cc_comp_t *)R;                                            // [6][NC] 30720 B
@@ -462,9 +481,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     const int lane_l = (nt >= 64 * CC_NLEV) ? ((tid & 63) == 0 ? (tid >> 6) : -1) : (tid < CC_NLEV ? tid : -1);
     if (lane_l >= 0 && lane_l < CC_NLEV) {
       unsigned *a = arr + lane_l * CC_NC;
-      ccsort::std_sort(a, n_lev[lane_l], [](unsigned x, unsigned y) { return (x >> 16) > (y >> 16); });
+      ccsort::std_sort(a, CC_NLEV_AT(lane_l), [](unsigned x, unsigned y) { return (x >> 16) > (y >> 16); },
+                       (unsigned *)R2 + lane_l * CC_SORT_STACK);  // R2 is unused until the keys phase
       int tot = 0;
-      for (int i = 0; i < n_lev[lane_l]; i++) tot += (int)(a[i] >> 16);
+      for (int i = 0; i < CC_NLEV_AT(lane_l); i++) tot += (int)(a[i] >> 16);
       sh2[lane_l] = tot;
     }
   }
@@ -494,8 +514,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
   }
   if (tid < CC_NLEV) {
-    desc->n_cont[tid] = n_lev[tid];
-    desc->n_stored[tid] = n_lev[tid] < CC_MAXC ? n_lev[tid] : CC_MAXC;
+    desc->n_cont[tid] = CC_NLEV_AT(tid);
+    desc->n_stored[tid] = CC_NLEV_AT(tid) < CC_MAXC ? CC_NLEV_AT(tid) : CC_MAXC;
     desc->layer_cell_cnt[tid] = sh2[tid];
   }
   if (tid == 0) {
@@ -533,8 +553,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     int ok = 0, acc = 0;
     if (seq < cfg.piv_firsts) {
       for (int s = 0; s <= seq; s++)
-        if (s < n_lev[ll]) acc += top[ll * CC_NDIST + s].cnt;  // accumulate_cell_cnt (contour_mng.h:705-706)
-      ok = (seq < n_lev[ll] && top[ll * CC_NDIST + seq].cnt >= cfg.min_cont_key_cnt) ? 1 : 0;
+        if (s < CC_NLEV_AT(ll)) acc += top[ll * CC_NDIST + s].cnt;  // accumulate_cell_cnt (contour_mng.h:705-706)
+      ok = (seq < CC_NLEV_AT(ll) && top[ll * CC_NDIST + seq].cnt >= cfg.min_cont_key_cnt) ? 1 : 0;
     }
     valid[tid] = ok;
     accum[tid] = acc;
@@ -652,7 +672,6 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     int bit;
     float r, theta;
   };
-  cc_relpt_t *bpts = (cc_relpt_t *)(R + 0);                        // [36][40] 17280 B  (T is dead now)
   bci_tmp *btmp = (bci_tmp *)(R + 17280);                          // [36][40] 23040 B  (T/skey/arr dead; ends < top)
   for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
     const int a = t / CC_BCI_MAXPTS, q = t - a * CC_BCI_MAXPTS;
@@ -664,7 +683,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     o.r = 0.f;
     o.theta = 0.f;
     const int lev = bl + 1;  // DIST_BIN_LAYERS = {1,2,3,4}
-    const int lim = cfg.dist_firsts < n_lev[lev] ? cfg.dist_firsts : n_lev[lev];
+    const int lim = cfg.dist_firsts < CC_NLEV_AT(lev) ? cfg.dist_firsts : CC_NLEV_AT(lev);
     if (valid[a] && j < lim && !(ll == lev && j == seq)) {
       const float vx = top[lev * CC_NDIST + j].pm[0] - top[ll * CC_NDIST + seq].pm[0];
       const float vy = top[lev * CC_NDIST + j].pm[1] - top[ll * CC_NDIST + seq].pm[1];
@@ -683,56 +702,73 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     btmp[t] = o;
   }
   __syncthreads();
+  // The neighbour points are sorted through 32-bit proxies (bit_pos << 8 | slot, compared on bit_pos only): the replay of
+  // std::sort depends on the comparison outcomes alone, so the proxies end up in the order the reference's
+  // RelativePoint records would.
+  unsigned *bkey = (unsigned *)(R + 0);                            // [36][40] (T is dead now)
+  int *bcnt = (int *)(R + 5760);                                   // [36] points per anchor
   if (tid < NA) {
     const int a = tid;
     const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-    cc_relpt_t *p = bpts + a * CC_BCI_MAXPTS;
+    unsigned *p = bkey + a * CC_BCI_MAXPTS;
     int n = 0;
-    unsigned long long bits[CC_BCI_LAYERS] = {0, 0, 0, 0};
+    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     for (int q = 0; q < CC_BCI_MAXPTS; q++) {
       const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
       if (!o.ok) continue;
-      cc_relpt_t rp;
-      rp.level = (int8_t)(q / CC_NDIST + 1);
-      rp.seq = (int8_t)(q % CC_NDIST);
-      rp.bit_pos = (int16_t)o.bit;
-      rp.r = o.r;
-      rp.theta = o.theta;
-      p[n++] = rp;
-      bits[o.bit >> 6] |= 1ull << (o.bit & 63);
+      p[n++] = ((unsigned)o.bit << 8) | (unsigned)q;
+      const unsigned long long m = 1ull << (o.bit & 63);
+      const int w = o.bit >> 6;
+      b0 |= w == 0 ? m : 0ull;
+      b1 |= w == 1 ? m : 0ull;
+      b2 |= w == 2 ? m : 0ull;
+      b3 |= w == 3 ? m : 0ull;
     }
-    ccsort::std_sort(p, n, [](const cc_relpt_t &x, const cc_relpt_t &y) { return x.bit_pos < y.bit_pos; });
+    // pending-halves stack of the sort replay: behind the key tables in R2 (divs 5040 B + 3 x 36 ints end at 5488)
+    ccsort::std_sort(p, n, [](unsigned x, unsigned y) { return (x >> 8) < (y >> 8); }, (unsigned *)(R2 + 5504) + a * CC_SORT_STACK);
+    bcnt[a] = n;
     cc_bci_t *ob = &desc->bcis[ll][seq];
-    for (int w = 0; w < CC_BCI_LAYERS; w++) ob->dist_bin[w] = bits[w];
+    ob->dist_bin[0] = b0;
+    ob->dist_bin[1] = b1;
+    ob->dist_bin[2] = b2;
+    ob->dist_bin[3] = b3;
     ob->piv_seq = (int8_t)seq;
     ob->level = (int8_t)ll;
     ob->n_pts = (uint8_t)n;
     int ns = 0;
     if (n > 0) {
       ob->segs[ns++] = 0;
-      int last = 0;
+      unsigned last = p[0] >> 8;
       for (int i = 0; i < n; i++)
-        if (p[last].bit_pos != p[i].bit_pos) {
+        if (last != (p[i] >> 8)) {
           ob->segs[ns++] = (uint16_t)i;
-          last = i;
+          last = p[i] >> 8;
         }
       ob->segs[ns++] = (uint16_t)n;
     }
     ob->n_segs = (uint8_t)ns;
     for (int i = ns; i < CC_BCI_MAXPTS + 2; i++) ob->segs[i] = 0;
-    for (int i = 0; i < CC_BCI_MAXPTS; i++) {
-      cc_relpt_t rp;
-      if (i < n)
-        rp = p[i];
-      else {
-        rp.level = 0;
-        rp.seq = 0;
-        rp.bit_pos = 0;
-        rp.r = 0.f;
-        rp.theta = 0.f;
-      }
-      ob->pts[i] = rp;
+  }
+  __syncthreads();
+  // the point records, all threads
+  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
+    const int a = t / CC_BCI_MAXPTS, i = t - a * CC_BCI_MAXPTS;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    unsigned w0 = 0u;
+    float r = 0.f, th = 0.f;
+    if (i < bcnt[a]) {
+      const unsigned k = bkey[a * CC_BCI_MAXPTS + i];
+      const int q = (int)(k & 0xFFu);
+      const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
+      // level (int8) | seq (int8) << 8 | bit_pos (int16) << 16
+      w0 = (unsigned)(q / CC_NDIST + 1) | ((unsigned)(q % CC_NDIST) << 8) | ((k >> 8) << 16);
+      r = o.r;
+      th = o.theta;
     }
+    unsigned *dst = (unsigned *)&desc->bcis[ll][seq].pts[i];
+    dst[0] = w0;
+    dst[1] = __float_as_uint(r);
+    dst[2] = __float_as_uint(th);
   }
   CC_K2_STAMP(8);
 }

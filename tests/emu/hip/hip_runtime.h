@@ -41,6 +41,10 @@ struct float4 {
 struct int2 {
   int x, y;
 };
+struct uint2 {
+  unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
 struct double2 {
   double x, y;
 };
