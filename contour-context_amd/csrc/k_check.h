@@ -104,7 +104,7 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
   const int NS = CC_NQLEV * CC_NPIV;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(gt / CC_CHK_STRIDE), t = (int)(gt - (size_t)q * CC_CHK_STRIDE);
-  if (q >= nq) return;  // whole waves: CC_CHK_STRIDE is a multiple of 64
+  const bool in_range = q < nq;  // whole waves: CC_CHK_STRIDE is a multiple of 64 (no early return: barriers below)
   const int lane = threadIdx.x & 63;
   const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
   bool anchor_ok = false, keep = false;
@@ -113,7 +113,7 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
   h.gidx = 0;
   h.level = h.seq = 0;
   h.dist_sq = 0.f;
-  if (j < hit_cnt[q * NS + slot]) {
+  if (in_range && j < hit_cnt[q * NS + slot]) {
     h = hits[((size_t)q * NS + slot) * CC_KNN_MAX + j];
     const int seq_tgt = CC_HIT_SEQ_TGT(h, slot), li = CC_HIT_LEVEL(h) - 1;
     const cc_hot_desc_t *src = db_hot + h.gidx, *tgt = qhot + q;
@@ -144,20 +144,30 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
       sc_max = max_one;
     }
   }
-  pass_ok[gt] = 0;
-  if (scores) {
+  if (in_range) pass_ok[gt] = 0;
+  if (scores && in_range) {
     int *sc = scores + gt * CC_NSCORE;
     sc[0] = sc_sum;
     sc[1] = sc_max;
     sc[2] = sc[3] = sc[4] = 0;
   }
+  // list append: one global atomic per workgroup (a single counter would otherwise see an atomic per wave, and
+  // same-address atomics are served one after the other)
+  __shared__ int s_wcnt[4], s_base;
   const unsigned long long mk = __ballot(keep), ma = __ballot(anchor_ok);
-  int base = 0;
+  const int wave = threadIdx.x >> 6;
   if (lane == 0) {
-    if (mk) base = atomicAdd(&cnt[CC_CNT_CHK], __popcll(mk));
+    s_wcnt[wave] = __popcll(mk);
     if (ma) atomicAdd(&pass_cnt[q * 4 + 1], __popcll(ma));
   }
-  base = __builtin_amdgcn_readfirstlane(base);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    s_base = tot ? atomicAdd(&cnt[CC_CNT_CHK], tot) : 0;
+  }
+  __syncthreads();
+  int base = s_base;
+  for (int w = 0; w < wave; w++) base += s_wcnt[w];
   if (keep) {
     cc_chk_item it;
     it.q = q;
@@ -510,6 +520,9 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     if (i + stride < n_items) it_nxt = items[REDO ? redo_idx[i + stride] : i + stride];
     const int q = it.q, t = it.t;
     const cc_knn_hit_t h = it.h;
+    // the check's constellation record sits at the check's own list position; n_in = 0 until (unless) it passes
+    cc_cstl_item *out = cstl + (REDO ? redo_idx[i] : i);
+    if (sl == 0) out->n_in = 0;
     const int slot = t / CC_KNN_MAX;
     const int level = CC_HIT_LEVEL(h), seq_src = h.seq, seq_tgt = CC_HIT_SEQ_TGT(h, slot);
     int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
@@ -572,7 +585,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     int npp = npp_all;
     if (npp > PPM) {
       if (!REDO) {  // left to the large instance
-        if (sl == 0) redo_idx[atomicAdd(&cnt[CC_CNT_REDO], 1)] = i;
+        if (sl == 0) redo_idx[atomicAdd(&cnt[CC_CNT_REDO], 1)] = i;  // rare: no contention to speak of
         continue;
       }
       npp = PPM;
@@ -621,13 +634,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       n_in = CC_CSTL_MAX;
       flags |= 1;
     }
-    int o = 0;
-    if (sl == 0) {
-      atomicAdd(&pass_cnt[q * 4 + 2], 1);
-      o = atomicAdd(&cnt[CC_CNT_CSTL], 1);
-    }
-    o = cc_group_bcast(o, 0);
-    cc_cstl_item *out = cstl + o;
+    if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
     for (int e = sl; e < n_in; e += G) {
       unsigned short v;
       if (e < longest && e < n_in - 1) {
@@ -650,6 +657,27 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       out->flags = flags;
     }
   }
+}
+
+// The constellations that passed, as a dense index list for stage B2 (order irrelevant: results are slot-indexed).
+// One global atomic per workgroup.  grid = ceil(n_chk_max / 256) (device-side bound check), block = 256
+__global__ void __launch_bounds__(256)
+cc_k_compact_cstl(const cc_cstl_item *__restrict__ cstl, int *__restrict__ cnt, int *__restrict__ cstl_idx) {
+  __shared__ int s_wcnt[4], s_base;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool ok = i < cnt[CC_CNT_CHK] && cstl[i].n_in != 0;
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) s_wcnt[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    s_base = tot ? atomicAdd(&cnt[CC_CNT_CSTL], tot) : 0;
+  }
+  __syncthreads();
+  int base = s_base;
+  for (int w = 0; w < wave; w++) base += s_wcnt[w];
+  if (ok) cstl_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // ---- stage B2 -------------------------------------------------------------------------------------------------------
@@ -675,15 +703,16 @@ __device__ __forceinline__ int cc_shaft_i(int pr) {
 // grid = any (grid-stride over the device-side list), block = 64
 __global__ void __launch_bounds__(64)
 cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_hot_desc_t *__restrict__ db_hot,
-              const cc_cstl_item *__restrict__ cstl, const int *__restrict__ cnt, cc_pass_rec *__restrict__ pass,
-              unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt, int *__restrict__ scores) {
+              const cc_cstl_item *__restrict__ cstl, const int *__restrict__ cstl_idx, const int *__restrict__ cnt,
+              cc_pass_rec *__restrict__ pass, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt,
+              int *__restrict__ scores) {
   __shared__ cc_b2_lds LG[CC_CHKB_GPW];
   const int G = CC_G;
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
   cc_b2_lds &L = LG[sub];
   const int n_items = cnt[CC_CNT_CSTL];
   for (int i = blockIdx.x * CC_CHKB_GPW + sub; i < n_items; i += gridDim.x * CC_CHKB_GPW) {
-    const cc_cstl_item *it = cstl + i;
+    const cc_cstl_item *it = cstl + cstl_idx[i];
     const int q = it->q, t = it->t, gidx = it->gidx, n_in = it->n_in;
     int flags = it->flags;
     int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
@@ -907,11 +936,12 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 // does (getTFFromConstell returns Isometry2d; addProposal and the pose output go through rotate(angle)).
 // grid = any (grid-stride), block = 256
 __global__ void __launch_bounds__(256)
-cc_k_check_c(const cc_cstl_item *__restrict__ cstl, const int *__restrict__ cnt, cc_pass_rec *__restrict__ pass,
-             const unsigned char *__restrict__ pass_ok) {
+cc_k_check_c(const cc_cstl_item *__restrict__ cstl, const int *__restrict__ cstl_idx, const int *__restrict__ cnt,
+             cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok) {
   const int n = cnt[CC_CNT_CSTL];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const size_t slot = (size_t)cstl[i].q * CC_CHK_STRIDE + cstl[i].t;
+    const cc_cstl_item *it = cstl + cstl_idx[i];
+    const size_t slot = (size_t)it->q * CC_CHK_STRIDE + it->t;
     if (!pass_ok[slot]) continue;
     cc_pass_rec *rec = &pass[slot];
     const double r00 = rec->cs[0], r10 = rec->cs[1];

@@ -212,12 +212,12 @@ __device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_
 // broadcast load); a selected pair's term is evaluated on the spot.
 // grid = any (grid-stride over the device-side problem count), block = 64
 __global__ void __launch_bounds__(64)
-cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_prob_p, int prob_cap,
+cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
               const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
-  int n_prob = *n_prob_p;
-  if (n_prob > prob_cap) n_prob = prob_cap;
-  for (int pidx = blockIdx.x * (64 / CC_G) + sub; pidx < n_prob; pidx += gridDim.x * (64 / CC_G)) {
+  const int n_prob = *n_prob_p;
+  for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G)) {
+    const int pidx = prob_list[pi];
     const cc_gmm_problem pb = probs[pidx];
     const cc_gmm_feat *fsrc = db_feat + pb.gidx;
     const cc_gmm_feat *ftgt = qfeat + pb.q;
@@ -907,10 +907,17 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
   ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; }, stk);
   const int pre = max_fine_opt < n ? max_fine_opt : n;
   // two lists: short pair lists go to the 16-lane refinement instance, long ones to the 64-lane instance
+  // (two atomics per query, not one per problem: same-address atomics are served one after the other)
+  int n_big = 0;
+  for (int i = 0; i < pre; i++) n_big += gres[gm[idx[i]]].n_pairs > CC_GMM_G16_MAX_PAIRS ? 1 : 0;
+  int o_small = (pre - n_big) ? atomicAdd(&n_sel[0], pre - n_big) : 0;
+  int o_big = n_big ? atomicAdd(&n_sel[1], n_big) : 0;
   for (int i = 0; i < pre; i++) {
     const int g = gm[idx[i]];
-    const int big = gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS ? 1 : 0;
-    sel_list[(size_t)big * sel_stride + atomicAdd(&n_sel[big], 1)] = g;
+    if (gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS)
+      sel_list[(size_t)sel_stride + o_big++] = g;
+    else
+      sel_list[o_small++] = g;
   }
 }
 

@@ -44,6 +44,7 @@ struct cc_merge_lds {
   unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
   int wsum[CC_MERGE_BLOCK / 64];
   int base;
+  unsigned char want[CC_CHK_STRIDE];       // candidate k goes on to the correlation
 };
 
 static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
@@ -53,7 +54,8 @@ __global__ void __launch_bounds__(CC_MERGE_BLOCK)
 cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__restrict__ qdesc,
            const cc_hot_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
            const int *__restrict__ pass_cnt, cc_cand_out *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
-           cc_gmm_problem *__restrict__ probs, int prob_cap, int *__restrict__ n_prob) {
+           cc_gmm_problem *__restrict__ probs /*[nq][CC_MAXCAND]: problem of candidate k of query q*/,
+           int *__restrict__ prob_list /*dense list of the problems that exist*/, int *__restrict__ n_prob) {
   __shared__ cc_merge_lds L;
   const int q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (q >= nq) return;
@@ -209,19 +211,19 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
       const double ex = 1.0 * mx + 0.0 * my + (-(1.0 * ox + 0.0 * oy)), ey = 0.0 * mx + 1.0 * my + (-(0.0 * ox + 1.0 * oy));
       const double neg = -sqrt(ex * ex + ey * ey);
       if (!(neg < (double)lb.neg_est_dist)) {
-        const int pi = atomicAdd(n_prob, 1);
-        if (pi < prob_cap) {
-          cc_gmm_problem pb;
-          pb.q = q;
-          pb.gidx = c->gidx;
-          pb.tf[0] = p0->tx;
-          pb.tf[1] = p0->ty;
-          pb.tf[2] = atan2(p0->s, p0->c);
-          probs[pi] = pb;
-          gi = pi;
-        }
+        // the candidate's correlation problem has a fixed place (no shared counter on this path: a single-address
+        // atomic per candidate would serialise the chunk); the dense list is built once per query below
+        gi = q * CC_MAXCAND + k;
+        cc_gmm_problem pb;
+        pb.q = q;
+        pb.gidx = c->gidx;
+        pb.tf[0] = p0->tx;
+        pb.tf[1] = p0->ty;
+        pb.tf[2] = atan2(p0->s, p0->c);
+        probs[gi] = pb;
       }
     }
+    L.want[k] = gi >= 0 ? 1 : 0;
     cc_cand_out o;
     o.gidx = c->gidx;
     o.nprops = c->nprops;
@@ -229,5 +231,27 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     o.pad = 0;
     cands_all[(size_t)q * CC_MAXCAND + k] = o;
   }
+  // ---- dense problem list: ordered ranks within the query, one global atomic per query
+  __syncthreads();
+  int n_want = 0;
+  for (int b0 = 0; b0 < nc; b0 += CC_MERGE_BLOCK) {
+    const int k = b0 + tid;
+    const bool w = k < nc && L.want[k];
+    const unsigned long long m = __ballot(w);
+    if (lane == 0) L.wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_want + __popcll(m & ((1ull << lane) - 1ull));
+    int tot = 0;
+    for (int wv = 0; wv < CC_MERGE_BLOCK / 64; wv++) {
+      if (wv < wave) off += L.wsum[wv];
+      tot += L.wsum[wv];
+    }
+    if (w) L.ord[off] = (unsigned short)k;  // ord (the check slots) is dead by now
+    n_want += tot;
+    __syncthreads();
+  }
+  if (tid == 0) L.base = n_want ? atomicAdd(n_prob, n_want) : 0;
+  __syncthreads();
+  for (int i = tid; i < n_want; i += CC_MERGE_BLOCK) prob_list[L.base + i] = q * CC_MAXCAND + (int)L.ord[i];
 }
 
