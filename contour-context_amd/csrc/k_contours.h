@@ -29,10 +29,15 @@ struct cc_comp_t {  // per kept component, spilled to global scratch between lev
   uint8_t r0, r1, c0, c1, cA, cB, pad[2];
 };  // 16 B
 
-struct cc_k2_scratch {  // per workgroup
+struct cc_k2_scratch {  // per scan of a launch
   cc_comp_t comp[CC_NLEV][CC_NC];
   cc_contour_t cont[CC_NLEV][CC_NC];
+  uint16_t wfirst[CC_NLEV][CC_NC], wlast[CC_NLEV][CC_NC];  // list positions of a component's first and last cell
+  uint16_t act[CC_MAX_CELLS];                               // active cells (above the lowest level), raster order
+  uint16_t compidx[CC_NLEV][CC_MAX_CELLS];                  // per level: component index of list entry i, 0x7FFF = none
 };
+#define CC_K2_OWN 4       // list entries a thread keeps in registers (beyond: read from the scratch block)
+#define CC_K2_CACHE 3072  // active cells whose height / position are staged in LDS for the walk
 
 struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
   float pm[2];
@@ -104,7 +109,8 @@ __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return
 // compaction of the kept-component tables W[7][CC_NC] / roots to the components with area >= min_cnt; dropped roots
 // become unmarked again.  Entries only move to lower indices, so chunks of blockDim components go front to back.
 // wsum: 8 ints of LDS.  Returns the new count (uniform).
-__device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *W, uint16_t *roots, uint16_t *LAB, int *wsum) {
+__device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *W, uint16_t *roots, uint16_t *LAB, int *wsum,
+                                            uint16_t *remap /*[old index] = new index or 0x7FFF*/) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave_id = tid >> 6, n_waves = nt >> 6;
   int n_new = 0;
   for (int k0 = 0; k0 < n_kept; k0 += nt) {
@@ -120,7 +126,7 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
       v5 = W[5 * CC_NC + k];
       v6 = W[6 * CC_NC + k];
       rt = roots[k];
-      keep = (int)v4 >= min_cnt;
+      keep = (int)v3 >= min_cnt;  // W[3] = area
     }
     const unsigned long long m = __ballot(keep);
     if (lane == 0) wsum[wave_id] = __popcll(m);
@@ -142,8 +148,10 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
         W[6 * CC_NC + off] = v6;
         roots[off] = (uint16_t)rt;
         LAB[rt] = (uint16_t)(0x8000u | (unsigned)off);
+        remap[k] = (uint16_t)off;
       } else {
         LAB[rt] = (uint16_t)rt;  // unmarked root: component not kept
+        remap[k] = (uint16_t)0x7FFFu;
       }
     }
     n_new += tot;
@@ -152,7 +160,8 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
   return n_new;
 }
 
-__global__ void __launch_bounds__(CC_K2_BLOCK)
+// 4 waves per SIMD = two 512-thread workgroups (scans) per CU: at most 128 VGPRs
+__global__ void __launch_bounds__(CC_K2_BLOCK, 4)
 cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
               cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk) {
@@ -184,14 +193,63 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   cc_k2_scratch *scr = scratch_all + scan;
   cc_scan_desc_t *desc = desc_out + scan;
 
-  for (int c = tid; c < n_cell; c += nt) {
+  // ---- level index of every cell; the ACTIVE cells (above the lowest level) as a raster-ordered list ----
+  // Everything below works on that list (a few hundred to a few thousand cells of the 22 500): thread t owns entries
+  // t, t + nt, ... and keeps its first CC_K2_OWN of them in registers; the list itself lives in the scan's scratch block.
+  const int chunk_len = (n_cell + nt - 1) / nt;
+  const int c_lo = tid * chunk_len < n_cell ? tid * chunk_len : n_cell;
+  const int c_hi = c_lo + chunk_len < n_cell ? c_lo + chunk_len : n_cell;
+  int my_act = 0;
+  for (int c = c_lo; c < c_hi; c++) {
     const float h = bev[c];
     int lv = 0;
     for (int e = 0; e < CC_NLEV; e++) lv += (h > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
     LV[c] = (unsigned char)lv;
+    LAB[c] = lv ? (uint16_t)c : (uint16_t)CC_LAB_NONE;  // an active cell starts as its own root
+    my_act += lv ? 1 : 0;
   }
-  if (tid < 32) sh[tid] = 0;
+  if (tid < 40) sh[tid] = 0;
   __syncthreads();
+  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  int n_act;
+  {
+    int incl = my_act;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh[24 + wave_id] = incl;
+    __syncthreads();
+    int off = incl - my_act;
+    n_act = 0;
+    for (int w = 0; w < n_waves; w++) {
+      if (w < wave_id) off += sh[24 + w];
+      n_act += sh[24 + w];
+    }
+    for (int c = c_lo; c < c_hi; c++)
+      if (LV[c]) scr->act[off++] = (uint16_t)c;
+  }
+  if (labels_dbg)
+    for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
+  __threadfence_block();
+  __syncthreads();
+  int mc[CC_K2_OWN];
+#pragma unroll
+  for (int u = 0; u < CC_K2_OWN; u++) mc[u] = tid + u * nt < n_act ? (int)scr->act[tid + u * nt] : -1;
+  // `body(c, i)` for every active cell c = act[i] this thread owns
+#define CC_K2_FOR_ACTIVE(...)                                                    \
+  {                                                                              \
+    _Pragma("unroll") for (int u_ = 0; u_ < CC_K2_OWN; u_++) {                   \
+      if (mc[u_] >= 0) {                                                         \
+        const int c = mc[u_], i = tid + u_ * nt;                                 \
+        __VA_ARGS__                                                               \
+      }                                                                          \
+    }                                                                            \
+    for (int i = tid + CC_K2_OWN * nt; i < n_act; i += nt) {                     \
+      const int c = (int)scr->act[i];                                            \
+      __VA_ARGS__                                                                 \
+    }                                                                            \
+  }
 
   int prev_n = 0;
   long long acc_ccl = 0, acc_enum = 0, acc_walk = 0, tmark = phase_clk ? (long long)wall_clock64() : 0;
@@ -203,76 +261,71 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       tmark = now_;                                        \
     }                                                      \
   } while (0)
-  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  unsigned *w_last = W, *w_minc = W + CC_NC, *w_maxc = W + 2 * CC_NC, *w_area = W + 3 * CC_NC, *w_cB = W + 4 * CC_NC,
+           *w_first = W + 5 * CC_NC;
+  const int n_w = (n_cell + 15) >> 4;
   for (int l = CC_NLEV - 1; l >= 0; --l) {
-    // (a) init labels.  LAB still holds the root labels of level l+1 (a subset of this level's cells, lv_grads ascending):
-    //     those components stay merged; cells new at this level (LV == l + 1) start as their own root.
-    if (l == CC_NLEV - 1) {
-      for (int c = tid; c < n_cell; c += nt) LAB[c] = (LV[c] > l) ? (uint16_t)c : (uint16_t)CC_LAB_NONE;
-    } else {
-      for (int c = tid; c < n_cell; c += nt)
-        if (LV[c] == l + 1) LAB[c] = (uint16_t)c;
-    }
-    __syncthreads();
-    // (b) 8-connected labelling: one union per adjacent pair (W, NW, N, NE of every cell) that involves a new cell --
-    //     two old neighbours already share a root -- then every cell is pointed at its root.
-    for (int c = tid; c < n_cell; c += nt) {
-      const int lvc = LV[c];
-      if (lvc <= l) continue;
-      const bool newc = lvc == l + 1;
-      const int r = c / n_col, cc = c - r * n_col;
-      if (cc > 0) {
-        const int lvn = LV[c - 1];
-        if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - 1);
-      }
-      if (r > 0) {
-        if (cc > 0) {
-          const int lvn = LV[c - n_col - 1];
-          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col - 1);
-        }
-        {
-          const int lvn = LV[c - n_col];
-          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col);
-        }
-        if (cc < n_col - 1) {
-          const int lvn = LV[c - n_col + 1];
-          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col + 1);
-        }
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < n_cell; c += nt) {
-      if (LV[c] <= l) continue;
-      const unsigned rt = cc_uf_find(LAB, c);
-      LAB[c] = (uint16_t)rt;
-    }
-    __syncthreads();
-    CC_K2_LAP(acc_ccl);
-    // (c) which roots own >= min_cont_cell_cnt_ (3) cells: 2-bit saturating counters
-    const int n_w = (n_cell + 15) >> 4;
+    // (a) 8-connected labelling of the level set LV > l.  LAB still holds the forest of level l+1 (a subset of this level's
+    //     cells, lv_grads ascending): those components stay merged; cells new at this level (LV == l + 1) are still their
+    //     own roots.  One union per adjacent pair (W, NW, N, NE of every cell) that involves a new cell -- two old
+    //     neighbours already share a root.
     for (int i = tid; i < n_w; i += nt) CNT2[i] = 0;
     if (tid == 0) sh[1] = 0;
-    __syncthreads();
-    const int need = cfg.min_cont_cell_cnt < 3 ? cfg.min_cont_cell_cnt : 3;
-    for (int c = tid; c < n_cell; c += nt) {
-      unsigned r = LAB[c];
-      if (r == CC_LAB_NONE) continue;
-      const int w = r >> 4, s2 = (r & 15) * 2;
-      unsigned old = CNT2[w];
-      while ((int)((old >> s2) & 3u) < 3) {
-        unsigned got = atomicCAS(&CNT2[w], old, old + (1u << s2));
-        if (got == old) break;
-        old = got;
+    CC_K2_FOR_ACTIVE({
+      (void)i;
+      const int lvc = LV[c];
+      if (lvc > l) {
+        const bool newc = lvc == l + 1;
+        const int r = c / n_col, cc = c - r * n_col;
+        if (cc > 0) {
+          const int lvn = LV[c - 1];
+          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - 1);
+        }
+        if (r > 0) {
+          if (cc > 0) {
+            const int lvn = LV[c - n_col - 1];
+            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col - 1);
+          }
+          {
+            const int lvn = LV[c - n_col];
+            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col);
+          }
+          if (cc < n_col - 1) {
+            const int lvn = LV[c - n_col + 1];
+            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col + 1);
+          }
+        }
       }
-    }
+    })
     __syncthreads();
-    // (d) enumerate kept roots, sorted by cell index
-    for (int c = tid; c < n_cell; c += nt) {
-      if (LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
+    // (b) every cell is pointed at its root (a concurrent find that passes through the cell meets either its old parent or
+    //     the root: both lead to the root), and the root's 2-bit saturating size counter is bumped: which roots own
+    //     >= min_cont_cell_cnt_ (3) cells
+    const int need = cfg.min_cont_cell_cnt < 3 ? cfg.min_cont_cell_cnt : 3;
+    CC_K2_FOR_ACTIVE({
+      (void)i;
+      if (LV[c] > l) {
+        const unsigned rt = cc_uf_find(LAB, c);
+        if (rt != (unsigned)c) LAB[c] = (uint16_t)rt;
+        const int w = rt >> 4, s2 = (rt & 15) * 2;
+        unsigned old = CNT2[w];
+        while ((int)((old >> s2) & 3u) < 3) {
+          unsigned got = atomicCAS(&CNT2[w], old, old + (1u << s2));
+          if (got == old) break;
+          old = got;
+        }
+      }
+    })
+    __syncthreads();
+    CC_K2_LAP(acc_ccl);
+    // (c) kept roots, then sorted by cell index = raster order of their first cells
+    CC_K2_FOR_ACTIVE({
+      (void)i;
+      if (LV[c] > l && LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
         int k = atomicAdd(&sh[1], 1);
         if (k < CC_NC) cand[k] = (uint16_t)c;
       }
-    }
+    })
     __syncthreads();
     int n_kept = sh[1];
     if (n_kept > CC_NC) {
@@ -285,127 +338,90 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       for (int j = 0; j < n_kept; j++) rk += (cand[j] < me) ? 1 : 0;
       roots[rk] = (uint16_t)me;
       LAB[me] = (uint16_t)(0x8000u | (unsigned)rk);  // nothing reads LAB in this loop
-    }
-    __syncthreads();
-    // (f) bbox / area via LDS atomics (W aliases CNT2; the kept test is done before W is re-initialised).
-    //     LAB keeps the root labels (they seed the next level); the component index is looked up in `roots`.
-    unsigned *w_minr = W, *w_maxr = W + CC_NC, *w_minc = W + 2 * CC_NC, *w_maxc = W + 3 * CC_NC, *w_area = W + 4 * CC_NC,
-             *w_cA = W + 5 * CC_NC, *w_cB = W + 6 * CC_NC;
-    __syncthreads();
-    for (int k = tid; k < n_kept; k += nt) {
-      w_minr[k] = 0xFFFFu;
-      w_maxr[k] = 0;
+      // working arrays of the kept components (W aliases CNT2: the kept test above is done)
+      w_last[k] = 0;
       w_minc[k] = 0xFFFFu;
       w_maxc[k] = 0;
       w_area[k] = 0;
-      w_cA[k] = 255;
       w_cB[k] = 255;
+      w_first[k] = 0;
     }
     __syncthreads();
-    // The root of a component is its first cell in raster order, i.e. (first row, first member column of that row): cA
-    // needs no search, and a cell knows its component's first row from its label alone, so the first member column of the
-    // second row (cB) is one more atomicMin in the same pass.
-    for (int c = tid; c < n_cell; c += nt) {
-      unsigned v = LAB[c];
-      unsigned root_cell = (unsigned)c;
-      if (!(v & 0x8000u)) {  // a non-root cell holds its root's cell index
-        root_cell = v;
-        v = LAB[v];
-      }
-      if (!(v & 0x8000u)) continue;  // unmarked root: component with < 3 cells (or beyond the capacity)
-      const unsigned j = v & 0x7FFFu;
-      if (j == CC_COMP_NONE) continue;  // empty cell
-      const int rr = c / n_col, cc = c - rr * n_col;
-      atomicMin(&w_minr[j], (unsigned)rr);
-      atomicMax(&w_maxr[j], (unsigned)rr);
-      atomicMin(&w_minc[j], (unsigned)cc);
-      atomicMax(&w_maxc[j], (unsigned)cc);
-      atomicAdd(&w_area[j], 1u);
-      if (rr == (int)(root_cell / (unsigned)n_col) + 1) atomicMin(&w_cB[j], (unsigned)cc);
+    // (d) per component: area, column range, last cell of the raster order, first member column of the second row
+    //     (the root IS the first cell: first row and its first member column need no search), and for the walk the
+    //     component index of every member cell (list position -> index, in the scratch block)
+    {
+      uint16_t *cidx = scr->compidx[l];
+      int16_t *ld = labels_dbg ? labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell : nullptr;
+      CC_K2_FOR_ACTIVE({
+        unsigned j = CC_COMP_NONE;
+        if (LV[c] > l) {
+          unsigned v = LAB[c];
+          unsigned root_cell = (unsigned)c;
+          if (!(v & 0x8000u)) {  // a non-root cell holds its root's cell index
+            root_cell = v;
+            v = LAB[v];
+          }
+          if (v & 0x8000u) {  // else: unmarked root, component with < 3 cells (or beyond the capacity)
+            j = v & 0x7FFFu;
+            const int rr = c / n_col, cc = c - rr * n_col;
+            atomicMax(&w_last[j], (unsigned)i);
+            atomicMin(&w_minc[j], (unsigned)cc);
+            atomicMax(&w_maxc[j], (unsigned)cc);
+            atomicAdd(&w_area[j], 1u);
+            if (rr == (int)(root_cell / (unsigned)n_col) + 1) atomicMin(&w_cB[j], (unsigned)cc);
+            if (root_cell == (unsigned)c) w_first[j] = (unsigned)i;
+            if (ld) ld[c] = (int16_t)j;
+          }
+        }
+        cidx[i] = (uint16_t)j;
+      })
     }
     __syncthreads();
     // min_cont_cell_cnt_ > 3: the saturating counters only prove ">= 3 cells"; with the exact areas known, drop the
     // components below the bar (stats(n,4) < cfg_.min_cont_cell_cnt_, contour_mng.cpp:303) and renumber the rest
-    if (cfg.min_cont_cell_cnt > 3) n_kept = cc_k2_drop_small(cfg.min_cont_cell_cnt, n_kept, W, roots, LAB, sh + 24);
-    for (int k = tid; k < n_kept; k += nt) w_cA[k] = (unsigned)roots[k] % (unsigned)n_col;
+    if (cfg.min_cont_cell_cnt > 3) {
+      const int n_before = n_kept;
+      n_kept = cc_k2_drop_small(cfg.min_cont_cell_cnt, n_kept, W, roots, LAB, sh + 24, cand);
+      if (n_kept != n_before) {  // uniform: the walk's index image follows the renumbering (cand[old] = new or 0x7FFF)
+        uint16_t *cidx = scr->compidx[l];
+        int16_t *ld = labels_dbg ? labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell : nullptr;
+        CC_K2_FOR_ACTIVE({
+          const unsigned j = cidx[i];
+          if (j != CC_COMP_NONE) {
+            const unsigned jn = cand[j];
+            cidx[i] = (uint16_t)jn;
+            if (ld) ld[c] = jn == CC_COMP_NONE ? (int16_t)-1 : (int16_t)jn;
+          }
+        })
+        __syncthreads();
+      }
+    }
     CC_K2_LAP(acc_enum);
-    // (g) parents of the level above (processed in the previous iteration): index of the root that owns the child's root cell
+    // (e) component records; parents of the level above (processed in the previous iteration): index of the root that
+    //     owns the child's root cell
     for (int k = tid; k < prev_n; k += nt) {
       unsigned j = cc_lab_comp(LAB, prev_root[k]);
       if (j == CC_COMP_NONE) j = 0xFFFF;
       scr->comp[l + 1][k].parent = (uint16_t)j;
     }
-    __syncthreads();
-    // (h) one WAVE per contour: raster-order running statistics (contour_mng.cpp:317-331).  The 64 lanes test 64 cells of a
-    //     bbox row at once; the members found (ballot) are then accumulated one by one, in column order, by all lanes
-    //     redundantly -- the exact sequence of f32/f64 additions of the reference -- with lane broadcasts for the operands.
-    for (int k = wave_id; k < n_kept; k += n_waves) {
+    for (int k = tid; k < n_kept; k += nt) {
       const unsigned root = roots[k];
-      const int r0 = w_minr[k], r1 = w_maxr[k], c0 = w_minc[k], c1 = w_maxc[k];
-      cc_running_stat rec;
-      rec.cnt = 0;
-      rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
-      rec.vol3 = 0.f;
-      int poi_r = -1, poi_c = -1;
-      for (int r = r0; r <= r1; r++) {
-        const int base = r * n_col;
-        for (int cb = c0; cb <= c1; cb += 64) {
-          const int col = cb + lane;
-          const bool mem = col <= c1 && cc_lab_comp(LAB, base + col) == (unsigned)k;
-          unsigned long long mask = __ballot(mem);
-          if (!mask) continue;
-          float h = 0.f, px = 0.f, py = 0.f;
-          if (mem) {
-            h = bev[base + col];
-            const float2 rc = pix[base + col];
-            px = rc.x;
-            py = rc.y;
-          }
-          while (mask) {
-            const int src = __ffsll((unsigned long long)mask) - 1;
-            mask &= mask - 1;
-            const float hh = cc_lane_bcast(h, src);
-            const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
-            rec.cnt += 1;
-            rec.ps_x += vr;
-            rec.ps_y += vc;
-            rec.t_xx += vr * vr;
-            rec.t_xy += vr * vc;
-            rec.t_yy += vc * vc;
-            rec.vol3 += hh;
-            rec.tq_x += (double)hh * vr;
-            rec.tq_y += (double)hh * vc;
-            poi_r = r;
-            poi_c = cb + src;
-          }
-        }
-      }
-      if (lane == 0) {
-        cc_contour_t cv;
-        cc_calc_stat_vals(cfg, rec, l, poi_r, poi_c, &cv);
-        scr->cont[l][k] = cv;
-        cc_comp_t cp;
-        cp.root = (uint16_t)root;
-        cp.area = (uint16_t)w_area[k];
-        cp.parent = 0xFFFF;
-        cp.rank = 0;
-        cp.r0 = (uint8_t)r0;
-        cp.r1 = (uint8_t)r1;
-        cp.c0 = (uint8_t)c0;
-        cp.c1 = (uint8_t)c1;
-        cp.cA = (uint8_t)w_cA[k];
-        cp.cB = (uint8_t)w_cB[k];
-        cp.pad[0] = cp.pad[1] = 0;
-        scr->comp[l][k] = cp;
-      }
-    }
-    // (i) parity/debug: component index image of this level (mapped to sorted seq at the end)
-    if (labels_dbg) {
-      int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
-      for (int c = tid; c < n_cell; c += nt) {
-        const unsigned jj = cc_lab_comp(LAB, c);
-        ld[c] = (int16_t)(jj == CC_COMP_NONE ? -1 : (int)jj);
-      }
+      cc_comp_t cp;
+      cp.root = (uint16_t)root;
+      cp.area = (uint16_t)w_area[k];
+      cp.parent = 0xFFFF;
+      cp.rank = 0;
+      cp.r0 = (uint8_t)(root / (unsigned)n_col);
+      cp.r1 = 0;
+      cp.c0 = (uint8_t)w_minc[k];
+      cp.c1 = (uint8_t)w_maxc[k];
+      cp.cA = (uint8_t)(root % (unsigned)n_col);
+      cp.cB = (uint8_t)w_cB[k];
+      cp.pad[0] = cp.pad[1] = 0;
+      scr->comp[l][k] = cp;
+      scr->wfirst[l][k] = (uint16_t)w_first[k];
+      scr->wlast[l][k] = (uint16_t)w_last[k];
     }
     __syncthreads();
     for (int k = tid; k < n_kept; k += nt) {
@@ -415,8 +431,90 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     if (tid == 0) sh[8 + l] = n_kept;
     prev_n = n_kept;
     __syncthreads();
-    CC_K2_LAP(acc_walk);
   }
+  // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331), one WAVE
+  //      per component, all levels side by side.  The members of a component are the list entries between its first and
+  //      last cell whose index image says so; the 64 lanes test 64 entries at once, the members found (ballot) are then
+  //      accumulated one by one, in list = raster order, by all lanes redundantly -- the exact sequence of f32/f64
+  //      additions of the reference -- with lane broadcasts for the operands.  Height and continuous position of the
+  //      first CC_K2_CACHE active cells are staged in LDS (the label image is dead by now).
+  __threadfence_block();
+  __syncthreads();
+  {
+    float *cbev = (float *)R;                                      // [CC_K2_CACHE]
+    float2 *cpix = (float2 *)(R + CC_K2_CACHE * 4);                // [CC_K2_CACHE]
+    const int n_cache = n_act < CC_K2_CACHE ? n_act : CC_K2_CACHE;
+    for (int i = tid; i < n_cache; i += nt) {
+      const int c = (int)scr->act[i];
+      cbev[i] = bev[c];
+      cpix[i] = pix[c];
+    }
+    __syncthreads();
+    int n_tot = 0, lev_base[CC_NLEV + 1];
+    for (int l = 0; l < CC_NLEV; l++) {
+      lev_base[l] = n_tot;
+      n_tot += sh[8 + l];
+    }
+    lev_base[CC_NLEV] = n_tot;
+    for (int w = wave_id; w < n_tot; w += n_waves) {
+      int l = 0;
+      for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
+      int kbase = 0;
+      for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
+      const int k = w - kbase;
+      const int i0 = scr->wfirst[l][k], i1 = scr->wlast[l][k];
+      const uint16_t *cidx = scr->compidx[l];
+      cc_running_stat rec;
+      rec.cnt = 0;
+      rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
+      rec.vol3 = 0.f;
+      int poi_i = -1;
+      for (int ib = i0; ib <= i1; ib += 64) {
+        const int i = ib + lane;
+        const bool mem = i <= i1 && cidx[i] == (unsigned)k;
+        unsigned long long mask = __ballot(mem);
+        if (!mask) continue;
+        float h = 0.f, px = 0.f, py = 0.f;
+        if (mem) {
+          if (i < n_cache) {
+            h = cbev[i];
+            const float2 rc = cpix[i];
+            px = rc.x;
+            py = rc.y;
+          } else {
+            const int c = (int)scr->act[i];
+            h = bev[c];
+            const float2 rc = pix[c];
+            px = rc.x;
+            py = rc.y;
+          }
+        }
+        while (mask) {
+          const int src = __ffsll((unsigned long long)mask) - 1;
+          mask &= mask - 1;
+          const float hh = cc_lane_bcast(h, src);
+          const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
+          rec.cnt += 1;
+          rec.ps_x += vr;
+          rec.ps_y += vc;
+          rec.t_xx += vr * vr;
+          rec.t_xy += vr * vc;
+          rec.t_yy += vc * vc;
+          rec.vol3 += hh;
+          rec.tq_x += (double)hh * vr;
+          rec.tq_y += (double)hh * vc;
+          poi_i = ib + src;
+        }
+      }
+      if (lane == 0) {
+        const int pc = poi_i >= 0 ? (int)scr->act[poi_i] : 0;
+        cc_contour_t cv;
+        cc_calc_stat_vals(cfg, rec, l, poi_i >= 0 ? pc / n_col : -1, poi_i >= 0 ? pc % n_col : -1, &cv);
+        scr->cont[l][k] = cv;
+      }
+    }
+  }
+  CC_K2_LAP(acc_walk);
   if (phase_clk && tid == 0) {
     phase_clk[(size_t)blockIdx.x * 16 + 1] = acc_ccl;
     phase_clk[(size_t)blockIdx.x * 16 + 2] = acc_enum;

@@ -18,6 +18,27 @@
 #define CC_K1_IDX_MASK 0x1FFFFFull
 #define CC_K1_U_DEFAULT 4  // points per lane and chunk (instances: 4 and 8)
 
+// value of the lane D places to the left / one place to the right inside the 16-lane row; 0 beyond the row's ends
+#ifndef CC_EMU
+template <int D>
+__device__ __forceinline__ int cc_row_shr(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int cc_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+#else
+template <int D>
+__device__ __forceinline__ int cc_row_shr(int v) {
+  const int sl = threadIdx.x & 15;
+  const int o = __shfl(v, sl >= D ? sl - D : sl, 16);
+  return sl >= D ? o : 0;
+}
+__device__ __forceinline__ int cc_row_shl1(int v) {
+  const int sl = threadIdx.x & 15;
+  const int o = __shfl(v, sl < 15 ? sl + 1 : sl, 16);
+  return sl < 15 ? o : 0;
+}
+#endif
+
 struct cc_k1_scan_out {
   float max_bin_val, min_bin_val;
   int n_pix;
@@ -108,11 +129,38 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
       int j = base + chunk + tid + u * nt;
       q[u] = (j < n_pts) ? P[j] : make_float4(1e9f, 1e9f, 0.f, 0.f);
     }
+    // Consecutive records are neighbouring azimuth steps of one laser: close to the sensor dozens of them fall into
+    // the same cell, and same-address LDS atomics of a wave are served one after the other.  So the lanes of a 16-lane
+    // row first combine their heights per run of equal cells (segmented max over DPP row shifts), and only the last
+    // lane of a run goes to the LDS, with the run's maximum.
 #pragma unroll
     for (int u = 0; u < CC_K1_U; u++) {
-      if (cell[u] >= 0) {
-        unsigned old = atomicMax(&hmax[cell[u]], key[u]);
-        if (old < key[u]) {
+      const int c1 = cell[u] + 1;  // 0 = rejected point (and what a row shift reads beyond the row's end)
+      unsigned k = cell[u] >= 0 ? key[u] : 0u;
+      {
+        const int oc = cc_row_shr<1>(c1);
+        const unsigned ok = (unsigned)cc_row_shr<1>((int)k);
+        if (oc == c1 && ok > k) k = ok;
+      }
+      {
+        const int oc = cc_row_shr<2>(c1);
+        const unsigned ok = (unsigned)cc_row_shr<2>((int)k);
+        if (oc == c1 && ok > k) k = ok;
+      }
+      {
+        const int oc = cc_row_shr<4>(c1);
+        const unsigned ok = (unsigned)cc_row_shr<4>((int)k);
+        if (oc == c1 && ok > k) k = ok;
+      }
+      {
+        const int oc = cc_row_shr<8>(c1);
+        const unsigned ok = (unsigned)cc_row_shr<8>((int)k);
+        if (oc == c1 && ok > k) k = ok;
+      }
+      const bool last_of_run = cc_row_shl1(c1) != c1;
+      if (cell[u] >= 0 && last_of_run) {
+        unsigned old = atomicMax(&hmax[cell[u]], k);
+        if (old < k) {
           const int w = cell[u] / 3, sh = (cell[u] - 3 * w) * CC_K1_IDX_BITS;
           atomicOr(&idx3[w], CC_K1_IDX_MASK << sh);
         }
