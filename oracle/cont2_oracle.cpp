@@ -157,6 +157,14 @@ void *orc_db_create(const cc_db_cfg_t *cfg) {
   return d;
 }
 void orc_db_free(void *d) { delete (DbH *)d; }
+// the query-side stage timers accumulated so far {KNN search, Constell, L2 opt} (seconds); reset != 0 clears them
+void orc_db_timers(void *d, double *out3, int reset) {
+  StageTimers &t = ((DbH *)d)->timers;
+  out3[0] = t.knn_search;
+  out3[1] = t.constell;
+  out3[2] = t.l2_opt;
+  if (reset) t = StageTimers();
+}
 void orc_db_add_scan(void *d, void *scan, double ts) { ((DbH *)d)->db->addScan(((ScanH *)scan)->cm, ts); }
 void orc_db_push_and_balance(void *d, int seed, double ts) { ((DbH *)d)->db->pushAndBalance(seed, ts); }
 void orc_db_bucket_state(void *d, int32_t *tree_sizes, float *ranges) {

@@ -57,6 +57,7 @@ def lib():
         _lib.orc_db_add_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         _lib.orc_db_push_and_balance.argtypes = [C.c_void_p, C.c_int, C.c_double]
         _lib.orc_db_bucket_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_db_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.orc_db_query.argtypes = [C.c_void_p] * 7
         _lib.orc_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.orc_ingest_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -143,6 +144,12 @@ class DB:
 
     def push_and_balance(self, seed, ts):
         lib().orc_db_push_and_balance(self.h, int(seed), float(ts))
+
+    def timers(self, reset=False):
+        """Accumulated reference stage timers of the queries so far: {"KNN search", "Constell", "L2 opt"} in seconds."""
+        t = np.zeros(3, np.float64)
+        lib().orc_db_timers(self.h, _p(t), 1 if reset else 0)
+        return {"KNN search": float(t[0]), "Constell": float(t[1]), "L2 opt": float(t[2])}
 
     def bucket_state(self):
         sizes = np.zeros((3, 6), np.int32)

@@ -1,6 +1,7 @@
 """Condense rocprofv3 output into the files kept under profiles/ (run on the GPU box, see README.md).
 
   python profiles/summarize.py <round-tag> <out-dir> <kernel_stats.csv> <kernel_trace.csv> <pmc_fetch.csv> <pmc_write.csv> <batch>
+                               [<db_scans> <workload> <git_head>]
 
 Writes <tag>_kernel_stats_cc_kernels.csv (rows of this repo's kernels), <tag>_kernel_trace_timed_launches.csv
 (per-kernel mean duration over the launches whose grid equals the timed <batch>-scan step), the per-dispatch
@@ -15,6 +16,9 @@ import sys
 
 tag, out, f_stats, f_trace, f_fetch, f_write, batch = sys.argv[1:8]
 batch = int(batch)
+db_scans = int(sys.argv[8]) if len(sys.argv) > 8 else None
+workload = sys.argv[9] if len(sys.argv) > 9 else "sparse"
+git_head = sys.argv[10] if len(sys.argv) > 10 else None
 os.makedirs(out, exist_ok=True)
 
 
@@ -62,7 +66,7 @@ if os.path.exists(f_trace):
             continue
         g = step_grid(k)
         gs = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
-        if g is None or gs == g or k in ("cc_k_gmm", "cc_k_ksort_new", "cc_k_ksort_merge", "cc_k_ksort_act", "cc_k_extract"):
+        if g is None or gs == g or k in ("cc_k_ksort_new", "cc_k_ksort_merge", "cc_k_ksort_act", "cc_k_extract"):
             acc[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(os.path.join(out, tag + "_kernel_trace_timed_launches.csv"), "w") as f:
         f.write("kernel,launches,mean_us,min_us,max_us\n")
@@ -72,7 +76,7 @@ if os.path.exists(f_trace):
 summ = {"note": "rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in separate runs); counter unit = KB. FETCH_SIZE on gfx950 "
                 "reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section): fetch_bytes_corrected "
                 "doubles it for cc_k_rasterize (16 B/lane float4 stream); other kernels' access widths are uncalibrated: raw value given.",
-        "batch_scans": batch, "kernels": {}}
+        "batch_scans": batch, "db_scans": db_scans, "workload": workload, "git_head": git_head, "kernels": {}}
 for fn, key, oname in ((f_fetch, "fetch_bytes_raw", "_pmc_fetch_cc_kernels.csv"), (f_write, "write_bytes", "_pmc_write_cc_kernels.csv")):
     if not os.path.exists(fn):
         continue

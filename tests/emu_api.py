@@ -25,8 +25,9 @@ class EmuApi:
         self.L = L
         self.lib = C.CDLL(build())
         self.lib.cc_last_error.restype = C.c_char_p
+        self.lib.cc_packed_sizes.restype = None
         for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state", "cc_db_check_hints"):
+                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state", "cc_db_check_hints", "cc_pack_scans", "cc_db_add_packed"):
             getattr(self.lib, f).restype = C.c_int
 
     def chk(self, rc, what):
@@ -82,6 +83,28 @@ class EmuApi:
         seeds = np.ascontiguousarray(seeds, np.int32)
         self.chk(self.lib.cc_db_add_scans(db, C.c_void_p(desc.ctypes.data), len(desc), C.c_void_p(ts.ctypes.data),
                                           C.c_void_p(seeds.ctypes.data), None), "cc_db_add_scans")
+
+    def packed_sizes(self):
+        hb, fb = C.c_size_t(), C.c_size_t()
+        self.lib.cc_packed_sizes(C.byref(hb), C.byref(fb))
+        return int(hb.value), int(fb.value)
+
+    def pack(self, ctx, desc):
+        """full descriptors -> (hot, feat) uint8 arrays [n, HOT_BYTES] / [n, FEAT_BYTES] (cc_pack_scans)"""
+        desc = np.ascontiguousarray(desc)
+        hb, fb = self.packed_sizes()
+        hot = np.zeros((len(desc), hb), np.uint8)
+        feat = np.zeros((len(desc), fb), np.uint8)
+        self.chk(self.lib.cc_pack_scans(ctx, C.c_void_p(desc.ctypes.data), len(desc), C.c_void_p(hot.ctypes.data),
+                                        C.c_void_p(feat.ctypes.data), None), "cc_pack_scans")
+        return hot, feat
+
+    def db_add_packed(self, db, hot, feat, ts, seeds):
+        hot, feat = np.ascontiguousarray(hot), np.ascontiguousarray(feat)
+        ts = np.ascontiguousarray(ts, np.float64)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        self.chk(self.lib.cc_db_add_packed(db, C.c_void_p(hot.ctypes.data), C.c_void_p(feat.ctypes.data), len(hot),
+                                           C.c_void_p(ts.ctypes.data), C.c_void_p(seeds.ctypes.data), None), "cc_db_add_packed")
 
     def db_query(self, db, qdesc, epochs, lb=None, ub=None, want_knn=False):
         L = self.L

@@ -1,5 +1,6 @@
-"""Multi-GPU path on CPU (gloo, world_size 2): scan-sharded ingest -> ONE all-gather of the descriptor blocks ->
-replicated DB -> query-sharded scoring.  Compute runs through the product's C-ABI in its CPU build (tests/emu);
+"""Multi-GPU path on CPU (gloo, world_size 2): scan-sharded ingest -> pack -> ONE all-gather of the compact per-scan
+records (18 KB hot record + 16 KB correlation inputs instead of the 169 KB descriptor) -> replicated DB via
+cc_db_add_packed -> query-sharded scoring; and the launcher path of `bench.py --gpus N`.  Compute runs through the product's C-ABI in its CPU build (tests/emu);
 the collective is torch.distributed exactly as bench.py uses it (nccl = RCCL on the GPU box)."""
 import os
 import sys
@@ -30,24 +31,29 @@ def _worker(rank, world, port, tmpdir):
     w = cc.synth.World(loop_len=40.0)
     n = 48
     shard = n // world
-    lo = rank * shard
-    x, _, _ = cc.synth.make_sequence(shard, world=w, beams=16, azim=450, start=lo)
+    mine = np.arange(rank, n, world)                       # scan-sharded ingest: rank r takes scans r, r + world, ...
+    x_all, _, _ = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+    x = x_all[mine]
     P = x.shape[1]
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=8)
     local = api.ingest(ctx, x.numpy().reshape(-1, 4), np.arange(shard + 1, dtype=np.int64) * P)
-    t_local = torch.from_numpy(local.view(np.uint8).reshape(shard, -1).copy())
-    t_all = torch.empty((n, t_local.shape[1]), dtype=torch.uint8)
-    dist.all_gather_into_tensor(t_all, t_local)          # the path's only exchange
-    desc_all = t_all.numpy().view(L.scan_desc_dt).reshape(-1)
+    hot, feat = api.pack(ctx, local)
+    rec_local = torch.from_numpy(np.concatenate([hot, feat], axis=1))   # one record per scan: hot | feat
+    rec_all = torch.empty((n, rec_local.shape[1]), dtype=torch.uint8)
+    dist.all_gather_into_tensor(rec_all, rec_local)          # the path's only exchange
+    hb = hot.shape[1]
+    # gathered order is rank-major; the DB wants the scans in time order
+    order = np.argsort(np.concatenate([np.arange(r, n, world) for r in range(world)]), kind="stable")
+    rec = rec_all.numpy()[order]
     ts = np.arange(n) / 10.0
     db = api.db_create(ctx, dcfg, cap=n)
-    api.db_add(db, desc_all, ts, np.arange(n, dtype=np.int32))
+    api.db_add_packed(db, rec[:, :hb], rec[:, hb:], ts, np.arange(n, dtype=np.int32))
     sizes, ranges = api.bucket_state(db)
-    qs = np.arange(40 + rank, 48, world).astype(np.int32)     # query-sharded
-    res = api.db_query(db, desc_all[qs], qs)
+    qs = mine[mine >= 40].astype(np.int32)                 # query-sharded: a rank's queries are scans it ingested
+    res = api.db_query(db, local[(qs - rank) // world], qs)
     np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), sizes=sizes, ranges=ranges, qs=qs, res=res.view(np.uint8),
-             desc=t_all.numpy())
+             rec=rec, desc=local.view(np.uint8).reshape(shard, -1), bytes_per_scan=rec_all.shape[1])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +63,8 @@ def test_sharded_ingest_allgather_query(tmp_path, cc, oracle):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["desc"], r1["desc"]), "all-gathered DB must be identical on every rank"
+    assert np.array_equal(r0["rec"], r1["rec"]), "all-gathered DB must be identical on every rank"
+    assert int(r0["bytes_per_scan"]) < 40000, "the exchange ships compact records, not 169 KB descriptors"
     assert np.array_equal(r0["sizes"], r1["sizes"]) and np.array_equal(r0["ranges"], r1["ranges"])
     # single-process oracle replay of the same sequence
     L = cc.L
@@ -69,11 +76,25 @@ def test_sharded_ingest_allgather_query(tmp_path, cc, oracle):
     ores, _, odesc = oracle.run_sequence(x.numpy().reshape(-1, 4), np.arange(49, dtype=np.int64) * P, ts,
                                          np.arange(48, dtype=np.int32), dcfg=dcfg, want_desc=True)
     from parity import compare_desc
-    got = r0["desc"].view(L.scan_desc_dt).reshape(-1)
-    for i in range(48):
-        assert not compare_desc(odesc[i], got[i], float_exact=True)
+    for r, rr in enumerate((r0, r1)):                      # rank r ingested scans r, r + 2, ...
+        got = rr["desc"].view(L.scan_desc_dt).reshape(-1)
+        for k in range(24):
+            assert not compare_desc(odesc[r + 2 * k], got[k], float_exact=True)
     for r in (r0, r1):
         res = r["res"].view(L.query_result_dt).reshape(-1)
         for k, qi in enumerate(r["qs"]):
             for f in ["n_res", "cand_gidx", "cand_aft_check3", "n_knn_hits"]:
                 assert ores[f][qi] == res[f][k], (qi, f)
+
+
+def test_bench_launcher_starts_ranks():
+    """`python bench.py --gpus 2` without an external launcher re-executes itself under torch.distributed.run; with
+    CC_BENCH_LAUNCH_PROBE=1 every rank only joins the process group (gloo here), and rank 0 reports the world size."""
+    import subprocess
+    env = dict(os.environ, CC_BENCH_LAUNCH_PROBE="1", CC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '"launch_probe_world": 2' in r.stdout, r.stdout[-500:]
