@@ -277,7 +277,8 @@ __device__ __forceinline__ void cc_gsync() {
 template <int G>
 __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, int np, int sl, const double p[3], double *cost,
                                             double grad[3]) {
-  const double c = cos(p[2]), s = sin(p[2]);
+  double c, s;
+  sincos(p[2], &s, &c);
   const double c2 = c * c - s * s, s2 = 2.0 * s * c;
   double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
   for (int i = sl; i < np; i += G) {
@@ -474,7 +475,21 @@ __device__ double cc_interp_step(const cc_fs &lo, const cc_fs &cur, double x_min
     }
   }
   double sol[4] = {0, 0, 0, 0};
-  cc_solve_fullpiv(A, b, nc, sol);
+  if (nc == 4 && cur.x != lo.x) {
+    // Both samples carry value and gradient (the case of every regular line-search step): the interpolating cubic in
+    // closed form -- Hermite coefficients about lo.x, expanded to the monomial basis the rest of this function works in --
+    // instead of the 4x4 full-pivot LU solve of the Vandermonde system; the same polynomial up to rounding.
+    const double x0 = lo.x, h = cur.x - lo.x, ih = 1.0 / h;
+    const double df = (cur.value - lo.value) * ih;
+    const double Ac = (lo.gradient + cur.gradient - 2.0 * df) * ih * ih;
+    const double Bc = (3.0 * df - 2.0 * lo.gradient - cur.gradient) * ih;
+    sol[0] = Ac;
+    sol[1] = Bc - 3.0 * Ac * x0;
+    sol[2] = lo.gradient - 2.0 * Bc * x0 + 3.0 * Ac * x0 * x0;
+    sol[3] = lo.value - lo.gradient * x0 + Bc * x0 * x0 - Ac * x0 * x0 * x0;
+  } else {
+    cc_solve_fullpiv(A, b, nc, sol);
+  }
   // poly[] right-aligned: coefficient of x^(np-1-i) at index 4 - np + i
   const int np = nc;
 #pragma unroll

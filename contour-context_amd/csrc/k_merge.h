@@ -10,7 +10,7 @@
 // candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
 // ------------------------------------------------------------------------------------------------
 #define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
-#define CC_MERGE_BLOCK 128
+#define CC_MERGE_BLOCK 64
 #define CC_MERGE_PER_T (CC_CHK_STRIDE / CC_MERGE_BLOCK)  // consecutive check slots scanned by one thread
 
 struct cc_gmm_problem {
@@ -45,6 +45,8 @@ struct cc_merge_lds {
   int wsum[CC_MERGE_BLOCK / 64];
   int base;
   unsigned char want[CC_CHK_STRIDE];       // candidate k goes on to the correlation
+  float tperc[CC_HOT_LEVELS][CC_NDIST];    // cont_perc_ of the query's top contours: cell_cnt * 1.0f / layer_cell_cnt
+  float sperc[CC_MERGE_BLOCK][CC_HOT_LEVELS * CC_NDIST];  // same of the lane's current candidate scan
 };
 
 static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
@@ -61,6 +63,11 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
   if (q >= nq) return;
   const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
   const cc_pass_rec *recs = pass + (size_t)q * CC_CHK_STRIDE;
+  if (tid < CC_HOT_LEVELS * CC_NDIST) {  // visible after the barriers of the list building below
+    const int l = tid / CC_NDIST, t_ = tid - l * CC_NDIST;
+    const cc_hot_desc_t *tq = qdesc + q;
+    L.tperc[l][t_] = (float)tq->cont[l][t_].cell_cnt * 1.0f / (float)tq->layer_cell_cnt[l];
+  }
   // ---- ordered list of the passing checks (slot order = the reference's iteration order)
   int n;
   {
@@ -129,7 +136,6 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     qstate[q] = st;
   }
   // ---- one lane per candidate
-  const cc_hot_desc_t *tl = qdesc + q;
   cc_dcand *c = &L.st[tid];
   for (int k = tid; k < nc; k += CC_MERGE_BLOCK) {
     int i = L.firstrec[k];
@@ -180,6 +186,17 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     }
     // tidyUpCandidates before the correlation (contour_db.h:503-546)
     const cc_hot_desc_t *sl = db_desc + c->gidx;
+    // the candidate's area fractions, fetched in one go (40 independent loads) instead of one dependent load per
+    // constellation pair inside the loops below
+    {
+      float *sp = L.sperc[tid];
+#pragma unroll
+      for (int l = 0; l < CC_HOT_LEVELS; l++) {
+        const float lcc = (float)sl->layer_cell_cnt[l];
+#pragma unroll
+        for (int s_ = 0; s_ < CC_NDIST; s_++) sp[l * CC_NDIST + s_] = (float)sl->cont[l][s_].cell_cnt * 1.0f / lcc;
+      }
+    }
     int idx_sel = 0;
     for (int pi = 0; pi < c->nprops; pi++) {
       float lev_perc[CC_NLEV] = {0, 0, 0, 0, 0, 0};
@@ -189,8 +206,8 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
           const int b = w * 64 + (__ffsll((unsigned long long)m) - 1);
           m &= m - 1;
           const int l = b / 100 + 1, s_ = (b % 100) / 10, t_ = b % 10;
-          const float psrc = (float)sl->cont[l - 1][s_].cell_cnt * 1.0f / (float)sl->layer_cell_cnt[l - 1];
-          const float ptgt = (float)tl->cont[l - 1][t_].cell_cnt * 1.0f / (float)tl->layer_cell_cnt[l - 1];
+          const float psrc = L.sperc[tid][(l - 1) * CC_NDIST + s_];
+          const float ptgt = L.tperc[l - 1][t_];
           lev_perc[l] += 0.5f * (psrc + ptgt);
         }
       }
