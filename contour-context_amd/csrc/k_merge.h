@@ -10,7 +10,7 @@
 // candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
 // ------------------------------------------------------------------------------------------------
 #define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
-#define CC_MERGE_BLOCK 64
+#define CC_MERGE_BLOCK 128
 #define CC_MERGE_PER_T (CC_CHK_STRIDE / CC_MERGE_BLOCK)  // consecutive check slots scanned by one thread
 
 struct cc_gmm_problem {
@@ -46,7 +46,6 @@ struct cc_merge_lds {
   int base;
   unsigned char want[CC_CHK_STRIDE];       // candidate k goes on to the correlation
   float tperc[CC_HOT_LEVELS][CC_NDIST];    // cont_perc_ of the query's top contours: cell_cnt * 1.0f / layer_cell_cnt
-  float sperc[CC_MERGE_BLOCK][CC_HOT_LEVELS * CC_NDIST];  // same of the lane's current candidate scan
 };
 
 static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
@@ -141,11 +140,26 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     int i = L.firstrec[k];
     c->gidx = L.gid[i];
     c->nprops = 0;
-    for (; i >= 0; i = L.next[i]) {
-      const cc_pass_rec *rec = &recs[L.ord[i]];
-      const int np = rec->n_pairs;
-      const double ptx = rec->tf[0], pty = rec->tf[1];
-      const double pc = rec->cs[0], ps = rec->cs[1];
+    // the replay is a serial chain per candidate (the hottest candidate of a query sets the kernel's latency): the next
+    // record's pose is fetched while the current one is worked on
+    const cc_pass_rec *rec = &recs[L.ord[i]];
+    int np_n = rec->n_pairs;
+    double ptx_n = rec->tf[0], pty_n = rec->tf[1], pc_n = rec->cs[0], ps_n = rec->cs[1], ang_n = rec->cs[2];
+    for (; i >= 0;) {
+      rec = &recs[L.ord[i]];
+      const int np = np_n;
+      const double ptx = ptx_n, pty = pty_n;
+      const double pc = pc_n, ps = ps_n, ang2_cur = ang_n;
+      i = L.next[i];
+      if (i >= 0) {
+        const cc_pass_rec *rn = &recs[L.ord[i]];
+        np_n = rn->n_pairs;
+        ptx_n = rn->tf[0];
+        pty_n = rn->tf[1];
+        pc_n = rn->cs[0];
+        ps_n = rn->cs[1];
+        ang_n = rn->cs[2];
+      }
       const int nprops = c->nprops;
       // CandidatePoseData::addProposal: first proposal within 2.0 (pixels) and 0.3 rad
       int hit = -1;
@@ -163,7 +177,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         p->vote_cnt += np;
         const int w1 = p->vote_cnt, w2 = np;
         const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
-        const double ang1 = atan2(p->s, p->c), ang2 = rec->cs[2];
+        const double ang1 = atan2(p->s, p->c), ang2 = ang2_cur;
         double diff = ang2 - ang1;
         if (diff < 0) diff += 2 * 3.14159265358979323846;
         if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
@@ -186,17 +200,6 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     }
     // tidyUpCandidates before the correlation (contour_db.h:503-546)
     const cc_hot_desc_t *sl = db_desc + c->gidx;
-    // the candidate's area fractions, fetched in one go (40 independent loads) instead of one dependent load per
-    // constellation pair inside the loops below
-    {
-      float *sp = L.sperc[tid];
-#pragma unroll
-      for (int l = 0; l < CC_HOT_LEVELS; l++) {
-        const float lcc = (float)sl->layer_cell_cnt[l];
-#pragma unroll
-        for (int s_ = 0; s_ < CC_NDIST; s_++) sp[l * CC_NDIST + s_] = (float)sl->cont[l][s_].cell_cnt * 1.0f / lcc;
-      }
-    }
     int idx_sel = 0;
     for (int pi = 0; pi < c->nprops; pi++) {
       float lev_perc[CC_NLEV] = {0, 0, 0, 0, 0, 0};
@@ -206,7 +209,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
           const int b = w * 64 + (__ffsll((unsigned long long)m) - 1);
           m &= m - 1;
           const int l = b / 100 + 1, s_ = (b % 100) / 10, t_ = b % 10;
-          const float psrc = L.sperc[tid][(l - 1) * CC_NDIST + s_];
+          const float psrc = (float)sl->cont[l - 1][s_].cell_cnt * 1.0f / (float)sl->layer_cell_cnt[l - 1];
           const float ptgt = L.tperc[l - 1][t_];
           lev_perc[l] += 0.5f * (psrc + ptgt);
         }

@@ -20,6 +20,22 @@
     }                                                                               \
   } while (0)
 
+// glog names the reference's headers and drivers use (abort on failure like glog; no logging back end)
+#ifndef CHECK
+#define CHECK(cond) CC_CHECK(cond)
+#define CHECK_GT(a, b) CC_CHECK((a) > (b))
+#define CHECK_GE(a, b) CC_CHECK((a) >= (b))
+#define CHECK_LT(a, b) CC_CHECK((a) < (b))
+#define CHECK_LE(a, b) CC_CHECK((a) <= (b))
+#define CHECK_EQ(a, b) CC_CHECK((a) == (b))
+#define CHECK_NE(a, b) CC_CHECK((a) != (b))
+#define DCHECK(cond) ((void)0)
+#endif
+static bool FLAGS_alsologtostderr __attribute__((unused)) = false;
+namespace google {
+inline void InitGoogleLogging(const char *) {}
+}  // namespace google
+
 namespace pcl {
 struct PointXYZ {
   float x, y, z;
@@ -85,6 +101,18 @@ struct Isometry2d {
     }
     return o;
   }
+};
+
+// 3-vector with the few operations the offline driver uses (batch_bin_test.cpp:143-145)
+struct Vector3d {
+  double v[3] = {0, 0, 0};
+  Vector3d() = default;
+  Vector3d(double x, double y, double z) : v{x, y, z} {}
+  double x() const { return v[0]; }
+  double y() const { return v[1]; }
+  double z() const { return v[2]; }
+  Vector3d operator*(double s) const { return Vector3d(v[0] * s, v[1] * s, v[2] * s); }
+  Vector3d operator/(double s) const { return Vector3d(v[0] / s, v[1] / s, v[2] / s); }
 };
 
 // 3-D rigid transform: what the evaluator keeps per scan (ground-truth sensor pose) and evalMetricEst consumes

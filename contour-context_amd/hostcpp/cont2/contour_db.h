@@ -1,7 +1,12 @@
 // Host mirror of include/cont2/contour_db.h (ContourDB, configs, CandidateScoreEnsemble) and of the two
 // ConstellCorrelation statics the drivers call (include/cont2/correlation.h:241-296), on top of the C-ABI.
 #pragma once
+#include "../tools/bm_util.h"
 #include "contour_mng.h"
+
+// As in the reference (contour_db.h:23): the library records its stage timers ("KNN search", "Constell", "L2 opt") into a
+// profiler object that the EXECUTABLE defines.
+extern SequentialTimeProfiler stp;
 
 // contour_db.h:54-57
 struct TreeBucketConfig {
@@ -25,7 +30,7 @@ struct ContourDBConfig {
 
 class ContourDB {
   const ContourDBConfig cfg_;
-  cc_db *db_ = nullptr;
+  mutable cc_db *db_ = nullptr;  // created lazily by the first call that sees a ContourManager (queryRangedKNN is const)
   int capacity_;
   std::vector<std::shared_ptr<const ContourManager>> all_bevs_;
 
@@ -41,7 +46,7 @@ class ContourDB {
     s.neg_est_dist = e.sim_post.neg_est_dist;
     return s;
   }
-  void ensure(const ContourManager &cm) {
+  void ensure(const ContourManager &cm) const {
     if (db_) return;
     cc_db_cfg_t d;
     cc_default_db_cfg(&d);
@@ -61,6 +66,7 @@ class ContourDB {
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }
+    cc_db_profile_enable(db_, 1);  // per-stage device times of every query, fed to `stp` below
   }
 
  public:
@@ -72,7 +78,7 @@ class ContourDB {
   // contour_db.h:698-703
   void queryRangedKNN(const std::shared_ptr<const ContourManager> &q_ptr, const CandidateScoreEnsemble &thres_lb,
                       const CandidateScoreEnsemble &thres_ub, std::vector<std::shared_ptr<const ContourManager>> &cand_ptrs,
-                      std::vector<double> &cand_corr, std::vector<Eigen::Isometry2d> &cand_tf) {
+                      std::vector<double> &cand_corr, std::vector<Eigen::Isometry2d> &cand_tf) const {
     cand_ptrs.clear();
     cand_corr.clear();
     cand_tf.clear();
@@ -82,6 +88,16 @@ class ContourDB {
     if (cc_db_query_host(db_, &q_ptr->desc(), &lb, &ub, &r) != CC_OK) {  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
+    }
+    {  // the reference's stage names (contour_db.h:755,772,787), with the device times of this query's kernels:
+       // retrieval | checks + proposal merge | correlation + selection
+      double ms[5];
+      int nq = 0;
+      if (cc_db_profile_read(db_, ms, &nq) == CC_OK && nq > 0) {
+        stp.addSample("KNN search", ms[0] * 1e-3);
+        stp.addSample("Constell", (ms[1] + ms[2]) * 1e-3);
+        stp.addSample("L2 opt", (ms[3] + ms[4]) * 1e-3);
+      }
     }
     if (r.n_res > 0) {
       cand_ptrs.push_back(all_bevs_[r.cand_gidx]);

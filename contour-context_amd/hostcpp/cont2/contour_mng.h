@@ -216,12 +216,14 @@ class ContourManager {
     return r;
   }
   RetrievalKey getRetrievalKey(int level, int seq) const { return getLevRetrievalKey(level)[seq]; }
-  std::vector<ContourView> getLevContours(int level) const {
+  // contour_mng.h:1066 (there: a const reference to the stored vector; here the views are rebuilt from the descriptor)
+  std::vector<std::shared_ptr<ContourView>> getLevContours(int level) const {
     const cc_scan_desc_t &d = desc();
-    std::vector<ContourView> v(d.n_stored[level]);
+    std::vector<std::shared_ptr<ContourView>> v(d.n_stored[level]);
     for (int j = 0; j < d.n_stored[level]; j++) {
       const cc_contour_t &c = d.cont[level][j];
-      ContourView &o = v[j];
+      v[j] = std::make_shared<ContourView>();
+      ContourView &o = *v[j];
       o.level_ = c.level;
       o.poi_[0] = c.poi[0];
       o.poi_[1] = c.poi[1];
@@ -240,6 +242,17 @@ class ContourManager {
   }
   int getLevTotalPix(int level) const { return desc().layer_cell_cnt[level]; }
   const cc_bci_t &getBCI(int level, int seq) const { return desc().bcis[level][seq]; }
+  // contour_mng.h:1079: the level's BCIs, one per anchor key that exists (valid key <=> a non-zero retrieval key)
+  std::vector<cc_bci_t> getLevBCI(int level) const {
+    std::vector<cc_bci_t> v;
+    const cc_scan_desc_t &d = desc();
+    for (int s = 0; s < CC_NPIV; s++) {
+      float sum = 0.f;
+      for (int k = 0; k < CC_KEY_DIM; k++) sum += d.keys[level][s][k];
+      if (sum != 0.f) v.push_back(d.bcis[level][s]);
+    }
+    return v;
+  }
   float getAreaPerc(const int8_t &lev, const int8_t &seq) const {
     return desc().cont[lev][seq].cell_cnt * 1.0f / desc().layer_cell_cnt[lev];
   }

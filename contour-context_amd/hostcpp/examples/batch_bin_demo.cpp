@@ -9,6 +9,8 @@
 
 #include "cont2/contour_db.h"
 
+SequentialTimeProfiler stp;  // the library's stage timers land here (contour_db.h: extern)
+
 template <typename PointType>
 typename pcl::PointCloud<PointType>::ConstPtr readKITTIPointCloudBin(const std::string &path) {  // tools/pointcloud_util.h:9-47
   auto out = std::make_shared<pcl::PointCloud<PointType>>();

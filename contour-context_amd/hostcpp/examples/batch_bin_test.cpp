@@ -5,6 +5,8 @@
 #include "eval/evaluator.h"
 #include "tools/config_handler.h"
 
+SequentialTimeProfiler stp;  // the library's stage timers land here (contour_db.h: extern)
+
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "usage: %s config.yaml\n", argv[0]);

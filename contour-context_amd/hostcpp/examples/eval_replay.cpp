@@ -3,6 +3,8 @@
 //   eval_replay <pose file> <scan list> <sim threshold> <predictions: `tgt src|-1 corr tx ty theta`> <outcome out>
 #include "eval/evaluator.h"
 
+SequentialTimeProfiler stp;  // the library's stage timers land here (contour_db.h: extern)
+
 int main(int argc, char **argv) {
   if (argc < 6) {
     fprintf(stderr, "usage: %s poses.txt scans.txt thres predictions.txt outcome.txt\n", argv[0]);
