@@ -47,7 +47,7 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_packed_sizes", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
-           "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host"]
+           "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host", "cc_db_debug_passes"]
 
 
 def lib():
@@ -268,6 +268,14 @@ class Database:
         _chk(lib().cc_db_check_hints(self.h, qdesc.data_ptr(), hints.ctypes.data, len(hints), C.addressof(lb), C.addressof(ub),
                                      int(max_fine_opt), res.ctypes.data, sc.ctypes.data, stream), "cc_db_check_hints")
         return res[0], sc
+
+    def debug_passes(self, cap=1152):
+        """Constellations of the last check_hints call that passed all gates: numpy array of L.pass_dbg_dt."""
+        out = np.zeros(cap, L.pass_dbg_dt)
+        n = C.c_int()
+        lib().cc_db_debug_passes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _chk(lib().cc_db_debug_passes(self.h, out.ctypes.data, cap, C.byref(n)), "cc_db_debug_passes")
+        return out[:n.value]
 
     def set_lanes(self, n):
         """1 = query chunks one after the other, 2 (default) = two 256-query chunks in flight on internal streams."""

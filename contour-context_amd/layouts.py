@@ -23,6 +23,13 @@ scan_desc_dt = np.dtype([
     ("max_bin_val", "<f4"), ("min_bin_val", "<f4"), ("n_pix", "<i4"), ("flags", "<i4"),
     ("keys", "<f4", (NLEV, NPIV, KEY_DIM)), ("bcis", bci_dt, (NLEV, NPIV)),
     ("cont", contour_dt, (NLEV, MAXC))], align=True)
+HOT_LEVELS, NDIST = 4, 10
+# cc_hot_desc_t: what the query path reads of a scan (levels 1..4): hot.X[l] = desc.X[l + 1]
+hot_desc_dt = np.dtype([
+    ("n_cont", "<i4", (HOT_LEVELS,)), ("layer_cell_cnt", "<i4", (HOT_LEVELS,)), ("flags", "<i4"), ("pad_", "<i4", (3,)),
+    ("keys", "<f4", (HOT_LEVELS, NPIV, KEY_DIM)), ("cont", contour_dt, (HOT_LEVELS, NDIST)),
+    ("bcis", bci_dt, (HOT_LEVELS, NPIV))], align=True)
+assert hot_desc_dt.itemsize == 18448
 knn_hit_dt = np.dtype([("gidx", "<i4"), ("level", "<i2"), ("seq", "<i2"), ("dist_sq", "<f4")], align=True)
 query_result_dt = np.dtype([
     ("n_res", "<i4"), ("cand_gidx", "<i4"), ("correlation", "<f8"), ("tf", "<f8", (3,)),
@@ -37,6 +44,8 @@ hint_dt = np.dtype([("cand_gidx", "<i4"), ("level", "i1"), ("seq_src", "i1"), ("
 hint_score_dt = np.dtype([("i_ovlp_sum", "<i4"), ("i_ovlp_max_one", "<i4"), ("i_in_ang_rng", "<i4"), ("i_indiv_sim", "<i4"),
                           ("i_orie_sim", "<i4"), ("passed", "<i4")], align=True)
 assert hint_dt.itemsize == 8 and hint_score_dt.itemsize == 24
+pass_dbg_dt = np.dtype([("hint", "<i4"), ("n_pairs", "<i4"), ("tf", "<f8", (3,)), ("pairs", "<u8", (7,))], align=True)
+assert pass_dbg_dt.itemsize == 88
 
 
 class ManagerCfg(C.Structure):

@@ -316,6 +316,17 @@ int cc_db_check_hints_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_hi
                            const cc_score_t *thres_lb, const cc_score_t *thres_ub, int max_fine_opt,
                            cc_query_result_t *h_res, cc_hint_score_t *h_scores);
 
+/* Parity / debug: the constellations of the LAST cc_db_check_hints[_host] call that passed all four gates, in hint
+ * order: the pose getTFFromConstell returned for each (contour_mng.h:1246-1277, before any proposal merging) and the
+ * constellation it was computed from, so that a test can redo the rigid fit independently (e.g. with an SVD). */
+typedef struct {
+  int32_t hint;          /* index into the call's hint array                                   */
+  int32_t n_pairs;       /* contours pairs in the constellation                                */
+  double tf[3];          /* T_pass = (x, y, theta), BEV pixel units / radians                  */
+  uint64_t pairs[7];     /* the pairs as a set: bit (level-1)*100 + seq_src*10 + seq_tgt       */
+} cc_pass_dbg_t;
+int cc_db_debug_passes(cc_db *db, cc_pass_dbg_t *h_out, int cap, int *n_out);
+
 /* ---- the compact per-scan records (multi-GPU exchange) ----
  * cc_pack_scans turns full descriptors into the two records the database keeps per scan: the hot record
  * (cc_hot_desc_t, 18 KB) and the correlation inputs (opaque, 16 KB; cc_packed_sizes gives both sizes).  A rank packs

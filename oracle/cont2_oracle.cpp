@@ -156,6 +156,14 @@ void *orc_db_create(const cc_db_cfg_t *cfg) {
   d->db->timers = &d->timers;
   return d;
 }
+// sensitivity knobs of the restated third-party pieces (orc_math.h: orc::Variant); 0 / 10 / 1e-4 / 0.9 = the restatement
+void orc_set_variant(unsigned label_shuffle_seed, int lbfgs_max_iterations, double wolfe_c1, double wolfe_c2) {
+  orc::Variant &v = orc::variant();
+  v.label_shuffle_seed = label_shuffle_seed;
+  v.lbfgs_max_iterations = lbfgs_max_iterations;
+  v.wolfe_sufficient_decrease = wolfe_c1;
+  v.wolfe_curvature = wolfe_c2;
+}
 void orc_db_free(void *d) { delete (DbH *)d; }
 // the query-side stage timers accumulated so far {KNN search, Constell, L2 opt} (seconds); reset != 0 clears them
 void orc_db_timers(void *d, double *out3, int reset) {

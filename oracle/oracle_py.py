@@ -58,6 +58,7 @@ def lib():
         _lib.orc_db_push_and_balance.argtypes = [C.c_void_p, C.c_int, C.c_double]
         _lib.orc_db_bucket_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_db_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_set_variant.argtypes = [C.c_uint, C.c_int, C.c_double, C.c_double]
         _lib.orc_db_query.argtypes = [C.c_void_p] * 7
         _lib.orc_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.orc_ingest_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -165,6 +166,12 @@ class DB:
         cnt = np.zeros((3, L.NPIV), np.int32) if want_knn else None
         lib().orc_db_query(self.h, scan.h, C.addressof(lb), C.addressof(ub), _p(res), _p(knn), _p(cnt))
         return (res[0], knn, cnt) if want_knn else res[0]
+
+
+def set_variant(label_shuffle_seed=0, lbfgs_max_iterations=10, wolfe_c1=1e-4, wolfe_c2=0.9):
+    """Sensitivity knobs of the pieces restated from third-party code (component numbering, Ceres line search); the
+    defaults are the restatement itself.  Tests only."""
+    lib().orc_set_variant(int(label_shuffle_seed), int(lbfgs_max_iterations), float(wolfe_c1), float(wolfe_c2))
 
 
 def run_sequence(xyzi, offsets, ts, seeds, mcfg=None, dcfg=None, lb=None, ub=None, want_desc=False):

@@ -387,6 +387,13 @@ inline int connectedComponentsWithStats8(const std::vector<uint8_t> &img, int ro
   std::vector<int> order(comps.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
   std::sort(order.begin(), order.end(), [&](int a, int b) { return comps[a].key < comps[b].key; });
+  if (orc::variant().label_shuffle_seed) {  // sensitivity knob (orc_math.h): any other numbering
+    unsigned st = orc::variant().label_shuffle_seed * 2654435761u + (unsigned)comps.size();
+    for (size_t i = order.size(); i > 1; i--) {
+      st = st * 1664525u + 1013904223u;
+      std::swap(order[i - 1], order[(st >> 8) % i]);
+    }
+  }
   std::vector<int> remap(comps.size() + 1, 0);
   stats.assign(comps.size() + 1, {0, 0, 0, 0, 0});
   for (size_t i = 0; i < order.size(); i++) {

@@ -617,6 +617,9 @@ inline void Solve(const GMMPair &prob, double *parameters, SolveSummary *summary
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const int max_num_line_search_direction_restarts = 5;
   LSOptions lsopt;
+  lsopt.sufficient_decrease = orc::variant().wolfe_sufficient_decrease;        // defaults unless a sensitivity test says otherwise
+  lsopt.sufficient_curvature_decrease = orc::variant().wolfe_curvature;
+  if (max_num_iterations == 10) max_num_iterations = orc::variant().lbfgs_max_iterations;
   struct State {
     double cost = 0, gradient[3] = {0, 0, 0}, gradient_squared_norm = 0, gradient_max_norm = 0;
     double search_direction[3] = {0, 0, 0}, directional_derivative = 0, step_size = 0;

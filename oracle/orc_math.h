@@ -8,6 +8,22 @@
 
 namespace orc {
 
+// SENSITIVITY KNOBS (tests only, all off by default).  The pieces of the reference that live in third-party code absent
+// from the tree are restated here from their published algorithms (see the header of cont2_oracle.cpp): the order in
+// which OpenCV numbers connected components, and Ceres' line-search minimiser.  These knobs perturb exactly those
+// pieces so that a test can show how much -- how little -- the end result depends on them.
+struct Variant {
+  unsigned label_shuffle_seed = 0;  // != 0: the components of a level are numbered in a seeded random order instead of the
+                                    // first-2x2-block order (changes which of two equal-size contours sorts first)
+  int lbfgs_max_iterations = 10;    // correlation.h:215 uses 10
+  double wolfe_sufficient_decrease = 1e-4, wolfe_curvature = 0.9;  // Ceres defaults
+};
+inline Variant &variant() {
+  static Variant v;
+  return v;
+}
+
+
 struct V2F {
   float x = 0, y = 0;
   V2F() = default;

@@ -27,6 +27,32 @@ def test_layout_sizes(cc, oracle):
     assert oracle.lib().orc_sizeof_desc() == L.scan_desc_dt.itemsize == cc.DESC_BYTES
     assert L.contour_dt.itemsize == 76 and L.bci_dt.itemsize == 600 and L.relpt_dt.itemsize == 12
     assert C.sizeof(L.ManagerCfg) == 80 and C.sizeof(L.DbCfg) == 64 and C.sizeof(L.Score) == 32
+    # the compact per-scan records (hot record + correlation inputs): sizes as the library reports them
+    lib = C.CDLL(cc.build())
+    hb, fb = C.c_size_t(), C.c_size_t()
+    lib.cc_packed_sizes.restype = None
+    lib.cc_packed_sizes(C.byref(hb), C.byref(fb))
+    assert hb.value == L.hot_desc_dt.itemsize == 18448 and fb.value == 16 + 16 + 8 + 4 * 128 * 32
+
+
+def test_hot_record_is_a_view_of_the_descriptor(cc, oracle):
+    """cc_pack_scans (CPU harness): hot.X[l] == desc.X[l + 1] for keys, BCIs, counts and the first 10 contour rows."""
+    import emu_api
+    from parity import terrain_scan
+    L = cc.L
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=2)
+    s = terrain_scan(4, n=8000)
+    desc = api.ingest(ctx, s, np.array([0, len(s)], np.int64))
+    hot, feat = api.pack(ctx, desc)
+    h = hot.view(L.hot_desc_dt).reshape(-1)[0]
+    d = desc[0]
+    assert np.array_equal(h["n_cont"], d["n_cont"][1:5]) and np.array_equal(h["layer_cell_cnt"], d["layer_cell_cnt"][1:5])
+    assert h["keys"].tobytes() == d["keys"][1:5].tobytes() and h["bcis"].tobytes() == d["bcis"][1:5].tobytes()
+    for l in range(4):
+        ns = min(int(d["n_stored"][l + 1]), 10)
+        assert h["cont"][l][:ns].tobytes() == d["cont"][l + 1][:ns].tobytes()
+        assert not h["cont"][l][ns:].tobytes().strip(b"\0")
 
 
 def test_defaults_match_shipped_yaml(cc):

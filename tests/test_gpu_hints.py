@@ -56,3 +56,55 @@ def test_check_hints_matches_oracle(cc, oracle):
     r2 = db.query(desc[100:], seeds[100:])
     assert r1.tobytes() == r2.tobytes()
     torch.cuda.synchronize()
+
+
+def test_umeyama_against_svd(cc):
+    """getTFFromConstell (2-D umeyama without scaling, contour_mng.h:1246-1277) as the device computes it -- a closed
+    form for SO(2) with parallel sums -- against an independent rigid fit: numpy SVD (Kabsch) over the very contour
+    centres of the constellation that the device reports for each passing check.  The oracle is not involved."""
+    import torch
+    L = cc.L
+    w = cc.synth.World(loop_len=100.0)
+    n = 130
+    xyzi, poses, ts = cc.synth.make_sequence(n, world=w, device="cuda")
+    P = xyzi.shape[1]
+    ctx = cc.Context(0, max_batch=128)
+    desc = ctx.ingest(xyzi.reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * P)
+    db = cc.Database(ctx, capacity=n)
+    db.add_scans(desc, ts, np.arange(n, dtype=np.int32))
+    hdesc = np.frombuffer(desc.cpu().numpy().tobytes(), dtype=L.scan_desc_dt)
+    n_checked = 0
+    worst = 0.0
+    for qi in (105, 118, 129):
+        cands = [qi - 100, qi - 101]
+        base = _demo_hints(L, hdesc, qi, cands)
+        h = np.zeros(len(base), L.hint_dt)
+        h["cand_gidx"] = np.array(cands)[base[:, 0]]
+        h["level"], h["seq_src"], h["seq_tgt"] = base[:, 1], base[:, 2], base[:, 3]
+        db.check_hints(desc[qi], h, max_fine_opt=5)
+        for p in db.debug_passes():
+            src, tgt = hdesc[int(h["cand_gidx"][p["hint"]])], hdesc[qi]
+            S, T = [], []
+            for wd in range(7):
+                m = int(p["pairs"][wd])
+                while m:
+                    b = wd * 64 + (m & -m).bit_length() - 1
+                    m &= m - 1
+                    l, s_, t_ = b // 100 + 1, (b % 100) // 10, b % 10
+                    S.append(src["cont"][l][s_]["pos_mean"])
+                    T.append(tgt["cont"][l][t_]["pos_mean"])
+            S, T = np.asarray(S, np.float64), np.asarray(T, np.float64)
+            assert len(S) == p["n_pairs"] >= 4
+            ms, mt = S.mean(0), T.mean(0)
+            U, _, Vt = np.linalg.svd((T - mt).T @ (S - ms))
+            D = np.diag([1.0, np.sign(np.linalg.det(U @ Vt))])
+            R = U @ D @ Vt
+            t = mt - R @ ms
+            th = np.arctan2(R[1, 0], R[0, 0])
+            err = max(abs(t[0] - p["tf"][0]), abs(t[1] - p["tf"][1]), abs(np.angle(np.exp(1j * (th - p["tf"][2])))))
+            worst = max(worst, err)
+            n_checked += 1
+    assert n_checked > 20
+    assert worst < 1e-9, worst
+    db.close()
+    ctx.close()
