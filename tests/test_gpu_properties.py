@@ -63,6 +63,57 @@ def _desc_same(cc, ta, tb):
     return True
 
 
+def knn_bruteforce_check(keys_by_level, dq, knn1, cnt1, ranges, n_db, qis, nnk=50, settle=600):
+    """KNN hit lists of a query batch against brute force over the DB's keys (numpy, f32, the reference's accumulation
+    order) under the visibility rules of the final epoch.  keys_by_level[ll]: [n_db * 6, 10] keys of query level ll in
+    insertion order (scan-major); which keys are searchable is the DB's own bookkeeping (buffers vs trees), so: every key
+    in a hit list must be valid, the list must be sorted, unique and inside dist_ub, and no visible key older than `settle`
+    scans may be closer than the worst hit."""
+    ranges = np.asarray(ranges, np.float32).reshape(3, 7)
+    qlev = [1, 2, 3]
+    for ll, lev in enumerate(qlev):
+        K = keys_by_level[ll]
+        valid = K.sum(1) != 0
+        for qi in qis:
+            for seq in range(6):
+                k = dq["keys"][qi, lev, seq].astype(np.float32)
+                m = int(cnt1[qi, ll, seq])
+                if k.sum() == 0:
+                    assert m == 0
+                    continue
+                hits = knn1[qi, ll, seq, :m]
+                assert np.all(np.diff(hits["dist_sq"]) >= 0), "hits sorted by distance"
+                ids = hits["gidx"].astype(np.int64) * 6 + hits["seq"]
+                assert len(set(ids.tolist())) == m, "no key twice"
+                assert valid[ids].all()
+                # distances recomputed in f32 with the reference's accumulation order
+                c = K[ids]
+                dd = (k - c).astype(np.float32)
+                r = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2] + dd[:, 3] * dd[:, 3]).astype(np.float32)
+                r = (r + (dd[:, 4] * dd[:, 4] + dd[:, 5] * dd[:, 5] + dd[:, 6] * dd[:, 6] + dd[:, 7] * dd[:, 7]).astype(np.float32)).astype(np.float32)
+                r = (r + dd[:, 8] * dd[:, 8]).astype(np.float32)
+                r = (r + dd[:, 9] * dd[:, 9]).astype(np.float32)
+                assert np.allclose(r, hits["dist_sq"], rtol=2e-6, atol=1e-6)
+                # dist_ub (contour_db.h:733-749)
+                ub = max((k[0] * 0.2) ** 2, (k[0] - k[0] / 0.8) ** 2) + max((k[1] * 0.2) ** 2, (k[1] - k[1] / 0.8) ** 2) + \
+                    max((k[2] - k[2] * 0.6) ** 2, (k[2] - k[2] / 0.6) ** 2)
+                assert m == 0 or hits["dist_sq"][-1] < ub * (1 + 1e-5)
+                if m == nnk:
+                    # nothing visible and searchable may be closer than the worst hit: check against all valid keys in the
+                    # buckets the search visits that are OLD enough to sit in a tree
+                    mid = int(np.searchsorted(ranges[ll], k[0], side="right") - 1)
+                    mid = min(max(mid, 0), 5)
+                    bk = np.searchsorted(ranges[ll], K[:, 0], side="right") - 1
+                    vis = ((bk <= mid) | (bk >= 2 * mid + 1)) & (bk >= 0) & (bk <= 5) & valid
+                    scan_of = np.arange(len(K)) // 6
+                    dall = ((k[None, :] - K[vis]) ** 2).sum(1)
+                    older = scan_of[vis] <= (n_db - 1 - settle)      # well past any insertion delay
+                    better = (dall < hits["dist_sq"][-1] * (1 - 1e-5)) & older
+                    got = set(ids.tolist())
+                    missing = [i for i in np.nonzero(vis)[0][better] if i not in got]
+                    assert not missing, "closer visible keys were not returned: %s" % missing[:5]
+
+
 def test_ingest_batch_invariance_and_determinism(cc, world_db):
     import torch
     ctx, desc, xq, qdesc, P = world_db
@@ -94,53 +145,8 @@ def test_query_batch_invariance_incremental_db_and_knn(cc, world_db):
     d = cc.desc_to_numpy(desc)
     dq = cc.desc_to_numpy(qdesc)
     _, ranges = db1.bucket_state()
-    ranges = np.asarray(ranges, np.float32).reshape(3, 7)
-    qlev = [1, 2, 3]
-    # which keys are searchable at the final epoch is the DB's own bookkeeping (buffers vs trees); here: every key that
-    # shows up in a hit list must be valid, and the list must be the top-k among the keys at least as good as its worst
-    for ll, lev in enumerate(qlev):
-        K = d["keys"][:, lev].reshape(-1, 10).astype(np.float32)        # key id = scan * 6 + seq only if all keys valid
-        valid = K.sum(1) != 0
-        for qi in (0, 31, N_Q - 1):
-            for seq in range(6):
-                k = dq["keys"][qi, lev, seq].astype(np.float32)
-                m = int(cnt1[qi, ll, seq])
-                if k.sum() == 0:
-                    assert m == 0
-                    continue
-                hits = knn1[qi, ll, seq, :m]
-                assert np.all(np.diff(hits["dist_sq"]) >= 0), "hits sorted by distance"
-                ids = hits["gidx"].astype(np.int64) * 6 + hits["seq"]
-                assert len(set(ids.tolist())) == m, "no key twice"
-                assert valid[ids].all()
-                # distances recomputed in f32 with the reference's accumulation order
-                c = K[ids]
-                dd = (k - c).astype(np.float32)
-                r = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2] + dd[:, 3] * dd[:, 3]).astype(np.float32)
-                r = (r + (dd[:, 4] * dd[:, 4] + dd[:, 5] * dd[:, 5] + dd[:, 6] * dd[:, 6] + dd[:, 7] * dd[:, 7]).astype(np.float32)).astype(np.float32)
-                r = (r + dd[:, 8] * dd[:, 8]).astype(np.float32)
-                r = (r + dd[:, 9] * dd[:, 9]).astype(np.float32)
-                assert np.allclose(r, hits["dist_sq"], rtol=2e-6, atol=1e-6)
-                # dist_ub (contour_db.h:733-749)
-                ub = max((k[0] * 0.2) ** 2, (k[0] - k[0] / 0.8) ** 2) + max((k[1] * 0.2) ** 2, (k[1] - k[1] / 0.8) ** 2) + \
-                    max((k[2] - k[2] * 0.6) ** 2, (k[2] - k[2] / 0.6) ** 2)
-                assert m == 0 or hits["dist_sq"][-1] < ub * (1 + 1e-5)
-                if m == 50:
-                    # nothing visible and searchable may be closer than the worst hit: check against all valid keys in the
-                    # buckets the search visits that are OLD enough to sit in a tree (scan index <= newest hit's)
-                    mid = int(np.searchsorted(ranges[ll], k[0], side="right") - 1)
-                    mid = min(max(mid, 0), 5)
-                    bk = np.searchsorted(ranges[ll], K[:, 0], side="right") - 1
-                    vis = ((bk <= mid) | (bk >= 2 * mid + 1)) & (bk >= 0) & (bk <= 5) & valid
-                    newest = hits["gidx"].max()
-                    scan_of = np.arange(len(K)) // 6
-                    cand = vis & (scan_of <= newest - 0)
-                    dall = ((k[None, :] - K[cand]) ** 2).sum(1)
-                    older = scan_of[cand] <= (N_DB - 1 - 600)      # well past any insertion delay
-                    better = (dall < hits["dist_sq"][-1] * (1 - 1e-5)) & older
-                    got = set(ids.tolist())
-                    missing = [i for i in np.nonzero(cand)[0][better] if i not in got]
-                    assert not missing, "closer visible keys were not returned: %s" % missing[:5]
+    knn_bruteforce_check([d["keys"][:, lev].reshape(-1, 10).astype(np.float32) for lev in (1, 2, 3)], dq, knn1, cnt1, ranges, N_DB,
+                         (0, 31, N_Q - 1))
     # ---- revisits are found
     assert (r1["n_res"] > 0).mean() > 0.9
     db1.close()
