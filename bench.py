@@ -43,6 +43,7 @@ def main():
                     help="N > 1: all-gather every batch's descriptors in the timed step (what appending them to all replicas needs)")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
+    ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
     ap.add_argument("--workload", choices=("sparse", "dense"), default="sparse",
                     help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
                          "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level")
@@ -129,6 +130,8 @@ def main():
     db = cc.Database(ctx, capacity=n_db + 16)
     if args.no_overlap:
         db.set_lanes(1)
+    elif args.lanes:
+        db.set_lanes(args.lanes)
     ts_db = np.arange(n_db, dtype=np.float64) / 10.0
     hot_db, feat_db = rec_db[:, :HB].contiguous(), rec_db[:, HB:].contiguous()
     db.add_packed(hot_db, feat_db, ts_db, np.arange(n_db, dtype=np.int32))
