@@ -32,6 +32,8 @@ def test_batch_eval_matches_online_loop(cc, oracle, tmp_path):
     cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
     cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 12.5").replace("min_elapse_: 15.0", "min_elapse_: 7.5")
     (tmp_path / "cfg.yaml").write_text(cfg)
+    for k in ("CC_B1_GRID", "CC_B2_GRID", "CC_GMM_GRID"):  # CPU harness: one OS thread per HIP thread, keep the grids small
+        os.environ.setdefault(k, "6")
     ev, res, summary = batch_eval.run(str(tmp_path / "cfg.yaml"), lib_path=emu_api.build(), chunk=8, verbose=False)
     dcfg = cc.L.default_db_cfg()
     dcfg.max_elapse, dcfg.min_elapse = 12.5, 7.5

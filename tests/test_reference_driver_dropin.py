@@ -35,7 +35,7 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
                            REF_DRIVER, "-I", os.path.join(PKG, "hostcpp"), "-I", os.path.join(ROOT, "include"),
                            "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so), "-pthread", "-o", exe])
     w = cc.synth.World(loop_len=40.0)
-    n = 60
+    n = 52
     x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
     ts = ts * 4.0  # 0.4 s per scan: a 40-scan lap takes 16 s, past the evaluator's 15 s exclusion window
     xs = x.numpy()
