@@ -18,6 +18,8 @@ struct cc_dev_cfg {
   float roi_radius;
   int min_cell_cov;
   float point_sigma, com_bias_thres;
+  float inv_row, inv_col;  // 1 / reso, exact when reso_pow2
+  int reso_pow2;           // both resolutions are powers of two (the shipped 1.0 and the paper's 2.0 are)
 };
 
 #define CC_BEV_EMPTY (-1000.0f)  // VAL_ABS_INF_, contour_mng.h:418,488
@@ -34,12 +36,15 @@ __device__ __forceinline__ float cc_funkey(unsigned k) {
 
 // hashPointToImage (contour_mng.h:448-463).  Returns cell index or -1 (rejected or row 0:
 // makeBEV only uses points with rc.first > 0, contour_mng.h:515).
+// POW2: the resolutions are powers of two, so x * (1 / reso) and x / reso are the correctly rounded value of the same real
+// number -- bit-identical, and an IEEE f32 division is ~11 instructions against one.
+template <bool POW2 = false>
 __device__ __forceinline__ int cc_point_cell(const cc_dev_cfg &c, float x, float y) {
   // written so that a NaN coordinate is rejected (the reference's int(floor(NaN)) is undefined behaviour); identical to
   // `x < lo || x > hi || ...` for every other value
   if (!(x >= c.x_lo && x <= c.x_hi && y >= c.y_lo && y <= c.y_hi) || (y * y + x * x) < c.blind_sq) return -1;
-  int row = (int)floorf(x / c.reso_row) + c.half_row;
-  int col = (int)floorf(y / c.reso_col) + c.half_col;
+  int row = (int)floorf(POW2 ? x * c.inv_row : x / c.reso_row) + c.half_row;
+  int col = (int)floorf(POW2 ? y * c.inv_col : y / c.reso_col) + c.half_col;
   if (row <= 0) return -1;
   return row * c.n_col + col;
 }

@@ -38,5 +38,12 @@ static inline int cc_make_dev_cfg(const cc_manager_cfg_t *m, cc_dev_cfg *c) {
   c->min_cell_cov = m->min_cell_cov;
   c->point_sigma = m->point_sigma;
   c->com_bias_thres = m->com_bias_thres;
+  {
+    int er = 0, ec = 0;
+    const bool p2 = frexpf(m->reso_row, &er) == 0.5f && frexpf(m->reso_col, &ec) == 0.5f && er > -100 && er < 100 && ec > -100 && ec < 100;
+    c->reso_pow2 = p2 ? 1 : 0;
+    c->inv_row = 1.0f / m->reso_row;
+    c->inv_col = 1.0f / m->reso_col;
+  }
   return 0;
 }

@@ -66,7 +66,7 @@ struct cc_ctx {
   bool has_last = false;
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   size_t lds1 = 0, lds2 = 0;
-  int k1_u = CC_K1_U_DEFAULT;
+  int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
   // optional per-kernel timing (cc_profile_*)
   bool prof = false;
   std::vector<hipEvent_t> ev;  // triplets (before K1, between, after K2)
@@ -174,11 +174,11 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   {
-    const char *e = getenv("CC_K1_U");  // tuning aid, read once: points per lane and chunk of the rasteriser
-    c->k1_u = (e && atoi(e) == 8) ? 8 : CC_K1_U_DEFAULT;
+    const char *e = getenv("CC_K1_DIV");  // tuning aid, read once
+    c->k1_div = (e && atoi(e) == 1) ? 1 : 0;
   }
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
 #undef CREATE_CHK
@@ -283,11 +283,11 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
       c->ev_used += 3;
       HIPCHK(hipEventRecord(pe[0], stream));
     }
-    if (c->k1_u == 8)
-      hipLaunchKernelGGL(cc_k_rasterize<8>, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
+    if (c->dcfg.reso_pow2 && !c->k1_div)
+      hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
                          c->d_bev, c->d_pix, c->d_k1);
     else
-      hipLaunchKernelGGL(cc_k_rasterize<4>, dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
+      hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
                          c->d_bev, c->d_pix, c->d_k1);
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;

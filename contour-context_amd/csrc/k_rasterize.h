@@ -16,7 +16,7 @@
 
 #define CC_K1_IDX_BITS 21
 #define CC_K1_IDX_MASK 0x1FFFFFull
-#define CC_K1_U_DEFAULT 4  // points per lane and chunk (instances: 4 and 8)
+#define CC_K1_U_DEFAULT 4  // points per lane and chunk (8 measured equal: the sweep is bound by instruction issue, not by loads in flight)
 
 // value of the lane D places to the left / one place to the right inside the 16-lane row; 0 beyond the row's ends
 #ifndef CC_EMU
@@ -65,7 +65,7 @@ __device__ __forceinline__ int cc_wave_sum(int v) {
 }
 
 // grid = n_scans, block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
-template <int CC_K1_U>
+template <int CC_K1_U, bool CC_K1_POW2>
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
                float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {
@@ -112,7 +112,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
     unsigned key[CC_K1_U];
 #pragma unroll
     for (int u = 0; u < CC_K1_U; u++) {
-      cell[u] = cc_point_cell(cfg, q[u].x, q[u].y);
+      cell[u] = cc_point_cell<CC_K1_POW2>(cfg, q[u].x, q[u].y);
       float h = cfg.lidar_height + q[u].z;
       key[u] = cc_fkey(h);
       // a NaN height never updates a cell or the max/min in the reference (`bev < NaN`, `max < NaN`, `min > NaN` are

@@ -117,3 +117,16 @@ def test_nan_heights_are_ignored(oracle):
     clean = s[~np.isnan(s[:, 2])]
     d = _check(oracle, [s])
     assert np.isfinite(d["max_bin_val"]).all() and d["n_pix"][0] == oracle.Scan(clean).desc()[0]["n_pix"]
+
+
+def test_resolutions_pow2_and_not(oracle):
+    """reso_row_/reso_col_ = 2.0 (the paper's setting, contour_mng.h:95) takes the multiply-by-reciprocal instance of the
+    rasteriser, 1.5 x 0.75 the IEEE-division instance; both must hash every point like `x / reso` does
+    (hashPointToImage, contour_mng.h:448-463)."""
+    s = terrain_scan(4, n=20000, scale=1.2)
+    for rr, rc, n in ((2.0, 2.0, 74), (1.5, 0.75, 100)):
+        cfg = oracle.L.default_manager_cfg()
+        cfg.reso_row, cfg.reso_col = rr, rc
+        cfg.n_row, cfg.n_col = n, n
+        d = _check(oracle, [s], cfg=cfg)
+        assert d["n_pix"][0] > 500

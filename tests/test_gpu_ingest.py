@@ -115,3 +115,16 @@ def test_ingest_min_cont_cell_cnt_and_nan(cc, oracle):
     s2[::7, 2] = np.nan
     report, _ = _run(cc, oracle, [s, s2], cfg=cfg)
     assert not report, "\n".join(report[:40])
+
+
+def test_ingest_resolutions_pow2_and_not(cc, oracle):
+    """2.0 m cells (contour_mng.h:95, multiply-by-reciprocal instance of the rasteriser) and 1.5 x 0.75 m cells (IEEE
+    division instance)."""
+    s = terrain_scan(4, n=20000, scale=1.2)
+    for rr, rc, n in ((2.0, 2.0, 74), (1.5, 0.75, 100)):
+        cfg = cc.L.default_manager_cfg()
+        cfg.reso_row, cfg.reso_col = rr, rc
+        cfg.n_row, cfg.n_col = n, n
+        report, d = _run(cc, oracle, [s], cfg=cfg)
+        assert not report, "\n".join(report[:40])
+        assert d["n_pix"][0] > 500
