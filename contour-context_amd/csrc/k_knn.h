@@ -8,17 +8,25 @@
 //
 // The reference keeps one kd-tree per bucket (nanoflann, src/cont2/contour_db.cpp:319-403); what it returns per anchor
 // key is the nnk nearest keys (squared L2 over 10 dims, ties by insertion) among the visible ones, within dist_ub.
-// Here each layer keeps its keys SORTED BY THE FIRST DIMENSION (the widest one, sqrt(eig_large * cell_cnt)); a search
-// starts at the anchor's own position and walks outwards in both directions, 64 keys at a time, and a direction stops
-// when (key[0] - q[0])^2 alone reaches the current radius -- the 1-D form of the kd-tree's pruning rule.  The radius
-// starts at dist_ub and drops to the nnk-th best distance as soon as nnk candidates are known, so a search typically
-// touches a few hundred keys of tens of thousands.
+// Here each layer keeps its keys SORTED BY THE FIRST DIMENSION (the widest one, sqrt(eig_large * cell_cnt): std 37
+// against 13 for the second and ~6 for the rest on Velodyne scans, so further index dimensions would prune next to
+// nothing).  One wave per search:
+//   * a bucket is an interval of the first dimension, i.e. an INDEX RANGE of the sorted layer: the ranges of the buckets
+//     layerKNNSearch visits ({0..mid} and {2 mid + 1..5}) and the anchor's own position are found with five
+//     simultaneous 9-ary searches (8 lanes each); keys of the other buckets are never touched;
+//   * the search walks outwards from the anchor in both directions over those ranges, 64 keys per direction and step (the
+//     next step's keys are requested as soon as the current ones are scored); a direction stops when
+//     (key[0] - q[0])^2 alone exceeds the radius -- the 1-D form of the kd-tree's pruning rule;
+//   * the radius starts at dist_ub and drops to the nnk-th best distance whenever 2 nnk candidates are pending; the
+//     candidates are ordered by (distance, key id) with a bitonic network held in registers (<= 4 entries per lane,
+//     cross-lane exchanges through ds_bpermute, no barriers).
+// The result is the exact set and order of the reference: any radius between the final nnk-th distance and dist_ub is
+// an admissible filter, only the survivors' order (distance, then key id) matters.
 // ------------------------------------------------------------------------------------------------
-// LDS candidate buffer per search (entries of 8 B).  Between two tightenings at most 2 * nnk - 1 kept candidates + one
-// 64-key step are pending (191 at nnk = CC_KNN_MAX = 64), and the bitonic sort pads that to the next power of two.
+// LDS candidate buffer per search (entries of 8 B): at most 2 * nnk - 1 kept candidates + one 64-key step per direction
+// are pending when the buffer is reduced (255 at nnk = CC_KNN_MAX = 64).
 #define CC_KNN_CAP 256
-static_assert(2 * CC_KNN_MAX - 1 + 64 <= CC_KNN_CAP && (CC_KNN_CAP & (CC_KNN_CAP - 1)) == 0,
-              "cc_k_knn: the padded sort width must fit the LDS buffer");
+static_assert(2 * CC_KNN_MAX - 1 + 128 <= CC_KNN_CAP && CC_KNN_MAX <= 64, "cc_k_knn: pending candidates must fit the LDS buffer");
 
 struct cc_knn_params {
   const float *skeys[CC_NQLEV];       // SoA [CC_KEY_DIM][cap_k], sorted by dim 0 (ties: insertion order)
@@ -39,21 +47,47 @@ struct cc_query_meta {  // per query scan, host-built
   float ranges[CC_NQLEV][7];       // LayerDB::bucket_ranges_ at this epoch
 };
 
-__device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n_pow2, int tid, int nt) {
-  for (int k = 2; k <= n_pow2; k <<= 1) {
+// hand-off of LDS data between the lanes of ONE wave (the searches run one wave per workgroup): LDS operations of a wave
+// execute in issue order, only the compiler has to be kept from reordering them.  The CPU harness runs the lanes as OS
+// threads and needs a real rendezvous.
+__device__ __forceinline__ void cc_wave_sync() {
+#ifndef CC_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
+  __syncthreads();
+#endif
+}
+
+// Ascending bitonic sort of 64 * R keys held R per lane: position p lives in v[p / 64] of lane p % 64.
+template <int R>
+__device__ __forceinline__ void cc_wave_bitonic_u64(unsigned long long (&v)[R], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += nt) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          unsigned long long x = a[i], y = a[ixj];
-          bool up = ((i & k) == 0);
-          if ((x > y) == up) {
-            a[i] = y;
-            a[ixj] = x;
+      if (j >= 64) {  // partner in the same lane
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+          const int b = a ^ (j >> 6);
+          if (b > a) {
+            const bool up = ((a * 64) & k) == 0;
+            const unsigned long long x = v[a], y = v[b];
+            if ((x > y) == up) {
+              v[a] = y;
+              v[b] = x;
+            }
           }
         }
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+          const unsigned long long o = __shfl_xor(v[a], j);
+          const bool up = (((a * 64 + lane) & k) == 0);
+          const bool lower = (lane & j) == 0;
+          const unsigned long long mn = o < v[a] ? o : v[a], mx = o < v[a] ? v[a] : o;
+          v[a] = (lower == up) ? mn : mx;
+        }
       }
-      __syncthreads();
     }
   }
 }
@@ -125,6 +159,20 @@ cc_k_ksort_act(const int *__restrict__ act, const int *__restrict__ sid, int n, 
   if (i < n) sact[i] = act[sid[i]];
 }
 
+// Keep the best nnk of the cnt pending candidates (sorted, at buf[0..nnk)); returns the nnk-th best distance.
+template <int R>
+__device__ __forceinline__ float cc_knn_reduce(unsigned long long *buf, int cnt, int nnk, int lane, unsigned long long &first) {
+  unsigned long long v[R];
+  cc_wave_sync();
+#pragma unroll
+  for (int a = 0; a < R; a++) v[a] = (a * 64 + lane < cnt) ? buf[a * 64 + lane] : ~0ull;
+  cc_wave_bitonic_u64<R>(v, lane);
+  cc_wave_sync();
+  if (lane < nnk) buf[lane] = v[0];
+  first = v[0];
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(v[0] >> 32), nnk - 1));
+}
+
 // grid = nq * CC_NQLEV * CC_NPIV, block = 64 (one wave per anchor key)
 __global__ void __launch_bounds__(64)
 cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta,
@@ -148,11 +196,12 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
     k[d] = qk[d];
     sum += k[d];
   }
-  if (!(sum != 0.f)) {  // q_keys[seq].sum() != 0 (contour_db.h:726)
+  const int n = P.n_sorted[ll];
+  if (!(sum != 0.f) || n <= 0) {  // q_keys[seq].sum() != 0 (contour_db.h:726)
     if (lane == 0) hit_cnt[blockIdx.x] = 0;
     return;
   }
-  const cc_query_meta qm = qmeta[q];
+  const cc_query_meta *qm = qmeta + q;
   // dist_ub (contour_db.h:733-749), f32 results of f64 products exactly as written there
   const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
   const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
@@ -161,160 +210,166 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
   const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
   const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
   float ub = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
-  // mid bucket and the buckets layerKNNSearch actually visits (src/cont2/contour_db.cpp:322-369):
-  // {0..mid} and {mid+i : i > mid, mid+i < 6}
-  float rg[7];
-#pragma unroll
-  for (int i = 0; i < 7; i++) rg[i] = qm.ranges[ll][i];
-  int mid = 0;
-  {
-    bool found = false;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-      if (!found && rg[i] <= k[0] && rg[i + 1] > k[0]) {
-        mid = i;
-        found = true;
-      }
-  }
-  unsigned vis = 0;
-#pragma unroll
-  for (int b = 0; b < 6; b++)
-    if (b <= mid || b >= 2 * mid + 1) vis |= 1u << b;
-  const int n = P.n_sorted[ll];
   const float *K = P.skeys[ll];
   const int *sid = P.sid[ll];
   const int *sact = P.sact[ll];
-  const int cap = P.cap_k;
-  const int epoch = qm.epoch;
+  const unsigned cap = (unsigned)P.cap_k;
+  const int epoch = qm->epoch;
   const int nnk = P.nnk;
-  // position of the anchor's first dimension in the sorted layer
-  int right;
+
+  // ---- index ranges of the visible buckets (src/cont2/contour_db.cpp:322-369: mid = the bucket of the anchor's first
+  // dimension, visited are {0..mid} and {mid + i : i > mid, mid + i < 6}) and the anchor's own position.
+  // A key sits in bucket b iff rg[b] <= key[0] < rg[b + 1], i.e. iff its sorted index is in [lb(rg[b]), lb(rg[b + 1])),
+  // lb(t) = number of keys with key[0] < t.
+  int L0, E1, S2, E2, right;
   {
+    float rg[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) rg[i] = qm->ranges[ll][i];
+    int mid = 0;
+    {
+      bool found = false;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+        if (!found && rg[i] <= k[0] && rg[i + 1] > k[0]) {
+          mid = i;
+          found = true;
+        }
+    }
+    float t_e1 = rg[6], t_s2 = rg[6];
+#pragma unroll
+    for (int i = 1; i < 7; i++) {
+      if (i == mid + 1) t_e1 = rg[i];
+      if (i == 2 * mid + 1) t_s2 = rg[i];
+    }
+    const int g = lane >> 3, sub = lane & 7;  // search g: 0 -> lb(rg[0]), 1 -> E1, 2 -> S2, 3 -> lb(rg[6]), 4.. -> lb(k[0])
+    const float tg = g == 0 ? rg[0] : g == 1 ? t_e1 : g == 2 ? t_s2 : g == 3 ? rg[6] : k[0];
     int lo = 0, hi = n;
-    while (lo < hi) {
-      const int md = (lo + hi) >> 1;
-      if (K[md] < k[0])
-        lo = md + 1;
-      else
-        hi = md;
-    }
-    right = lo;
-  }
-  int left = right - 1;  // next index to visit on the low side
-  int cnt = 0;
-  bool tightened = false;
-  bool open[2] = {right < n, left >= 0};  // [0]: upwards, [1]: downwards
-  // one 64-key step per direction and iteration; the next step's keys are loaded while the current one is scored
-  float c[2][CC_KEY_DIM], cn[2][CC_KEY_DIM];
-  int act[2], actn[2], kid[2], kidn[2];
-  int id[2] = {right + lane, left - lane};
-#pragma unroll
-  for (int dir = 0; dir < 2; dir++) {
-    act[dir] = 0x7fffffff;
-    kid[dir] = 0;
-#pragma unroll
-    for (int d = 0; d < CC_KEY_DIM; d++) c[dir][d] = 0.f;
-    if (id[dir] >= 0 && id[dir] < n) {
-      act[dir] = sact[id[dir]];
-      kid[dir] = sid[id[dir]];
-#pragma unroll
-      for (int d = 0; d < CC_KEY_DIM; d++) c[dir][d] = K[(size_t)d * cap + id[dir]];
-    }
-  }
-  while (open[0] || open[1]) {
-    int idn[2] = {id[0] + 64, id[1] - 64};
-#pragma unroll
-    for (int dir = 0; dir < 2; dir++) {
-      actn[dir] = 0x7fffffff;
-      kidn[dir] = 0;
-#pragma unroll
-      for (int d = 0; d < CC_KEY_DIM; d++) cn[dir][d] = 0.f;
-      if (open[dir] && idn[dir] >= 0 && idn[dir] < n) {
-        actn[dir] = sact[idn[dir]];
-        kidn[dir] = sid[idn[dir]];
-#pragma unroll
-        for (int d = 0; d < CC_KEY_DIM; d++) cn[dir][d] = K[(size_t)d * cap + idn[dir]];
+    while (__ballot(hi > lo) != 0ull) {
+      const int len = hi - lo;
+      const int w = (len + 8) / 9 > 0 ? (len + 8) / 9 : 1;
+      // probes p_j = min(lo + (j + 1) w - 1, hi - 1), j = 0..7: key[0] < target is true up to some j, false after
+      int p = lo + (sub + 1) * w - 1;
+      p = p < hi - 1 ? p : hi - 1;
+      const bool below = (len > 0) && (K[(unsigned)(p < 0 ? 0 : p)] < tg);
+      const int c = __popc((unsigned)(__ballot(below) >> (lane & 56)) & 0xFFu);
+      if (len > 0) {
+        int pl = lo + c * w - 1;  // p_{c-1}
+        pl = pl < hi - 1 ? pl : hi - 1;
+        int ph = lo + (c + 1) * w - 1;  // p_c
+        ph = ph < hi - 1 ? ph : hi - 1;
+        if (c < 8) hi = ph;
+        if (c > 0) lo = pl + 1;
       }
     }
+    L0 = __builtin_amdgcn_readlane(lo, 0);
+    E1 = __builtin_amdgcn_readlane(lo, 8);
+    S2 = __builtin_amdgcn_readlane(lo, 16);
+    E2 = __builtin_amdgcn_readlane(lo, 24);
+    right = __builtin_amdgcn_readlane(lo, 32);
+  }
+  // upwards: indices >= right of [L0, E1) then of [S2, E2); downwards: indices < right of [S2, E2) then of [L0, E1),
+  // each as one run of "virtual" positions 0, 1, 2, ...
+  const int ua0 = L0 > right ? L0 : right, ua_len = E1 > ua0 ? E1 - ua0 : 0;
+  const int ub0 = S2 > right ? S2 : right, ub_len = E2 > ub0 ? E2 - ub0 : 0;
+  const int db_top = (E2 < right ? E2 : right) - 1, db_len = db_top + 1 > S2 ? db_top + 1 - S2 : 0;
+  const int da_top = (E1 < right ? E1 : right) - 1, da_len = da_top + 1 > L0 ? da_top + 1 - L0 : 0;
+  const int tot[2] = {ua_len + ub_len, db_len + da_len};
+
+  int cnt = 0;
+  bool tightened = false;
+  bool open[2] = {tot[0] > 0, tot[1] > 0};
+  int vpos[2] = {lane, lane};  // this lane's virtual position in the current step of each direction
+  float c[2][CC_KEY_DIM];
+  int act[2], kid[2];
+  bool inside[2];
+#define CC_KNN_FETCH(dir)                                                                                        \
+  {                                                                                                              \
+    const int v_ = vpos[dir];                                                                                    \
+    inside[dir] = v_ < tot[dir];                                                                                 \
+    int i_ = (dir) == 0 ? (v_ < ua_len ? ua0 + v_ : ub0 + (v_ - ua_len)) : (v_ < db_len ? db_top - v_ : da_top - (v_ - db_len)); \
+    i_ = inside[dir] ? i_ : 0;                                                                                   \
+    const unsigned u_ = (unsigned)i_;                                                                            \
+    act[dir] = sact[u_];                                                                                         \
+    kid[dir] = sid[u_];                                                                                          \
+    _Pragma("unroll") for (int d = 0; d < CC_KEY_DIM; d++) c[dir][d] = K[(size_t)d * cap + u_];                 \
+  }
+  if (open[0]) CC_KNN_FETCH(0)
+  if (open[1]) CC_KNN_FETCH(1)
+  while (open[0] || open[1]) {
+    bool pass[2] = {false, false};
+    float res[2] = {0.f, 0.f};
+    int kcur[2] = {0, 0};
+    bool last_in[2] = {false, false};
+    float far2[2] = {0.f, 0.f};
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
       if (!open[dir]) continue;  // wave-uniform
-      bool pass = false;
-      float res = 0.f;
-      const bool inside = id[dir] >= 0 && id[dir] < n;
-      const float c0 = c[dir][0];
-      const float e0 = k[0] - c0;
-      if (inside && act[dir] <= epoch) {
-        int bk = -1;
-#pragma unroll
-        for (int b = 0; b < 6; b++)
-          if (bk < 0 && rg[b] <= c0 && c0 < rg[b + 1]) bk = b;
-        if (bk >= 0 && ((vis >> bk) & 1u)) {
-          // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-          float d0 = e0, d1 = k[1] - c[dir][1], d2 = k[2] - c[dir][2], d3 = k[3] - c[dir][3];
-          res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-          d0 = k[4] - c[dir][4];
-          d1 = k[5] - c[dir][5];
-          d2 = k[6] - c[dir][6];
-          d3 = k[7] - c[dir][7];
-          res += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-          d0 = k[8] - c[dir][8];
-          res += d0 * d0;
-          d0 = k[9] - c[dir][9];
-          res += d0 * d0;
-          // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
-          // distance still compete, on the key id
-          pass = tightened ? (res <= ub) : (res < ub);
-        }
+      const float e0 = k[0] - c[dir][0];
+      {
+        // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+        float r = 0.f;
+        float d0 = e0, d1 = k[1] - c[dir][1], d2 = k[2] - c[dir][2], d3 = k[3] - c[dir][3];
+        r += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        d0 = k[4] - c[dir][4];
+        d1 = k[5] - c[dir][5];
+        d2 = k[6] - c[dir][6];
+        d3 = k[7] - c[dir][7];
+        r += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        d0 = k[8] - c[dir][8];
+        r += d0 * d0;
+        d0 = k[9] - c[dir][9];
+        r += d0 * d0;
+        res[dir] = r;
+        // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
+        // distance still compete, on the key id
+        pass[dir] = inside[dir] && act[dir] <= epoch && (tightened ? (r <= ub) : (r < ub));
       }
-      const unsigned long long m = __ballot(pass);
-      if (pass) buf[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(res) << 32) | (unsigned)kid[dir];
-      cnt += __popcll(m);
-      __syncthreads();
-      if (cnt >= 2 * nnk || (!tightened && cnt >= nnk)) {  // keep the best nnk (by distance, then key id); the radius follows
-        int np2 = 64;
-        while (np2 < cnt) np2 <<= 1;
-        for (int i = cnt + lane; i < np2; i += 64) buf[i] = ~0ull;
-        __syncthreads();
-        cc_bitonic_sort_u64(buf, np2, lane, 64);
-        ub = __uint_as_float((unsigned)(buf[nnk - 1] >> 32));
-        cnt = nnk;
-        tightened = true;
-        __syncthreads();
-      }
+      kcur[dir] = kid[dir];
       // the step's outermost key decides whether the direction goes on: (key[0] - q[0])^2 is a lower bound of the
       // distance and grows outwards
-      const int last_in = __builtin_amdgcn_readlane((int)inside, 63);
+      last_in[dir] = __builtin_amdgcn_readlane((int)inside[dir], 63) != 0;
       const float e_far = cc_lane_bcast(e0, 63);
-      const float far2 = e_far * e_far;
-      open[dir] = last_in && (tightened ? (far2 <= ub) : (far2 < ub));
+      far2[dir] = e_far * e_far;
+      // the next step's keys travel while this step's candidates are filed
+      vpos[dir] += 64;
+      CC_KNN_FETCH(dir)
     }
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
-      id[dir] = idn[dir];
-      act[dir] = actn[dir];
-      kid[dir] = kidn[dir];
-#pragma unroll
-      for (int d = 0; d < CC_KEY_DIM; d++) c[dir][d] = cn[dir][d];
+      if (!open[dir]) continue;
+      const unsigned long long m = __ballot(pass[dir]);
+      if (pass[dir]) buf[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(res[dir]) << 32) | (unsigned)kcur[dir];
+      cnt += __popcll(m);
     }
+    if (cnt >= 2 * nnk || (!tightened && cnt >= nnk)) {  // keep the best nnk (by distance, then key id); the radius follows
+      unsigned long long first;
+      ub = cnt <= 128 ? cc_knn_reduce<2>(buf, cnt, nnk, lane, first) : cc_knn_reduce<4>(buf, cnt, nnk, lane, first);
+      cnt = nnk;
+      tightened = true;
+      cc_wave_sync();
+    }
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++)
+      if (open[dir]) open[dir] = last_in[dir] && (tightened ? (far2[dir] <= ub) : (far2[dir] < ub));
   }
+#undef CC_KNN_FETCH
   {
-    int np2 = 64;
-    while (np2 < cnt) np2 <<= 1;
-    for (int i = cnt + lane; i < np2; i += 64) buf[i] = ~0ull;
-    __syncthreads();
-    cc_bitonic_sort_u64(buf, np2, lane, 64);
+    unsigned long long first;
+    if (cnt <= 128)
+      cc_knn_reduce<2>(buf, cnt, nnk, lane, first);
+    else
+      cc_knn_reduce<4>(buf, cnt, nnk, lane, first);
     const int mm = cnt < nnk ? cnt : nnk;
-    for (int i = lane; i < mm; i += 64) {
-      const unsigned id = (unsigned)(buf[i] & 0xFFFFFFFFu);
+    if (lane < mm) {
+      const unsigned id = (unsigned)(first & 0xFFFFFFFFu);
       cc_knn_hit_t h;
       h.gidx = P.kgidx[ll][id];
       h.level = (int16_t)level;
       h.seq = (int16_t)P.kseq[ll][id];
-      h.dist_sq = __uint_as_float((unsigned)(buf[i] >> 32));
-      out[i] = h;
+      h.dist_sq = __uint_as_float((unsigned)(first >> 32));
+      out[lane] = h;
     }
     if (lane == 0) hit_cnt[blockIdx.x] = mm;
   }
 }
-
