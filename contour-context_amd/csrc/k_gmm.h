@@ -180,12 +180,18 @@ __device__ __forceinline__ cc_gterm cc_gmm_term(const cc_gpair &P, double px, do
   return r;
 }
 
-// the pair pre-selection test of GMMPair's ctor (correlation.h:85-96) at T_init = (tx, ty, rotation ct0/st0)
-__device__ __forceinline__ bool cc_gmm_pair_sel(const cc_ell &es, float tmx, float tmy, float tmaj, double ct0, double st0, double tx,
-                                                double ty) {
-  const double dx = (ct0 * (double)es.mx + (-st0) * (double)es.my + tx) - (double)tmx;
-  const double dy = (st0 * (double)es.mx + ct0 * (double)es.my + ty) - (double)tmy;
-  return sqrt(dx * dx + dy * dy) < 3.0 * (double)(es.maj + tmaj);
+// the pair pre-selection test of GMMPair's ctor (correlation.h:85-96) on dx, dy = transformed src mean - tgt mean:
+//   sqrt(dx^2 + dy^2) < 3 (maj_s + maj_t)
+// decided without the f64 square root whenever x = dx^2 + dy^2 is not within 1e-12 (relative) of y^2: the correctly
+// rounded sqrt(x) is within 1.2e-16 of the real root and y * y, y^2 (1 +- 1e-12) carry three roundings, so outside that
+// band the comparison of the squares and the reference's comparison agree; inside it the reference's expression decides.
+__device__ __forceinline__ bool cc_gmm_pair_near(double dx, double dy, float smaj, float tmaj) {
+  const double x = dx * dx + dy * dy;
+  const double y = 3.0 * (double)(smaj + tmaj);
+  const double y2 = y * y;
+  if (x < y2 * (1.0 - 1e-12)) return true;
+  if (x > y2 * (1.0 + 1e-12)) return false;
+  return sqrt(x) < y;
 }
 __device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_ell &et) {
   cc_gpair P;
@@ -207,14 +213,96 @@ __device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_
   return P;
 }
 
-// K5a: initial correlation of every problem (tryProblem, correlation.h:196-202).  16 lanes per problem: a lane owns the
-// src ellipses sl, sl + 16, ... of a level and walks the level's tgt ellipses (the same address in all lanes: one
-// broadcast load); a selected pair's term is evaluated on the spot.
+// hand-off between the G lanes of a problem through memory (lockstep on the GPU: a compiler fence; the CPU test harness
+// needs its threads to meet)
+template <int G>
+__device__ __forceinline__ void cc_gsync() {
+  if (G == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef CC_EMU
+    (void)__shfl(0, 0);
+#endif
+  } else {
+    cc_group_sync();
+  }
+}
+
+// ---- the selected (src, tgt) ellipse pairs of one problem -------------------------------------------------------------
+// G lanes own G src ellipses of a level at a time and walk the level's tgt ellipses, whose (mean, major axis) sit in LDS
+// (64 at a time, one broadcast ds_read per test); the pairs that pass GMMPair's test are filed in an LDS list as
+// (level, src, tgt) codes, compacted with a group ballot, and handed to `flush` whenever the list is nearly full and at
+// the end -- so the expensive per-pair work (term evaluation, pool record) runs on full lanes instead of the ~1 % of the
+// (src, tgt) grid that is selected.
+#define CC_GMM_TCHUNK 64
+#define CC_GMM_LIST_CAP 256
+struct cc_gmm_scan_lds {
+  float4 T[CC_GMM_TCHUNK];  // (mx, my, maj, -) of the current tgt chunk
+  unsigned short code[CC_GMM_LIST_CAP];
+};
+static_assert(CC_GMM_ECAP_L <= 128 && CC_GMM_LEVELS <= 4, "pair codes are level:2 | src:7 | tgt:7 bits");
+
+template <int G>
+__device__ __forceinline__ unsigned long long cc_gballot(bool pred) {
+  if (G == 64) return __ballot(pred);
+  return (unsigned long long)cc_group_ballot(pred);
+}
+
+// returns the number of selected pairs; flush(n) consumes L.code[0..n)
+template <int G, typename Flush>
+__device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__ fsrc, const cc_gmm_feat *__restrict__ ftgt, double tx, double ty,
+                                                 double ct0, double st0, cc_gmm_scan_lds &L, int sl, Flush flush) {
+  int cnt = 0, total = 0;
+  for (int li = 0; li < CC_GMM_LEVELS; li++) {
+    const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
+    if (ns <= 0) continue;
+    for (int t0 = 0; t0 < ntg; t0 += CC_GMM_TCHUNK) {
+      const int tn = ntg - t0 < CC_GMM_TCHUNK ? ntg - t0 : CC_GMM_TCHUNK;
+      cc_gsync<G>();  // the previous chunk is no longer read
+      for (int j = sl; j < tn; j += G) {
+        const cc_ell *pt = &ftgt->ell[li][t0 + j];
+        L.T[j] = make_float4(pt->mx, pt->my, pt->maj, 0.f);
+      }
+      cc_gsync<G>();
+      for (int s0 = 0; s0 < ns; s0 += G) {
+        const int si = s0 + sl;
+        const bool valid = si < ns;
+        double sx = 0.0, sy = 0.0;
+        float smaj = 0.f;
+        if (valid) {
+          const cc_ell *ps = &fsrc->ell[li][si];
+          const double mx = (double)ps->mx, my = (double)ps->my;
+          sx = ct0 * mx + (-st0) * my + tx;  // T_init applied to the src mean, as written at correlation.h:87-90
+          sy = st0 * mx + ct0 * my + ty;
+          smaj = ps->maj;
+        }
+        for (int tj = 0; tj < tn; tj++) {
+          const float4 t = L.T[tj];
+          const bool sel = valid && cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z);
+          const unsigned long long m = cc_gballot<G>(sel);
+          if (sel) L.code[cnt + __popcll(m & ((1ull << sl) - 1ull))] = (unsigned short)((li << 14) | (si << 7) | (t0 + tj));
+          cnt += __popcll(m);
+          if (cnt > CC_GMM_LIST_CAP - G) {
+            flush(cnt);
+            total += cnt;
+            cnt = 0;
+          }
+        }
+      }
+    }
+  }
+  if (cnt > 0) flush(cnt);
+  return total + cnt;
+}
+
+// K5a: initial correlation of every problem (tryProblem, correlation.h:196-202).  16 lanes per problem; the selected pairs'
+// terms are evaluated from the compacted list, 16 pairs at a time.
 // grid = any (grid-stride over the device-side problem count), block = 64
 __global__ void __launch_bounds__(64)
 cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
               const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
+  __shared__ cc_gmm_scan_lds lds[64 / CC_G];
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
+  cc_gmm_scan_lds &L = lds[sub];
   const int n_prob = *n_prob_p;
   for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G)) {
     const int pidx = prob_list[pi];
@@ -224,23 +312,17 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
     const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
     const double c2 = ct0 * ct0 - st0 * st0, s2 = 2.0 * st0 * ct0;
     double acc = 0.0;
-    int np = 0;
-    for (int li = 0; li < CC_GMM_LEVELS; li++) {
-      const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
-      for (int si = sl; si < ns; si += CC_G) {
-        const cc_ell es = fsrc->ell[li][si];
-        for (int ti = 0; ti < ntg; ti++) {
-          const cc_ell *pt = &ftgt->ell[li][ti];
-          if (cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1])) {
-            const cc_gpair P = cc_gmm_make_pair(es, *pt);
-            acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
-            np++;
-          }
-        }
+    const int np = cc_gmm_scan_pairs<CC_G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
+      cc_gsync<CC_G>();
+      for (int e = sl; e < n; e += CC_G) {
+        const int code = L.code[e];
+        const int li = code >> 14, si = (code >> 7) & 127, ti = code & 127;
+        const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
+        acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
       }
-    }
+      cc_gsync<CC_G>();
+    });
     const double cost = cc_group_sum_d(acc);
-    np = cc_group_sum_i(np);
     if (sl == 0) {
       cc_gmm_result R;
       R.corr_init = -cost / sqrt(fsrc->ac * ftgt->ac);
@@ -256,20 +338,6 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
       R.pad = 0;
       results[pidx] = R;
     }
-  }
-}
-
-// hand-off between the G lanes of a problem through memory (lockstep on the GPU: a compiler fence; the CPU test harness
-// needs its threads to meet)
-template <int G>
-__device__ __forceinline__ void cc_gsync() {
-  if (G == 64) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef CC_EMU
-    (void)__shfl(0, 0);
-#endif
-  } else {
-    cc_group_sync();
   }
 }
 
@@ -685,20 +753,6 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 }
 
 
-template <int G>
-__device__ __forceinline__ int cc_gscan_incl(int v, int *total) {  // inclusive prefix sum over the G lanes of a problem
-  int incl = cc_group_scan_incl(v);
-  int tot = cc_group_sum_i(v);
-  if (G == 64) {
-    const int row = (threadIdx.x & 63) >> 4;
-    const int t0 = __shfl(tot, 0), t1 = __shfl(tot, 16), t2 = __shfl(tot, 32), t3 = __shfl(tot, 48);
-    incl += (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
-    tot = t0 + t1 + t2 + t3;
-  }
-  *total = tot;
-  return incl;
-}
-
 // K5b: calcCorrelation (correlation.h:206-238) for the problems cc_k_select listed: LineSearchMinimizer, LBFGS rank 20,
 // Wolfe / cubic interpolation, <= 10 iterations.  G lanes per problem.
 // grid = any (grid-stride over the device-side list), block = 64
@@ -708,8 +762,10 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
                 cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
   __shared__ double hist_all[64 / G][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
+  __shared__ cc_gmm_scan_lds scan_lds[64 / G];
   const int sub = threadIdx.x / G, sl = threadIdx.x % G;
   double *hist = hist_all[sub];
+  cc_gmm_scan_lds &L = scan_lds[sub];
   const int n_sel = *n_sel_p;
   for (int k = blockIdx.x * (64 / G) + sub; k < n_sel; k += gridDim.x * (64 / G)) {
     const int pidx = sel_list[k];
@@ -718,7 +774,7 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     const cc_gmm_problem pb = probs[pidx];
     const cc_gmm_feat *fsrc = db_feat + pb.gidx;
     const cc_gmm_feat *ftgt = qfeat + pb.q;
-    // ---- the problem's pair list (GMMPair ctor order: level, src ellipse, tgt ellipse) into the pool
+    // ---- the problem's pair list into the pool (any fixed order: the evaluations sum it lane-strided)
     const int np = R.n_pairs;
     int off = 0;
     if (sl == 0) off = atomicAdd(pool_head, np);
@@ -729,32 +785,17 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     }
     {
       const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
-      int run = 0;
-      for (int li = 0; li < CC_GMM_LEVELS; li++) {
-        const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
-        for (int s0 = 0; s0 < ns; s0 += G) {
-          const int si = s0 + sl;
-          cc_ell es;
-          int c = 0;
-          if (si < ns) {
-            es = fsrc->ell[li][si];
-            for (int ti = 0; ti < ntg; ti++) {
-              const cc_ell *pt = &ftgt->ell[li][ti];
-              c += cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1]) ? 1 : 0;
-            }
-          }
-          int tot;
-          const int incl = cc_gscan_incl<G>(c, &tot);
-          if (c > 0) {
-            int o = off + run + incl - c;
-            for (int ti = 0; ti < ntg; ti++) {
-              const cc_ell *pt = &ftgt->ell[li][ti];
-              if (cc_gmm_pair_sel(es, pt->mx, pt->my, pt->maj, ct0, st0, pb.tf[0], pb.tf[1])) pool[o++] = cc_gmm_make_pair(es, *pt);
-            }
-          }
-          run += tot;
+      int done = 0;
+      cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
+        cc_gsync<G>();
+        for (int e = sl; e < n; e += G) {
+          const int code = L.code[e];
+          const int li = code >> 14, si = (code >> 7) & 127, ti = code & 127;
+          pool[off + done + e] = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
         }
-      }
+        done += n;
+        cc_gsync<G>();
+      });
     }
     __threadfence_block();  // the pairs are read back by all lanes of the problem
     cc_gsync<G>();
