@@ -43,6 +43,8 @@ def main():
                     help="N > 1: all-gather every batch's descriptors in the timed step (what appending them to all replicas needs)")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
+    ap.add_argument("--sync-query", action="store_true",
+                    help="cc_db_query_batch per step (collects every batch before the next one is queued) instead of cc_db_query_submit + one cc_db_query_wait")
     ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
     ap.add_argument("--workload", choices=("sparse", "dense"), default="sparse",
                     help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
@@ -171,6 +173,7 @@ def main():
     def run_steps(first, count):
         """ingest + query of batches[first : first+count], software-pipelined; returns #loop closures found."""
         found = 0
+        pending = []
         ev = ingest_async(batches[first], 0) if not args.no_overlap else None
         for k in range(count):
             slot = k & 1
@@ -186,9 +189,15 @@ def main():
                 rec_q[:, :HB] = hq
                 rec_q[:, HB:] = fq
                 dist.all_gather_into_tensor(gathered, rec_q)
-            res = db.query(q, epochs)
+            if args.sync_query or args.no_overlap:
+                res = db.query(q, epochs)
+            else:  # queue the batch; its chunks are collected when their lanes are needed again, the last ones below
+                res = db.query_submit(q, epochs)
+            pending.append(res)
+        db.query_wait()
+        for res in pending:
             found += int((res["n_res"] > 0).sum())
-            run_steps.last = res
+        run_steps.last = pending[-1]
         return found
 
     run_steps(0, W)

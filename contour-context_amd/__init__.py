@@ -43,7 +43,7 @@ _lib = None
 # every symbol include/cont2_amd.h declares
 EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-           "cc_db_add_scans", "cc_db_query_batch", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
+           "cc_db_add_scans", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
            "cc_packed_sizes", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
@@ -66,6 +66,8 @@ def lib():
         _lib.cc_db_size.argtypes = [C.c_void_p]
         _lib.cc_db_add_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_db_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        _lib.cc_db_query_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        _lib.cc_db_query_wait.argtypes = [C.c_void_p]
         for f in ("cc_db_hot_ptr", "cc_db_feat_ptr"):
             getattr(_lib, f).argtypes = [C.c_void_p]
             getattr(_lib, f).restype = C.c_void_p
@@ -238,6 +240,28 @@ class Database:
         if want_knn:
             return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
         return res
+
+    def query_submit(self, qdesc, epochs, lb=None, ub=None):
+        """Asynchronous form of query(): queues the batch and returns the result array, which is only valid after
+        query_wait() (cc_db_query_submit / cc_db_query_wait).  qdesc may be overwritten by work queued afterwards on the
+        current stream."""
+        import torch
+        if lb is None:
+            lb, ub = L.default_thresholds()
+        epochs = np.ascontiguousarray(epochs, np.int32)
+        nq = qdesc.shape[0]
+        assert qdesc.is_cuda and qdesc.is_contiguous() and len(epochs) == nq
+        res = np.zeros(nq, L.query_result_dt)
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append(res)  # the library writes into it until query_wait
+        stream = torch.cuda.current_stream(qdesc.device).cuda_stream
+        _chk(lib().cc_db_query_submit(self.h, qdesc.data_ptr(), nq, epochs.ctypes.data, C.addressof(lb), C.addressof(ub),
+                                      res.ctypes.data, None, None, stream), "cc_db_query_submit")
+        return res
+
+    def query_wait(self):
+        _chk(lib().cc_db_query_wait(self.h), "cc_db_query_wait")
+        self._pending = []
 
     def add_packed(self, hot, feat, ts, seeds):
         """hot / feat: torch uint8 CUDA [n, HOT_BYTES] / [n, FEAT_BYTES] as produced by Context.pack (possibly gathered from

@@ -278,6 +278,19 @@ int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const in
                       cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,
                       void *stream);
 
+/* The same call split in two, for callers that stream batch after batch (offline evaluation of whole sequences,
+ * tools/batch_eval.py, bench.py): cc_db_query_submit queues the batch's launch chains and returns; a chunk's results
+ * reach h_res when its lane is needed again (a later submit) or at cc_db_query_wait, so the tail of one batch's chains
+ * runs next to the head of the next batch's.  h_res must stay valid until cc_db_query_wait returned; d_qdesc may be
+ * overwritten by work queued on `stream` after the call.  An error of an earlier batch's chunk (capacity flags) is
+ * reported by the call that collects it.  cc_db_query_batch == submit + wait; every other cc_db_* call that changes or
+ * reuses what chunks in flight read (add, check_hints, set_lanes, destroy) waits first. */
+int cc_db_query_submit(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const int32_t *h_epoch,
+                       const cc_score_t *thres_lb, const cc_score_t *thres_ub,
+                       cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,
+                       void *stream);
+int cc_db_query_wait(cc_db *db);
+
 /* Host-descriptor variants (one H2D copy each) used by the C++ class mirror, where a ContourManager owns a
  * host copy of its descriptor: ContourDB::addScan + pushAndBalance for one scan, and queryRangedKNN for one
  * query against the current DB state. */

@@ -27,7 +27,7 @@ class EmuApi:
         self.lib.cc_last_error.restype = C.c_char_p
         self.lib.cc_packed_sizes.restype = None
         for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_bucket_state", "cc_db_check_hints", "cc_pack_scans", "cc_db_add_packed"):
+                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_bucket_state", "cc_db_check_hints", "cc_pack_scans", "cc_db_add_packed"):
             getattr(self.lib, f).restype = C.c_int
 
     def chk(self, rc, what):
@@ -121,6 +121,20 @@ class EmuApi:
                                             C.c_void_p(knn.ctypes.data) if want_knn else None,
                                             C.c_void_p(cnt.ctypes.data) if want_knn else None, None), "cc_db_query_batch")
         return (res, knn, cnt) if want_knn else res
+
+    def db_query_submit(self, db, qdesc, epochs):
+        """cc_db_query_submit: returns (result array, keep-alive tuple); valid after db_query_wait."""
+        L = self.L
+        lb, ub = L.default_thresholds()
+        qdesc = np.ascontiguousarray(qdesc)
+        epochs = np.ascontiguousarray(epochs, np.int32)
+        res = np.zeros(len(qdesc), L.query_result_dt)
+        self.chk(self.lib.cc_db_query_submit(db, C.c_void_p(qdesc.ctypes.data), len(qdesc), C.c_void_p(epochs.ctypes.data), C.byref(lb),
+                                             C.byref(ub), C.c_void_p(res.ctypes.data), None, None, None), "cc_db_query_submit")
+        return res, (qdesc, epochs)
+
+    def db_query_wait(self, db):
+        self.chk(self.lib.cc_db_query_wait(db), "cc_db_query_wait")
 
     def check_hints(self, db, qdesc, hints, lb=None, ub=None, max_fine_opt=10):
         L = self.L

@@ -124,3 +124,9 @@ def test_golden_query_fixture(oracle):
     got = api.db_query(db, desc[qs], qs)
     for k, qi in enumerate(qs):
         _same_result(exp[qi], got[k], 1e-6)
+    # the same queries as two submitted batches, collected by one wait (cc_db_query_submit / cc_db_query_wait): a lane's
+    # chunk of the first batch is collected when the second batch needs the lane
+    r1, k1 = api.db_query_submit(db, desc[qs[:4]], qs[:4])
+    r2, k2 = api.db_query_submit(db, desc[qs[3:]], qs[3:])
+    api.db_query_wait(db)
+    assert np.array_equal(r1.tobytes(), got[:4].tobytes()) and np.array_equal(r2.tobytes(), got[3:].tobytes())

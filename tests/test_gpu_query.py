@@ -114,6 +114,18 @@ def test_golden_query_fixture(cc):
     assert (exp["n_res"] > 0).sum() == 31
     for i in range(n):
         _same_result(exp[i], got[i], 1e-4)
+    # the asynchronous form (cc_db_query_submit / cc_db_query_wait): three batches in flight over the two lanes, the query
+    # descriptors of a batch overwritten as soon as the submit returned
+    parts = [(0, 24), (24, 40), (40, 64)]
+    buf = torch.empty_like(ddesc[:24])
+    outs = []
+    for a, b in parts:
+        buf[:b - a].copy_(ddesc[a:b])
+        outs.append(db.query_submit(buf[:b - a], seeds[a:b]))
+    buf.zero_()
+    db.query_wait()
+    for (a, b), r in zip(parts, outs):
+        assert r.tobytes() == got[a:b].tobytes()
 
 
 def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10):
