@@ -30,6 +30,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL bet
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+PROF_EVERY = 3  # the library's stage events ride on every 3rd chunk launch of the timed region (they cost throughput)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +46,9 @@ def main():
                     help="N > 1: all-gather every batch's descriptors in the timed step (what appending them to all replicas needs)")
     ap.add_argument("--no-overlap", action="store_true", help="everything on one stream: ingest, then the query chunks one by one")
     ap.add_argument("--stats", action="store_true", help="print the per-query check funnel of the last step to stderr")
+    ap.add_argument("--ab-env", default="",
+                    help="tuning aid: 'VAR=v[,VAR2=v2];VAR=w...': after the timed run, for each setting rebuild the DB with those "
+                         "environment variables and time the same K steps the same way (scans/s to stderr)")
     ap.add_argument("--sync-query", action="store_true",
                     help="cc_db_query_batch per step (collects every batch before the next one is queued) instead of cc_db_query_submit + one cc_db_query_wait")
     ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
@@ -137,7 +143,7 @@ def main():
     ts_db = np.arange(n_db, dtype=np.float64) / 10.0
     hot_db, feat_db = rec_db[:, :HB].contiguous(), rec_db[:, HB:].contiguous()
     db.add_packed(hot_db, feat_db, ts_db, np.arange(n_db, dtype=np.int32))
-    if not args.tune_sweep:
+    if not args.tune_sweep and not args.ab_env:
         del hot_db, feat_db
     del rec_db
     # ---------------- query batches (resident in HBM before the timed region) ----------------
@@ -205,7 +211,7 @@ def main():
     if world > 1:
         dist.barrier()
     cc.lib().cc_profile_enable(ctx.h, 1)
-    cc.lib().cc_db_profile_enable(db.h, 1)
+    cc.lib().cc_db_profile_enable(db.h, PROF_EVERY)  # stage events on every 3rd chunk launch (alternating lanes)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n_found = run_steps(W, K)
@@ -239,10 +245,33 @@ def main():
     # chunk of <= 512 queries on the query side).  Launches of different streams overlap each other, so these are durations of
     # kernels SHARING the GPU, and a chunk pair's durations add up although they ran side by side.
     kms = read_kernel_ms()
+    if args.ab_env and rank == 0:
+        for spec in [""] + args.ab_env.split(";"):
+            kv = [a.split("=") for a in spec.split(",") if a]
+            for k_, v_ in kv:
+                os.environ[k_] = v_
+            db2 = cc.Database(ctx, capacity=n_db + 16)
+            lanes_ = int(dict(kv).get("LANES", args.lanes))  # pseudo-variable: cc_db_set_lanes
+            if lanes_:
+                db2.set_lanes(lanes_)
+            db2.add_packed(hot_db, feat_db, ts_db, np.arange(n_db, dtype=np.int32))
+            db_saved, db = db, db2
+            run_steps(0, W)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(W, K)
+            torch.cuda.synchronize()
+            print("ab-env [%s]: %.0f scans/s" % (spec, K * B / (time.perf_counter() - t1)), file=sys.stderr)
+            db = db_saved
+            db2.close()
+            for k_, _ in kv:
+                os.environ.pop(k_, None)
+        read_kernel_ms()  # drop what these runs added to the profiling sums
     kms_iso = None
     if not args.no_overlap:         # the same kernels strictly one after the other (2 extra, untimed steps): isolated durations
         args.no_overlap = True
         db.set_lanes(1)
+        cc.lib().cc_db_profile_enable(db.h, 1)
         run_steps(W, min(2, K))
         torch.cuda.synchronize()
         kms_iso = read_kernel_ms()
@@ -317,6 +346,8 @@ def main():
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "kernels_ms_per_launch": kms, "kernels_ms_per_launch_isolated": kms_iso,
                          "streams": 1 if kms_iso is None else 3,
+                         "event_sampling": "query-side stage events on every %d. chunk launch of the timed region, ingest events on every step" % PROF_EVERY,
+                         "query_protocol": "cc_db_query_batch per step" if (args.sync_query or kms_iso is None) else "cc_db_query_submit per step, one cc_db_query_wait inside the timed region",
                          "rasterize_GBs": k1_bytes / ((kms_iso or kms)["cc_k_rasterize"] * 1e-3) / 1e9 if k1_ms > 0 else None},
             "setup_s": setup_s,
         }

@@ -356,7 +356,9 @@ const void *cc_db_hot_ptr(const cc_db *db);
 const void *cc_db_feat_ptr(const cc_db *db);
 
 /* Same for the query kernels: accumulated ms {K3 knn, K4 check, K4b merge, K5 gmm, K6 final} summed over the chunk
- * launches (chunks in flight together overlap in time), and the number of QUERIES the sums cover (*n_launches). */
+ * launches (chunks in flight together overlap in time), and the number of QUERIES the sums cover (*n_launches).
+ * on = 0: off; 1: every chunk carries the six stage events; n > 1: every n-th chunk does (the events cost throughput:
+ * ~7 % on the bench when every chunk is timed; the sums are normalised by the queries they cover either way). */
 int cc_db_profile_enable(cc_db *db, int on);
 int cc_db_profile_read(cc_db *db, double ms_out[5], int *n_launches);
 
