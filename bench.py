@@ -249,12 +249,15 @@ def main():
         for spec in [""] + args.ab_env.split(";"):
             kv = [a.split("=") for a in spec.split(",") if a]
             for k_, v_ in kv:
-                os.environ[k_] = v_
+                if k_ not in ("LANES", "PROF"):
+                    os.environ[k_] = v_
             db2 = cc.Database(ctx, capacity=n_db + 16)
             lanes_ = int(dict(kv).get("LANES", args.lanes))  # pseudo-variable: cc_db_set_lanes
             if lanes_:
                 db2.set_lanes(lanes_)
             db2.add_packed(hot_db, feat_db, ts_db, np.arange(n_db, dtype=np.int32))
+            if "PROF" in dict(kv):  # pseudo-variable: stage events on every n-th chunk launch
+                cc.lib().cc_db_profile_enable(db2.h, int(dict(kv)["PROF"]))
             db_saved, db = db, db2
             run_steps(0, W)
             torch.cuda.synchronize()

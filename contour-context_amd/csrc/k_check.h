@@ -496,8 +496,8 @@ __device__ __forceinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, 
 // Two instances: <CC_PP_SMALL, false> handles every check with <= 64 potential pairs and lists the others;
 // <CC_PP_MAX, true> then runs only those.
 // grid = any (grid-stride over the device-side list), block = 64
-template <int PPM, bool REDO>
-__global__ void __launch_bounds__(64)
+template <int PPM, bool REDO, int WPE = 4>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_hot_desc_t *__restrict__ db_hot,
               const cc_chk_item *__restrict__ items, int *__restrict__ redo_idx, int *__restrict__ cnt, cc_cstl_item *__restrict__ cstl,
               int *__restrict__ pass_cnt, int *__restrict__ scores /*see cc_k_check_a; or nullptr*/) {
