@@ -130,3 +130,24 @@ def test_golden_query_fixture(oracle):
     r2, k2 = api.db_query_submit(db, desc[qs[3:]], qs[3:])
     api.db_query_wait(db)
     assert np.array_equal(r1.tobytes(), got[:4].tobytes()) and np.array_equal(r2.tobytes(), got[3:].tobytes())
+
+
+def test_submit_is_drained_by_calls_that_change_the_db(oracle):
+    """cc_db_add_scans while a submitted batch is in flight: the add collects the batch first (its results are complete when
+    the add returns), and the later wait has nothing left to do."""
+    L = oracle.L
+    desc, ts, exp, d = _load_query_fixture(L)
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, d, cap=len(desc))
+    seeds = np.arange(len(desc), dtype=np.int32)
+    api.db_add(db, desc[:60], ts[:60], seeds[:60])
+    hit = np.nonzero(exp["n_res"][:60] > 0)[0]
+    qs = hit[[2, 12, 22]].astype(np.int32)
+    res, keep = api.db_query_submit(db, desc[qs], qs)
+    api.db_add(db, desc[60:], ts[60:], seeds[60:])
+    for k, qi in enumerate(qs):
+        _same_result(exp[qi], res[k], 1e-6)
+    api.db_query_wait(db)
+    got = api.db_query(db, desc[[62]], np.array([62], np.int32))
+    _same_result(exp[62], got[0], 1e-6)
