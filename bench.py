@@ -147,7 +147,9 @@ def main():
         del hot_db, feat_db
     del rec_db
     # ---------------- query batches (resident in HBM before the timed region) ----------------
-    n_steps_total = W + K
+    # every step gets its own batch of scans up to 48 distinct batches (95 GB at the default shape); longer runs go round
+    # the ring -- the work per step is the same, only the inputs repeat
+    n_steps_total = min(W + K, 48)
     batches = []
     for s in range(n_steps_total):
         start = n_db + (s * world + rank) * B
@@ -180,15 +182,15 @@ def main():
         """ingest + query of batches[first : first+count], software-pipelined; returns #loop closures found."""
         found = 0
         pending = []
-        ev = ingest_async(batches[first], 0) if not args.no_overlap else None
+        ev = ingest_async(batches[first % len(batches)], 0) if not args.no_overlap else None
         for k in range(count):
             slot = k & 1
             if args.no_overlap:
-                ctx.ingest(batches[first + k], offs, out=qdesc2[slot])
+                ctx.ingest(batches[(first + k) % len(batches)], offs, out=qdesc2[slot])
             else:
                 s_main.wait_event(ev)
                 if k + 1 < count:
-                    ev = ingest_async(batches[first + k + 1], slot ^ 1)
+                    ev = ingest_async(batches[(first + k + 1) % len(batches)], slot ^ 1)
             q = qdesc2[slot]
             if share:  # what appending the batch to every replica needs: its compact records on every rank
                 hq, fq = ctx.pack(q)
@@ -355,7 +357,7 @@ def main():
             "setup_s": setup_s,
         }
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W], P, min(args.cpu_sample, B))
+            out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W % len(batches)], P, min(args.cpu_sample, B))
         print(json.dumps(out), flush=True)
     db.close()
     ctx.close()
