@@ -1,6 +1,7 @@
 """Kernel + host logic of the query path on the CPU (product TU compiled against tests/emu) vs the oracle's replay of
 the reference loop, on a short looping sequence (shortened DB delays so revisits are searchable early)."""
 import numpy as np
+import pytest
 
 import emu_api
 
@@ -101,7 +102,8 @@ def _same_result(exp, got, tol):
         assert abs(exp["correlation"] - got["correlation"]) < tol and np.abs(exp["tf"] - got["tf"]).max() < tol
 
 
-def test_golden_query_fixture(oracle):
+@pytest.mark.parametrize("share", [0, 4])
+def test_golden_query_fixture(oracle, share, monkeypatch):
     """Committed descriptors + expected results (tests/golden/make_query_golden.py): the oracle, replaying the driver loop
     from the descriptors, still reproduces them, and the emulated query kernels match them."""
     L = oracle.L
@@ -114,6 +116,7 @@ def test_golden_query_fixture(oracle):
         _same_result(exp[i], odb.query(s), 1e-12)
         odb.add_scan(s, ts[i])
         odb.push_and_balance(i, ts[i])
+    monkeypatch.setenv("CC_KNN_SHARE", str(share))  # 4: the shared-walk form of K3 (read at cc_db_create)
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=8)
     db = api.db_create(ctx, d, cap=n)

@@ -2,6 +2,7 @@
 against the oracle's restatement of TreeBucket/LayerDB, on thousands of hand-made keys that force every bucket to
 be used.  Runs the product's C-ABI through the CPU build (tests/emu)."""
 import numpy as np
+import pytest
 
 import emu_api
 
@@ -48,7 +49,8 @@ def test_bucket_timeline_matches_oracle(oracle):
     assert (osz > 0).sum() >= 12, "the test should populate most buckets"
 
 
-def test_knn_with_buckets_matches_oracle(oracle):
+@pytest.mark.parametrize("share", [0, 4])
+def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
     """K3 through the C-ABI (CPU build) on a DB spread over several buckets, incl. the bucket-skip quirk of
     layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
     L = oracle.L
@@ -57,6 +59,7 @@ def test_knn_with_buckets_matches_oracle(oracle):
     desc = _fake_desc(L, rng, n, 3.0, 40.0)
     ts = np.arange(n) * 0.1
     seeds = np.arange(n, dtype=np.int32)
+    monkeypatch.setenv("CC_KNN_SHARE", str(share))  # 4: the shared-walk form of K3 (read at cc_db_create)
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=4)
     db = api.db_create(ctx, cap=n)
@@ -80,7 +83,8 @@ def test_knn_with_buckets_matches_oracle(oracle):
                 assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
 
 
-def test_knn_crowded_layer_matches_oracle(oracle):
+@pytest.mark.parametrize("share", [0, 4])
+def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
     """Thousands of near-identical keys: every 64-key step of a search passes the radius test, so the pending candidate
     list grows to 2 * nnk - 1 + 64 entries before it is tightened and the bitonic sort pads it to 256 (the LDS buffer
     must hold the padded width; found by an ASAN run of this harness in round 1's review)."""
@@ -97,6 +101,7 @@ def test_knn_crowded_layer_matches_oracle(oracle):
     for nnk in (64,):  # the capacity case: 2 * 64 - 1 + 64 pending candidates before a tightening
         dcfg = L.default_db_cfg()
         dcfg.nnk = nnk
+        monkeypatch.setenv("CC_KNN_SHARE", str(share))
         api = emu_api.EmuApi(L)
         ctx = api.create(max_batch=4)
         db = api.db_create(ctx, dcfg, cap=n)
