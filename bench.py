@@ -26,6 +26,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between the ranks of one node); must precede torch
+# The step runs on four streams (caller, ingest, two query lanes).  HIP hands a process' hardware queues (4 by default) to
+# streams in creation order, and two busy streams on one queue serialise; with eight queues no
+# creation order -- e.g. RCCL's own streams in a multi-GPU run -- can make two of them share (measured equal at N = 1:
+# profiles/r2g_bench_line_lanes2_hwq8.json).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
