@@ -42,7 +42,7 @@ _lib = None
 
 # every symbol include/cont2_amd.h declares
 EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
-           "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
+           "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_ingest_host_bev", "cc_db_create", "cc_db_destroy", "cc_db_size",
            "cc_db_add_scans", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
            "cc_packed_sizes", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
@@ -61,6 +61,7 @@ def lib():
         _lib.cc_destroy.argtypes = [C.c_void_p]
         _lib.cc_ingest_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.cc_ingest_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.cc_ingest_host_bev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.cc_db_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib.cc_db_destroy.argtypes = [C.c_void_p]
         _lib.cc_db_size.argtypes = [C.c_void_p]

@@ -309,25 +309,37 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
 }
 
 int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *h_out) {
+  return cc_ingest_host_bev(c, h_xyzi, h_offsets, n_scans, h_out, nullptr);
+}
+
+int cc_ingest_host_bev(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *h_out, float *h_bev) {
   if (!c || !h_xyzi || !h_offsets || !h_out || n_scans < 1) return set_err(CC_EINVAL, "cc_ingest_host: bad argument");
   HIPCHK(hipSetDevice(c->device));
   const int64_t base = h_offsets[0], total = h_offsets[n_scans] - base;
-  float *d_x = nullptr;
+  const size_t bev_bytes = sizeof(float) * (size_t)c->dcfg.n_cell * (size_t)n_scans;
+  float *d_x = nullptr, *d_b = nullptr;
   cc_scan_desc_t *d_o = nullptr;
   HIPCHK(hipMalloc(&d_x, sizeof(float) * 4 * (size_t)total));
   hipError_t e = hipMalloc(&d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans);
+  if (e == hipSuccess && h_bev) e = hipMalloc(&d_b, bev_bytes);
   if (e != hipSuccess) {
     hipFree(d_x);
+    hipFree(d_o);
     return set_err(CC_EHIP, "cc_ingest_host: hipMalloc", e);
   }
+  cc_ingest_debug_t dbg;
+  dbg.d_bev = d_b;
+  dbg.d_pix_rc = nullptr;
+  dbg.d_labels = nullptr;
   int rc = CC_OK;
   std::vector<int64_t> off(n_scans + 1);
   for (int i = 0; i <= n_scans; i++) off[i] = h_offsets[i] - base;
   e = hipMemcpy(d_x, h_xyzi + 4 * base, sizeof(float) * 4 * (size_t)total, hipMemcpyHostToDevice);
   if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: H2D", e);
-  if (rc == CC_OK) rc = cc_ingest_batch(c, d_x, off.data(), n_scans, d_o, nullptr, nullptr);
+  if (rc == CC_OK) rc = cc_ingest_batch(c, d_x, off.data(), n_scans, d_o, h_bev ? &dbg : nullptr, nullptr);
   if (rc == CC_OK) {
     e = hipMemcpy(h_out, d_o, sizeof(cc_scan_desc_t) * (size_t)n_scans, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h_bev) e = hipMemcpy(h_bev, d_b, bev_bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = set_err(CC_EHIP, "cc_ingest_host: D2H", e);
   }
   if (rc == CC_OK)
@@ -339,6 +351,7 @@ int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int
       }
   hipFree(d_x);
   hipFree(d_o);
+  hipFree(d_b);
   return rc;
 }
 

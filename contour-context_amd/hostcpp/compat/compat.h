@@ -36,6 +36,91 @@ namespace google {
 inline void InitGoogleLogging(const char *) {}
 }  // namespace google
 
+// ---- images without OpenCV: what ContourManager::getBevImage / getContourImage return and what cv::imwrite(".png")
+// of a CV_8U single-channel matrix stores (an 8-bit grey PNG; written here with stored deflate blocks) ----
+namespace cc_host {
+template <typename T>
+struct Image {
+  int rows = 0, cols = 0;
+  std::vector<T> data;  // row-major
+  Image() {}
+  Image(int r, int c, T fill) : rows(r), cols(c), data((size_t)r * c, fill) {}
+  T &at(int r, int c) { return data[(size_t)r * cols + c]; }
+  const T &at(int r, int c) const { return data[(size_t)r * cols + c]; }
+  bool empty() const { return data.empty(); }
+  // cv::Mat::copyTo(dst(cv::Rect(x, y, cols, rows)))
+  void copyTo(Image<T> &dst, int x, int y) const {
+    for (int r = 0; r < rows; r++)
+      for (int c = 0; c < cols; c++) dst.at(y + r, x + c) = at(r, c);
+  }
+};
+inline uint32_t png_crc(const unsigned char *p, size_t n, uint32_t crc = 0) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  crc ^= 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+  return crc ^ 0xFFFFFFFFu;
+}
+inline bool write_png_gray8(const std::string &path, const Image<unsigned char> &img) {
+  auto be32 = [](std::vector<unsigned char> &v, uint32_t x) {
+    for (int s = 24; s >= 0; s -= 8) v.push_back((unsigned char)(x >> s));
+  };
+  auto chunk = [&](std::vector<unsigned char> &out, const char *type, const std::vector<unsigned char> &body) {
+    be32(out, (uint32_t)body.size());
+    std::vector<unsigned char> td(type, type + 4);
+    td.insert(td.end(), body.begin(), body.end());
+    out.insert(out.end(), td.begin(), td.end());
+    be32(out, png_crc(td.data(), td.size()));
+  };
+  std::vector<unsigned char> raw;  // scanlines, filter type 0
+  raw.reserve((size_t)img.rows * (img.cols + 1));
+  for (int r = 0; r < img.rows; r++) {
+    raw.push_back(0);
+    raw.insert(raw.end(), img.data.begin() + (size_t)r * img.cols, img.data.begin() + (size_t)(r + 1) * img.cols);
+  }
+  std::vector<unsigned char> z = {0x78, 0x01};  // zlib header, then stored (uncompressed) deflate blocks
+  uint32_t a = 1, b = 0;
+  for (size_t i = 0; i < raw.size(); i++) {
+    a = (a + raw[i]) % 65521u;
+    b = (b + a) % 65521u;
+  }
+  size_t pos = 0;
+  do {
+    const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+    z.push_back(pos + n == raw.size() ? 1 : 0);
+    z.push_back((unsigned char)(n & 0xFF));
+    z.push_back((unsigned char)(n >> 8));
+    z.push_back((unsigned char)(~n & 0xFF));
+    z.push_back((unsigned char)((~n >> 8) & 0xFF));
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+    pos += n;
+  } while (pos < raw.size());
+  be32(z, (b << 16) | a);
+  std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<unsigned char> ihdr;
+  be32(ihdr, (uint32_t)img.cols);
+  be32(ihdr, (uint32_t)img.rows);
+  const unsigned char tail[5] = {8, 0, 0, 0, 0};  // 8 bit, grey, deflate, no filter method, no interlace
+  ihdr.insert(ihdr.end(), tail, tail + 5);
+  chunk(out, "IHDR", ihdr);
+  chunk(out, "IDAT", z);
+  chunk(out, "IEND", {});
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok;
+}
+}  // namespace cc_host
+
 namespace pcl {
 struct PointXYZ {
   float x, y, z;

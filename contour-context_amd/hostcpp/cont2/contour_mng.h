@@ -161,6 +161,7 @@ inline cc_ctx *context(const cc_manager_cfg_t &m) {
 
 // contour_mng.h:414-1314 (public surface used by the drivers)
 class ContourManager {
+  static constexpr float VAL_ABS_INF_ = 1e3f;  // contour_mng.h:418: the "no point" height is -VAL_ABS_INF_
   const ContourManagerConfig cfg_;
   cc_manager_cfg_t ccfg_;
   int int_id_;
@@ -168,6 +169,9 @@ class ContourManager {
   std::vector<float> xyzi_;  // staged by makeBEV, consumed by makeContoursRecurs
   std::unique_ptr<cc_scan_desc_t> desc_;
   mutable std::vector<std::vector<RetrievalKey>> keys_cache_;
+  // the occupied cells of bev_ (cell index, height): the role of bev_pixfs_ (contour_mng.h:433) for getBevImage; only
+  // fetched from the device when images are wanted (keepImages())
+  std::vector<std::pair<int, float>> bev_cells_;
 
  public:
   explicit ContourManager(const ContourManagerConfig &config, int int_id) : cfg_(config), int_id_(int_id) {
@@ -191,19 +195,84 @@ class ContourManager {
     str_id_ = !str_id.empty() ? std::move(str_id) : std::to_string(ptr_gapc->header.stamp);
   }
 
+  // Whether a scan's max-height image is brought back from the device with its descriptor (90 KB extra per scan on the
+  // way, the occupied cells kept afterwards).  On when the reference would write its SAVE_MID_FILE artefacts
+  // (CMakeLists.txt:17), or switched on by the caller before makeContoursRecurs().
+  static bool &keepImages() {
+#if defined(SAVE_MID_FILE) && SAVE_MID_FILE
+    static bool keep = true;
+#else
+    static bool keep = false;
+#endif
+    return keep;
+  }
+
   // contour_mng.h:588: rasterise + contours + keys + BCIs on the device
   void makeContoursRecurs() {
     CC_CHECK(!xyzi_.empty());
     desc_.reset(new cc_scan_desc_t);
     const int64_t off[2] = {0, (int64_t)(xyzi_.size() / 4)};
-    if (cc_ingest_host(cc_host::context(ccfg_), xyzi_.data(), off, 1, desc_.get()) != CC_OK) {
+    std::vector<float> bev;
+    if (keepImages()) bev.resize((size_t)cfg_.n_row_ * cfg_.n_col_);
+    if (cc_ingest_host_bev(cc_host::context(ccfg_), xyzi_.data(), off, 1, desc_.get(), keepImages() ? bev.data() : nullptr) != CC_OK) {
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }
+    bev_cells_.clear();
+    for (size_t i = 0; i < bev.size(); i++)
+      if (bev[i] != -VAL_ABS_INF_) bev_cells_.emplace_back((int)i, bev[i]);
     xyzi_.clear();
     xyzi_.shrink_to_fit();
   }
-  void clearImage() {}  // the BEV image never leaves the device
+  void clearImage() {}  // the dense image is never kept here (see bev_cells_)
+
+  // contour_mng.h:573-586: the dense max-height image, -VAL_ABS_INF_ where no point fell
+  cc_host::Image<float> getBevImage() const {
+    cc_host::Image<float> img(cfg_.n_row_, cfg_.n_col_, -VAL_ABS_INF_);
+    for (const auto &c : bev_cells_) img.data[c.first] = c.second;
+    return img;
+  }
+  // contour_mng.h:1041-1049: cv::threshold(bev, lv_grads_[level], THRESH_TOZERO) then cv::normalize(0, 255, NORM_MINMAX,
+  // CV_8U).  Restated from OpenCV's documented semantics (OpenCV is absent here): TOZERO keeps src where src > thresh;
+  // MINMAX maps [min, max] of that image to [0, 255] with scale = 255 / (max - min) (0 when max - min <= DBL_EPSILON),
+  // shift = -min * scale, evaluated per pixel in f32 and rounded half-to-even with saturation (convertTo to CV_8U).
+  cc_host::Image<unsigned char> getContourImage(int level) const {
+    CC_CHECK(level >= 0 && level < (int)cfg_.lv_grads_.size());
+    cc_host::Image<float> m = getBevImage();
+    const float thr = cfg_.lv_grads_[level];
+    double mn = 0, mx = 0;
+    bool first = true;
+    for (float &v : m.data) {
+      v = v > thr ? v : 0.f;
+      if (first || v < mn) mn = v;
+      if (first || v > mx) mx = v;
+      first = false;
+    }
+    const double scale = 255.0 * ((mx - mn) > 2.220446049250313e-16 ? 1.0 / (mx - mn) : 0.0), shift = 0.0 - mn * scale;
+    const float a = (float)scale, b = (float)shift;
+    cc_host::Image<unsigned char> out(m.rows, m.cols, 0);
+    for (size_t i = 0; i < m.data.size(); i++) {
+      const long r = lrintf(m.data[i] * a + b);
+      out.data[i] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    return out;
+  }
+  // contour_mng.cpp (saveContourImage): cv::imwrite(fpath, getContourImage(level))
+  void saveContourImage(const std::string &fpath, int level) const {
+    if (!cc_host::write_png_gray8(fpath, getContourImage(level))) std::cerr << "Error opening " << fpath << std::endl;
+  }
+  // contour_mng.h:1286-1311: the level images of two scans, cm1's on the top row and cm2's below, one column per level,
+  // separated by one white pixel
+  static void saveMatchedPairImg(const std::string &fpath, const ContourManager &cm1, const ContourManager &cm2) {
+    const ContourManagerConfig config = cm2.getConfig();
+    const int n_lev = (int)config.lv_grads_.size();
+    cc_host::Image<unsigned char> output(config.n_row_ * 2 + 1, (config.n_col_ + 1) * n_lev, 255);
+    for (int i = 0; i < n_lev; i++) {
+      cm1.getContourImage(i).copyTo(output, i * config.n_col_ + i, 0);
+      cm2.getContourImage(i).copyTo(output, i * config.n_col_ + i, config.n_row_ + 1);
+    }
+    if (!cc_host::write_png_gray8(fpath, output)) std::cerr << "Error opening " << fpath << std::endl;
+  }
 
   const cc_scan_desc_t &desc() const {
     CC_CHECK(desc_);

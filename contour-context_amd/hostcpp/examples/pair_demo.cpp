@@ -4,7 +4,9 @@
 // sensor frame).  Output: one line per hint `H level seq_src seq_tgt  ovlp_sum max_one in_ang_rng  indiv_sim orie_sim`,
 // then `R n_res correlation x y theta  sens_x sens_y sens_theta`.
 //   g++ -O2 -std=c++17 pair_demo.cpp -I.. -I../../../include -L../.. -lcont2_amd -Wl,-rpath,$PWD/../.. -L/opt/rocm/lib -lamdhip64
-//   ./pair_demo old.bin new.bin [max_fine_opt]
+//   ./pair_demo old.bin new.bin [max_fine_opt [image_prefix]]
+// With image_prefix the SAVE_MID_FILE artefacts of the reference drivers are written too: <prefix>_pair.png
+// (ContourManager::saveMatchedPairImg, kitti_read_bin_test.cpp:301) and <prefix>_lv2.png (saveContourImage of level 2).
 #include <cmath>
 
 #include "cont2/contour_db.h"
@@ -42,9 +44,14 @@ int main(int argc, char **argv) {
     return 2;
   }
   const int max_fine_opt = argc >= 4 ? atoi(argv[3]) : 5;  // kitti_read_bin_test.cpp:278
+  if (argc >= 5) ContourManager::keepImages() = true;      // before the scans are ingested
   ContourManagerConfig config;
   config.lv_grads_ = {1.5f, 2.f, 2.5f, 3.f, 3.5f, 4.f};
   auto cm_old = load(config, argv[1], 0), cm_new = load(config, argv[2], 1);
+  if (argc >= 5) {
+    ContourManager::saveMatchedPairImg(std::string(argv[4]) + "_pair.png", *cm_old, *cm_new);
+    cm_new->saveContourImage(std::string(argv[4]) + "_lv2.png", 2);
+  }
 
   CandidateScoreEnsemble lb, ub;  // shipped thresholds (config/batch_bin_test_config.yaml:69-87)
   lb.sim_constell.i_ovlp_sum = lb.sim_constell.i_ovlp_max_one = lb.sim_constell.i_in_ang_rng = 3;

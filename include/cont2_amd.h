@@ -250,6 +250,11 @@ int cc_ingest_batch(cc_ctx *ctx, const float *d_xyzi, const int64_t *h_offsets, 
  * h_out.  This is what the ContourManager host mirror calls for a single scan. */
 int cc_ingest_host(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offsets, int n_scans,
                    cc_scan_desc_t *h_out);
+/* Same, and the max-height images too: h_bev [n_scans][n_row*n_col] f32 (bev_, contour_mng.h:432; -1000 = empty cell) --
+ * what ContourManager::getBevImage / getContourImage / saveContourImage / saveMatchedPairImg read
+ * (contour_mng.h:573-586, 1039-1049, 1286-1311; the SAVE_MID_FILE artefacts of the drivers).  h_bev may be NULL. */
+int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offsets, int n_scans,
+                       cc_scan_desc_t *h_out, float *h_bev);
 
 /* ---------------------------------------------------------------------- database -------- */
 /* Replaces ContourDB::ContourDB (contour_db.h:680-684). */

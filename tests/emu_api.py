@@ -20,6 +20,11 @@ def build():
     return SO
 
 
+# one OS thread per HIP thread: keep the grids of the list-driven kernels small on the harness (read at cc_db_create).
+# Tests that run a program of their own on the harness pass this to the subprocess; it must never reach the GPU library.
+SMALL_GRIDS = {"CC_B1_GRID": "6", "CC_B2_GRID": "6", "CC_GMM_GRID": "6"}
+
+
 class EmuApi:
     def __init__(self, L):
         self.L = L
@@ -69,9 +74,8 @@ class EmuApi:
         return desc
 
     def db_create(self, ctx, cfg=None, cap=1024):
-        # one OS thread per HIP thread: keep the grids of the list-driven kernels small here (read at cc_db_create)
-        for k in ("CC_B1_GRID", "CC_B2_GRID", "CC_GMM_GRID"):
-            os.environ.setdefault(k, "6")
+        for k, v in SMALL_GRIDS.items():
+            os.environ.setdefault(k, v)
         cfg = cfg or self.L.default_db_cfg()
         h = C.c_void_p()
         self.chk(self.lib.cc_db_create(ctx, C.byref(cfg), cap, C.byref(h)), "cc_db_create")
