@@ -18,8 +18,9 @@ REF_DRIVER = "/root/reference/test/batch_bin_test.cpp"
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="reference tree not present")
 
 
-def test_reference_driver_compiles_unchanged():
-    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPUB_ROS_MSG=0", "-DSAVE_MID_FILE=0", '-DPJSRCDIR="/tmp"',
+@pytest.mark.parametrize("save_mid_file", [0, 1])  # 1: the driver also calls saveContourImage / saveMatchedPairImg
+def test_reference_driver_compiles_unchanged(save_mid_file):
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPUB_ROS_MSG=0", "-DSAVE_MID_FILE=%d" % save_mid_file, '-DPJSRCDIR="/tmp"',
                         "-I", os.path.join(PKG, "hostcpp"), "-I", os.path.join(ROOT, "include"), REF_DRIVER],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
