@@ -3,8 +3,10 @@
 
 Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W
   * one "step" = one pass of the hot path over one batch of synthetic query scans that are already
-    resident in HBM: cc_ingest_batch (BEV rasterise -> contours -> keys/BCI) + cc_db_query_batch
-    (KNN preselect -> constellation checks -> GMM-L2 + L-BFGS) against a prebuilt 5 000-scan DB;
+    resident in HBM: cc_ingest_batch (BEV rasterise -> contours -> keys/BCI) + the batched query
+    (KNN preselect -> constellation checks -> GMM-L2 + L-BFGS) against a prebuilt 5 000-scan DB.  The steps are
+    streamed: cc_db_query_submit per step (the lanes are not drained between batches) and one cc_db_query_wait before
+    the timed region closes, so every result is on the host inside it (--sync-query: cc_db_query_batch per step);
   * N > 1: launched by torch.distributed.run, one rank per GPU.  The DB build is scan-sharded
     (each rank ingests n_db/N scans and packs them into the 35 KB per-scan records the DB keeps) followed by ONE
     all-gather of those records over RCCL (the path's only exchange: every replica needs every DB scan); in the timed step every rank ingests + queries its own
