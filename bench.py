@@ -189,6 +189,8 @@ def main():
         """ingest + query of batches[first : first+count], software-pipelined; returns #loop closures found."""
         found = 0
         pending = []
+        if count <= 0:
+            return 0
         ev = ingest_async(batches[first % len(batches)], 0) if not args.no_overlap else None
         for k in range(count):
             slot = k & 1
