@@ -94,3 +94,36 @@ def test_hint_validation(cc, oracle):
         assert "not in the DB" in str(e)
     else:
         raise AssertionError("expected CC_EINVAL")
+
+
+def test_hints_dense_world_long_pair_lists(cc, oracle):
+    """The cluttered world (tens of contours per level): a candidate's correlation then selects hundreds of ellipse pairs, so
+    the pair list of cc_k_gmm_init is flushed while it is being built and the refinement runs in its 64-lane instance
+    (more than CC_GMM_G16_MAX_PAIRS = 96 pairs).  Descriptors come from the oracle; the candidates are the scans taken a
+    moment before the query, the flow is the hint-driven one."""
+    L = oracle.L
+    dcfg = L.default_db_cfg()
+    w = cc.synth.World(dense=True)
+    n = 5
+    x, poses, ts = cc.synth.make_sequence(n, world=w)
+    P = x.shape[1]
+    odesc = oracle.ingest_batch(x.numpy().reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * P)
+    assert odesc["n_cont"][:, 1:3].mean() > 25, "the dense world should give tens of contours on the low levels"
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, dcfg, cap=n)
+    api.db_add(db, odesc, ts, np.arange(n, dtype=np.int32))
+    qi, cands = 4, [3, 1]
+    hints = _demo_hints(L, odesc, qi, cands)
+    oscans = [oracle.Scan.from_desc(odesc[g], int_id=int(g)) for g in cands]
+    otgt = oracle.Scan.from_desc(odesc[qi], int_id=int(qi))
+    eres, esc = oracle.check_hints(otgt, oscans, hints, sim=dcfg.cont_sim, max_fine_opt=5)
+    h = np.zeros(len(hints), L.hint_dt)
+    h["cand_gidx"] = np.array(cands)[hints[:, 0]]
+    h["level"], h["seq_src"], h["seq_tgt"] = hints[:, 1], hints[:, 2], hints[:, 3]
+    res, sc = api.check_hints(db, odesc[qi:qi + 1], h, max_fine_opt=5)
+    got = np.stack([sc[f] for f in ("i_ovlp_sum", "i_ovlp_max_one", "i_in_ang_rng", "i_indiv_sim", "i_orie_sim", "passed")], 1)
+    assert np.array_equal(got, esc) and got[:, 5].sum() > 0
+    assert eres["n_res"] == res["n_res"] == 1
+    assert cands[int(eres["cand_gidx"])] == res["cand_gidx"]
+    assert abs(eres["correlation"] - res["correlation"]) < 1e-6 and np.abs(eres["tf"] - res["tf"]).max() < 1e-6
