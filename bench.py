@@ -43,7 +43,7 @@ PROF_EVERY = 3  # the library's stage events ride on every 3rd chunk launch of t
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 8; --workload seq: the whole sequence)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--db-scans", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=1024, help="query scans per step per GPU")
@@ -59,13 +59,23 @@ def main():
     ap.add_argument("--sync-query", action="store_true",
                     help="cc_db_query_batch per step (collects every batch before the next one is queued) instead of cc_db_query_submit + one cc_db_query_wait")
     ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
-    ap.add_argument("--workload", choices=("sparse", "dense"), default="sparse",
+    ap.add_argument("--workload", choices=("sparse", "dense", "seq"), default="sparse",
                     help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
-                         "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level")
+                         "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level; "
+                         "seq: BASELINE config 2's shape -- the reference's ONLINE loop (test/batch_bin_test.cpp:131-237) over one "
+                         "long sequence of the dense world from an empty DB: per sub-batch ingest -> addScan/pushAndBalance -> query "
+                         "(scan i against epoch i), the DB update INSIDE the timed region; a step = one sub-batch of --seq-batch scans")
+    ap.add_argument("--seq-scans", type=int, default=4096, help="--workload seq: scans of the sequence (KITTI-08 has 4071)")
+    ap.add_argument("--seq-batch", type=int, default=256, help="--workload seq: scans per ingest/add/query sub-batch")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` measurements of the default run (online replay)")
     ap.add_argument("--tune-sweep", default="",
                     help="tuning aid (library built with -DCC_TUNE): 'VAR=v1,v2;VAR2=...': after the timed run, rebuild the DB "
                          "handle under each setting and print the isolated per-kernel ms of two steps to stderr")
     args = ap.parse_args()
+    steps_given = args.steps is not None
+    if args.steps is None:
+        args.steps = 8
+    args.steps_given = steps_given
 
     # `python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run
     # (one process per GPU, RCCL over xGMI) and let rank 0's JSON line through.
@@ -111,7 +121,9 @@ def main():
 
     n_db, B, K, W = args.db_scans, args.batch, args.steps, args.warmup
     P = 64 * 1875
-    wld = cc.synth.World(dense=(args.workload == "dense"))
+    wld = cc.synth.World(dense=(args.workload in ("dense", "seq")))
+    if args.workload == "seq":
+        return bench_seq(cc, args, dev, local_rank, world, rank, dist)
     ctx = cc.Context(local_rank, max_batch=max(B, 256))
 
     # ---------------- DB build (untimed): scan-sharded ingest, pack, ONE all-gather of the compact records ----------------
@@ -365,10 +377,188 @@ def main():
                          "rasterize_GBs": k1_bytes / ((kms_iso or kms)["cc_k_rasterize"] * 1e-3) / 1e9 if k1_ms > 0 else None},
             "setup_s": setup_s,
         }
+        out["roofline"]["step_hbm_frac"] = sum(alg.values()) / (elapsed / K) / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["step_algorithmic_bytes"] = sum(alg.values())
+        out["roofline"]["ingest_roofline_scans_per_s"] = HBM_PEAK_GBS * 1e9 / (P * 16)
+        out["roofline"]["value_over_ingest_roofline"] = value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))
+        if world == 1 and not args.no_extra:
+            # the reference's online loop on the scans already resident: from an empty DB, per 256-scan sub-batch
+            # ingest -> add -> query at the scan's own epoch; with the DB update inside the timed region and without
+            nrep = min(4, len(batches)) * B
+            out["extra"] = {"online_replay": online_replay(cc, ctx, [b for b in batches[:min(4, len(batches))]], B, P, nrep, 256, dev)}
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W % len(batches)], P, min(args.cpu_sample, B))
         print(json.dumps(out), flush=True)
     db.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add):
+    """One pass of the online loop over `chunks` (device tensors of sub*P points): ingest of sub-batch k+1 runs on its own
+    stream while sub-batch k is added (add=True) and queried; scan i is queried against epoch i.  Returns the results."""
+    import torch
+    s_main = torch.cuda.current_stream(dev)
+    s_ing = torch.cuda.Stream(device=dev)
+    slots = [torch.empty((sub, cc.DESC_BYTES), dtype=torch.uint8, device=dev) for _ in range(3)]
+
+    def ingest_async(k):
+        s_ing.wait_stream(s_main)
+        with torch.cuda.stream(s_ing):
+            ctx.ingest(chunks[k], offs, out=slots[k % 3])
+            ev = torch.cuda.Event()
+            ev.record(s_ing)
+        return ev
+
+    pending = []
+    ev = ingest_async(0)
+    for k in range(len(chunks)):
+        s_main.wait_event(ev)
+        if k + 1 < len(chunks):
+            ev = ingest_async(k + 1)
+        q = slots[k % 3]
+        i0 = k * sub
+        if add:
+            db.add_scans(q, ts[i0:i0 + sub], np.arange(i0, i0 + sub, dtype=np.int32))
+        pending.append(db.query_submit(q, np.arange(i0, i0 + sub, dtype=np.int32)))
+    db.query_wait()
+    return np.concatenate(pending)
+
+
+def online_replay(cc, ctx, batches, B, P, n, sub, dev):
+    """BASELINE config 2's loop shape on n scans that are already in HBM: DB empty at the start, then per sub-batch of
+    `sub` scans ingest -> cc_db_add_scans (addScan + pushAndBalance per scan) -> query with scan i at epoch i, everything
+    inside the timed region (`with_update`); and the same pass against a DB that already holds all n scans, the epochs
+    giving every query the same view (`without_update`: ingest + query only).  Both passes must return identical results."""
+    import torch
+    chunks = []
+    for b in batches:
+        for j in range(0, B, sub):
+            chunks.append(b[j * P:(j + sub) * P])
+    chunks = chunks[:n // sub]
+    n = len(chunks) * sub
+    offs = np.arange(sub + 1, dtype=np.int64) * P
+    ts = np.arange(n, dtype=np.float64) / 10.0
+    out = {"scans": n, "sub_batch": sub, "what": "empty DB, then per sub-batch: ingest -> addScan/pushAndBalance -> query (scan i at epoch i); "
+           "10 Hz stamps, shipped 15 s / 25 s delays (test/batch_bin_test.cpp:131-237, contour_db.h:814-843)"}
+    res = {}
+    for mode in ("warmup", "with_update", "without_update"):
+        db = cc.Database(ctx, capacity=n + 16)
+        if mode == "without_update":
+            for k, c in enumerate(chunks):
+                d = ctx.ingest(c, offs)
+                db.add_scans(d, ts[k * sub:(k + 1) * sub], np.arange(k * sub, (k + 1) * sub, dtype=np.int32))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add=(mode != "without_update"))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[mode] = r
+        if mode != "warmup":
+            out["scans_per_s_" + mode] = n / dt
+            out["ms_per_sub_batch_" + mode] = dt / len(chunks) * 1e3
+        db.close()
+    out["loop_closures"] = int((res["with_update"]["n_res"] > 0).sum())
+    out["identical_results"] = bool(res["with_update"].tobytes() == res["without_update"].tobytes())
+    return out
+
+
+def bench_seq(cc, args, dev, local_rank, world, rank, dist):
+    """--workload seq: the online loop over one long dense-world sequence; a step = one sub-batch (ingest + DB update +
+    query), W warm-up sub-batches from the start of the sequence, then exactly K timed ones (the DB keeps growing)."""
+    import torch
+    sub, P = args.seq_batch, 64 * 1875
+    n = (args.seq_scans // sub) * sub
+    nchunk = n // sub
+    W = min(args.warmup, nchunk - 1)
+    K = min(args.steps if args.steps_given else nchunk - W, nchunk - W)
+    wld = cc.synth.World(dense=True)
+    ctx = cc.Context(local_rank, max_batch=max(sub, 256))
+    t_setup = time.time()
+    chunks = []
+    for k in range(W + K):   # every rank replays its own stretch of the trajectory (weak scaling, independent sequences)
+        x, _, _ = cc.synth.make_sequence(sub, world=wld, device=dev, start=rank * n + k * sub)
+        chunks.append(x.reshape(-1, 4).contiguous())
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+    offs = np.arange(sub + 1, dtype=np.int64) * P
+    ts = np.arange((W + K) * sub, dtype=np.float64) / 10.0
+    out_modes = {}
+    for mode in ("with_update", "without_update"):
+        db = cc.Database(ctx, capacity=(W + K) * sub + 16)
+        if mode == "without_update":
+            for k, c in enumerate(chunks):
+                d = ctx.ingest(c, offs)
+                db.add_scans(d, ts[k * sub:(k + 1) * sub], np.arange(k * sub, (k + 1) * sub, dtype=np.int32))
+        # warm-up sub-batches (they also fill the DB in the with_update pass), then the K timed ones in ONE pipelined pass
+        s_main = torch.cuda.current_stream(dev)
+        s_ing = torch.cuda.Stream(device=dev)
+        slots = [torch.empty((sub, cc.DESC_BYTES), dtype=torch.uint8, device=dev) for _ in range(3)]
+
+        def ingest_async(k):
+            s_ing.wait_stream(s_main)
+            with torch.cuda.stream(s_ing):
+                ctx.ingest(chunks[k], offs, out=slots[k % 3])
+                ev = torch.cuda.Event()
+                ev.record(s_ing)
+            return ev
+
+        def one(k, ev):
+            s_main.wait_event(ev)
+            nxt = ingest_async(k + 1) if k + 1 < W + K else None
+            q = slots[k % 3]
+            idx = np.arange(k * sub, (k + 1) * sub, dtype=np.int32)
+            if mode == "with_update":
+                db.add_scans(q, ts[k * sub:(k + 1) * sub], idx)
+            return db.query_submit(q, idx), nxt
+
+        res = []
+        ev = ingest_async(0)
+        for k in range(W):
+            r, ev = one(k, ev)
+            res.append(r)
+        db.query_wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(W, W + K):
+            r, ev = one(k, ev)
+            res.append(r)
+        db.query_wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out_modes[mode] = (dt, np.concatenate(res))
+        db.close()
+    if rank == 0:
+        dt, r = out_modes["with_update"]
+        dt2, r2 = out_modes["without_update"]
+        value = K * sub * world / dt
+        out = {"metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
+               "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "online replay of one synthetic Velodyne-64 sequence (64x1875=120000 pts, dense world, 10 Hz, "
+                                      "%d scans per rank from an empty DB): per %d-scan sub-batch ingest -> addScan/pushAndBalance -> query, "
+                                      "scan i at epoch i; the DB update is INSIDE the timed step (BASELINE config 2's loop, "
+                                      "test/batch_bin_test.cpp:131-237)" % ((W + K) * sub, sub),
+                          "world": "dense", "seq_scans": (W + K) * sub, "sub_batch": sub, "points_per_scan": P,
+                          "parallelism": "independent sequences x%d" % world},
+               "extra": {"online_replay": {"scans_per_s_with_update": value, "scans_per_s_without_update": K * sub * world / dt2,
+                                           "ms_per_sub_batch_with_update": dt / K * 1e3, "ms_per_sub_batch_without_update": dt2 / K * 1e3,
+                                           "loop_closures": int((r["n_res"] > 0).sum()),
+                                           "identical_results": bool(r.tobytes() == r2.tobytes())}},
+               "roofline": {"bound": "hbm", "kernel": "whole step", "achieved": value / world * P * 16 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": value / world * P * 16 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "note": "point stream bytes (16 B x 120000 per scan) over the whole online step; per-kernel figures: default run"},
+               "setup_s": setup_s}
+        print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -513,6 +703,7 @@ def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q):
                      % (n_q, n_db, t_build, "reference nanoflann (oracle/_ref)" if kd else "exact scan", found),
            "seconds_per_scan": {"make bev": t_ing / n_q, "KNN search": tq["KNN search"] / n_q, "Constell": tq["Constell"] / n_q,
                                 "L2 opt": tq["L2 opt"] / n_q, "Update database (outside `value`, like the GPU step)": t_upd / n_q},
+           "online_loop_scans_per_s": n_q / (dt + t_upd),
            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
     # ---- measured all-cores figure: N independent single-threaded copies on disjoint scans
     try:

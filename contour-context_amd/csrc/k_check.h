@@ -590,6 +590,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       }
       npp = PPM;
       flags |= 1;
+      if (sl == 0) atomicOr((unsigned *)&pass_cnt[q * 4 + 0], (unsigned)CC_QF_CHECK_CAP);  // whether or not the check goes on to pass
     }
     cc_group_sync();
     if (npp == 0) {
@@ -633,6 +634,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     if (n_in > CC_CSTL_MAX) {
       n_in = CC_CSTL_MAX;
       flags |= 1;
+      if (sl == 0) atomicOr((unsigned *)&pass_cnt[q * 4 + 0], (unsigned)CC_QF_CHECK_CAP);
     }
     if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
     for (int e = sl; e < n_in; e += G) {
@@ -911,7 +913,6 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     cc_pass_rec *rec = &pass[(size_t)q * CC_CHK_STRIDE + t];
     if (sl == 0) {
       atomicAdd(&pass_cnt[q * 4 + 3], 1);
-      atomicAdd(&pass_cnt[q * 4 + 0], 1);
       rec->q = q;
       rec->order = t;
       rec->gidx = gidx;

@@ -997,6 +997,7 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   if (q >= nq) return;
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
   const int nc = qstate[q].n_cand;
+  int gfl = 0;  // capacity flags of the query's correlation problems (every one of them gates or ranks a candidate)
   for (int k = lane; k < nc; k += 64) {
     const int g = cands[k].gmm_idx;
     idx[k] = (unsigned short)k;
@@ -1006,10 +1007,12 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
     if (g >= 0) {
       h = !((float)gres[g].corr_init < corr_lb);
       co = (float)gres[g].corr_opt;
+      gfl |= gres[g].flags;
     }
     has[k] = h ? 1 : 0;
     corr_o[k] = co;
   }
+  for (int o = 32; o > 0; o >>= 1) gfl |= __shfl_xor(gfl, o);
   int tot = 0;
   for (int s2 = lane; s2 < CC_NQLEV * CC_NPIV; s2 += 64) tot += hit_cnt[q * CC_NQLEV * CC_NPIV + s2];
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
@@ -1026,6 +1029,8 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   r.cand_aft_check3 = pass_cnt[q * 4 + 3];
   r.n_cand_pose = nc;
   r.n_knn_hits = s_tot;
+  r.flags = (pass_cnt[q * 4 + 0] & CC_QF_CHECK_CAP) | ((gfl & 1) ? CC_QF_GMM_CAP : 0) | ((gfl & 4) ? CC_QF_DESC_CAP : 0);
+  r.pad_ = 0;
   // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592
   int p1 = 0, p2 = nc - 1;
   while (p1 <= p2) {

@@ -93,8 +93,68 @@ __device__ __forceinline__ void cc_wave_bitonic_u64(unsigned long long (&v)[R], 
 }
 
 // ---- maintenance of the sorted view when keys are appended (ids [n_old, n_old + m) of the insertion-ordered arrays).
-// A: every new key finds its rank among the new keys (brute force, tiles through LDS) and among the old sorted ones
-//    (binary search); B: every old key is shifted by the number of new keys below it; both write into the other buffer.
+// A: every new key finds its rank among the new keys and among the old sorted ones (binary search); B: every old key is
+//    shifted by the number of new keys below it; both write into the other buffer.
+// Rank among the new keys: one workgroup sorts (key[0], arrival index) pairs in LDS when the append is small (an online
+// add of a few hundred scans: m <= CC_KSORT_LDS keys); a bulk load of a prebuilt database falls back to counting.
+
+// workgroup-wide bitonic sort of n_pow2 keys in LDS
+__device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n_pow2, int tid, int nt) {
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n_pow2; i += nt) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = a[i], y = a[ixj];
+          const bool up = ((i & k) == 0);
+          if ((x > y) == up) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#define CC_KSORT_LDS 4096
+// grid = 1, block = 1024; m <= CC_KSORT_LDS.  Keys are compared as floats by cc_k_ksort_merge's searches, so the sort key
+// must order exactly like `<` on floats: -0 is folded onto +0 first (NaN keys never get here: pushBuffer drops them).
+__global__ void __launch_bounds__(1024)
+cc_k_ksort_new_lds(const float *__restrict__ keys /*insertion order, SoA*/, int n_old, int m,
+                   const float *__restrict__ s_old0 /*sorted dim 0, n_old entries*/, int *__restrict__ newpos,
+                   float *__restrict__ new_sorted0) {
+  __shared__ unsigned long long a[CC_KSORT_LDS];
+  const int tid = threadIdx.x;
+  int np2 = 64;
+  while (np2 < m) np2 <<= 1;
+  for (int i = tid; i < np2; i += 1024) {
+    unsigned long long v = ~0ull;
+    if (i < m) {
+      const float c = keys[n_old + i] + 0.f;  // -0 -> +0
+      v = ((unsigned long long)cc_fkey(c) << 32) | (unsigned)i;
+    }
+    a[i] = v;
+  }
+  __syncthreads();
+  cc_bitonic_sort_u64(a, np2, tid, 1024);
+  for (int r = tid; r < m; r += 1024) {
+    const int j = (int)(a[r] & 0xFFFFFFFFu);
+    const float c = keys[n_old + j];
+    int lo = 0, hi = n_old;  // #old keys with c0 <= c (old keys precede new ones among equals)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_old0[mid] <= c)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    newpos[j] = lo + r;
+    new_sorted0[r] = c;
+  }
+}
+
 // grid = ceil(m / 256), block = 256
 __global__ void __launch_bounds__(256)
 cc_k_ksort_new(const float *__restrict__ keys /*insertion order, SoA*/, int cap_k, int n_old, int m,
@@ -125,6 +185,37 @@ cc_k_ksort_new(const float *__restrict__ keys /*insertion order, SoA*/, int cap_
   }
   newpos[j] = lo + r_new;
   new_sorted0[r_new] = c;
+}
+
+// The new keys of an append, written from the scans' hot records (already in the DB's array) into the layer's
+// insertion-ordered SoA key matrix; `ent` packs (scan index << 3 | anchor) per new key, layer after layer.
+// grid = ceil(total / 256), block = 256
+struct cc_kappend_params {
+  float *keys[CC_NQLEV];
+  int *kgidx[CC_NQLEV];
+  unsigned char *kseq[CC_NQLEV];
+  int first[CC_NQLEV + 1];  // entries of layer l: [first[l], first[l + 1])
+  int n_old[CC_NQLEV];
+  int q_levels[CC_NQLEV];
+  int cap_k;
+};
+__global__ void __launch_bounds__(256)
+cc_k_keys_append(cc_kappend_params P, const cc_hot_desc_t *__restrict__ hot, const int *__restrict__ ent) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.first[CC_NQLEV]) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < CC_NQLEV; i++)
+    if (t >= P.first[i]) l = i;
+  const int j = t - P.first[l];
+  const int e = ent[t];
+  const int gidx = e >> 3, seq = e & 7;
+  const float *k = &hot[gidx].keys[P.q_levels[l] - 1][seq][0];
+  const size_t dst = (size_t)(P.n_old[l] + j);
+#pragma unroll
+  for (int d = 0; d < CC_KEY_DIM; d++) P.keys[l][(size_t)d * P.cap_k + dst] = k[d];
+  P.kgidx[l][dst] = gidx;
+  P.kseq[l][dst] = (unsigned char)seq;
 }
 
 // grid = ceil((n_old + m) / 256), block = 256
@@ -391,26 +482,6 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
 // ------------------------------------------------------------------------------------------------
 #define CC_KNN_S 4
 #define CC_KNN_ORDER_CAP 4096  // searches of one layer in a chunk (QB * CC_NPIV = 3072), padded to a power of two
-
-// workgroup-wide bitonic sort of n_pow2 keys in LDS
-__device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n_pow2, int tid, int nt) {
-  for (int k = 2; k <= n_pow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += nt) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long x = a[i], y = a[ixj];
-          const bool up = ((i & k) == 0);
-          if ((x > y) == up) {
-            a[i] = y;
-            a[ixj] = x;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
 
 // grid = n_q_levels, block = 1024.  order[ll][i] = search (q * CC_NPIV + seq) with the i-th smallest key[0] among the
 // layer's searches that have a key (q_keys[seq].sum() != 0, contour_db.h:726); the others get their empty result here.

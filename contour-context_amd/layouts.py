@@ -34,11 +34,16 @@ knn_hit_dt = np.dtype([("gidx", "<i4"), ("level", "<i2"), ("seq", "<i2"), ("dist
 query_result_dt = np.dtype([
     ("n_res", "<i4"), ("cand_gidx", "<i4"), ("correlation", "<f8"), ("tf", "<f8", (3,)),
     ("cand_aft_check1", "<i4"), ("cand_aft_check2", "<i4"), ("cand_aft_check3", "<i4"),
+    ("n_cand_pose", "<i4"), ("n_cand_tidy", "<i4"), ("n_knn_hits", "<i4"), ("flags", "<i4"), ("pad_", "<i4")], align=True)
+# the record before `flags` was added (tests/golden/query_fixture.npz stores it)
+query_result_v1_dt = np.dtype([
+    ("n_res", "<i4"), ("cand_gidx", "<i4"), ("correlation", "<f8"), ("tf", "<f8", (3,)),
+    ("cand_aft_check1", "<i4"), ("cand_aft_check2", "<i4"), ("cand_aft_check3", "<i4"),
     ("n_cand_pose", "<i4"), ("n_cand_tidy", "<i4"), ("n_knn_hits", "<i4")], align=True)
 
 assert contour_dt.itemsize == 76 and relpt_dt.itemsize == 12 and bci_dt.itemsize == 600
 assert scan_desc_dt.itemsize == 169048, scan_desc_dt.itemsize
-assert knn_hit_dt.itemsize == 12 and query_result_dt.itemsize == 64, query_result_dt.itemsize
+assert knn_hit_dt.itemsize == 12 and query_result_dt.itemsize == 72 and query_result_v1_dt.itemsize == 64, query_result_dt.itemsize
 # cc_hint_t / cc_hint_score_t (cc_db_check_hints)
 hint_dt = np.dtype([("cand_gidx", "<i4"), ("level", "i1"), ("seq_src", "i1"), ("seq_tgt", "i1"), ("pad", "i1")], align=True)
 hint_score_dt = np.dtype([("i_ovlp_sum", "<i4"), ("i_ovlp_max_one", "<i4"), ("i_in_ang_rng", "<i4"), ("i_indiv_sim", "<i4"),

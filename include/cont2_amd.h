@@ -213,7 +213,15 @@ typedef struct {
   int32_t n_cand_pose;  /* candidates_.size() before tidyUpCandidates                        */
   int32_t n_cand_tidy;  /* candidates_.size() after tidyUpCandidates                         */
   int32_t n_knn_hits;   /* total KNN results over all query keys                             */
+  int32_t flags;        /* CC_QF_* bits; 0 = exact.  Non-zero: an internal capacity was hit while this query was
+                           scored (the reference has none), the result may differ from the reference's; the call
+                           that collects the query returns CC_ECAPACITY (all results are still delivered)        */
+  int32_t pad_;
 } cc_query_result_t;
+#define CC_QF_CHECK_CAP 1 /* a constellation check had more than 256 potential neighbour pairs (contour_mng.h:311-336)
+                             or a rotation window of more than 63 pairs (:344-366): pairs were dropped              */
+#define CC_QF_GMM_CAP 2   /* a scan of a correlation problem has more than 128 ellipses on a level (correlation.h:55-78) */
+#define CC_QF_DESC_CAP 4  /* the correlation needed a contour beyond the CC_MAXC stored per level                     */
 
 /* ------------------------------------------------------------------------ context ------- */
 typedef struct cc_ctx cc_ctx; /* opaque: device id, configs, scratch, streams */
@@ -267,7 +275,12 @@ int cc_db_size(const cc_db *db);
  * for i in [0,n): addScan(desc[i], h_ts[i]); pushAndBalance(h_seed[i], h_ts[i]).
  * The descriptors are appended to the device-resident DB; the bucket bookkeeping (which key
  * is searchable from which epoch on, bucket ranges per epoch) runs on the host.
- * Epoch e = state after e scans have been added and balanced. */
+ * Epoch e = state after e scans have been added and balanced.
+ * An append does NOT wait for query chunks in flight (cc_db_query_submit): they were submitted against an earlier epoch
+ * and keep reading the state they were submitted with (the sorted key view is double-buffered and a buffer is rewritten
+ * only after its readers have finished -- a device-side wait; everything else is append-only).  So the online loop
+ * ingest -> add -> submit(query at its own epoch) streams batch after batch without draining the GPU.  The call itself
+ * returns when its own device work is done (it synchronises `stream`). */
 int cc_db_add_scans(cc_db *db, const cc_scan_desc_t *d_desc, int n, const double *h_ts,
                     const int32_t *h_seed, void *stream);
 
@@ -288,8 +301,8 @@ int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const in
  * reach h_res when its lane is needed again (a later submit) or at cc_db_query_wait, so the tail of one batch's chains
  * runs next to the head of the next batch's.  h_res must stay valid until cc_db_query_wait returned; d_qdesc may be
  * overwritten by work queued on `stream` after the call.  An error of an earlier batch's chunk (capacity flags) is
- * reported by the call that collects it.  cc_db_query_batch == submit + wait; every other cc_db_* call that changes or
- * reuses what chunks in flight read (add, check_hints, set_lanes, destroy) waits first. */
+ * reported by the call that collects it.  cc_db_query_batch == submit + wait; cc_db_check_hints, cc_db_set_lanes and
+ * cc_db_destroy collect the chunks in flight first; the appends do not need to (see cc_db_add_scans). */
 int cc_db_query_submit(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const int32_t *h_epoch,
                        const cc_score_t *thres_lb, const cc_score_t *thres_ub,
                        cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,

@@ -262,41 +262,54 @@ template <typename K, typename... Args>
 void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args);
 }  // namespace emu
 namespace emu {
+// One set of `block` OS threads per launch, reused for every workgroup of the grid (workgroups run one after the other:
+// `__shared__` variables are function-local statics shared by all threads).  A thread that returns early from the kernel
+// simply waits at the end-of-workgroup barrier.
 template <typename K, typename... Args>
 void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args) {
   if (block % 64 != 0) {
     fprintf(stderr, "emu: block size must be a multiple of 64\n");
     abort();
   }
-  for (unsigned b = 0; b < grid; b++) {
-    BlockCtx ctx;
-    pthread_barrier_init(&ctx.bar, nullptr, block);
-    ctx.waves.resize(block / 64);
-    for (auto &w : ctx.waves) {
-      pthread_barrier_init(&w.bar, nullptr, 64);
-      for (auto &g : w.gbar) pthread_barrier_init(&g, nullptr, 16);
-    }
-    std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
-    ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
-    std::vector<std::thread> th;
-    th.reserve(block);
-    for (unsigned t = 0; t < block; t++) {
-      th.emplace_back([&, t]() {
-        t_threadIdx = dim3(t);
+  if (grid == 0) return;
+  BlockCtx ctx;
+  pthread_barrier_init(&ctx.bar, nullptr, block);
+  ctx.waves.resize(block / 64);
+  for (auto &w : ctx.waves) {
+    pthread_barrier_init(&w.bar, nullptr, 64);
+    for (auto &g : w.gbar) pthread_barrier_init(&g, nullptr, 16);
+  }
+  pthread_barrier_t next_bar;  // between workgroups (separate from ctx.bar: a kernel may leave threads at different phases)
+  pthread_barrier_init(&next_bar, nullptr, block);
+  std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
+  ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+  std::vector<std::thread> th;
+  th.reserve(block);
+  for (unsigned t = 0; t < block; t++) {
+    th.emplace_back([&, t]() {
+      t_threadIdx = dim3(t);
+      t_blockDim = dim3(block);
+      t_gridDim = dim3(grid);
+      t_block = &ctx;
+      t_wave = &ctx.waves[t / 64];
+      t_lane = t % 64;
+      for (unsigned b = 0; b < grid; b++) {
         t_blockIdx = dim3(b);
-        t_blockDim = dim3(block);
-        t_gridDim = dim3(grid);
-        t_block = &ctx;
-        t_wave = &ctx.waves[t / 64];
-        t_lane = t % 64;
         t_coll = 0;
         t_gcoll = 0;
         kernel(args...);
-      });
-    }
-    for (auto &x : th) x.join();
-    pthread_barrier_destroy(&ctx.bar);
-    for (auto &w : ctx.waves) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_wait(&next_bar);
+        if (t == 0 && dyn_smem) memset(ctx.dyn_smem, 0x5a, dyn_smem);
+        if (dyn_smem) pthread_barrier_wait(&next_bar);
+      }
+    });
+  }
+  for (auto &x : th) x.join();
+  pthread_barrier_destroy(&ctx.bar);
+  pthread_barrier_destroy(&next_bar);
+  for (auto &w : ctx.waves) {
+    pthread_barrier_destroy(&w.bar);
+    for (auto &g : w.gbar) pthread_barrier_destroy(&g);
   }
 }
 }  // namespace emu

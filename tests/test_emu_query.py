@@ -89,7 +89,10 @@ def _load_query_fixture(L):
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "query_fixture.npz"))
     desc = np.frombuffer(z["desc"].tobytes(), dtype=L.scan_desc_dt)
-    res = np.frombuffer(z["res"].tobytes(), dtype=L.query_result_dt)
+    r1 = np.frombuffer(z["res"].tobytes(), dtype=L.query_result_v1_dt)  # stored before `flags` joined the record
+    res = np.zeros(len(r1), L.query_result_dt)
+    for f in r1.dtype.names:
+        res[f] = r1[f]
     d = L.default_db_cfg()
     d.min_elapse, d.max_elapse = float(z["elapse"][0]), float(z["elapse"][1])
     return desc, z["ts"], res, d
@@ -135,9 +138,10 @@ def test_golden_query_fixture(oracle, share, monkeypatch):
     assert np.array_equal(r1.tobytes(), got[:4].tobytes()) and np.array_equal(r2.tobytes(), got[3:].tobytes())
 
 
-def test_submit_is_drained_by_calls_that_change_the_db(oracle):
-    """cc_db_add_scans while a submitted batch is in flight: the add collects the batch first (its results are complete when
-    the add returns), and the later wait has nothing left to do."""
+def test_append_while_a_submitted_batch_is_in_flight(oracle):
+    """cc_db_add_scans does not collect submitted chunks (it never touches what they read: the sorted key view is
+    double-buffered, everything else is append-only): the batch submitted before the append still gets the results of its
+    own epochs at the wait, and queries submitted afterwards see the appended scans."""
     L = oracle.L
     desc, ts, exp, d = _load_query_fixture(L)
     api = emu_api.EmuApi(L)
@@ -149,8 +153,36 @@ def test_submit_is_drained_by_calls_that_change_the_db(oracle):
     qs = hit[[2, 12, 22]].astype(np.int32)
     res, keep = api.db_query_submit(db, desc[qs], qs)
     api.db_add(db, desc[60:], ts[60:], seeds[60:])
+    api.db_query_wait(db)
     for k, qi in enumerate(qs):
         _same_result(exp[qi], res[k], 1e-6)
-    api.db_query_wait(db)
     got = api.db_query(db, desc[[62]], np.array([62], np.int32))
     _same_result(exp[62], got[0], 1e-6)
+
+
+def test_online_loop_in_sub_batches(oracle):
+    """The online loop as bench.py --workload seq and the GPU replay test run it: per sub-batch append, then submit the
+    sub-batch's queries at their own epochs, nothing collected until the end (two appends happen while earlier chunks are
+    still uncollected, so both buffers of the sorted view get rewritten)."""
+    L = oracle.L
+    desc, ts, exp, d = _load_query_fixture(L)
+    n = len(desc)
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, d, cap=n)
+    seeds = np.arange(n, dtype=np.int32)
+    hit = set(np.nonzero(exp["n_res"] > 0)[0].tolist())
+    outs = []
+    for b0 in range(0, n, 16):
+        api.db_add(db, desc[b0:b0 + 16], ts[b0:b0 + 16], seeds[b0:b0 + 16])
+        hs = [i for i in range(b0, b0 + 16) if i in hit]
+        qs = np.asarray((hs[:1] + hs[-1:] if hs else []) + [b0 + 5], np.int32)
+        r, keep = api.db_query_submit(db, desc[qs], qs)
+        outs.append((qs, r, keep))
+    api.db_query_wait(db)
+    n_hit = 0
+    for qs, r, _ in outs:
+        for k, qi in enumerate(qs):
+            _same_result(exp[qi], r[k], 1e-6)
+            n_hit += int(exp["n_res"][qi] > 0)
+    assert n_hit >= 4

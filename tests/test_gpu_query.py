@@ -180,3 +180,115 @@ def test_sequence_dense_world(cc, oracle):
     w = cc.synth.World(dense=True, loop_len=150.0)
     xyzi, poses, ts = cc.synth.make_sequence(330, world=w, device="cuda")
     _seq_vs_oracle(cc, oracle, xyzi, ts)
+
+
+def _write_eval_files(tmp_path, poses, ts):
+    """pose file (13 columns) and scan list file in the reference's formats (scripts/gen_batch_bin_configs.py:101-159)"""
+    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
+    with open(lst, "w") as f, open(pos, "w") as g:
+        for i in range(len(ts)):
+            f.write("%.6f %d /synthetic/%06d.bin\n" % (ts[i], i, i))
+            c, s_ = np.cos(poses[i, 2]), np.sin(poses[i, 2])
+            g.write("%.6f %.9f %.9f 0 %.9f %.9f %.9f 0 %.9f 0 0 1 0\n" % (ts[i], c, -s_, poses[i, 0], s_, c, poses[i, 1]))
+    return str(pos), str(lst)
+
+
+def _outcome_and_pr(cc, tmp_path, tag, pos, lst, res, sim_thres=0.64928):
+    """results of the online loop -> ContLCDEvaluator -> outcome file -> max-F1 / PR points / TP pose errors"""
+    import importlib.util
+    import os
+    pk = os.path.dirname(cc.__file__)
+    mods = {}
+    for name in ("evaluator", "pr_eval"):
+        spec = importlib.util.spec_from_file_location("cc_" + name, os.path.join(pk, name + ".py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    ev = mods["evaluator"].ContLCDEvaluator(pos, lst, sim_thres)
+    for i in range(len(res)):
+        r = res[i]
+        if r["n_res"] > 0:
+            ev.add_prediction(i, float(r["correlation"]), int(r["cand_gidx"]), tuple(float(v) for v in r["tf"]))
+        else:
+            ev.add_prediction(i, 0.0)
+    path = str(tmp_path / ("outcome-%s.txt" % tag))
+    ev.save_prediction_results(path)
+    pr = mods["pr_eval"]
+    return path, pr.evaluate(pr.load_gt_poses(pos), pr.load_outcome(path)), ev
+
+
+def test_full_sequence_online_replay(cc, oracle, tmp_path):
+    """BASELINE config 2 at its size: one 4 096-scan sequence (KITTI-08 has 4 071) of full-size scans in the dense world,
+    10 Hz stamps, the shipped 15 s / 25 s delays, replayed the way the reference's driver runs it
+    (test/batch_bin_test.cpp:131-237): scan i is ingested, queried against the DB of the i scans before it, then added.
+    The HIP path does that in sub-batches of 256 (ingest -> cc_db_add_scans -> cc_db_query_submit with epoch i, chunks of
+    earlier sub-batches still in flight while the DB is appended to); the oracle does it scan by scan.  Every integer of
+    every result must agree, correlation and pose within 1e-4, and the two outcome files must give the same max-F1, PR
+    points and true-positive pose errors."""
+    import torch
+    n, sub = 4096, 256
+    w = cc.synth.World(dense=True)  # the bench's dense world: 1.5 km figure-eight, laps 2 and 3 revisit lap 1
+    ctx = cc.Context(0, max_batch=sub)
+    db = cc.Database(ctx, capacity=n)
+    odb = oracle.DB()
+    ores = np.zeros(n, cc.L.query_result_dt)
+    parts, poses, ts_all = [], [], []
+    n_desc_checked = 0
+    from parity import compare_desc
+    for k in range(n // sub):
+        x, p, ts = cc.synth.make_sequence(sub, world=w, device="cuda", start=k * sub)
+        P = x.shape[1]
+        idx = np.arange(k * sub, (k + 1) * sub, dtype=np.int32)
+        desc = ctx.ingest(x.reshape(-1, 4), np.arange(sub + 1, dtype=np.int64) * P)
+        db.add_scans(desc, ts, idx)
+        parts.append(db.query_submit(desc, idx))  # not collected here: the next append runs next to these chunks
+        xh = x.cpu().numpy()
+        dh = cc.desc_to_numpy(desc[::32])
+        assert (cc.desc_to_numpy(desc)["flags"] == 0).all()
+        for i in range(sub):
+            gi = k * sub + i
+            s = oracle.Scan(xh[i], int_id=gi, keep_cells=False)
+            if i % 32 == 0:
+                bad = compare_desc(s.desc()[0], dh[i // 32], float_exact=False)
+                assert not bad, "scan %d: %s" % (gi, bad[:5])
+                n_desc_checked += 1
+            s.clear_image()
+            ores[gi] = odb.query(s)
+            odb.add_scan(s, ts[i])
+            odb.push_and_balance(gi, ts[i])
+        poses.append(p)
+        ts_all.append(ts)
+    db.query_wait()
+    torch.cuda.synchronize()
+    res = np.concatenate(parts)
+    poses, ts_all = np.concatenate(poses), np.concatenate(ts_all)
+    assert np.array_equal(odb.bucket_state()[0], db.bucket_state()[0]) and np.array_equal(odb.bucket_state()[1], db.bucket_state()[1])
+    hit = ores["n_res"] > 0
+    assert hit.sum() > 1000, "laps 2 and 3 should close loops (%d)" % hit.sum()
+    bad = []
+    for f in INT_FIELDS:
+        for i in np.nonzero(ores[f] != res[f])[0][:10]:
+            bad.append("query %d: %s oracle=%d got=%d" % (i, f, ores[f][i], res[f][i]))
+    dc = np.abs(ores["correlation"][hit] - res["correlation"][hit])
+    dt = np.abs(ores["tf"][hit] - res["tf"][hit]).max(axis=1)
+    if dc.max() > 1e-4 or dt.max() > 1e-4:
+        bad.append("correlation max diff %g, pose max diff %g" % (dc.max(), dt.max()))
+    assert not bad, "%d mismatches\n" % len(bad) + "\n".join(bad[:40])
+    # outcome files through the evaluator -> max-F1 / PR / pose errors
+    pos, lst = _write_eval_files(tmp_path, poses, ts_all)
+    f_o, pr_o, ev_o = _outcome_and_pr(cc, tmp_path, "oracle", pos, lst, ores)
+    f_g, pr_g, ev_g = _outcome_and_pr(cc, tmp_path, "hip", pos, lst, res)
+    rows_o = [l.split("\t") for l in open(f_o)]
+    rows_g = [l.split("\t") for l in open(f_g)]
+    assert len(rows_o) == len(rows_g) == n
+    for a, b in zip(rows_o, rows_g):
+        assert a[0] == b[0] and a[1] == b[1], (a, b)                     # TP/FP/TN/FN label, matched pair
+        assert abs(float(a[2]) - float(b[2])) <= 1e-4 and all(abs(float(a[j]) - float(b[j])) <= 1e-4 for j in (3, 4, 5)), (a, b)
+    assert pr_g["max_f1"] == pr_o["max_f1"] and pr_g["max_f1_idx"] == pr_o["max_f1_idx"] and pr_g["tp_count"] == pr_o["tp_count"]
+    assert np.array_equal(pr_g["pr_points"], pr_o["pr_points"])
+    for f in ("rot_mean_deg", "rot_rmse_deg", "trans_mean", "trans_rmse"):
+        assert abs(pr_g[f] - pr_o[f]) < 1e-4, (f, pr_g[f], pr_o[f])
+    assert pr_o["max_f1"] > 0.8, pr_o["max_f1"]   # the synthetic loop closures are found, and found right
+    print("online replay: %d scans, %d loop closures, max-F1 %.6f at %.6f, %d TP, %d descriptors compared"
+          % (n, int(hit.sum()), pr_o["max_f1"], pr_o["sim_thres"], pr_o["tp_count"], n_desc_checked))
+    db.close()
+    ctx.close()
