@@ -29,7 +29,7 @@
 static_assert(2 * CC_KNN_MAX - 1 + 128 <= CC_KNN_CAP && CC_KNN_MAX <= 64, "cc_k_knn: pending candidates must fit the LDS buffer");
 
 struct cc_knn_params {
-  const float *skeys[CC_NQLEV];       // SoA [CC_KEY_DIM][cap_k], sorted by dim 0 (ties: insertion order)
+  const float *skeys[CC_NQLEV];       // SoA [CC_KEY_DIM + 1][cap_k], sorted by dim 0 (ties: insertion order); last row = |key|^2
   const int *sid[CC_NQLEV];           // insertion index (key id) of the i-th sorted key
   const int *sact[CC_NQLEV];          // first epoch at which that key sits in a tree
   const int *kgidx[CC_NQLEV];         // by key id: scan index
@@ -234,11 +234,17 @@ cc_k_ksort_merge(const float *__restrict__ keys, int cap_k, int n_old, int m, co
         hi = mid;
     }
     const int dst = i + lo;
-    for (int d = 0; d < CC_KEY_DIM; d++) s_new[(size_t)d * cap_k + dst] = s_old[(size_t)d * cap_k + i];
+    for (int d = 0; d <= CC_KEY_DIM; d++) s_new[(size_t)d * cap_k + dst] = s_old[(size_t)d * cap_k + i];  // row CC_KEY_DIM: |key|^2
     sid_new[dst] = sid_old[i];
   } else if (i < n_old + m) {
     const int j = i - n_old, dst = newpos[j];
-    for (int d = 0; d < CC_KEY_DIM; d++) s_new[(size_t)d * cap_k + dst] = keys[(size_t)d * cap_k + n_old + j];
+    float nrm = 0.f;
+    for (int d = 0; d < CC_KEY_DIM; d++) {
+      const float v = keys[(size_t)d * cap_k + n_old + j];
+      s_new[(size_t)d * cap_k + dst] = v;
+      nrm += v * v;
+    }
+    s_new[(size_t)CC_KEY_DIM * cap_k + dst] = nrm;  // input of the tiled search's prefilter only (cc_k_knn_tile)
     sid_new[dst] = n_old + j;
   }
 }
@@ -783,4 +789,287 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     }
   }
 #undef CC_KNN_FETCH2
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3, tiled form (the default; cc_db: env CC_KNN_MODE=2): 16 searches per wave, distances on the matrix cores.
+//
+// The wave-per-search walk evaluates ~15 % of a layer per search whatever the layer's size (the 50-th neighbour in ten
+// dimensions is far in every single one), ~100 vector instructions per 64 keys and search: at a 50 000-scan DB that is
+// 830 M key evaluations per 1 024 queries and 60 % of the step.  Here a wave takes 16 searches that are adjacent in the
+// chunk's key[0] order (cc_k_knn_order) -- their windows of the sorted view nearly coincide -- and walks the union of
+// their windows once, 64 keys per step and direction:
+//   * PREFILTER on v_mfma_f32_16x16x4_f32: with the keys as rows (k_0..k_9, |k|^2, 1) and the searches as columns
+//     (-2 q_0..-2 q_9, 1, |q|^2) three instructions give the 16 x 16 squared distances of a tile, four tiles per step.
+//     The result is a k-ordered fmaf chain, NOT nanoflann's sum, so it only FILTERS: a pair goes on iff its value is
+//     <= the search's current radius + a bound on what the chain can be off by (cc_knn_tile_slack).  Every pair whose
+//     reference distance is inside the radius passes; about 1 % of all pairs do.
+//   * EXACT path for the pairs that pass: the squared distance in nanoflann's accumulation order, the epoch mask, the
+//     bucket index ranges, then the search's candidate buffer and radius handling -- exactly cc_k_knn's.
+// Which keys a search ends up with does not depend on the filter (any superset of the final set gives the same result):
+// hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an 11th row (cc_k_ksort_merge).
+// ------------------------------------------------------------------------------------------------
+#define CC_KNN_TQ 16    // searches per wave = columns of a 16x16x4 tile
+#define CC_KNN_TCAP 256 // candidate buffer per search (as CC_KNN_CAP: <= 2 nnk - 1 kept + 64 new per step and direction)
+typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
+
+// |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
+// search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
+// to that sum), its two norm inputs carry <= 10 * 2^-24 relative error each, and |k| <= |q| + sqrt(ub) for such a key.
+// 2^-18 * (2 |q| + sqrt(ub))^2 is more than ten times that.
+__device__ __forceinline__ float cc_knn_tile_slack(float qnorm2, float ub) {
+  const float s = 2.f * sqrtf(qnorm2) + sqrtf(ub);
+  return s * s * (1.f / 262144.f);
+}
+
+struct cc_knn_tstate {  // per search of a wave
+  float ub;
+  int cnt, tight;
+};
+
+// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64
+__global__ void __launch_bounds__(64)
+cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
+              const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
+  __shared__ unsigned long long buf[CC_KNN_TQ][CC_KNN_TCAP];
+  __shared__ cc_knn_tstate st[CC_KNN_TQ];
+  __shared__ int bnd[CC_KNN_TQ * 5];
+  const int lane = threadIdx.x;
+  const int nblk = (nq * CC_NPIV + CC_KNN_TQ - 1) / CC_KNN_TQ;
+  const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
+  if (ll >= P.n_q_levels) return;
+  const int nv = n_valid[ll];
+  const int base = w * CC_KNN_TQ;
+  if (base >= nv) return;
+  const int ns = nv - base < CC_KNN_TQ ? nv - base : CC_KNN_TQ;  // searches of this wave
+  const int level = P.q_levels[ll];
+  const int n = P.n_sorted[ll];
+  const float *K = P.skeys[ll];
+  const int *sid = P.sid[ll];
+  const int *sact = P.sact[ll];
+  const size_t cap = (size_t)P.cap_k;
+  const int nnk = P.nnk;
+  const int j = lane & 15, kq = lane >> 4;  // this lane's search (column) and its k-slice of every 4-wide MFMA step
+
+  // ---- this lane's search: key, dist_ub, epoch, bucket thresholds (cc_k_knn); padding columns repeat search 0
+  const int srch = order[ll * CC_KNN_ORDER_CAP + base + (j < ns ? j : 0)];
+  const int q = srch / CC_NPIV, seq = srch - q * CC_NPIV;
+  float k[CC_KEY_DIM];
+  {
+    const float *qk = &qhot[q].keys[level - 1][seq][0];
+#pragma unroll
+    for (int d = 0; d < CC_KEY_DIM; d++) k[d] = qk[d];
+  }
+  const cc_query_meta *qm = qmeta + q;
+  const int epoch = qm->epoch;
+  float ub0;
+  {
+    const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
+    const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
+    const float b20 = (float)((double)k[2] * 0.8 * 0.75), b21 = (float)((double)k[2] / (0.8 * 0.75));
+    const float t0a = (k[0] - b00) * (k[0] - b00), t0b = (k[0] - b01) * (k[0] - b01);
+    const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
+    const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
+    ub0 = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
+  }
+  float qn2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < CC_KEY_DIM; d++) qn2 += k[d] * k[d];
+  // B operand: column j of (-2 q_0 .. -2 q_9, 1, |q|^2), this lane's element of k-step s is 4 s + kq
+  float bop[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < CC_KEY_DIM; d++)
+      if (d == 4 * s + kq) v = -2.f * k[d];
+    if (4 * s + kq == 10) v = 1.f;
+    if (4 * s + kq == 11) v = qn2;
+    bop[s] = v;
+  }
+  // index boundaries: lane (j, kq) finds lb(target kq) of search j, kq = 0..3 -> rg[0], t_e1, t_s2, rg[6]; a second pass
+  // (lanes kq == 0) finds lb(key[0]).  lb(t) = number of keys with key[0] < t.
+  {
+    float rg[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) rg[i] = qm->ranges[ll][i];
+    int mid = 0;
+    {
+      bool found = false;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+        if (!found && rg[i] <= k[0] && rg[i + 1] > k[0]) {
+          mid = i;
+          found = true;
+        }
+    }
+    float t_e1 = rg[6], t_s2 = rg[6];
+#pragma unroll
+    for (int i = 1; i < 7; i++) {
+      if (i == mid + 1) t_e1 = rg[i];
+      if (i == 2 * mid + 1) t_s2 = rg[i];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const float tg = pass ? k[0] : (kq == 0 ? rg[0] : kq == 1 ? t_e1 : kq == 2 ? t_s2 : rg[6]);
+      int lo = 0, hi = (pass && kq != 0) ? 0 : n;
+      while (lo < hi) {
+        const int m_ = (lo + hi) >> 1;
+        if (K[m_] < tg)
+          lo = m_ + 1;
+        else
+          hi = m_;
+      }
+      if (!pass)
+        bnd[j * 5 + kq] = lo;
+      else if (kq == 0)
+        bnd[j * 5 + 4] = lo;
+    }
+    if (kq == 0) {
+      st[j].ub = ub0;
+      st[j].cnt = 0;
+      st[j].tight = 0;
+    }
+  }
+  cc_wave_sync();
+  const int L0 = bnd[j * 5 + 0], E1 = bnd[j * 5 + 1], S2 = bnd[j * 5 + 2], E2 = bnd[j * 5 + 3];
+  const int p0 = __builtin_amdgcn_readfirstlane(bnd[4]);  // search 0's own position splits the walk
+  const bool valid = j < ns;
+  float ubj = ub0;
+  int tightj = 0;
+  const float slack = cc_knn_tile_slack(qn2, ub0);
+  float thr = ubj + slack;
+
+  // ---- the common walk: upwards over [p0, n), downwards over [0, p0), 64 keys per step
+  bool open_up = valid && p0 < E2 && p0 < n;
+  bool open_dn = valid && p0 > L0 && p0 > 0;
+  bool any[2] = {__ballot(open_up) != 0ull, __ballot(open_dn) != 0ull};
+  int sbase[2] = {p0, p0 - 64};  // first index of the current step of each direction (ascending inside a step)
+  float a[2][4][3];              // A operand of the fetched step: tile t = keys sbase + 16 t + (lane & 15), element 4 s + kq
+#define CC_KNN_TFETCH(dir)                                                                             \
+  {                                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                    \
+      int i_ = sbase[dir] + 16 * t + j;                                                                \
+      i_ = i_ < 0 ? 0 : (i_ >= n ? n - 1 : i_);                                                        \
+      _Pragma("unroll") for (int s = 0; s < 3; s++) {                                                  \
+        const int row_ = 4 * s + kq; /* 0..9 key dims, 10 = |k|^2, 11 = the constant 1 */             \
+        a[dir][t][s] = row_ < CC_KEY_DIM + 1 ? K[(size_t)row_ * cap + (unsigned)i_] : 1.f;             \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  if (any[0]) CC_KNN_TFETCH(0)
+  if (any[1]) CC_KNN_TFETCH(1)
+  while (any[0] || any[1]) {
+    float far0[2] = {0.f, 0.f};
+    int nxt[2] = {0, 0};
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      if (!any[dir]) continue;  // wave-uniform
+      const int sb = sbase[dir];
+      cc_f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        acc[t] = (cc_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; s++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[dir][t][s], bop[s], acc[t], 0, 0, 0);
+      }
+      // the step's outermost key[0] (row 0 lives in the lanes kq == 0, element s = 0): upwards the last key, downwards the first
+      far0[dir] = dir == 0 ? cc_lane_bcast(a[0][3][0], 15) : cc_lane_bcast(a[1][0][0], 0);
+      // the next step's keys travel while this step's pairs are filtered
+      sbase[dir] += dir == 0 ? 64 : -64;
+      nxt[dir] = sbase[dir];
+      CC_KNN_TFETCH(dir)
+      // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack
+      unsigned m = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) m |= (acc[t][r] <= thr) ? (1u << (4 * t + r)) : 0u;
+      // exact path, one pair per lane and round
+      while (__ballot(m != 0u) != 0ull) {
+        if (m != 0u) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1u;
+          const int idx = sb + 16 * (bit >> 2) + 4 * kq + (bit & 3);
+          if (idx >= 0 && idx < n && valid && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2)) && sact[idx] <= epoch) {
+            const unsigned u_ = (unsigned)idx;
+            // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+            float r_ = 0.f;
+            float d0 = k[0] - K[u_], d1 = k[1] - K[cap + u_], d2 = k[2] - K[2 * cap + u_], d3 = k[3] - K[3 * cap + u_];
+            r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            d0 = k[4] - K[4 * cap + u_];
+            d1 = k[5] - K[5 * cap + u_];
+            d2 = k[6] - K[6 * cap + u_];
+            d3 = k[7] - K[7 * cap + u_];
+            r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            d0 = k[8] - K[8 * cap + u_];
+            r_ += d0 * d0;
+            d0 = k[9] - K[9 * cap + u_];
+            r_ += d0 * d0;
+            if (tightj ? (r_ <= ubj) : (r_ < ubj)) {
+              const int slot = atomicAdd(&st[j].cnt, 1);
+              buf[j][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)sid[u_];
+            }
+          }
+        }
+      }
+    }
+    cc_wave_sync();
+    // keep the best nnk of a search whose buffer has filled up; its radius follows
+    for (int jj = 0; jj < ns; jj++) {
+      const int cnt = __builtin_amdgcn_readfirstlane(st[jj].cnt);
+      const int tight = __builtin_amdgcn_readfirstlane(st[jj].tight);
+      if (!(cnt >= 2 * nnk || (!tight && cnt >= nnk))) continue;
+      unsigned long long first;
+      const float nub = cnt <= 128 ? cc_knn_reduce<2>(buf[jj], cnt, nnk, lane, first) : cc_knn_reduce<4>(buf[jj], cnt, nnk, lane, first);
+      if (lane == 0) {
+        st[jj].ub = nub;
+        st[jj].cnt = nnk;
+        st[jj].tight = 1;
+      }
+    }
+    cc_wave_sync();
+    ubj = st[j].ub;
+    tightj = st[j].tight;
+    thr = ubj + slack;
+    // who goes on, in which direction: a search leaves a direction when the step's outermost key lies beyond its own
+    // key[0] on that side by more than its radius, or past its visible ranges
+    if (any[0]) {
+      const float e = k[0] - far0[0];
+      const bool out = (e < 0.f) && (tightj ? (e * e > ubj) : (e * e >= ubj));
+      open_up = open_up && !out && nxt[0] < E2 && nxt[0] < n;
+      any[0] = __ballot(open_up) != 0ull;
+    }
+    if (any[1]) {
+      const float e = k[0] - far0[1];
+      const bool out = (e > 0.f) && (tightj ? (e * e > ubj) : (e * e >= ubj));
+      open_dn = open_dn && !out && nxt[1] + 64 > L0 && nxt[1] + 64 > 0;
+      any[1] = __ballot(open_dn) != 0ull;
+    }
+  }
+#undef CC_KNN_TFETCH
+  cc_wave_sync();
+  for (int jj = 0; jj < ns; jj++) {
+    const int cnt = __builtin_amdgcn_readfirstlane(st[jj].cnt);
+    unsigned long long first;
+    if (cnt <= 128)
+      cc_knn_reduce<2>(buf[jj], cnt, nnk, lane, first);
+    else
+      cc_knn_reduce<4>(buf[jj], cnt, nnk, lane, first);
+    const int s_ = order[ll * CC_KNN_ORDER_CAP + base + jj];
+    const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
+    const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;
+    const int mm = cnt < nnk ? cnt : nnk;
+    if (lane < mm) {
+      const unsigned id = (unsigned)(first & 0xFFFFFFFFu);
+      cc_knn_hit_t h;
+      h.gidx = P.kgidx[ll][id];
+      h.level = (int16_t)level;
+      h.seq = (int16_t)P.kseq[ll][id];
+      h.dist_sq = __uint_as_float((unsigned)(first >> 32));
+      hits[(size_t)slot * CC_KNN_MAX + lane] = h;
+    }
+    if (lane == 0) hit_cnt[slot] = mm;
+    cc_wave_sync();
+  }
 }
