@@ -119,14 +119,31 @@ __device__ __forceinline__ void cc_bitonic_sort_u64(unsigned long long *a, int n
 }
 
 #define CC_KSORT_LDS 4096
-// grid = 1, block = 1024; m <= CC_KSORT_LDS.  Keys are compared as floats by cc_k_ksort_merge's searches, so the sort key
+// One append touches every query layer: the three kernels below take all layers in ONE launch each (the layer is the
+// slow index of the 1-D grid), so an online append is a chain of four short launches, not ten.
+struct cc_ksort_params {
+  const float *keys[CC_NQLEV];     // insertion order, SoA [CC_KEY_DIM][cap_k]
+  const float *s_old[CC_NQLEV];    // sorted view before the append ([CC_KEY_DIM + 1][cap_k]) ...
+  const int *sid_old[CC_NQLEV];
+  float *s_new[CC_NQLEV];          // ... and after it (the other buffer); == s_old when the layer got no new key
+  int *sid_new[CC_NQLEV];
+  int *newpos[CC_NQLEV];           // scratch per layer: position of the j-th new key in the new view
+  float *newsorted0[CC_NQLEV];     // scratch per layer: key[0] of the new keys, ascending
+  const int *act[CC_NQLEV];        // by key id: first epoch at which the key sits in a tree
+  int *sact_new[CC_NQLEV];         // the same in the new view's order
+  int n_old[CC_NQLEV], m[CC_NQLEV];
+  int cap_k, n_layers, blocks_per_layer;
+};
+
+// grid = n_layers, block = 1024; m <= CC_KSORT_LDS.  Keys are compared as floats by cc_k_ksort_merge's searches, so the sort key
 // must order exactly like `<` on floats: -0 is folded onto +0 first (NaN keys never get here: pushBuffer drops them).
 __global__ void __launch_bounds__(1024)
-cc_k_ksort_new_lds(const float *__restrict__ keys /*insertion order, SoA*/, int n_old, int m,
-                   const float *__restrict__ s_old0 /*sorted dim 0, n_old entries*/, int *__restrict__ newpos,
-                   float *__restrict__ new_sorted0) {
+cc_k_ksort_new_lds(cc_ksort_params P) {
   __shared__ unsigned long long a[CC_KSORT_LDS];
-  const int tid = threadIdx.x;
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const int m = P.m[l], n_old = P.n_old[l];
+  if (m <= 0 || m > CC_KSORT_LDS) return;  // nothing new / counted by cc_k_ksort_new instead
+  const float *keys = P.keys[l], *s_old0 = P.s_old[l];
   int np2 = 64;
   while (np2 < m) np2 <<= 1;
   for (int i = tid; i < np2; i += 1024) {
@@ -150,8 +167,8 @@ cc_k_ksort_new_lds(const float *__restrict__ keys /*insertion order, SoA*/, int 
       else
         hi = mid;
     }
-    newpos[j] = lo + r;
-    new_sorted0[r] = c;
+    P.newpos[l][j] = lo + r;
+    P.newsorted0[l][r] = c;
   }
 }
 
@@ -218,11 +235,16 @@ cc_k_keys_append(cc_kappend_params P, const cc_hot_desc_t *__restrict__ hot, con
   P.kseq[l][dst] = (unsigned char)seq;
 }
 
-// grid = ceil((n_old + m) / 256), block = 256
+// grid = n_layers * blocks_per_layer (blocks_per_layer >= ceil(max_l(n_old + m) / 256)), block = 256
 __global__ void __launch_bounds__(256)
-cc_k_ksort_merge(const float *__restrict__ keys, int cap_k, int n_old, int m, const float *__restrict__ s_old, const int *__restrict__ sid_old,
-                 const int *__restrict__ newpos, const float *__restrict__ new_sorted0, float *__restrict__ s_new, int *__restrict__ sid_new) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+cc_k_ksort_merge(cc_ksort_params P) {
+  const int l = blockIdx.x / P.blocks_per_layer;
+  const int i = (blockIdx.x - l * P.blocks_per_layer) * blockDim.x + threadIdx.x;
+  const int n_old = P.n_old[l], m = P.m[l];
+  if (m <= 0) return;  // the layer keeps its buffer
+  const size_t cap_k = (size_t)P.cap_k;
+  const float *s_old = P.s_old[l], *keys = P.keys[l], *new_sorted0 = P.newsorted0[l];
+  float *s_new = P.s_new[l];
   if (i < n_old) {
     const float c = s_old[i];
     int lo = 0, hi = m;  // #new keys with c0 < c
@@ -235,9 +257,10 @@ cc_k_ksort_merge(const float *__restrict__ keys, int cap_k, int n_old, int m, co
     }
     const int dst = i + lo;
     for (int d = 0; d <= CC_KEY_DIM; d++) s_new[(size_t)d * cap_k + dst] = s_old[(size_t)d * cap_k + i];  // row CC_KEY_DIM: |key|^2
-    sid_new[dst] = sid_old[i];
+    P.sid_new[l][dst] = P.sid_old[l][i];
+    P.sact_new[l][dst] = P.act[l][P.sid_old[l][i]];
   } else if (i < n_old + m) {
-    const int j = i - n_old, dst = newpos[j];
+    const int j = i - n_old, dst = P.newpos[l][j];
     float nrm = 0.f;
     for (int d = 0; d < CC_KEY_DIM; d++) {
       const float v = keys[(size_t)d * cap_k + n_old + j];
@@ -245,15 +268,19 @@ cc_k_ksort_merge(const float *__restrict__ keys, int cap_k, int n_old, int m, co
       nrm += v * v;
     }
     s_new[(size_t)CC_KEY_DIM * cap_k + dst] = nrm;  // input of the tiled search's prefilter only (cc_k_knn_tile)
-    sid_new[dst] = n_old + j;
+    P.sid_new[l][dst] = n_old + j;
+    P.sact_new[l][dst] = P.act[l][n_old + j];
   }
 }
 
-// activation epochs in sorted order (they change when the host moves keys from a bucket's buffer into its tree)
+// activation epochs in sorted order for the layers that got no new key (they change when the host moves keys from a
+// bucket's buffer into its tree); the layers that did get theirs from the merge.  Same grid as cc_k_ksort_merge.
 __global__ void __launch_bounds__(256)
-cc_k_ksort_act(const int *__restrict__ act, const int *__restrict__ sid, int n, int *__restrict__ sact) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) sact[i] = act[sid[i]];
+cc_k_ksort_act(cc_ksort_params P) {
+  const int l = blockIdx.x / P.blocks_per_layer;
+  const int i = (blockIdx.x - l * P.blocks_per_layer) * blockDim.x + threadIdx.x;
+  if (P.m[l] > 0 || i >= P.n_old[l]) return;
+  P.sact_new[l][i] = P.act[l][P.sid_old[l][i]];
 }
 
 // Keep the best nnk of the cnt pending candidates (sorted, at buf[0..nnk)); returns the nnk-th best distance.
@@ -792,7 +819,7 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3, tiled form (the default; cc_db: env CC_KNN_MODE=2): 16 searches per wave, distances on the matrix cores.
+// K3, tiled form (cc_db: env CC_KNN_MODE=2): 16 searches per wave, distances on the matrix cores.
 //
 // The wave-per-search walk evaluates ~15 % of a layer per search whatever the layer's size (the 50-th neighbour in ten
 // dimensions is far in every single one), ~100 vector instructions per 64 keys and search: at a 50 000-scan DB that is
@@ -802,16 +829,20 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 //   * PREFILTER on v_mfma_f32_16x16x4_f32: with the keys as rows (k_0..k_9, |k|^2, 1) and the searches as columns
 //     (-2 q_0..-2 q_9, 1, |q|^2) three instructions give the 16 x 16 squared distances of a tile, four tiles per step.
 //     The result is a k-ordered fmaf chain, NOT nanoflann's sum, so it only FILTERS: a pair goes on iff its value is
-//     <= the search's current radius + a bound on what the chain can be off by (cc_knn_tile_slack).  Every pair whose
-//     reference distance is inside the radius passes; about 1 % of all pairs do.
-//   * EXACT path for the pairs that pass: the squared distance in nanoflann's accumulation order, the epoch mask, the
-//     bucket index ranges, then the search's candidate buffer and radius handling -- exactly cc_k_knn's.
+//     <= the search's current radius + a bound on what the chain can be off by (cc_knn_tile_slack) and the key's index
+//     lies in the search's visible bucket ranges.  Every pair whose reference distance is inside the radius passes;
+//     about 1 % of all pairs do.  The sixteen compares of a step each yield a wave mask; most are empty.
+//   * the pairs that pass are queued in LDS and worked off 64 at a time (one pair per lane, every load independent):
+//     the squared distance in nanoflann's accumulation order, the epoch mask, then the search's candidate buffer and
+//     radius handling -- exactly cc_k_knn's.  A radius that is tightened a few steps late only lets more pairs through.
 // Which keys a search ends up with does not depend on the filter (any superset of the final set gives the same result):
 // hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an 11th row (cc_k_ksort_merge).
 // ------------------------------------------------------------------------------------------------
 #define CC_KNN_TQ 16    // searches per wave = columns of a 16x16x4 tile
-#define CC_KNN_TCAP 256 // candidate buffer per search (as CC_KNN_CAP: <= 2 nnk - 1 kept + 64 new per step and direction)
+#define CC_KNN_TCAP 256 // candidate buffer per search: <= 2 nnk - 1 kept + 64 from one pass of the queue
+#define CC_KNN_TWL 2176 // queue of filtered pairs: < 64 left over + 2 directions x 1024 pairs of one round
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
+static_assert(2 * CC_KNN_MAX - 1 + 64 <= CC_KNN_TCAP, "cc_k_knn_tile: a pass of the queue must fit the candidate buffers");
 
 // |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
 // search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
@@ -826,14 +857,70 @@ struct cc_knn_tstate {  // per search of a wave
   float ub;
   int cnt, tight;
 };
+struct cc_knn_tlds {
+  unsigned long long buf[CC_KNN_TQ][CC_KNN_TCAP];
+  unsigned wl[CC_KNN_TWL];          // (search << 28) | sorted index
+  float qk[CC_KNN_TQ][CC_KEY_DIM];  // the searches' keys, for the lanes that work off other searches' pairs
+  int qb[CC_KNN_TQ][5];             // L0, E1, S2, E2 (visible index ranges), then the epoch
+  cc_knn_tstate st[CC_KNN_TQ];
+};
+
+// Work off the last `take` (<= 64) pairs of the queue: exact distance, epoch mask, candidate buffers; then keep the best
+// nnk of every search whose buffer has filled up.
+__device__ __forceinline__ void cc_knn_tile_pass(cc_knn_tlds &L, const float *__restrict__ K, const int *__restrict__ sid,
+                                                 const int *__restrict__ sact, size_t cap, int from, int take, int ns, int nnk, int lane) {
+  if (lane < take) {
+    const unsigned ent = L.wl[from + lane];
+    const int js = (int)(ent >> 28);
+    const unsigned u_ = ent & 0x0FFFFFFFu;
+    const int act = sact[u_];
+    const int kid = sid[u_];
+    float c[CC_KEY_DIM];
+#pragma unroll
+    for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + u_];
+    const float *k = L.qk[js];
+    // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+    float r_ = 0.f;
+    float d0 = k[0] - c[0], d1 = k[1] - c[1], d2 = k[2] - c[2], d3 = k[3] - c[3];
+    r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    d0 = k[4] - c[4];
+    d1 = k[5] - c[5];
+    d2 = k[6] - c[6];
+    d3 = k[7] - c[7];
+    r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    d0 = k[8] - c[8];
+    r_ += d0 * d0;
+    d0 = k[9] - c[9];
+    r_ += d0 * d0;
+    const float ub = L.st[js].ub;
+    // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best distance
+    // still compete, on the key id
+    if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
+      const int slot = atomicAdd(&L.st[js].cnt, 1);
+      L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
+    }
+  }
+  cc_wave_sync();
+  for (int jj = 0; jj < ns; jj++) {
+    const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
+    const int tight = __builtin_amdgcn_readfirstlane(L.st[jj].tight);
+    if (!(cnt >= 2 * nnk || (!tight && cnt >= nnk))) continue;
+    unsigned long long first;
+    const float nub = cnt <= 128 ? cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first) : cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
+    if (lane == 0) {
+      L.st[jj].ub = nub;
+      L.st[jj].cnt = nnk;
+      L.st[jj].tight = 1;
+    }
+  }
+  cc_wave_sync();
+}
 
 // grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64
 __global__ void __launch_bounds__(64)
 cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
               const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
-  __shared__ unsigned long long buf[CC_KNN_TQ][CC_KNN_TCAP];
-  __shared__ cc_knn_tstate st[CC_KNN_TQ];
-  __shared__ int bnd[CC_KNN_TQ * 5];
+  __shared__ cc_knn_tlds L;
   const int lane = threadIdx.x;
   const int nblk = (nq * CC_NPIV + CC_KNN_TQ - 1) / CC_KNN_TQ;
   const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
@@ -861,7 +948,6 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     for (int d = 0; d < CC_KEY_DIM; d++) k[d] = qk[d];
   }
   const cc_query_meta *qm = qmeta + q;
-  const int epoch = qm->epoch;
   float ub0;
   {
     const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
@@ -921,19 +1007,24 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           hi = m_;
       }
       if (!pass)
-        bnd[j * 5 + kq] = lo;
+        L.qb[j][kq] = lo;
       else if (kq == 0)
-        bnd[j * 5 + 4] = lo;
+        L.qb[j][4] = lo;  // the search's own position, replaced by the epoch below
     }
     if (kq == 0) {
-      st[j].ub = ub0;
-      st[j].cnt = 0;
-      st[j].tight = 0;
+      L.st[j].ub = ub0;
+      L.st[j].cnt = 0;
+      L.st[j].tight = 0;
+#pragma unroll
+      for (int d = 0; d < CC_KEY_DIM; d++) L.qk[j][d] = k[d];
     }
   }
   cc_wave_sync();
-  const int L0 = bnd[j * 5 + 0], E1 = bnd[j * 5 + 1], S2 = bnd[j * 5 + 2], E2 = bnd[j * 5 + 3];
-  const int p0 = __builtin_amdgcn_readfirstlane(bnd[4]);  // search 0's own position splits the walk
+  const int L0 = L.qb[j][0], E1 = L.qb[j][1], S2 = L.qb[j][2], E2 = L.qb[j][3];
+  const int p0 = __builtin_amdgcn_readfirstlane(L.qb[0][4]);  // search 0's own position splits the walk
+  cc_wave_sync();
+  if (kq == 0) L.qb[j][4] = qm->epoch;
+  cc_wave_sync();
   const bool valid = j < ns;
   float ubj = ub0;
   int tightj = 0;
@@ -945,6 +1036,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   bool open_dn = valid && p0 > L0 && p0 > 0;
   bool any[2] = {__ballot(open_up) != 0ull, __ballot(open_dn) != 0ull};
   int sbase[2] = {p0, p0 - 64};  // first index of the current step of each direction (ascending inside a step)
+  int wn = 0;                    // pairs in the queue (wave-uniform)
   float a[2][4][3];              // A operand of the fetched step: tile t = keys sbase + 16 t + (lane & 15), element 4 s + kq
 #define CC_KNN_TFETCH(dir)                                                                             \
   {                                                                                                    \
@@ -968,70 +1060,42 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       const int sb = sbase[dir];
       cc_f32x4 acc[4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        acc[t] = (cc_f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; t++) acc[t] = (cc_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 3; s++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[dir][t][s], bop[s], acc[t], 0, 0, 0);
-      }
+      for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[dir][t][s], bop[s], acc[t], 0, 0, 0);
       // the step's outermost key[0] (row 0 lives in the lanes kq == 0, element s = 0): upwards the last key, downwards the first
       far0[dir] = dir == 0 ? cc_lane_bcast(a[0][3][0], 15) : cc_lane_bcast(a[1][0][0], 0);
       // the next step's keys travel while this step's pairs are filtered
       sbase[dir] += dir == 0 ? 64 : -64;
       nxt[dir] = sbase[dir];
       CC_KNN_TFETCH(dir)
-      // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack
-      unsigned m = 0;
+      // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack, key inside the search's visible index ranges
 #pragma unroll
       for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) m |= (acc[t][r] <= thr) ? (1u << (4 * t + r)) : 0u;
-      // exact path, one pair per lane and round
-      while (__ballot(m != 0u) != 0ull) {
-        if (m != 0u) {
-          const int bit = __ffs(m) - 1;
-          m &= m - 1u;
-          const int idx = sb + 16 * (bit >> 2) + 4 * kq + (bit & 3);
-          if (idx >= 0 && idx < n && valid && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2)) && sact[idx] <= epoch) {
-            const unsigned u_ = (unsigned)idx;
-            // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-            float r_ = 0.f;
-            float d0 = k[0] - K[u_], d1 = k[1] - K[cap + u_], d2 = k[2] - K[2 * cap + u_], d3 = k[3] - K[3 * cap + u_];
-            r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-            d0 = k[4] - K[4 * cap + u_];
-            d1 = k[5] - K[5 * cap + u_];
-            d2 = k[6] - K[6 * cap + u_];
-            d3 = k[7] - K[7 * cap + u_];
-            r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-            d0 = k[8] - K[8 * cap + u_];
-            r_ += d0 * d0;
-            d0 = k[9] - K[9 * cap + u_];
-            r_ += d0 * d0;
-            if (tightj ? (r_ <= ubj) : (r_ < ubj)) {
-              const int slot = atomicAdd(&st[j].cnt, 1);
-              buf[j][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)sid[u_];
-            }
-          }
+        for (int r = 0; r < 4; r++) {
+          const bool hit = acc[t][r] <= thr;
+          if (__ballot(hit) == 0ull) continue;  // wave-uniform: most of the sixteen masks are empty
+          const int idx = sb + 16 * t + 4 * kq + r;
+          const bool push = hit && valid && idx >= 0 && idx < n && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2));
+          const unsigned long long mk = __ballot(push);
+          if (push) L.wl[wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)idx;
+          wn += __popcll(mk);
         }
-      }
     }
-    cc_wave_sync();
-    // keep the best nnk of a search whose buffer has filled up; its radius follows
-    for (int jj = 0; jj < ns; jj++) {
-      const int cnt = __builtin_amdgcn_readfirstlane(st[jj].cnt);
-      const int tight = __builtin_amdgcn_readfirstlane(st[jj].tight);
-      if (!(cnt >= 2 * nnk || (!tight && cnt >= nnk))) continue;
-      unsigned long long first;
-      const float nub = cnt <= 128 ? cc_knn_reduce<2>(buf[jj], cnt, nnk, lane, first) : cc_knn_reduce<4>(buf[jj], cnt, nnk, lane, first);
-      if (lane == 0) {
-        st[jj].ub = nub;
-        st[jj].cnt = nnk;
-        st[jj].tight = 1;
+    // work the queue off in full passes; what is left (< 64 pairs) waits for more
+    if (wn >= 64) {
+      cc_wave_sync();
+      while (wn >= 64) {
+        wn -= 64;
+        cc_knn_tile_pass(L, K, sid, sact, cap, wn, 64, ns, nnk, lane);
       }
+      ubj = L.st[j].ub;
+      tightj = L.st[j].tight;
+      thr = ubj + slack;
     }
-    cc_wave_sync();
-    ubj = st[j].ub;
-    tightj = st[j].tight;
-    thr = ubj + slack;
     // who goes on, in which direction: a search leaves a direction when the step's outermost key lies beyond its own
     // key[0] on that side by more than its radius, or past its visible ranges
     if (any[0]) {
@@ -1049,13 +1113,18 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   }
 #undef CC_KNN_TFETCH
   cc_wave_sync();
+  while (wn > 0) {  // the rest of the queue
+    const int take = wn < 64 ? wn : 64;
+    wn -= take;
+    cc_knn_tile_pass(L, K, sid, sact, cap, wn, take, ns, nnk, lane);
+  }
   for (int jj = 0; jj < ns; jj++) {
-    const int cnt = __builtin_amdgcn_readfirstlane(st[jj].cnt);
+    const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
     unsigned long long first;
     if (cnt <= 128)
-      cc_knn_reduce<2>(buf[jj], cnt, nnk, lane, first);
+      cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
     else
-      cc_knn_reduce<4>(buf[jj], cnt, nnk, lane, first);
+      cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
     const int s_ = order[ll * CC_KNN_ORDER_CAP + base + jj];
     const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
     const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;
