@@ -54,7 +54,9 @@ __device__ __forceinline__ void cc_wave_sync() {
 #ifndef CC_EMU
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #else
-  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  (void)__ballot(1);  // rendezvous of the wave's 64 OS threads (a workgroup may hold several waves)
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
 }
 
@@ -819,30 +821,35 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3, tiled form (cc_db: env CC_KNN_MODE=2): 16 searches per wave, distances on the matrix cores.
+// K3, tiled form (cc_db: env CC_KNN_MODE=2): 16 searches per workgroup of four waves, distances on the matrix cores.
 //
 // The wave-per-search walk evaluates ~15 % of a layer per search whatever the layer's size (the 50-th neighbour in ten
 // dimensions is far in every single one), ~100 vector instructions per 64 keys and search: at a 50 000-scan DB that is
-// 830 M key evaluations per 1 024 queries and 60 % of the step.  Here a wave takes 16 searches that are adjacent in the
-// chunk's key[0] order (cc_k_knn_order) -- their windows of the sorted view nearly coincide -- and walks the union of
-// their windows once, 64 keys per step and direction:
+// 830 M key evaluations per 1 024 queries and 60 % of the step.  Here a workgroup takes 16 searches that are adjacent in
+// the chunk's key[0] order (cc_k_knn_order) -- their windows of the sorted view nearly coincide -- and walks the union
+// of their windows once; per round its four waves take the next two 64-key steps upwards and the next two downwards:
 //   * PREFILTER on v_mfma_f32_16x16x4_f32: with the keys as rows (k_0..k_9, |k|^2, 1) and the searches as columns
 //     (-2 q_0..-2 q_9, 1, |q|^2) three instructions give the 16 x 16 squared distances of a tile, four tiles per step.
 //     The result is a k-ordered fmaf chain, NOT nanoflann's sum, so it only FILTERS: a pair goes on iff its value is
 //     <= the search's current radius + a bound on what the chain can be off by (cc_knn_tile_slack) and the key's index
 //     lies in the search's visible bucket ranges.  Every pair whose reference distance is inside the radius passes;
 //     about 1 % of all pairs do.  The sixteen compares of a step each yield a wave mask; most are empty.
-//   * the pairs that pass are queued in LDS and worked off 64 at a time (one pair per lane, every load independent):
-//     the squared distance in nanoflann's accumulation order, the epoch mask, then the search's candidate buffer and
-//     radius handling -- exactly cc_k_knn's.  A radius that is tightened a few steps late only lets more pairs through.
-// Which keys a search ends up with does not depend on the filter (any superset of the final set gives the same result):
-// hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an 11th row (cc_k_ksort_merge).
+//   * the pairs that pass are queued in LDS (one queue per wave) and worked off by all 256 threads once 256 are pending
+//     (one pair per thread, every load independent): the squared distance in nanoflann's accumulation order, the epoch
+//     mask, then the search's candidate buffer.  A buffer that fills up is cut back to the candidates within its nnk-th
+//     smallest distance (found by bisection on the distance bits with wave ballots -- no sort), which becomes the radius.
+//     A radius that is tightened late only lets more pairs through.
+// Which keys a search ends up with does not depend on the filter (any superset of the final set gives the same result);
+// the final order is (distance, key id): hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an
+// 11th row (cc_k_ksort_merge).
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_TQ 16    // searches per wave = columns of a 16x16x4 tile
-#define CC_KNN_TCAP 256 // candidate buffer per search: <= 2 nnk - 1 kept + 64 from one pass of the queue
-#define CC_KNN_TWL 2176 // queue of filtered pairs: < 64 left over + 2 directions x 1024 pairs of one round
+#define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
+#define CC_KNN_TW 4       // waves per workgroup
+#define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
+#define CC_KNN_TCAP 384   // candidate buffer per search: < CC_KNN_TTRIG kept + 256 from one pass of the queue
+#define CC_KNN_TWL 1280   // queue per wave: < 256 left pending by the whole workgroup + 1024 pairs of one step
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
-static_assert(2 * CC_KNN_MAX - 1 + 64 <= CC_KNN_TCAP, "cc_k_knn_tile: a pass of the queue must fit the candidate buffers");
+static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + 64 * CC_KNN_TW <= CC_KNN_TCAP, "cc_k_knn_tile: buffer bounds");
 
 // |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
 // search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
@@ -853,82 +860,69 @@ __device__ __forceinline__ float cc_knn_tile_slack(float qnorm2, float ub) {
   return s * s * (1.f / 262144.f);
 }
 
-struct cc_knn_tstate {  // per search of a wave
+struct cc_knn_tstate {  // per search of a workgroup
   float ub;
   int cnt, tight;
 };
 struct cc_knn_tlds {
   unsigned long long buf[CC_KNN_TQ][CC_KNN_TCAP];
-  unsigned wl[CC_KNN_TWL];          // (search << 28) | sorted index
-  float qk[CC_KNN_TQ][CC_KEY_DIM];  // the searches' keys, for the lanes that work off other searches' pairs
-  int qb[CC_KNN_TQ][5];             // L0, E1, S2, E2 (visible index ranges), then the epoch
+  unsigned wl[CC_KNN_TW][CC_KNN_TWL];  // (search << 28) | sorted index
+  float qk[CC_KNN_TQ][CC_KEY_DIM];     // the searches' keys, for the threads that work off other searches' pairs
+  int qb[CC_KNN_TQ][6];                // L0, E1, S2, E2 (visible index ranges), the epoch, the search's own position
   cc_knn_tstate st[CC_KNN_TQ];
+  int wn[CC_KNN_TW];                   // pairs pending in each wave's queue
+  int any[2];                          // some search still walks upwards / downwards
 };
 
-// Work off the last `take` (<= 64) pairs of the queue: exact distance, epoch mask, candidate buffers; then keep the best
-// nnk of every search whose buffer has filled up.
-__device__ __forceinline__ void cc_knn_tile_pass(cc_knn_tlds &L, const float *__restrict__ K, const int *__restrict__ sid,
-                                                 const int *__restrict__ sact, size_t cap, int from, int take, int ns, int nnk, int lane) {
-  if (lane < take) {
-    const unsigned ent = L.wl[from + lane];
-    const int js = (int)(ent >> 28);
-    const unsigned u_ = ent & 0x0FFFFFFFu;
-    const int act = sact[u_];
-    const int kid = sid[u_];
-    float c[CC_KEY_DIM];
+// Cut a search's buffer back to the candidates within its nnk-th smallest distance; returns that distance and the number
+// kept (>= nnk: ties at the distance stay, the final order by key id decides among them).  One wave, cnt <= 64 * R.
+template <int R>
+__device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt, int nnk, int lane, int &kept) {
+  unsigned long long v[R];
+  unsigned d[R];
+  cc_wave_sync();
 #pragma unroll
-    for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + u_];
-    const float *k = L.qk[js];
-    // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-    float r_ = 0.f;
-    float d0 = k[0] - c[0], d1 = k[1] - c[1], d2 = k[2] - c[2], d3 = k[3] - c[3];
-    r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-    d0 = k[4] - c[4];
-    d1 = k[5] - c[5];
-    d2 = k[6] - c[6];
-    d3 = k[7] - c[7];
-    r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-    d0 = k[8] - c[8];
-    r_ += d0 * d0;
-    d0 = k[9] - c[9];
-    r_ += d0 * d0;
-    const float ub = L.st[js].ub;
-    // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best distance
-    // still compete, on the key id
-    if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
-      const int slot = atomicAdd(&L.st[js].cnt, 1);
-      L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
-    }
+  for (int a = 0; a < R; a++) {
+    v[a] = (a * 64 + lane < cnt) ? buf[a * 64 + lane] : ~0ull;
+    d[a] = (unsigned)(v[a] >> 32);  // squared distances are >= 0: their bit patterns order like the values
+  }
+  unsigned lo = 0u, hi = 0x7F800000u;  // smallest x with #(d <= x) >= nnk
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+#pragma unroll
+    for (int a = 0; a < R; a++) c += __popcll(__ballot(d[a] <= mid));
+    if (c >= nnk)
+      hi = mid;
+    else
+      lo = mid + 1u;
   }
   cc_wave_sync();
-  for (int jj = 0; jj < ns; jj++) {
-    const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
-    const int tight = __builtin_amdgcn_readfirstlane(L.st[jj].tight);
-    if (!(cnt >= 2 * nnk || (!tight && cnt >= nnk))) continue;
-    unsigned long long first;
-    const float nub = cnt <= 128 ? cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first) : cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
-    if (lane == 0) {
-      L.st[jj].ub = nub;
-      L.st[jj].cnt = nnk;
-      L.st[jj].tight = 1;
-    }
+  int off = 0;
+#pragma unroll
+  for (int a = 0; a < R; a++) {
+    const bool keep = d[a] <= lo;
+    const unsigned long long m = __ballot(keep);
+    if (keep) buf[off + __popcll(m & ((1ull << lane) - 1ull))] = v[a];
+    off += __popcll(m);
   }
-  cc_wave_sync();
+  kept = off;
+  return __uint_as_float(lo);
 }
 
-// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64
-__global__ void __launch_bounds__(64)
+// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64 * CC_KNN_TW
+__global__ void __launch_bounds__(64 * CC_KNN_TW)
 cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
               const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
   __shared__ cc_knn_tlds L;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nblk = (nq * CC_NPIV + CC_KNN_TQ - 1) / CC_KNN_TQ;
   const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
   if (ll >= P.n_q_levels) return;
   const int nv = n_valid[ll];
   const int base = w * CC_KNN_TQ;
   if (base >= nv) return;
-  const int ns = nv - base < CC_KNN_TQ ? nv - base : CC_KNN_TQ;  // searches of this wave
+  const int ns = nv - base < CC_KNN_TQ ? nv - base : CC_KNN_TQ;  // searches of this workgroup
   const int level = P.q_levels[ll];
   const int n = P.n_sorted[ll];
   const float *K = P.skeys[ll];
@@ -937,6 +931,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   const size_t cap = (size_t)P.cap_k;
   const int nnk = P.nnk;
   const int j = lane & 15, kq = lane >> 4;  // this lane's search (column) and its k-slice of every 4-wide MFMA step
+  const int dir = wave >> 1, sub = wave & 1;  // this wave's direction and which of the round's two steps it takes
 
   // ---- this lane's search: key, dist_ub, epoch, bucket thresholds (cc_k_knn); padding columns repeat search 0
   const int srch = order[ll * CC_KNN_ORDER_CAP + base + (j < ns ? j : 0)];
@@ -973,9 +968,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     if (4 * s + kq == 11) v = qn2;
     bop[s] = v;
   }
-  // index boundaries: lane (j, kq) finds lb(target kq) of search j, kq = 0..3 -> rg[0], t_e1, t_s2, rg[6]; a second pass
-  // (lanes kq == 0) finds lb(key[0]).  lb(t) = number of keys with key[0] < t.
-  {
+  // index boundaries lb(t) = number of keys with key[0] < t: wave 0, lane (j, kq) -> target kq of search j (rg[0], t_e1,
+  // t_s2, rg[6]); wave 1, lanes kq == 0 -> the search's own key[0]
+  if (wave < 2) {
     float rg[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) rg[i] = qm->ranges[ll][i];
@@ -995,82 +990,81 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       if (i == mid + 1) t_e1 = rg[i];
       if (i == 2 * mid + 1) t_s2 = rg[i];
     }
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const float tg = pass ? k[0] : (kq == 0 ? rg[0] : kq == 1 ? t_e1 : kq == 2 ? t_s2 : rg[6]);
-      int lo = 0, hi = (pass && kq != 0) ? 0 : n;
-      while (lo < hi) {
-        const int m_ = (lo + hi) >> 1;
-        if (K[m_] < tg)
-          lo = m_ + 1;
-        else
-          hi = m_;
-      }
-      if (!pass)
-        L.qb[j][kq] = lo;
-      else if (kq == 0)
-        L.qb[j][4] = lo;  // the search's own position, replaced by the epoch below
+    const float tg = wave ? k[0] : (kq == 0 ? rg[0] : kq == 1 ? t_e1 : kq == 2 ? t_s2 : rg[6]);
+    int lo = 0, hi = (wave && kq != 0) ? 0 : n;
+    while (lo < hi) {
+      const int m_ = (lo + hi) >> 1;
+      if (K[m_] < tg)
+        lo = m_ + 1;
+      else
+        hi = m_;
     }
+    if (!wave)
+      L.qb[j][kq] = lo;
+    else if (kq == 0)
+      L.qb[j][5] = lo;
+  } else if (wave == 2) {
     if (kq == 0) {
       L.st[j].ub = ub0;
       L.st[j].cnt = 0;
       L.st[j].tight = 0;
+      L.qb[j][4] = qm->epoch;
 #pragma unroll
       for (int d = 0; d < CC_KEY_DIM; d++) L.qk[j][d] = k[d];
     }
+  } else if (lane < CC_KNN_TW) {
+    L.wn[lane] = 0;
   }
-  cc_wave_sync();
+  __syncthreads();
   const int L0 = L.qb[j][0], E1 = L.qb[j][1], S2 = L.qb[j][2], E2 = L.qb[j][3];
-  const int p0 = __builtin_amdgcn_readfirstlane(L.qb[0][4]);  // search 0's own position splits the walk
-  cc_wave_sync();
-  if (kq == 0) L.qb[j][4] = qm->epoch;
-  cc_wave_sync();
+  const int p0 = __builtin_amdgcn_readfirstlane(L.qb[0][5]);  // search 0's own position splits the walk
   const bool valid = j < ns;
   float ubj = ub0;
   int tightj = 0;
   const float slack = cc_knn_tile_slack(qn2, ub0);
   float thr = ubj + slack;
 
-  // ---- the common walk: upwards over [p0, n), downwards over [0, p0), 64 keys per step
-  bool open_up = valid && p0 < E2 && p0 < n;
-  bool open_dn = valid && p0 > L0 && p0 > 0;
-  bool any[2] = {__ballot(open_up) != 0ull, __ballot(open_dn) != 0ull};
-  int sbase[2] = {p0, p0 - 64};  // first index of the current step of each direction (ascending inside a step)
-  int wn = 0;                    // pairs in the queue (wave-uniform)
-  float a[2][4][3];              // A operand of the fetched step: tile t = keys sbase + 16 t + (lane & 15), element 4 s + kq
-#define CC_KNN_TFETCH(dir)                                                                             \
-  {                                                                                                    \
-    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                    \
-      int i_ = sbase[dir] + 16 * t + j;                                                                \
-      i_ = i_ < 0 ? 0 : (i_ >= n ? n - 1 : i_);                                                        \
-      _Pragma("unroll") for (int s = 0; s < 3; s++) {                                                  \
-        const int row_ = 4 * s + kq; /* 0..9 key dims, 10 = |k|^2, 11 = the constant 1 */             \
-        a[dir][t][s] = row_ < CC_KEY_DIM + 1 ? K[(size_t)row_ * cap + (unsigned)i_] : 1.f;             \
-      }                                                                                                \
-    }                                                                                                  \
+  // ---- the common walk: upwards over [p0, n), downwards over [0, p0); round r: this wave takes step 2 r + sub of its direction
+  bool open_d = valid && (dir == 0 ? (p0 < E2 && p0 < n) : (p0 > L0 && p0 > 0));  // this lane's search, this wave's direction
+  {
+    const bool any_d = __ballot(open_d) != 0ull;
+    if (sub == 0 && lane == 0) L.any[dir] = any_d ? 1 : 0;
   }
-  if (any[0]) CC_KNN_TFETCH(0)
-  if (any[1]) CC_KNN_TFETCH(1)
-  while (any[0] || any[1]) {
-    float far0[2] = {0.f, 0.f};
-    int nxt[2] = {0, 0};
-#pragma unroll
-    for (int dir = 0; dir < 2; dir++) {
-      if (!any[dir]) continue;  // wave-uniform
-      const int sb = sbase[dir];
+  __syncthreads();
+  int sb = dir == 0 ? p0 + 64 * sub : p0 - 64 * (sub + 1);  // first index of this wave's current step (ascending inside a step)
+  int wn = 0;                                              // pairs pending in this wave's queue (wave-uniform)
+  float a[4][3];  // A operand of the fetched step: tile t = keys sb + 16 t + (lane & 15), element 4 s + kq
+#define CC_KNN_TFETCH()                                                                              \
+  {                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                  \
+      int i_ = sb + 16 * t + j;                                                                      \
+      i_ = i_ < 0 ? 0 : (i_ >= n ? n - 1 : i_);                                                      \
+      _Pragma("unroll") for (int s = 0; s < 3; s++) {                                                \
+        const int row_ = 4 * s + kq; /* 0..9 key dims, 10 = |k|^2, 11 = the constant 1 */           \
+        a[t][s] = row_ < CC_KEY_DIM + 1 ? K[(size_t)row_ * cap + (unsigned)i_] : 1.f;                \
+      }                                                                                              \
+    }                                                                                                \
+  }
+  bool mine = L.any[dir] != 0;  // wave-uniform: this wave's direction is still being walked
+  if (mine) CC_KNN_TFETCH()
+  while (true) {
+    float far0 = 0.f;
+    int nxt = 0;
+    if (mine) {
+      const int sb_cur = sb;
       cc_f32x4 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; t++) acc[t] = (cc_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[dir][t][s], bop[s], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], bop[s], acc[t], 0, 0, 0);
       // the step's outermost key[0] (row 0 lives in the lanes kq == 0, element s = 0): upwards the last key, downwards the first
-      far0[dir] = dir == 0 ? cc_lane_bcast(a[0][3][0], 15) : cc_lane_bcast(a[1][0][0], 0);
-      // the next step's keys travel while this step's pairs are filtered
-      sbase[dir] += dir == 0 ? 64 : -64;
-      nxt[dir] = sbase[dir];
-      CC_KNN_TFETCH(dir)
+      far0 = dir == 0 ? cc_lane_bcast(a[3][0], 15) : cc_lane_bcast(a[0][0], 0);
+      // the next round's keys travel while this step's pairs are filtered
+      sb += dir == 0 ? 128 : -128;
+      nxt = dir == 0 ? sb_cur + 64 : sb_cur - 64;  // where the walk of this direction would go on after this step
+      CC_KNN_TFETCH()
       // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack, key inside the search's visible index ranges
 #pragma unroll
       for (int t = 0; t < 4; t++)
@@ -1078,53 +1072,148 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
         for (int r = 0; r < 4; r++) {
           const bool hit = acc[t][r] <= thr;
           if (__ballot(hit) == 0ull) continue;  // wave-uniform: most of the sixteen masks are empty
-          const int idx = sb + 16 * t + 4 * kq + r;
+          const int idx = sb_cur + 16 * t + 4 * kq + r;
           const bool push = hit && valid && idx >= 0 && idx < n && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2));
           const unsigned long long mk = __ballot(push);
-          if (push) L.wl[wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)idx;
+          if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)idx;
           wn += __popcll(mk);
         }
+      if (lane == 0) L.wn[wave] = wn;
     }
-    // work the queue off in full passes; what is left (< 64 pairs) waits for more
-    if (wn >= 64) {
-      cc_wave_sync();
-      while (wn >= 64) {
-        wn -= 64;
-        cc_knn_tile_pass(L, K, sid, sact, cap, wn, 64, ns, nnk, lane);
+    __syncthreads();
+    // ---- the queues: worked off by everybody once 256 pairs are pending
+    int c0 = L.wn[0], c1 = L.wn[1], c2 = L.wn[2], c3 = L.wn[3];
+    if (c0 + c1 + c2 + c3 >= 64 * CC_KNN_TW) {
+      const int tot = c0 + c1 + c2 + c3;
+      for (int e0 = 0; e0 < tot; e0 += 64 * CC_KNN_TW) {
+        const int e = e0 + tid;
+        if (e < tot) {
+          const unsigned ent = e < c0 ? L.wl[0][e] : e < c0 + c1 ? L.wl[1][e - c0] : e < c0 + c1 + c2 ? L.wl[2][e - c0 - c1] : L.wl[3][e - c0 - c1 - c2];
+          const int js = (int)(ent >> 28);
+          const unsigned u_ = ent & 0x0FFFFFFFu;
+          const int act = sact[u_];
+          const int kid = sid[u_];
+          float c[CC_KEY_DIM];
+#pragma unroll
+          for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + u_];
+          const float *kk = L.qk[js];
+          // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
+          float r_ = 0.f;
+          float d0 = kk[0] - c[0], d1 = kk[1] - c[1], d2 = kk[2] - c[2], d3 = kk[3] - c[3];
+          r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          d0 = kk[4] - c[4];
+          d1 = kk[5] - c[5];
+          d2 = kk[6] - c[6];
+          d3 = kk[7] - c[7];
+          r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          d0 = kk[8] - c[8];
+          r_ += d0 * d0;
+          d0 = kk[9] - c[9];
+          r_ += d0 * d0;
+          const float ub = L.st[js].ub;
+          // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
+          // distance still compete, on the key id
+          if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
+            const int slot = atomicAdd(&L.st[js].cnt, 1);
+            L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
+          }
+        }
+        __syncthreads();
+        // cut back the buffers that filled up: wave w looks after the searches w, w + 4, ...
+        for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
+          const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
+          const int tight = __builtin_amdgcn_readfirstlane(L.st[jj].tight);
+          if (!(cnt >= CC_KNN_TTRIG || (!tight && cnt >= nnk))) continue;
+          int kept;
+          float nub = cnt <= 128 ? cc_knn_select<2>(L.buf[jj], cnt, nnk, lane, kept)
+                    : cnt <= 256 ? cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<6>(L.buf[jj], cnt, nnk, lane, kept);
+          if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
+                            // in the result -- order them and drop the rest, so that the buffer bound holds
+            unsigned long long first;
+            nub = kept <= 128 ? cc_knn_reduce<2>(L.buf[jj], kept, nnk, lane, first)
+                : kept <= 256 ? cc_knn_reduce<4>(L.buf[jj], kept, nnk, lane, first) : cc_knn_reduce<8>(L.buf[jj], kept, nnk, lane, first);
+            kept = nnk;
+          }
+          if (lane == 0) {
+            L.st[jj].ub = nub;
+            L.st[jj].cnt = kept;
+            L.st[jj].tight = 1;
+          }
+        }
+        __syncthreads();
       }
+      wn = 0;
+      if (lane == 0) L.wn[wave] = 0;
       ubj = L.st[j].ub;
       tightj = L.st[j].tight;
       thr = ubj + slack;
     }
-    // who goes on, in which direction: a search leaves a direction when the step's outermost key lies beyond its own
+    // ---- who goes on: a search leaves a direction when the outermost key of the round's further step lies beyond its own
     // key[0] on that side by more than its radius, or past its visible ranges
-    if (any[0]) {
-      const float e = k[0] - far0[0];
-      const bool out = (e < 0.f) && (tightj ? (e * e > ubj) : (e * e >= ubj));
-      open_up = open_up && !out && nxt[0] < E2 && nxt[0] < n;
-      any[0] = __ballot(open_up) != 0ull;
+    if (mine && sub == 1) {
+      const float e = k[0] - far0;
+      const bool beyond = dir == 0 ? (e < 0.f) : (e > 0.f);
+      const bool out = beyond && (tightj ? (e * e > ubj) : (e * e >= ubj));
+      const bool more = dir == 0 ? (nxt < E2 && nxt < n) : (nxt + 64 > L0 && nxt + 64 > 0);
+      open_d = open_d && !out && more;
+      const bool any_d = __ballot(open_d) != 0ull;
+      if (lane == 0) L.any[dir] = any_d ? 1 : 0;
     }
-    if (any[1]) {
-      const float e = k[0] - far0[1];
-      const bool out = (e > 0.f) && (tightj ? (e * e > ubj) : (e * e >= ubj));
-      open_dn = open_dn && !out && nxt[1] + 64 > L0 && nxt[1] + 64 > 0;
-      any[1] = __ballot(open_dn) != 0ull;
-    }
+    __syncthreads();
+    mine = L.any[dir] != 0;
+    if (!(L.any[0] | L.any[1])) break;
   }
 #undef CC_KNN_TFETCH
-  cc_wave_sync();
-  while (wn > 0) {  // the rest of the queue
-    const int take = wn < 64 ? wn : 64;
-    wn -= take;
-    cc_knn_tile_pass(L, K, sid, sact, cap, wn, take, ns, nnk, lane);
+  // ---- the rest of the queues (fewer than 256 pairs): as above
+  {
+    int c0 = L.wn[0], c1 = L.wn[1], c2 = L.wn[2], c3 = L.wn[3];
+    const int tot = c0 + c1 + c2 + c3;
+    if (tid < tot) {
+      const int e = tid;
+      const unsigned ent = e < c0 ? L.wl[0][e] : e < c0 + c1 ? L.wl[1][e - c0] : e < c0 + c1 + c2 ? L.wl[2][e - c0 - c1] : L.wl[3][e - c0 - c1 - c2];
+      const int js = (int)(ent >> 28);
+      const unsigned u_ = ent & 0x0FFFFFFFu;
+      const int act = sact[u_];
+      const int kid = sid[u_];
+      float c[CC_KEY_DIM];
+#pragma unroll
+      for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + u_];
+      const float *kk = L.qk[js];
+      float r_ = 0.f;
+      float d0 = kk[0] - c[0], d1 = kk[1] - c[1], d2 = kk[2] - c[2], d3 = kk[3] - c[3];
+      r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      d0 = kk[4] - c[4];
+      d1 = kk[5] - c[5];
+      d2 = kk[6] - c[6];
+      d3 = kk[7] - c[7];
+      r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      d0 = kk[8] - c[8];
+      r_ += d0 * d0;
+      d0 = kk[9] - c[9];
+      r_ += d0 * d0;
+      const float ub = L.st[js].ub;
+      if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
+        const int slot = atomicAdd(&L.st[js].cnt, 1);
+        L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
+      }
+    }
   }
-  for (int jj = 0; jj < ns; jj++) {
-    const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
+  __syncthreads();
+  // ---- results: the nnk best by (distance, key id); wave w writes the searches w, w + 4, ...
+  for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
+    int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
+    if (cnt > 128) {  // ties aside, what is within the nnk-th distance fits the sorting network
+      int kept;
+      cnt <= 256 ? cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<6>(L.buf[jj], cnt, nnk, lane, kept);
+      cnt = kept;
+    }
     unsigned long long first;
     if (cnt <= 128)
       cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
-    else
+    else if (cnt <= 256)
       cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
+    else
+      cc_knn_reduce<8>(L.buf[jj], cnt, nnk, lane, first);
     const int s_ = order[ll * CC_KNN_ORDER_CAP + base + jj];
     const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
     const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;
@@ -1139,6 +1228,5 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       hits[(size_t)slot * CC_KNN_MAX + lane] = h;
     }
     if (lane == 0) hit_cnt[slot] = mm;
-    cc_wave_sync();
   }
 }
