@@ -65,6 +65,12 @@ struct cc_ctx {
   hipStream_t last_stream = nullptr;
   bool has_last = false;
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
+  // the per-scan loop (cc_scan_*): own stream, pinned + device point staging, a pool of device descriptor slots
+  hipStream_t s_loop = nullptr;
+  float *h_pts = nullptr, *d_pts = nullptr;
+  int64_t pts_cap = 0;  // points
+  std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
+  float *d_loop_bev = nullptr;
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
   // optional per-kernel timing (cc_profile_*)
@@ -242,6 +248,14 @@ int cc_destroy(cc_ctx *c) {
   }
   if (c->ev_last) hipEventDestroy(c->ev_last);
   hipFree(c->d_phase_clk);
+  if (c->s_loop) {
+    hipStreamSynchronize(c->s_loop);
+    hipStreamDestroy(c->s_loop);
+  }
+  if (c->h_pts) hipHostFree(c->h_pts);
+  hipFree(c->d_pts);
+  hipFree(c->d_loop_bev);
+  for (auto *b : c->slot_blocks) hipFree(b);
   delete c;
   return CC_OK;
 }
@@ -362,6 +376,147 @@ void cc_est_sens_tf(const double tf_bev[3], int n_row, int n_col, double tf_sens
   tf_sens[0] = c * ox - s * oy + tf_bev[0] - ox;
   tf_sens[1] = s * ox + c * oy + tf_bev[1] - oy;
   tf_sens[2] = tf_bev[2];
+}
+
+// ------------------------------------------------------------------------------------------ per-scan loop
+struct cc_scan {
+  cc_ctx *ctx = nullptr;
+  cc_scan_desc_t *d_desc = nullptr;  // device slot (nullptr once offloaded)
+  cc_scan_desc_t *h_desc = nullptr;  // host copy (malloc), fetched on demand
+  float *h_bev = nullptr;            // host copy of the max-height image, if it was asked for
+  bool bev_pending = false;
+};
+
+static int loop_reserve_points(cc_ctx *c, int64_t n_points) {
+  if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
+  if (n_points <= c->pts_cap) return CC_OK;
+  HIPCHK(hipStreamSynchronize(c->s_loop));
+  if (c->h_pts) hipHostFree(c->h_pts);
+  hipFree(c->d_pts);
+  c->h_pts = c->d_pts = nullptr;
+  c->pts_cap = 0;
+  const int64_t cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
+  HIPCHK(hipHostMalloc((void **)&c->h_pts, sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&c->d_pts, sizeof(float) * 4 * (size_t)cap));
+  c->pts_cap = cap;
+  return CC_OK;
+}
+
+float *cc_stage_points(cc_ctx *c, int64_t n_points) {
+  if (!c || n_points < 1) return nullptr;
+  if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+  // the previous scan's H2D copy may still read the buffer
+  if (c->s_loop && hipStreamSynchronize(c->s_loop) != hipSuccess) return nullptr;
+  if (loop_reserve_points(c, n_points) != CC_OK) return nullptr;
+  return c->h_pts;
+}
+
+int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out) {
+  if (!c || !h_xyzi || !out || n_points < 1) return set_err(CC_EINVAL, "cc_scan_ingest: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (h_xyzi != c->h_pts) {
+    if (c->s_loop) HIPCHK(hipStreamSynchronize(c->s_loop));  // the staging buffer is about to be overwritten
+    int rc = loop_reserve_points(c, n_points);
+    if (rc != CC_OK) return rc;
+    memcpy(c->h_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_points);
+  } else if (n_points > c->pts_cap) {
+    return set_err(CC_EINVAL, "cc_scan_ingest: more points than were staged");
+  }
+  if (c->slot_free.empty()) {
+    const int nblk = 64;
+    cc_scan_desc_t *blk = nullptr;
+    HIPCHK(hipMalloc(&blk, sizeof(cc_scan_desc_t) * nblk));
+    c->slot_blocks.push_back(blk);
+    for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
+  }
+  if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
+  cc_scan *sc = new cc_scan();
+  sc->ctx = c;
+  sc->d_desc = c->slot_free.back();
+  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
+  const int64_t off[2] = {0, n_points};
+  cc_ingest_debug_t dbg;
+  dbg.d_bev = want_bev ? c->d_loop_bev : nullptr;
+  dbg.d_pix_rc = nullptr;
+  dbg.d_labels = nullptr;
+  const int rc = cc_ingest_batch(c, c->d_pts, off, 1, sc->d_desc, want_bev ? &dbg : nullptr, c->s_loop);
+  if (rc != CC_OK) {
+    delete sc;
+    return rc;
+  }
+  c->slot_free.pop_back();
+  if (want_bev) {  // the image scratch is shared: bring it over now (asynchronously, into the handle's own buffer)
+    sc->h_bev = (float *)malloc(sizeof(float) * (size_t)c->dcfg.n_cell);
+    if (!sc->h_bev) {
+      c->slot_free.push_back(sc->d_desc);
+      delete sc;
+      return set_err(CC_ENOMEM, "cc_scan_ingest: out of host memory");
+    }
+    HIPCHK(hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_loop));
+    sc->bev_pending = true;
+  }
+  *out = sc;
+  return CC_OK;
+}
+
+static int scan_fetch(cc_scan *sc) {
+  if (sc->h_desc) return CC_OK;
+  if (!sc->d_desc) return set_err(CC_EINVAL, "cc_scan: the descriptor is neither on the device nor on the host");
+  sc->h_desc = (cc_scan_desc_t *)malloc(sizeof(cc_scan_desc_t));
+  if (!sc->h_desc) return set_err(CC_ENOMEM, "cc_scan: out of host memory");
+  HIPCHK(hipSetDevice(sc->ctx->device));
+  HIPCHK(hipMemcpyAsync(sc->h_desc, sc->d_desc, sizeof(cc_scan_desc_t), hipMemcpyDeviceToHost, sc->ctx->s_loop));
+  HIPCHK(hipStreamSynchronize(sc->ctx->s_loop));
+  sc->bev_pending = false;
+  return CC_OK;
+}
+
+int cc_scan_desc(cc_scan *sc, const cc_scan_desc_t **h_desc) {
+  if (!sc || !h_desc) return set_err(CC_EINVAL, "cc_scan_desc: bad argument");
+  const int rc = scan_fetch(sc);
+  if (rc != CC_OK) return rc;
+  *h_desc = sc->h_desc;
+  if (sc->h_desc->flags & (CC_DESC_INEXACT_COMPONENTS | CC_DESC_INEXACT_KEYS))
+    return set_err(CC_ECAPACITY, "cc_scan_desc: the scan exceeds a fixed capacity of the contour kernel (more than CC_MAXC components on a "
+                                 "level, or an over-full key RoI): its descriptor is not exact");
+  return CC_OK;
+}
+
+int cc_scan_bev(cc_scan *sc, const float **h_bev) {
+  if (!sc || !h_bev) return set_err(CC_EINVAL, "cc_scan_bev: bad argument");
+  if (!sc->h_bev) return set_err(CC_EINVAL, "cc_scan_bev: the image was not asked for at cc_scan_ingest");
+  if (sc->bev_pending) {
+    HIPCHK(hipSetDevice(sc->ctx->device));
+    HIPCHK(hipStreamSynchronize(sc->ctx->s_loop));
+    sc->bev_pending = false;
+  }
+  *h_bev = sc->h_bev;
+  return CC_OK;
+}
+
+int cc_scan_offload(cc_scan *sc) {
+  if (!sc) return set_err(CC_EINVAL, "cc_scan_offload: bad argument");
+  if (!sc->d_desc) return CC_OK;
+  const int rc = scan_fetch(sc);
+  if (rc != CC_OK) return rc;
+  sc->ctx->slot_free.push_back(sc->d_desc);  // reuse is ordered behind everything queued on the loop stream so far
+  sc->d_desc = nullptr;
+  return CC_OK;
+}
+
+int cc_scan_on_device(const cc_scan *sc) { return sc && sc->d_desc ? 1 : 0; }
+
+int cc_scan_release(cc_scan *sc) {
+  if (!sc) return CC_OK;
+  if (sc->d_desc || sc->bev_pending) {
+    hipSetDevice(sc->ctx->device);
+    if (sc->ctx->s_loop) hipStreamSynchronize(sc->ctx->s_loop);  // queued work may still read the slot / write the image
+    if (sc->d_desc) sc->ctx->slot_free.push_back(sc->d_desc);
+  }
+  free(sc->h_desc);
+  free(sc->h_bev);
+  delete sc;
+  return CC_OK;
 }
 
 #include "cc_db_api.inc"

@@ -985,7 +985,7 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
 __global__ void __launch_bounds__(64)
 cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
            const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
-           cc_query_result_t *__restrict__ out) {
+           const cc_hot_desc_t *__restrict__ qhot, cc_query_result_t *__restrict__ out) {
   // one wave per query: lanes fetch the per-candidate inputs in parallel, lane 0 replays the order-dependent part on LDS
   __shared__ unsigned short idx[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
@@ -1029,7 +1029,8 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   r.cand_aft_check3 = pass_cnt[q * 4 + 3];
   r.n_cand_pose = nc;
   r.n_knn_hits = s_tot;
-  r.flags = (pass_cnt[q * 4 + 0] & CC_QF_CHECK_CAP) | ((gfl & 1) ? CC_QF_GMM_CAP : 0) | ((gfl & 4) ? CC_QF_DESC_CAP : 0);
+  r.flags = (pass_cnt[q * 4 + 0] & CC_QF_CHECK_CAP) | ((gfl & 1) ? CC_QF_GMM_CAP : 0) | ((gfl & 4) ? CC_QF_DESC_CAP : 0) |
+            ((qhot[q].flags & (CC_DESC_INEXACT_COMPONENTS | CC_DESC_INEXACT_KEYS)) ? CC_QF_QUERY_INEXACT : 0);
   r.pad_ = 0;
   // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592
   int p1 = 0, p2 = nc - 1;

@@ -846,10 +846,14 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
 #define CC_KNN_TW 4       // waves per workgroup
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
-#define CC_KNN_TCAP 384   // candidate buffer per search: < CC_KNN_TTRIG kept + 256 from one pass of the queue
-#define CC_KNN_TWL 1280   // queue per wave: < 256 left pending by the whole workgroup + 1024 pairs of one step
+#define CC_KNN_TPASS 128  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one
+#define CC_KNN_TCAP 256   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
+#define CC_KNN_TWL 1216   // queue per wave: < CC_KNN_TPASS left pending by the whole workgroup + 1024 pairs of one step
+// LDS: 32 KB of buffers + 19 KB of queues + 1.3 KB: three workgroups per CU, so the 576 workgroups of a 512-query chunk
+// (3 layers x 192) are resident at once
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
-static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + 64 * CC_KNN_TW <= CC_KNN_TCAP, "cc_k_knn_tile: buffer bounds");
+static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS - 1 + 1024 <= CC_KNN_TWL &&
+                  CC_KNN_TPASS <= 64 * CC_KNN_TW, "cc_k_knn_tile: buffer bounds");
 
 // |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
 // search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
@@ -870,8 +874,9 @@ struct cc_knn_tlds {
   float qk[CC_KNN_TQ][CC_KEY_DIM];     // the searches' keys, for the threads that work off other searches' pairs
   int qb[CC_KNN_TQ][6];                // L0, E1, S2, E2 (visible index ranges), the epoch, the search's own position
   cc_knn_tstate st[CC_KNN_TQ];
-  int wn[CC_KNN_TW];                   // pairs pending in each wave's queue
-  int any[2];                          // some search still walks upwards / downwards
+  // per round parity (a wave may be one round ahead of another between two barriers):
+  int wn[2][CC_KNN_TW];                // pairs pending in each wave's queue
+  int go[2][CC_KNN_TW];                // the wave's sub-walk (every other step of its direction) still has a search to serve
 };
 
 // Cut a search's buffer back to the candidates within its nnk-th smallest distance; returns that distance and the number
@@ -1012,8 +1017,6 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
 #pragma unroll
       for (int d = 0; d < CC_KEY_DIM; d++) L.qk[j][d] = k[d];
     }
-  } else if (lane < CC_KNN_TW) {
-    L.wn[lane] = 0;
   }
   __syncthreads();
   const int L0 = L.qb[j][0], E1 = L.qb[j][1], S2 = L.qb[j][2], E2 = L.qb[j][3];
@@ -1024,15 +1027,14 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   const float slack = cc_knn_tile_slack(qn2, ub0);
   float thr = ubj + slack;
 
-  // ---- the common walk: upwards over [p0, n), downwards over [0, p0); round r: this wave takes step 2 r + sub of its direction
+  // ---- the common walk: upwards over [p0, n), downwards over [0, p0).  Each wave walks every other 64-key step of its
+  // direction (steps sub, sub + 2, ...) and stops on its own: once the outermost key of ITS step lies beyond a search's
+  // radius (or past its ranges) so does everything further out.  One barrier per round.
   bool open_d = valid && (dir == 0 ? (p0 < E2 && p0 < n) : (p0 > L0 && p0 > 0));  // this lane's search, this wave's direction
-  {
-    const bool any_d = __ballot(open_d) != 0ull;
-    if (sub == 0 && lane == 0) L.any[dir] = any_d ? 1 : 0;
-  }
-  __syncthreads();
   int sb = dir == 0 ? p0 + 64 * sub : p0 - 64 * (sub + 1);  // first index of this wave's current step (ascending inside a step)
-  int wn = 0;                                              // pairs pending in this wave's queue (wave-uniform)
+  if (sub == 1) open_d = open_d && (dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0));
+  bool mine = __ballot(open_d) != 0ull;  // wave-uniform
+  int wn = 0;                            // pairs pending in this wave's queue (wave-uniform)
   float a[4][3];  // A operand of the fetched step: tile t = keys sb + 16 t + (lane & 15), element 4 s + kq
 #define CC_KNN_TFETCH()                                                                              \
   {                                                                                                  \
@@ -1045,11 +1047,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       }                                                                                              \
     }                                                                                                \
   }
-  bool mine = L.any[dir] != 0;  // wave-uniform: this wave's direction is still being walked
   if (mine) CC_KNN_TFETCH()
-  while (true) {
-    float far0 = 0.f;
-    int nxt = 0;
+  for (int par = 0;; par ^= 1) {
     if (mine) {
       const int sb_cur = sb;
       cc_f32x4 acc[4];
@@ -1060,10 +1059,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], bop[s], acc[t], 0, 0, 0);
       // the step's outermost key[0] (row 0 lives in the lanes kq == 0, element s = 0): upwards the last key, downwards the first
-      far0 = dir == 0 ? cc_lane_bcast(a[3][0], 15) : cc_lane_bcast(a[0][0], 0);
-      // the next round's keys travel while this step's pairs are filtered
+      const float far0 = dir == 0 ? cc_lane_bcast(a[3][0], 15) : cc_lane_bcast(a[0][0], 0);
+      // the wave's next step travels while this one's pairs are filtered
       sb += dir == 0 ? 128 : -128;
-      nxt = dir == 0 ? sb_cur + 64 : sb_cur - 64;  // where the walk of this direction would go on after this step
       CC_KNN_TFETCH()
       // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack, key inside the search's visible index ranges
 #pragma unroll
@@ -1078,16 +1076,31 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)idx;
           wn += __popcll(mk);
         }
-      if (lane == 0) L.wn[wave] = wn;
+      // who goes on with this wave: a search leaves when the step's outermost key lies beyond its own key[0] on that side by
+      // more than its radius (the radius may be a pass old: then it only leaves later), or when the wave's next step is past
+      // its visible ranges
+      {
+        const float e = k[0] - far0;
+        const bool beyond = dir == 0 ? (e < 0.f) : (e > 0.f);
+        const bool out = beyond && (tightj ? (e * e > ubj) : (e * e >= ubj));
+        const bool more = dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0);
+        open_d = open_d && !out && more;
+        mine = __ballot(open_d) != 0ull;
+      }
+    }
+    if (lane == 0) {
+      L.wn[par][wave] = wn;
+      L.go[par][wave] = mine ? 1 : 0;
     }
     __syncthreads();
-    // ---- the queues: worked off by everybody once 256 pairs are pending
-    int c0 = L.wn[0], c1 = L.wn[1], c2 = L.wn[2], c3 = L.wn[3];
-    if (c0 + c1 + c2 + c3 >= 64 * CC_KNN_TW) {
-      const int tot = c0 + c1 + c2 + c3;
-      for (int e0 = 0; e0 < tot; e0 += 64 * CC_KNN_TW) {
+    // ---- the queues: worked off once CC_KNN_TPASS pairs are pending, or when the walk is over
+    const int c0 = L.wn[par][0], c1 = L.wn[par][1], c2 = L.wn[par][2], c3 = L.wn[par][3];
+    const int tot = c0 + c1 + c2 + c3;
+    const bool walking = (L.go[par][0] | L.go[par][1] | L.go[par][2] | L.go[par][3]) != 0;
+    if (tot >= CC_KNN_TPASS || (!walking && tot > 0)) {
+      for (int e0 = 0; e0 < tot; e0 += CC_KNN_TPASS) {
         const int e = e0 + tid;
-        if (e < tot) {
+        if (tid < CC_KNN_TPASS && e < tot) {
           const unsigned ent = e < c0 ? L.wl[0][e] : e < c0 + c1 ? L.wl[1][e - c0] : e < c0 + c1 + c2 ? L.wl[2][e - c0 - c1] : L.wl[3][e - c0 - c1 - c2];
           const int js = (int)(ent >> 28);
           const unsigned u_ = ent & 0x0FFFFFFFu;
@@ -1125,13 +1138,11 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           const int tight = __builtin_amdgcn_readfirstlane(L.st[jj].tight);
           if (!(cnt >= CC_KNN_TTRIG || (!tight && cnt >= nnk))) continue;
           int kept;
-          float nub = cnt <= 128 ? cc_knn_select<2>(L.buf[jj], cnt, nnk, lane, kept)
-                    : cnt <= 256 ? cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<6>(L.buf[jj], cnt, nnk, lane, kept);
+          float nub = cnt <= 128 ? cc_knn_select<2>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept);
           if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
                             // in the result -- order them and drop the rest, so that the buffer bound holds
             unsigned long long first;
-            nub = kept <= 128 ? cc_knn_reduce<2>(L.buf[jj], kept, nnk, lane, first)
-                : kept <= 256 ? cc_knn_reduce<4>(L.buf[jj], kept, nnk, lane, first) : cc_knn_reduce<8>(L.buf[jj], kept, nnk, lane, first);
+            nub = kept <= 128 ? cc_knn_reduce<2>(L.buf[jj], kept, nnk, lane, first) : cc_knn_reduce<4>(L.buf[jj], kept, nnk, lane, first);
             kept = nnk;
           }
           if (lane == 0) {
@@ -1143,77 +1154,26 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
         __syncthreads();
       }
       wn = 0;
-      if (lane == 0) L.wn[wave] = 0;
       ubj = L.st[j].ub;
       tightj = L.st[j].tight;
       thr = ubj + slack;
     }
-    // ---- who goes on: a search leaves a direction when the outermost key of the round's further step lies beyond its own
-    // key[0] on that side by more than its radius, or past its visible ranges
-    if (mine && sub == 1) {
-      const float e = k[0] - far0;
-      const bool beyond = dir == 0 ? (e < 0.f) : (e > 0.f);
-      const bool out = beyond && (tightj ? (e * e > ubj) : (e * e >= ubj));
-      const bool more = dir == 0 ? (nxt < E2 && nxt < n) : (nxt + 64 > L0 && nxt + 64 > 0);
-      open_d = open_d && !out && more;
-      const bool any_d = __ballot(open_d) != 0ull;
-      if (lane == 0) L.any[dir] = any_d ? 1 : 0;
-    }
-    __syncthreads();
-    mine = L.any[dir] != 0;
-    if (!(L.any[0] | L.any[1])) break;
+    if (!walking) break;
   }
 #undef CC_KNN_TFETCH
-  // ---- the rest of the queues (fewer than 256 pairs): as above
-  {
-    int c0 = L.wn[0], c1 = L.wn[1], c2 = L.wn[2], c3 = L.wn[3];
-    const int tot = c0 + c1 + c2 + c3;
-    if (tid < tot) {
-      const int e = tid;
-      const unsigned ent = e < c0 ? L.wl[0][e] : e < c0 + c1 ? L.wl[1][e - c0] : e < c0 + c1 + c2 ? L.wl[2][e - c0 - c1] : L.wl[3][e - c0 - c1 - c2];
-      const int js = (int)(ent >> 28);
-      const unsigned u_ = ent & 0x0FFFFFFFu;
-      const int act = sact[u_];
-      const int kid = sid[u_];
-      float c[CC_KEY_DIM];
-#pragma unroll
-      for (int d = 0; d < CC_KEY_DIM; d++) c[d] = K[(size_t)d * cap + u_];
-      const float *kk = L.qk[js];
-      float r_ = 0.f;
-      float d0 = kk[0] - c[0], d1 = kk[1] - c[1], d2 = kk[2] - c[2], d3 = kk[3] - c[3];
-      r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-      d0 = kk[4] - c[4];
-      d1 = kk[5] - c[5];
-      d2 = kk[6] - c[6];
-      d3 = kk[7] - c[7];
-      r_ += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-      d0 = kk[8] - c[8];
-      r_ += d0 * d0;
-      d0 = kk[9] - c[9];
-      r_ += d0 * d0;
-      const float ub = L.st[js].ub;
-      if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
-        const int slot = atomicAdd(&L.st[js].cnt, 1);
-        L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
-      }
-    }
-  }
-  __syncthreads();
   // ---- results: the nnk best by (distance, key id); wave w writes the searches w, w + 4, ...
   for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
     int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
-    if (cnt > 128) {  // ties aside, what is within the nnk-th distance fits the sorting network
+    if (cnt > 128) {  // ties aside, what is within the nnk-th distance fits the smaller sorting network
       int kept;
-      cnt <= 256 ? cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<6>(L.buf[jj], cnt, nnk, lane, kept);
+      cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept);
       cnt = kept;
     }
     unsigned long long first;
     if (cnt <= 128)
       cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
-    else if (cnt <= 256)
-      cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
     else
-      cc_knn_reduce<8>(L.buf[jj], cnt, nnk, lane, first);
+      cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
     const int s_ = order[ll * CC_KNN_ORDER_CAP + base + jj];
     const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
     const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;

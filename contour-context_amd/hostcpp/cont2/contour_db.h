@@ -66,7 +66,9 @@ class ContourDB {
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }
-    cc_db_profile_enable(db_, 1);  // per-stage device times of every query, fed to `stp` below
+    // per-stage DEVICE times of every query under the reference's stage names (six events per query: they cost a few
+    // per cent, so only on request); the wall time of the call is recorded either way
+    if (getenv("CC_STP_DEVICE_TIMERS")) cc_db_profile_enable(db_, 1);
   }
 
  public:
@@ -85,15 +87,21 @@ class ContourDB {
     ensure(*q_ptr);
     const cc_score_t lb = to_c(thres_lb), ub = to_c(thres_ub);
     cc_query_result_t r;
-    if (cc_db_query_host(db_, &q_ptr->desc(), &lb, &ub, &r) != CC_OK) {  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.
+    TicToc wall;
+    // the scan is normally still on the device (made by makeBEV just before); one that was offloaded goes by its host copy
+    const int rc = q_ptr->scanHandle() && cc_scan_on_device(q_ptr->scanHandle())
+                       ? cc_db_query_scan(db_, q_ptr->scanHandle(), &lb, &ub, &r)
+                       : cc_db_query_host(db_, &q_ptr->desc(), &lb, &ub, &r);
+    if (rc != CC_OK) {  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.; also CC_ECAPACITY (the reference has no capacities)
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }
+    stp.addSample("queryRangedKNN (wall)", wall.toc());
     {  // the reference's stage names (contour_db.h:755,772,787), with the device times of this query's kernels:
        // retrieval | checks + proposal merge | correlation + selection
       double ms[5];
       int nq = 0;
-      if (cc_db_profile_read(db_, ms, &nq) == CC_OK && nq > 0) {
+      if (getenv("CC_STP_DEVICE_TIMERS") && cc_db_profile_read(db_, ms, &nq) == CC_OK && nq > 0) {
         stp.addSample("KNN search", ms[0] * 1e-3);
         stp.addSample("Constell", (ms[1] + ms[2]) * 1e-3);
         stp.addSample("L2 opt", (ms[3] + ms[4]) * 1e-3);
@@ -118,7 +126,15 @@ class ContourDB {
     // the C-ABI couples addScan + pushAndBalance (they are always called back to back, batch_bin_test.cpp:234-237)
     CC_CHECK(pending_);
     (void)curr_timestamp;
-    if (cc_db_add_scan_host(db_, &pending_->desc(), pending_ts_, seed) != CC_OK) {
+    cc_scan *h = pending_->scanHandle();
+    const int rc = h && cc_scan_on_device(h) ? cc_db_add_scan(db_, h, pending_ts_, seed) : cc_db_add_scan_host(db_, &pending_->desc(), pending_ts_, seed);
+    if (rc != CC_OK) {
+      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+      abort();
+    }
+    // the DB keeps its own compact records of the scan: the descriptor moves to the host (the getters keep working) and its
+    // device slot goes back to the context's pool
+    if (h && cc_scan_offload(h) != CC_OK) {
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }

@@ -143,14 +143,19 @@ inline cc_manager_cfg_t to_c(const ContourManagerConfig &c) {
   m.roi_radius = c.roi_radius_;
   return m;
 }
-// one device context per process and config (the reference has no such object: created lazily)
+// one device context per process and config (the reference has no such object: created lazily).  The device is HIP
+// device 0 unless the environment names another one (CC_DEVICE=<n>: one process per GPU in a multi-GPU deployment).
+inline int device_id() {
+  const char *e = getenv("CC_DEVICE");
+  return e ? atoi(e) : 0;
+}
 inline cc_ctx *context(const cc_manager_cfg_t &m) {
   static std::map<std::string, cc_ctx *> pool;
   std::string key((const char *)&m, sizeof(m));
   auto it = pool.find(key);
   if (it != pool.end()) return it->second;
   cc_ctx *c = nullptr;
-  if (cc_create(0, &m, 8, &c) != CC_OK) {
+  if (cc_create(device_id(), &m, 8, &c) != CC_OK) {
     fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
     abort();
   }
@@ -166,12 +171,11 @@ class ContourManager {
   cc_manager_cfg_t ccfg_;
   int int_id_;
   std::string str_id_;
-  std::vector<float> xyzi_;  // staged by makeBEV, consumed by makeContoursRecurs
-  std::unique_ptr<cc_scan_desc_t> desc_;
-  mutable std::vector<std::vector<RetrievalKey>> keys_cache_;
-  // the occupied cells of bev_ (cell index, height): the role of bev_pixfs_ (contour_mng.h:433) for getBevImage; only
-  // fetched from the device when images are wanted (keepImages())
-  std::vector<std::pair<int, float>> bev_cells_;
+  // The scan on the device (cc_scan, include/cont2_amd.h): makeBEV writes the points straight into the context's pinned
+  // staging buffer and queues rasterisation + contours + keys + BCIs; the descriptor stays on the device for
+  // ContourDB::queryRangedKNN / addScan, its host copy (what the getters below read) is fetched on first use.
+  cc_scan *scan_ = nullptr;
+  bool want_images_ = false;
 
  public:
   explicit ContourManager(const ContourManagerConfig &config, int int_id) : cfg_(config), int_id_(int_id) {
@@ -180,24 +184,12 @@ class ContourManager {
     ccfg_ = cc_host::to_c(cfg_);
   }
 
-  // contour_mng.h:505: keeps x,y,z of every point (KITTI layout, intensity unused)
-  template <typename PointType>
-  void makeBEV(typename pcl::PointCloud<PointType>::ConstPtr &ptr_gapc, std::string str_id = "") {
-    CC_CHECK(ptr_gapc);
-    CC_CHECK(ptr_gapc->size() > 10);
-    xyzi_.resize(ptr_gapc->size() * 4);
-    for (size_t i = 0; i < ptr_gapc->size(); i++) {
-      xyzi_[4 * i] = ptr_gapc->points[i].x;
-      xyzi_[4 * i + 1] = ptr_gapc->points[i].y;
-      xyzi_[4 * i + 2] = ptr_gapc->points[i].z;
-      xyzi_[4 * i + 3] = 0.f;
-    }
-    str_id_ = !str_id.empty() ? std::move(str_id) : std::to_string(ptr_gapc->header.stamp);
-  }
+  ~ContourManager() { cc_scan_release(scan_); }
+  ContourManager(const ContourManager &) = delete;
+  ContourManager &operator=(const ContourManager &) = delete;
 
-  // Whether a scan's max-height image is brought back from the device with its descriptor (90 KB extra per scan on the
-  // way, the occupied cells kept afterwards).  On when the reference would write its SAVE_MID_FILE artefacts
-  // (CMakeLists.txt:17), or switched on by the caller before makeContoursRecurs().
+  // Whether a scan's max-height image is brought back from the device (90 KB extra per scan).  On when the reference
+  // would write its SAVE_MID_FILE artefacts (CMakeLists.txt:17), or switched on by the caller before makeBEV().
   static bool &keepImages() {
 #if defined(SAVE_MID_FILE) && SAVE_MID_FILE
     static bool keep = true;
@@ -207,29 +199,40 @@ class ContourManager {
     return keep;
   }
 
-  // contour_mng.h:588: rasterise + contours + keys + BCIs on the device
-  void makeContoursRecurs() {
-    CC_CHECK(!xyzi_.empty());
-    desc_.reset(new cc_scan_desc_t);
-    const int64_t off[2] = {0, (int64_t)(xyzi_.size() / 4)};
-    std::vector<float> bev;
-    if (keepImages()) bev.resize((size_t)cfg_.n_row_ * cfg_.n_col_);
-    if (cc_ingest_host_bev(cc_host::context(ccfg_), xyzi_.data(), off, 1, desc_.get(), keepImages() ? bev.data() : nullptr) != CC_OK) {
-      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
-      abort();
+  // contour_mng.h:505: x,y,z of every point (KITTI layout, intensity unused) -> the device; the kernels are queued here
+  // already (nothing of them is observable before makeContoursRecurs() in the reference either)
+  template <typename PointType>
+  void makeBEV(typename pcl::PointCloud<PointType>::ConstPtr &ptr_gapc, std::string str_id = "") {
+    CC_CHECK(ptr_gapc);
+    CC_CHECK(ptr_gapc->size() > 10);
+    CC_CHECK(!scan_);
+    cc_ctx *ctx = cc_host::context(ccfg_);
+    const size_t n = ptr_gapc->size();
+    float *dst = cc_stage_points(ctx, (int64_t)n);
+    if (!dst) die();
+    for (size_t i = 0; i < n; i++) {
+      dst[4 * i] = ptr_gapc->points[i].x;
+      dst[4 * i + 1] = ptr_gapc->points[i].y;
+      dst[4 * i + 2] = ptr_gapc->points[i].z;
+      dst[4 * i + 3] = 0.f;
     }
-    bev_cells_.clear();
-    for (size_t i = 0; i < bev.size(); i++)
-      if (bev[i] != -VAL_ABS_INF_) bev_cells_.emplace_back((int)i, bev[i]);
-    xyzi_.clear();
-    xyzi_.shrink_to_fit();
+    want_images_ = keepImages();
+    if (cc_scan_ingest(ctx, dst, (int64_t)n, want_images_ ? 1 : 0, &scan_) != CC_OK) die();
+    str_id_ = !str_id.empty() ? std::move(str_id) : std::to_string(ptr_gapc->header.stamp);
   }
+
+  // contour_mng.h:588: the work was queued by makeBEV; results are waited for where they are read
+  void makeContoursRecurs() { CC_CHECK(scan_); }
   void clearImage() {}  // the dense image is never kept here (see bev_cells_)
 
   // contour_mng.h:573-586: the dense max-height image, -VAL_ABS_INF_ where no point fell
   cc_host::Image<float> getBevImage() const {
     cc_host::Image<float> img(cfg_.n_row_, cfg_.n_col_, -VAL_ABS_INF_);
-    for (const auto &c : bev_cells_) img.data[c.first] = c.second;
+    if (want_images_) {
+      const float *bev = nullptr;
+      if (cc_scan_bev(scan_, &bev) != CC_OK) die();
+      std::memcpy(img.data.data(), bev, sizeof(float) * img.data.size());
+    }
     return img;
   }
   // contour_mng.h:1041-1049: cv::threshold(bev, lv_grads_[level], THRESH_TOZERO) then cv::normalize(0, 255, NORM_MINMAX,
@@ -274,10 +277,18 @@ class ContourManager {
     if (!cc_host::write_png_gray8(fpath, output)) std::cerr << "Error opening " << fpath << std::endl;
   }
 
-  const cc_scan_desc_t &desc() const {
-    CC_CHECK(desc_);
-    return *desc_;
+  static void die() {
+    fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+    abort();
   }
+  // the host copy of everything the reference's ContourManager keeps after makeContoursRecurs() + clearImage()
+  const cc_scan_desc_t &desc() const {
+    CC_CHECK(scan_);
+    const cc_scan_desc_t *d = nullptr;
+    if (cc_scan_desc(scan_, &d) != CC_OK) die();  // includes CC_ECAPACITY: the reference has no capacities to exceed
+    return *d;
+  }
+  cc_scan *scanHandle() const { return scan_; }
   const cc_manager_cfg_t &ccfg() const { return ccfg_; }
   std::vector<RetrievalKey> getLevRetrievalKey(int level) const {
     std::vector<RetrievalKey> r(cfg_.piv_firsts_);

@@ -222,6 +222,8 @@ typedef struct {
                              or a rotation window of more than 63 pairs (:344-366): pairs were dropped              */
 #define CC_QF_GMM_CAP 2   /* a scan of a correlation problem has more than 128 ellipses on a level (correlation.h:55-78) */
 #define CC_QF_DESC_CAP 4  /* the correlation needed a contour beyond the CC_MAXC stored per level                     */
+#define CC_QF_QUERY_INEXACT 8 /* the query scan's own descriptor is flagged CC_DESC_INEXACT_* (it exceeded a capacity of the
+                                 contour kernel at ingest)                                                             */
 
 /* ------------------------------------------------------------------------ context ------- */
 typedef struct cc_ctx cc_ctx; /* opaque: device id, configs, scratch, streams */
@@ -263,6 +265,30 @@ int cc_ingest_host(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offsets, i
  * (contour_mng.h:573-586, 1039-1049, 1286-1311; the SAVE_MID_FILE artefacts of the drivers).  h_bev may be NULL. */
 int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offsets, int n_scans,
                        cc_scan_desc_t *h_out, float *h_bev);
+
+/* ---- the per-scan loop (test/batch_bin_test.cpp:131-237 at sensor rate) ----
+ * A cc_scan is ONE scan's descriptor kept on the device between ContourManager::makeContoursRecurs (contour_mng.h:588),
+ * ContourDB::queryRangedKNN (contour_db.h:698) and ContourDB::addScan (:814): the class mirror's ContourManager holds one.
+ * Nothing is allocated per scan: the context owns a pinned staging buffer for the points, a device point buffer and a pool
+ * of descriptor slots; the calls only queue work on the context's own stream, the host copy of the descriptor (and of the
+ * max-height image, if asked for) is fetched when a getter needs it.
+ *   cc_stage_points  : pinned buffer for n_points x (x,y,z,i) f32, valid until the next cc_scan_ingest (write the points
+ *                      there to save a host copy), NULL on failure
+ *   cc_scan_ingest   : makeBEV + makeContoursRecurs for the points at h_xyzi (may be the staging pointer); want_bev != 0
+ *                      keeps the max-height image for cc_scan_bev.  Returns at once (work is queued).
+ *   cc_scan_desc     : host copy of the descriptor (first call: one D2H copy + sync); CC_ECAPACITY if the scan exceeded a
+ *                      capacity of the contour kernel (flags CC_DESC_INEXACT_*), the copy is delivered all the same
+ *   cc_scan_offload  : move the descriptor to the host and give the device slot back (the mirror does this once the scan
+ *                      is in the DB, which keeps its own compact records); cc_scan_desc keeps working
+ *   cc_scan_release  : free the handle */
+typedef struct cc_scan cc_scan;
+float *cc_stage_points(cc_ctx *ctx, int64_t n_points);
+int cc_scan_ingest(cc_ctx *ctx, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out);
+int cc_scan_desc(cc_scan *scan, const cc_scan_desc_t **h_desc);
+int cc_scan_bev(cc_scan *scan, const float **h_bev);
+int cc_scan_offload(cc_scan *scan);
+int cc_scan_on_device(const cc_scan *scan); /* 1: the descriptor still sits in a device slot, 0: offloaded (or NULL) */
+int cc_scan_release(cc_scan *scan);
 
 /* ---------------------------------------------------------------------- database -------- */
 /* Replaces ContourDB::ContourDB (contour_db.h:680-684). */
@@ -315,6 +341,11 @@ int cc_db_query_wait(cc_db *db);
 int cc_db_add_scan_host(cc_db *db, const cc_scan_desc_t *h_desc, double ts, int32_t seed);
 int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t *thres_lb, const cc_score_t *thres_ub,
                      cc_query_result_t *h_res);
+
+/* The same two calls for a scan that is still on the device (cc_scan_ingest): no descriptor copy in either direction.
+ * cc_db_query_scan answers against the current DB state; cc_db_add_scan = addScan + pushAndBalance. */
+int cc_db_query_scan(cc_db *db, cc_scan *scan, const cc_score_t *thres_lb, const cc_score_t *thres_ub, cc_query_result_t *h_res);
+int cc_db_add_scan(cc_db *db, cc_scan *scan, double ts, int32_t seed);
 
 /* The two batched calls with host descriptor buffers (one H2D copy each): for drivers that keep descriptors on the host,
  * e.g. an offline replay of a whole sequence (all scans added, then scan i queried against epoch i). */

@@ -53,7 +53,7 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
     cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
     cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 10.0").replace("min_elapse_: 15.0", "min_elapse_: 6.0")
     (proj / "config" / "batch_bin_test_config.yaml").write_text(cfg)
-    env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6")
+    env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_STP_DEVICE_TIMERS="1")  # device stage timers: on request
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "outcome.txt")]
@@ -72,5 +72,5 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
             assert abs(float(r[2]) - ores["correlation"][i]) < 1e-5
     # the library's stage timers went through the executable's `stp` (the five reference stage names)
     timing = (proj / "log" / "timing_cont2.txt").read_text()
-    for name in ("make bev", "KNN search", "Constell", "L2 opt", "Update database"):
+    for name in ("make bev", "KNN search", "Constell", "L2 opt", "Update database", "queryRangedKNN (wall)"):
         assert name in timing, timing
