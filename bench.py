@@ -128,32 +128,29 @@ def main():
 
     # ---------------- DB build (untimed): scan-sharded ingest, pack, ONE all-gather of the compact records ----------------
     t_setup = time.time()
-    shard = (n_db + world - 1) // world
-    lo, hi = min(rank * shard, n_db), min((rank + 1) * shard, n_db)
+    SH = cc.sharding
+    shard = SH.shard_len(n_db, world)
+    mine = SH.my_scans(n_db, rank, world)              # interleaved: rank r takes DB scans r, r + world, ...
     HB, FB = cc.packed_sizes()
     rec_local = torch.zeros((shard, HB + FB), dtype=torch.uint8, device=dev)  # per scan: hot record | correlation inputs
     desc_tmp = torch.empty((128, cc.DESC_BYTES), dtype=torch.uint8, device=dev)
     keep_desc = args.tune_sweep or (world == 1 and not args.no_cpu and args.cpu_sample > 0)
     desc_keep = torch.empty((n_db, cc.DESC_BYTES), dtype=torch.uint8, device="cpu", pin_memory=True) if keep_desc else None
     CH = 128
-    for c0 in range(lo, hi, CH):
-        c1 = min(c0 + CH, hi)
-        xyzi, _, _ = cc.synth.make_sequence(c1 - c0, world=wld, device=dev, start=c0)
+    for c0 in range(0, len(mine), CH):
+        c1 = min(c0 + CH, len(mine))
+        xyzi, _, _ = cc.synth.make_sequence(0, world=wld, device=dev, indices=mine[c0:c1])
         d = ctx.ingest(xyzi.reshape(-1, 4), np.arange(c1 - c0 + 1, dtype=np.int64) * P, out=desc_tmp[:c1 - c0])
         hot, feat = ctx.pack(d)
-        rec_local[c0 - lo:c1 - lo, :HB] = hot
-        rec_local[c0 - lo:c1 - lo, HB:] = feat
+        rec_local[c0:c1, :HB] = hot
+        rec_local[c0:c1, HB:] = feat
         if keep_desc:
-            desc_keep[c0:c1].copy_(d)
+            desc_keep[c0:c1].copy_(d)   # world == 1: mine == all scans in order
     torch.cuda.synchronize()
-    exchange_bytes = 0
-    if world > 1:
-        rec_all = torch.empty((world * shard, HB + FB), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(rec_all, rec_local)   # RCCL over xGMI: 35 KB per scan (the full descriptor is 169 KB)
-        exchange_bytes = int(rec_all.numel())
-        rec_db = rec_all[:n_db]
-    else:
-        rec_db = rec_local[:n_db]
+    t_x = time.perf_counter()
+    rec_db, exchange_bytes = SH.gather_records(rec_local, n_db, world, dist)   # RCCL over xGMI: 35 KB per scan (the descriptor is 169 KB)
+    torch.cuda.synchronize()
+    exchange_ms = (time.perf_counter() - t_x) * 1e3 if world > 1 else 0.0
     db = cc.Database(ctx, capacity=n_db + 16)
     if args.no_overlap:
         db.set_lanes(1)
@@ -180,6 +177,7 @@ def main():
     share = world > 1 and args.share_descriptors
     gathered = torch.empty((world * B, HB + FB), dtype=torch.uint8, device=dev) if share else None
     rec_q = torch.empty((B, HB + FB), dtype=torch.uint8, device=dev) if share else None
+    share_ev = []  # (start, end) events around the per-step all-gather
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -217,7 +215,11 @@ def main():
                 hq, fq = ctx.pack(q)
                 rec_q[:, :HB] = hq
                 rec_q[:, HB:] = fq
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 dist.all_gather_into_tensor(gathered, rec_q)
+                e1.record()
+                share_ev.append((e0, e1))
             if args.sync_query or args.no_overlap:
                 res = db.query(q, epochs)
             else:  # queue the batch; its chunks are collected when their lanes are needed again, the last ones below
@@ -246,10 +248,13 @@ def main():
     if args.stats and rank == 0:
         for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy"):
             print("funnel %-16s mean %8.1f  max %6d" % (k, float(res[k].mean()), int(res[k].max())), file=sys.stderr)
+    per_rank = [K * B / elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        tl = torch.zeros(world, dtype=torch.float64, device=dev)
+        tl[rank] = elapsed
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM)    # every rank's own time (tiny; after the timed region)
+        per_rank = [K * B / float(v) for v in tl.tolist()]
+        elapsed = float(tl.max().item())
 
     import ctypes as C
 
@@ -386,6 +391,10 @@ def main():
             # ingest -> add -> query at the scan's own epoch; with the DB update inside the timed region and without
             nrep = min(4, len(batches)) * B
             out["extra"] = {"online_replay": online_replay(cc, ctx, [b for b in batches[:min(4, len(batches))]], B, P, nrep, 256, dev)}
+            try:
+                out["extra"]["dropin_loop"] = dropin_loop(batches[0], P, min(B, 1024))
+            except Exception as e:  # the headline stands on its own
+                out["extra"]["dropin_loop"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W % len(batches)], P, min(args.cpu_sample, B))
         print(json.dumps(out), flush=True)
@@ -562,6 +571,58 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def dropin_loop(batch0, P, n):
+    """The reference's per-scan driver loop through the C++ class mirror (hostcpp/examples/batch_bin_test.cpp: the
+    reference's test/batch_bin_test.cpp without ROS, same ContourManager / ContourDB calls): n KITTI-format .bin files are
+    read one by one, makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance per scan, DB empty at the
+    start.  Wall-clock seconds per call from the driver's own stage timers (tools/bm_util.h)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "contour-context_amd", "hostcpp", "bin", "batch_bin_test")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        exe = __graft_entry__.build_dropin_driver()
+    tmp = tempfile.mkdtemp(prefix="cc_dropin_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        xs = batch0[:n * P].cpu().numpy().reshape(n, P, 4)
+        with open(os.path.join(tmp, "scans.txt"), "w") as f, open(os.path.join(tmp, "poses.txt"), "w") as g:
+            for i in range(n):
+                p = os.path.join(tmp, "%06d.bin" % i)
+                xs[i].tofile(p)
+                f.write("%.6f %d %s\n" % (i / 10.0, i, p))
+                g.write("%.6f 1 0 0 %.3f 0 1 0 0 0 0 1 0\n" % (i / 10.0, float(i)))
+        cfg = open(os.path.join(ROOT, "contour-context_amd", "hostcpp", "examples", "batch_bin_test_config.yaml")).read()
+        cfg = cfg.replace("/path/to/ts-sens_pose-kitti08.txt", os.path.join(tmp, "poses.txt"))
+        cfg = cfg.replace("/path/to/ts-lidar_bins-kitti08.txt", os.path.join(tmp, "scans.txt"))
+        cfg = cfg.replace("/path/to/outcome-kitti08.txt", os.path.join(tmp, "outcome.txt"))
+        open(os.path.join(tmp, "cfg.yaml"), "w").write(cfg)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, os.path.join(tmp, "cfg.yaml")], capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "driver exit code %d: %s" % (r.returncode, r.stderr[-300:])}
+        out = {"scans": n, "what": "hostcpp/examples/batch_bin_test (the reference driver's loop through the class mirror): per scan "
+               ".bin file -> makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance, DB empty at the start; "
+               "seconds per call = wall clock inside the driver", "process_wall_s": wall}
+        for line in r.stdout.splitlines():
+            p = line.split()
+            for name in ("make bev", "queryRangedKNN (wall)", "Update database"):
+                if name in line and len(p) >= 6:
+                    try:
+                        out.setdefault("seconds_per_call", {})[name] = float(p[-5])
+                    except ValueError:
+                        pass
+            if line.startswith("Loop wall time:"):
+                out["loop_wall_s"] = float(p[3])
+                out["scans_per_s"] = n / float(p[3])
+        if "seconds_per_call" in out:
+            out["ms_per_scan_three_calls"] = 1e3 * sum(out["seconds_per_call"].values())
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _cpu_model():

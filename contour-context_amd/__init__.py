@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _HERE)
 import layouts as L  # noqa: E402
 import synth  # noqa: E402,F401
+import sharding  # noqa: E402,F401
 
 LIB_PATH = os.path.join(_HERE, "libcont2_amd.so")
 _SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_group.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "k_rasterize.h", "k_contours.h",

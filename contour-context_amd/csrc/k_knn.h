@@ -918,8 +918,17 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
 // grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64 * CC_KNN_TW
 __global__ void __launch_bounds__(64 * CC_KNN_TW)
 cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
-              const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
+              const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt,
+              long long *__restrict__ phase_clk /*tuning aid (CC_KNN_PHASES=1), else nullptr: [grid][8] ticks of 10 ns*/) {
   __shared__ cc_knn_tlds L;
+  long long pc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup | step | barrier | pass | cut-back | results | rounds | passes
+  long long pt_ = phase_clk ? wall_clock64() : 0;
+#define CC_KNN_TICK(slot)                      \
+  if (phase_clk) {                             \
+    const long long now_ = wall_clock64();     \
+    pc_[slot] += now_ - pt_;                   \
+    pt_ = now_;                                \
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nblk = (nq * CC_NPIV + CC_KNN_TQ - 1) / CC_KNN_TQ;
   const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
@@ -1048,7 +1057,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     }                                                                                                \
   }
   if (mine) CC_KNN_TFETCH()
+  CC_KNN_TICK(0)
   for (int par = 0;; par ^= 1) {
+    pc_[6]++;
     if (mine) {
       const int sb_cur = sb;
       cc_f32x4 acc[4];
@@ -1092,7 +1103,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       L.wn[par][wave] = wn;
       L.go[par][wave] = mine ? 1 : 0;
     }
+    CC_KNN_TICK(1)
     __syncthreads();
+    CC_KNN_TICK(2)
     // ---- the queues: worked off once CC_KNN_TPASS pairs are pending, or when the walk is over
     const int c0 = L.wn[par][0], c1 = L.wn[par][1], c2 = L.wn[par][2], c3 = L.wn[par][3];
     const int tot = c0 + c1 + c2 + c3;
@@ -1132,6 +1145,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           }
         }
         __syncthreads();
+        pc_[7]++;
+        CC_KNN_TICK(3)
         // cut back the buffers that filled up: wave w looks after the searches w, w + 4, ...
         for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
           const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
@@ -1152,6 +1167,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           }
         }
         __syncthreads();
+        CC_KNN_TICK(4)
       }
       wn = 0;
       ubj = L.st[j].ub;
@@ -1189,4 +1205,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     }
     if (lane == 0) hit_cnt[slot] = mm;
   }
+  CC_KNN_TICK(5)
+#undef CC_KNN_TICK
+  if (phase_clk && tid == 0)
+    for (int i = 0; i < 8; i++) phase_clk[(size_t)blockIdx.x * 8 + i] = pc_[i];
 }

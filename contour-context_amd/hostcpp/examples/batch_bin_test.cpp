@@ -64,9 +64,15 @@ int main(int argc, char **argv) {
   }
   ContLCDEvaluator evaluator(fpath_sens_gt_pose, fpath_lidar_bins, corr_thres);
   ContourDB contour_db(db_config, 65536);
-  int cnt_tp = 0, cnt_fn = 0, cnt_fp = 0;
+  int cnt_tp = 0, cnt_fn = 0, cnt_fp = 0, n_loops = 0;
+  stp = SequentialTimeProfiler(sav_path);
+  TicToc loop_clk;
   while (evaluator.loadNewScan()) {
+    // stage timers as in the reference's spinner (test/batch_bin_test.cpp:131-134, 231-238)
+    stp.lap();
+    stp.start();
     std::shared_ptr<ContourManager> cm_tgt = evaluator.getCurrContourManager(cm_config);
+    stp.record("make bev");
     const auto info = evaluator.getCurrScanInfo();
     cm_tgt->clearImage();
     std::vector<std::shared_ptr<const ContourManager>> cands;
@@ -79,9 +85,15 @@ int main(int argc, char **argv) {
     cnt_tp += pred.tfpn == PredictionOutcome::TP;
     cnt_fp += pred.tfpn == PredictionOutcome::FP;
     cnt_fn += pred.tfpn == PredictionOutcome::FN;
+    stp.start();
     contour_db.addScan(cm_tgt, info.ts);
     contour_db.pushAndBalance(info.seq, info.ts);
+    stp.record("Update database");
+    n_loops++;
   }
+  const double loop_s = loop_clk.toc();
+  stp.printScreen(true);
+  printf("Loop wall time: %.6f s for %d scans (%.1f scans/s, file reading included)\n", loop_s, n_loops, n_loops / loop_s);
   printf("Accumulated tp poses: %d\nAccumulated fn poses: %d\nAccumulated fp poses: %d\n", cnt_tp, cnt_fn, cnt_fp);
   printf("TP Error mean: t:%7.4f m, r:%7.4f rad\n", evaluator.getTPMeanTrans(), evaluator.getTPMeanRot());
   printf("TP Error rmse: t:%7.4f m, r:%7.4f rad\n", evaluator.getTPRMSETrans(), evaluator.getTPRMSERot());

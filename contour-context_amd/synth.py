@@ -300,17 +300,19 @@ def cast_scan(world, pose, beams=64, azim=1875, device="cpu", noise_sigma=0.02, 
 
 
 def make_sequence(n_scans, beams=64, azim=1875, device="cpu", seed=20260926, step=1.0, loop_len=1500.0,
-                  start=0, world=None, noise_sigma=0.02, elev_deg=None):
-    """Scans `start .. start+n_scans-1` of the seeded trajectory: returns (xyzi [n, P, 4] f32, poses [n,3], ts [n])."""
+                  start=0, world=None, noise_sigma=0.02, elev_deg=None, indices=None):
+    """Scans `start .. start+n_scans-1` of the seeded trajectory (or the scans `indices`, e.g. one rank's interleaved
+    share): returns (xyzi [n, P, 4] f32, poses [n,3], ts [n]).  Scan i is the same whoever asks for it."""
     world = world or World(seed, loop_len=loop_len)
-    total = start + n_scans
+    idx = np.arange(start, start + n_scans) if indices is None else np.asarray(indices, dtype=np.int64)
+    total = int(idx.max()) + 1 if len(idx) else 0
     x, y, yaw = trajectory(total, step=step, loop_len=world.loop_len, tile=world.tile)
     gen = torch.Generator(device=torch.device(device))
     out = []
-    for i in range(start, total):
+    for i in idx.tolist():
         gen.manual_seed(seed * 1000003 + i)
         out.append(cast_scan(world, (x[i], y[i], yaw[i]), beams, azim, device, noise_sigma, gen, elev_deg=elev_deg))
     xyzi = torch.stack(out, dim=0)
-    poses = np.stack([x[start:total], y[start:total], yaw[start:total]], axis=1)
-    ts = np.arange(start, total, dtype=np.float64) / 10.0
+    poses = np.stack([x[idx], y[idx], yaw[idx]], axis=1)
+    ts = idx.astype(np.float64) / 10.0
     return xyzi, poses, ts

@@ -30,22 +30,21 @@ def _worker(rank, world, port, tmpdir):
     dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
     w = cc.synth.World(loop_len=40.0)
     n = 48
-    shard = n // world
-    mine = np.arange(rank, n, world)                       # scan-sharded ingest: rank r takes scans r, r + world, ...
-    x_all, _, _ = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
-    x = x_all[mine]
+    SH = cc.sharding                                       # the same helpers bench.py builds its replicas with
+    mine = SH.my_scans(n, rank, world)                     # scan-sharded ingest: rank r takes scans r, r + world, ...
+    shard = SH.shard_len(n, world)
+    x, _, _ = cc.synth.make_sequence(0, world=w, beams=16, azim=450, indices=mine)
     P = x.shape[1]
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=8)
-    local = api.ingest(ctx, x.numpy().reshape(-1, 4), np.arange(shard + 1, dtype=np.int64) * P)
+    local = api.ingest(ctx, x.numpy().reshape(-1, 4), np.arange(len(mine) + 1, dtype=np.int64) * P)
     hot, feat = api.pack(ctx, local)
-    rec_local = torch.from_numpy(np.concatenate([hot, feat], axis=1))   # one record per scan: hot | feat
-    rec_all = torch.empty((n, rec_local.shape[1]), dtype=torch.uint8)
-    dist.all_gather_into_tensor(rec_all, rec_local)          # the path's only exchange
+    rec_local = torch.zeros((shard, hot.shape[1] + feat.shape[1]), dtype=torch.uint8)   # one record per scan: hot | feat
+    rec_local[:len(mine)] = torch.from_numpy(np.concatenate([hot, feat], axis=1))
+    rec_t, moved = SH.gather_records(rec_local, n, world, dist)  # the path's only exchange; comes back in scan order
+    rec_all = rec_t
     hb = hot.shape[1]
-    # gathered order is rank-major; the DB wants the scans in time order
-    order = np.argsort(np.concatenate([np.arange(r, n, world) for r in range(world)]), kind="stable")
-    rec = rec_all.numpy()[order]
+    rec = rec_t.numpy()
     ts = np.arange(n) / 10.0
     db = api.db_create(ctx, dcfg, cap=n)
     api.db_add_packed(db, rec[:, :hb], rec[:, hb:], ts, np.arange(n, dtype=np.int32))
@@ -53,7 +52,7 @@ def _worker(rank, world, port, tmpdir):
     qs = mine[mine >= 40].astype(np.int32)                 # query-sharded: a rank's queries are scans it ingested
     res = api.db_query(db, local[(qs - rank) // world], qs)
     np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), sizes=sizes, ranges=ranges, qs=qs, res=res.view(np.uint8),
-             rec=rec, desc=local.view(np.uint8).reshape(shard, -1), bytes_per_scan=rec_all.shape[1])
+             rec=rec, desc=local.view(np.uint8).reshape(len(mine), -1), bytes_per_scan=rec_all.shape[1])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,6 +84,89 @@ def test_sharded_ingest_allgather_query(tmp_path, cc, oracle):
         for k, qi in enumerate(r["qs"]):
             for f in ["n_res", "cand_gidx", "cand_aft_check3", "n_knn_hits"]:
                 assert ores[f][qi] == res[f][k], (qi, f)
+
+
+def _online_worker(rank, world, port, tmpdir):
+    """An online multi-GPU deployment (bench.py --share-descriptors): every block of new scans is ingested scan-sharded, the
+    block's packed records are all-gathered, EVERY rank appends the whole block to its replica, and each rank queries its
+    own scans of the block at their own epochs."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cc_amd
+    import emu_api
+    cc = cc_amd.load()
+    L = cc.L
+    SH = cc.sharding
+    dcfg = L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
+    w = cc.synth.World(loop_len=40.0)
+    n, blk = 48, 6
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=8)
+    db = api.db_create(ctx, dcfg, cap=n)
+    qs_all, res_all = [], []
+    for b0 in range(0, n, blk):
+        mine = SH.my_scans(blk, rank, world, first=b0)
+        x, _, _ = cc.synth.make_sequence(0, world=w, beams=16, azim=450, indices=mine)
+        local = api.ingest(ctx, x.numpy().reshape(-1, 4), np.arange(len(mine) + 1, dtype=np.int64) * x.shape[1])
+        hot, feat = api.pack(ctx, local)
+        rec_local = torch.zeros((SH.shard_len(blk, world), hot.shape[1] + feat.shape[1]), dtype=torch.uint8)
+        rec_local[:len(mine)] = torch.from_numpy(np.concatenate([hot, feat], axis=1))
+        rec, _ = SH.gather_records(rec_local, blk, world, dist)
+        rec = rec.numpy()
+        ids = np.arange(b0, b0 + blk)
+        api.db_add_packed(db, rec[:, :hot.shape[1]], rec[:, hot.shape[1]:], ids / 10.0, ids.astype(np.int32))
+        if b0 >= 36:                                        # the later blocks revisit the first lap: query them
+            qs = mine.astype(np.int32)
+            qs_all.append(qs)
+            res_all.append(api.db_query(db, local, qs))     # scan i against the DB of the i scans before it
+    sizes, ranges = api.bucket_state(db)
+    np.savez(os.path.join(tmpdir, "online%d.npz" % rank), sizes=sizes, ranges=ranges, qs=np.concatenate(qs_all),
+             res=np.concatenate(res_all).view(np.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_online_sharded_loop_with_shared_records(tmp_path, cc, oracle):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_online_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "online0.npz"), np.load(tmp_path / "online1.npz")
+    assert np.array_equal(r0["sizes"], r1["sizes"]) and np.array_equal(r0["ranges"], r1["ranges"]), "replicas must agree"
+    L = cc.L
+    dcfg = L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
+    w = cc.synth.World(loop_len=40.0)
+    x, _, ts = cc.synth.make_sequence(48, world=w, beams=16, azim=450)
+    ores, _, _ = oracle.run_sequence(x.numpy().reshape(-1, 4), np.arange(49, dtype=np.int64) * x.shape[1], ts,
+                                     np.arange(48, dtype=np.int32), dcfg=dcfg)
+    seen, hits = set(), 0
+    for r in (r0, r1):
+        res = r["res"].view(L.query_result_dt).reshape(-1)
+        for k, qi in enumerate(r["qs"]):
+            seen.add(int(qi))
+            hits += int(ores["n_res"][qi] > 0)
+            for f in ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy", "n_knn_hits"]:
+                assert ores[f][qi] == res[f][k], (qi, f, ores[f][qi], res[f][k])
+            if ores["n_res"][qi]:
+                assert abs(ores["correlation"][qi] - res["correlation"][k]) < 1e-6
+    assert seen == set(range(36, 48)) and hits >= 3
+
+
+def test_sharding_helpers_pad_and_order():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cc_sharding", os.path.join(ROOT, "contour-context_amd", "sharding.py"))
+    SH = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SH)
+    for n, world in ((10, 4), (48, 2), (7, 8), (5000, 8), (1, 3)):
+        s = SH.shard_len(n, world)
+        gathered = np.full(world * s, -1, np.int64)
+        for r in range(world):
+            m = SH.my_scans(n, r, world)
+            gathered[r * s:r * s + len(m)] = m
+        assert np.array_equal(gathered[SH.scan_order(n, world)], np.arange(n)), (n, world)
 
 
 def test_bench_launcher_starts_ranks():
