@@ -1045,16 +1045,21 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   bool mine = __ballot(open_d) != 0ull;  // wave-uniform
   int wn = 0;                            // pairs pending in this wave's queue (wave-uniform)
   float a[4][3];  // A operand of the fetched step: tile t = keys sb + 16 t + (lane & 15), element 4 s + kq
-#define CC_KNN_TFETCH()                                                                              \
-  {                                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                  \
-      int i_ = sb + 16 * t + j;                                                                      \
-      i_ = i_ < 0 ? 0 : (i_ >= n ? n - 1 : i_);                                                      \
-      _Pragma("unroll") for (int s = 0; s < 3; s++) {                                                \
-        const int row_ = 4 * s + kq; /* 0..9 key dims, 10 = |k|^2, 11 = the constant 1 */           \
-        a[t][s] = row_ < CC_KEY_DIM + 1 ? K[(size_t)row_ * cap + (unsigned)i_] : 1.f;                \
-      }                                                                                              \
-    }                                                                                                \
+  // this lane's three rows of the sorted view (0..9 key dims, 10 = |k|^2; row 11 is the constant 1: any readable row, not used)
+  const float *Krow[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) Krow[s] = K + (size_t)(4 * s + kq < CC_KEY_DIM + 1 ? 4 * s + kq : 0) * cap;
+  const bool one_row = kq == 3;  // element 11
+#define CC_KNN_TFETCH()                                                  \
+  {                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                      \
+      int i_ = sb + 16 * t + j;                                          \
+      i_ = i_ < 0 ? 0 : (i_ >= n ? n - 1 : i_);                          \
+      a[t][0] = Krow[0][(unsigned)i_];                                   \
+      a[t][1] = Krow[1][(unsigned)i_];                                   \
+      const float v2_ = Krow[2][(unsigned)i_];                           \
+      a[t][2] = one_row ? 1.f : v2_;                                     \
+    }                                                                    \
   }
   if (mine) CC_KNN_TFETCH()
   CC_KNN_TICK(0)
@@ -1074,19 +1079,39 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       // the wave's next step travels while this one's pairs are filtered
       sb += dir == 0 ? 128 : -128;
       CC_KNN_TFETCH()
-      // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack, key inside the search's visible index ranges
+      // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack -> one bit per pair, this lane's sixteen
+      unsigned m = 0u;
 #pragma unroll
       for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const bool hit = acc[t][r] <= thr;
-          if (__ballot(hit) == 0ull) continue;  // wave-uniform: most of the sixteen masks are empty
-          const int idx = sb_cur + 16 * t + 4 * kq + r;
-          const bool push = hit && valid && idx >= 0 && idx < n && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2));
-          const unsigned long long mk = __ballot(push);
-          if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)idx;
-          wn += __popcll(mk);
+        for (int r = 0; r < 4; r++) m |= (acc[t][r] <= thr) ? (1u << (4 * t + r)) : 0u;
+      if (!valid) m = 0u;
+      // ... and the key inside the search's visible index ranges.  Usually the whole step lies inside one range of every
+      // search (wave-uniform test); at a range's end the lane's bits are checked one by one
+      {
+        const int s0 = sb_cur, s1 = sb_cur + 64;  // the step's indices [s0, s1)
+        const bool whole = s0 >= 0 && s1 <= n && ((s0 >= L0 && s1 <= E1) || (s0 >= S2 && s1 <= E2));
+        if (__ballot(valid && !whole) != 0ull) {
+          unsigned vis = 0u;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int idx = sb_cur + 16 * t + 4 * kq + r;
+              vis |= (idx >= 0 && idx < n && ((idx >= L0 && idx < E1) || (idx >= S2 && idx < E2))) ? (1u << (4 * t + r)) : 0u;
+            }
+          m &= vis;
         }
+      }
+      // queue the pairs, one per lane and turn
+      while (__ballot(m != 0u) != 0ull) {
+        const bool push = m != 0u;
+        const int bit = __ffs(m) - 1;  // -1 when m == 0 (unused)
+        m &= m - 1u;
+        const unsigned long long mk = __ballot(push);
+        if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)(sb_cur + 16 * (bit >> 2) + 4 * kq + (bit & 3));
+        wn += __popcll(mk);
+      }
       // who goes on with this wave: a search leaves when the step's outermost key lies beyond its own key[0] on that side by
       // more than its radius (the radius may be a pass old: then it only leaves later), or when the wave's next step is past
       // its visible ranges
@@ -1097,6 +1122,29 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
         const bool more = dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0);
         open_d = open_d && !out && more;
         mine = __ballot(open_d) != 0ull;
+        // Buckets the searches do not visit (contour_db.cpp:341-369: the right neighbours mid + 1 .. 2 mid) are whole index
+        // ranges: when the wave's next step touches no open search's visible range, jump to the first of its steps that does
+        if (mine) {
+          const int s0 = sb, s1 = sb + 64;
+          const bool touch = open_d && ((s0 < E1 && s1 > L0) || (s0 < E2 && s1 > S2));
+          if (__ballot(touch) == 0ull) {
+            int tgt;  // nearest visible index in walking direction, as a distance >= 0 from the step's near end
+            if (dir == 0)
+              tgt = !open_d ? 0x7fffffff : (s0 < E1 ? (L0 > s0 ? L0 - s0 : 0) : (s0 < E2 ? (S2 > s0 ? S2 - s0 : 0) : 0x7fffffff));
+            else
+              tgt = !open_d ? 0x7fffffff : (s1 > S2 ? (s1 > E2 ? s1 - E2 : 0) : (s1 > L0 ? (s1 > E1 ? s1 - E1 : 0) : 0x7fffffff));
+            for (int o = 32; o > 0; o >>= 1) {
+              const int v = __shfl_xor(tgt, o);
+              tgt = v < tgt ? v : tgt;
+            }
+            tgt = __builtin_amdgcn_readfirstlane(tgt);
+            if (tgt != 0x7fffffff && tgt >= 64) {
+              const int kk = (tgt - 63 + 127) / 128;  // steps of 128 until the wave's step reaches that index
+              sb += dir == 0 ? 128 * kk : -128 * kk;
+              CC_KNN_TFETCH()
+            }
+          }
+        }
       }
     }
     if (lane == 0) {
@@ -1148,10 +1196,12 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
         pc_[7]++;
         CC_KNN_TICK(3)
         // cut back the buffers that filled up: wave w looks after the searches w, w + 4, ...
-        for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
-          const int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
-          const int tight = __builtin_amdgcn_readfirstlane(L.st[jj].tight);
-          if (!(cnt >= CC_KNN_TTRIG || (!tight && cnt >= nnk))) continue;
+        const int cnt_l = L.st[j].cnt, tight_l = L.st[j].tight;  // lane (j, kq): search j's
+        unsigned long long due = __ballot(kq == 0 && j < ns && (j & (CC_KNN_TW - 1)) == wave && (cnt_l >= CC_KNN_TTRIG || (!tight_l && cnt_l >= nnk)));
+        while (due) {
+          const int jj = __ffsll((unsigned long long)due) - 1;
+          due &= due - 1ull;
+          const int cnt = __builtin_amdgcn_readlane(cnt_l, jj);
           int kept;
           float nub = cnt <= 128 ? cc_knn_select<2>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept);
           if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up

@@ -1,0 +1,219 @@
+"""Real-shaped stress on the GPU (VERDICT r2, weak points 2 and 3): scans with the occupancy and contour counts of real
+KITTI scans (4-9 k occupied cells, 100+ contours on a level -- the looping synthetic worlds top out at 2.7 k / 52), every
+capacity of the kernels hit on hardware, and a number for what a last-ulp difference of a retrieval key can change.
+
+  * n_act > CC_K2_CACHE (3 072 active cells): the cross-level walk's spill path (k_contours.h);
+  * more than CC_MAXC = 320 components on a level -> CC_DESC_INEXACT_COMPONENTS, cc_ingest_host / cc_db_add_scans refuse;
+  * a key RoI with more than CC_KEYS_CAP = 416 cells (roi_radius_ = 12) -> CC_DESC_INEXACT_KEYS;
+  * the pair pool of the correlation refinement overflowing -> CC_ECAPACITY from the collecting call;
+  * stage B1's 256-pair instance and the 64-pair constellation cap on crowded BCIs, against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy",
+              "n_knn_hits"]
+
+
+def real_shaped_scan(seed, n_cells=7500, pts_per_cell=16, scale=1.5):
+    """120 000 points over ~7 500 cells of a rough random height field: KITTI-like occupancy (4-9 k cells), many small
+    contours on every level (high spatial frequencies), point noise inside a cell (max-height ties are rare but occur)."""
+    rng = np.random.default_rng(seed)
+    cells = rng.choice(150 * 150, size=n_cells, replace=False)
+    cx = (cells // 150).astype(np.float64) - 75 + 0.5
+    cy = (cells % 150).astype(np.float64) - 75 + 0.5
+    xy = np.stack([np.repeat(cx, pts_per_cell), np.repeat(cy, pts_per_cell)], 1) + rng.uniform(-0.49, 0.49, (n_cells * pts_per_cell, 2))
+    z = np.zeros(len(xy))
+    for _ in range(14):
+        f = rng.uniform(0.05, 0.9, 2)
+        ph = rng.uniform(0, 6.28, 2)
+        z += rng.uniform(0.25, 0.9) * np.sin(f[0] * xy[:, 0] + ph[0]) * np.sin(f[1] * xy[:, 1] + ph[1])
+    z = z * scale + rng.normal(0, 0.1, len(z))
+    pts = np.zeros((len(xy), 4), np.float32)
+    pts[:, :2] = xy
+    pts[:, 2] = z
+    return pts
+
+
+def _ingest(cc, scans, mcfg=None):
+    import torch
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
+    x = torch.from_numpy(np.ascontiguousarray(np.concatenate(scans), np.float32)).cuda()
+    ctx = cc.Context(0, mcfg, max_batch=8)
+    d, dbg = ctx.ingest(x, offs, debug=True)
+    torch.cuda.synchronize()
+    return ctx, d, dbg
+
+
+def test_real_shaped_scans_bit_exact(cc, oracle):
+    from parity import compare_desc
+    scans = [real_shaped_scan(s) for s in range(4)] + [real_shaped_scan(10, n_cells=8900, pts_per_cell=13, scale=2.0)]
+    assert all(len(s) > 110000 for s in scans)
+    ctx, d, dbg = _ingest(cc, scans)
+    got = cc.desc_to_numpy(d)
+    lab = dbg["labels"].cpu().numpy()
+    for i, s in enumerate(scans):
+        o = oracle.Scan(s)
+        od = o.desc()[0]
+        assert 4000 <= od["n_pix"] <= 9000, od["n_pix"]                 # occupied cells: SURVEY.md 8(d)'s real-scan range
+        assert od["layer_cell_cnt"][0] > 3072, od["layer_cell_cnt"]     # active cells beyond CC_K2_CACHE: the spill path of the walk
+        assert od["n_cont"].max() >= 100 and od["flags"] == 0, od["n_cont"]
+        bad = compare_desc(od, got[i], float_exact=False)
+        assert not bad, "scan %d: %s" % (i, bad[:5])
+        assert np.array_equal(o.labels(), lab[i]), "canonical label images differ (scan %d)" % i
+    ctx.close()
+
+
+def _blob_field(n_blobs, height=2.3):
+    """n_blobs isolated 3-cell L-shaped blobs at `height` (above the two lowest levels), 3 cells apart"""
+    pts = []
+    per_row = 45
+    for b in range(n_blobs):
+        r, c = 4 + 3 * (b // per_row), 4 + 3 * (b % per_row)
+        for dr, dc in ((0, 0), (0, 1), (1, 0)):
+            x, y = (r + dr) - 75 + 0.5, (c + dc) - 75 + 0.5
+            if x * x + y * y < 16:
+                continue
+            pts.append((x, y, height - 2.0 + 0.001 * (b % 7), 0.0))
+    return np.asarray(pts, np.float32)
+
+
+def test_component_and_key_capacities_are_flagged(cc, oracle):
+    L = cc.L
+    # (a) 400 components on the two lowest levels: the device must say so, the host-buffer entry points must refuse
+    blobs = _blob_field(400)
+    ctx, d, _ = _ingest(cc, [blobs, real_shaped_scan(3)])
+    got = cc.desc_to_numpy(d)
+    od = oracle.Scan(blobs).desc()[0]
+    assert od["n_cont"][0] > 320 and (od["flags"] & 1)                  # the restatement stores the 320 largest and says TRUNCATED
+    assert got["flags"][0] & 2, got["flags"]                            # CC_DESC_INEXACT_COMPONENTS
+    assert got["flags"][1] == 0
+    with pytest.raises(cc.CCError, match="capacity"):
+        ctx.ingest_host(blobs, np.array([0, len(blobs)], np.int64))
+    db = cc.Database(ctx, capacity=8)
+    with pytest.raises(cc.CCError, match="inexact"):
+        db.add_scans(d[:1], np.zeros(1), np.zeros(1, np.int32))
+    assert len(db) == 0
+    db.add_scans(d[1:2], np.zeros(1), np.zeros(1, np.int32))           # the handle stays usable
+    assert len(db) == 1
+    # a flagged QUERY scan is reported by the collecting call
+    with pytest.raises(cc.CCError, match="capacity"):
+        db.query(d[:1], np.ones(1, np.int32))
+    db.close()
+    ctx.close()
+    # (b) roi_radius_ = 12: a key RoI holds up to ~450 cells, more than the kernel's list
+    mcfg = L.default_manager_cfg()
+    mcfg.roi_radius = 12.0
+    dense = real_shaped_scan(5, n_cells=21000, pts_per_cell=5, scale=1.5)
+    dense[:, 2] += 1.0   # most cells above lv_grads_[1]
+    ctx, d, _ = _ingest(cc, [dense], mcfg)
+    got = cc.desc_to_numpy(d)
+    assert got["flags"][0] & 4, got["flags"]                            # CC_DESC_INEXACT_KEYS
+    ctx.close()
+
+
+def test_pair_pool_overflow_is_reported(cc, monkeypatch):
+    import torch
+    monkeypatch.setenv("CC_GMM_POOL_PER_QUERY", "2")                    # read at cc_db_create: 1 024 pairs per lane
+    scans = [real_shaped_scan(20 + s) for s in range(2)]
+    ctx, d, _ = _ingest(cc, [scans[0], scans[0], scans[1]])
+    db = cc.Database(ctx, capacity=8)
+    db.add_scans(d[:2], np.array([0.0, 0.1]), np.arange(2, dtype=np.int32))
+    # the first scan against its own copy: every gate passes, the refinement wants hundreds of pairs
+    with pytest.raises(cc.CCError, match="pool"):
+        db.query(d[:1], np.full(1, 2, np.int32))
+    monkeypatch.delenv("CC_GMM_POOL_PER_QUERY")
+    db2 = cc.Database(ctx, capacity=8)
+    db2.add_scans(d[:2], np.array([0.0, 0.1]), np.arange(2, dtype=np.int32))
+    r = db2.query(d[:1], np.full(1, 2, np.int32))
+    assert r["n_res"][0] == 1 and r["flags"][0] == 0 and r["correlation"][0] > 0.9
+    db.close()
+    db2.close()
+    ctx.close()
+
+
+def test_crowded_constellations_on_the_gpu(cc, oracle):
+    """tests/test_emu_dense_constellations.py's rewrite (every anchor's neighbours crowded into three adjacent distance
+    bins: 100+ potential pairs per check with many equal orientation differences) on hardware: B1's 256-pair instance, the
+    sort replay on ties, the 64-pair constellation cap."""
+    import torch
+    from test_emu_dense_constellations import _crowd
+    L = cc.L
+    dcfg = L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
+    w = cc.synth.World(loop_len=40.0)
+    n = 56
+    x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+    _, _, odesc = oracle.run_sequence(x.numpy().reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * x.shape[1], ts,
+                                      np.arange(n, dtype=np.int32), dcfg=dcfg, want_desc=True)
+    desc, n_big = _crowd(odesc)
+    assert n_big > 100
+    odb = oracle.DB(dcfg)
+    exp = []
+    for i in range(n):
+        s = oracle.Scan.from_desc(desc[i], int_id=i)
+        exp.append(odb.query(s))
+        odb.add_scan(s, ts[i])
+        odb.push_and_balance(i, ts[i])
+    exp = np.array(exp)
+    assert exp["cand_aft_check2"].max() > 20
+    dd = torch.from_numpy(np.frombuffer(desc.tobytes(), np.uint8).reshape(n, cc.DESC_BYTES).copy()).cuda()
+    ctx = cc.Context(0, max_batch=8)
+    db = cc.Database(ctx, cfg=dcfg, capacity=n)
+    seeds = np.arange(n, dtype=np.int32)
+    db.add_scans(dd, ts, seeds)
+    res = db.query(dd, seeds)
+    assert (res["flags"] == 0).all()
+    for f in INT_FIELDS:
+        assert np.array_equal(exp[f], res[f]), f
+    m = exp["n_res"] > 0
+    assert np.abs(exp["correlation"][m] - res["correlation"][m]).max() < 1e-4 and np.abs(exp["tf"][m] - res["tf"][m]).max() < 1e-4
+    db.close()
+    ctx.close()
+
+
+def test_key_ulp_sensitivity(cc, oracle):
+    """How much can a last-ulp difference of a retrieval key (device exp / atan2f vs glibc) change?  2 000 full-size scans
+    of the looping sparse world are ingested on the GPU; the oracle replays the online loop on the device's descriptors
+    twice -- as they are, and with every non-zero key component moved by a random -1 / 0 / +1 ulp.  The number of queries
+    whose KNN hit count, match or outcome changes is the bound the parity note in DESIGN.md quotes."""
+    n = 2000
+    w = cc.synth.World(loop_len=600.0)
+    ctx = cc.Context(0, max_batch=128)
+    descs = []
+    for c0 in range(0, n, 125):
+        x, _, _ = cc.synth.make_sequence(125, world=w, device="cuda", start=c0)
+        descs.append(cc.desc_to_numpy(ctx.ingest(x.reshape(-1, 4), np.arange(126, dtype=np.int64) * x.shape[1])))
+    desc = np.concatenate(descs)
+    ctx.close()
+    rng = np.random.default_rng(1)
+    pert = desc.copy()
+    k = pert["keys"].view(np.int32)
+    k += np.where(pert["keys"] != 0, rng.integers(-1, 2, k.shape, dtype=np.int32), 0)
+    ts = np.arange(n) / 10.0
+
+    def replay(dd):
+        odb = oracle.DB()
+        out = np.zeros(n, cc.L.query_result_dt)
+        for i in range(n):
+            s = oracle.Scan.from_desc(dd[i], int_id=i)
+            out[i] = odb.query(s)
+            odb.add_scan(s, ts[i])
+            odb.push_and_balance(i, ts[i])
+        return out
+    a, b = replay(desc), replay(pert)
+    closed = a["n_res"] > 0
+    assert closed.sum() > 800
+    d_hits = int((a["n_knn_hits"] != b["n_knn_hits"]).sum())
+    d_match = int((a["cand_gidx"] != b["cand_gidx"]).sum())
+    d_res = int((a["n_res"] != b["n_res"]).sum())
+    same = closed & (a["cand_gidx"] == b["cand_gidx"])
+    d_corr = float(np.abs(a["correlation"][same] - b["correlation"][same]).max())
+    print("key +-1 ulp on %d scans (%d loop closures): n_knn_hits differs on %d queries, the matched scan on %d, a result "
+          "appears/disappears on %d; max |d correlation| on unchanged matches %.2e" % (n, int(closed.sum()), d_hits, d_match, d_res, d_corr))
+    # a key on the edge of the 50-th neighbour distance or of dist_ub may flip; the evaluation must not notice
+    assert d_hits <= n // 50 and d_match <= n // 200 and d_res <= 2 and d_corr < 1e-6
