@@ -879,9 +879,12 @@ struct cc_knn_tlds {
   int go[2][CC_KNN_TW];                // the wave's sub-walk (every other step of its direction) still has a search to serve
 };
 
-// Cut a search's buffer back to the candidates within its nnk-th smallest distance; returns that distance and the number
-// kept (>= nnk: ties at the distance stay, the final order by key id decides among them).  One wave, cnt <= 64 * R.
-template <int R>
+// Cut a search's buffer back: keep the candidates with distance <= x for an x with nnk <= #kept <= nnk + SLACK (bisection
+// on the distance bits with wave ballots, no sort); returns x -- an admissible radius: at least the nnk-th smallest distance,
+// so every key that can still make the result passes r <= x.  SLACK = 0 gives exactly the nnk-th smallest distance (more
+// than nnk are kept only when distances tie there); a few more kept candidates cost nothing and save most of the
+// bisection's ~31 rounds.  One wave, cnt <= 64 * R.
+template <int R, int SLACK>
 __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt, int nnk, int lane, int &kept) {
   unsigned long long v[R];
   unsigned d[R];
@@ -891,40 +894,43 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
     v[a] = (a * 64 + lane < cnt) ? buf[a * 64 + lane] : ~0ull;
     d[a] = (unsigned)(v[a] >> 32);  // squared distances are >= 0: their bit patterns order like the values
   }
-  unsigned lo = 0u, hi = 0x7F800000u;  // smallest x with #(d <= x) >= nnk
+  unsigned lo = 0u, hi = 0x7F800000u;  // invariant: #(d <= hi) >= nnk, #(d < lo) < nnk
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo) >> 1);
     int c = 0;
 #pragma unroll
     for (int a = 0; a < R; a++) c += __popcll(__ballot(d[a] <= mid));
-    if (c >= nnk)
+    if (c >= nnk) {
       hi = mid;
-    else
+      if (c <= nnk + SLACK) break;
+    } else {
       lo = mid + 1u;
+    }
   }
   cc_wave_sync();
   int off = 0;
 #pragma unroll
   for (int a = 0; a < R; a++) {
-    const bool keep = d[a] <= lo;
+    const bool keep = d[a] <= hi;
     const unsigned long long m = __ballot(keep);
     if (keep) buf[off + __popcll(m & ((1ull << lane) - 1ull))] = v[a];
     off += __popcll(m);
   }
   kept = off;
-  return __uint_as_float(lo);
+  return __uint_as_float(hi);
 }
 
-// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64 * CC_KNN_TW
+// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64 * CC_KNN_TW.  PH: the phase timers (tuning aid) are compiled in.
+template <bool PH>
 __global__ void __launch_bounds__(64 * CC_KNN_TW)
 cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
               const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt,
               long long *__restrict__ phase_clk /*tuning aid (CC_KNN_PHASES=1), else nullptr: [grid][8] ticks of 10 ns*/) {
   __shared__ cc_knn_tlds L;
   long long pc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup | step | barrier | pass | cut-back | results | rounds | passes
-  long long pt_ = phase_clk ? wall_clock64() : 0;
+  long long pt_ = PH ? wall_clock64() : 0;
 #define CC_KNN_TICK(slot)                      \
-  if (phase_clk) {                             \
+  if (PH) {                                    \
     const long long now_ = wall_clock64();     \
     pc_[slot] += now_ - pt_;                   \
     pt_ = now_;                                \
@@ -1064,7 +1070,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   if (mine) CC_KNN_TFETCH()
   CC_KNN_TICK(0)
   for (int par = 0;; par ^= 1) {
-    pc_[6]++;
+    if (PH) pc_[6]++;
     if (mine) {
       const int sb_cur = sb;
       cc_f32x4 acc[4];
@@ -1193,7 +1199,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           }
         }
         __syncthreads();
-        pc_[7]++;
+        if (PH) pc_[7]++;
         CC_KNN_TICK(3)
         // cut back the buffers that filled up: wave w looks after the searches w, w + 4, ...
         const int cnt_l = L.st[j].cnt, tight_l = L.st[j].tight;  // lane (j, kq): search j's
@@ -1203,7 +1209,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           due &= due - 1ull;
           const int cnt = __builtin_amdgcn_readlane(cnt_l, jj);
           int kept;
-          float nub = cnt <= 128 ? cc_knn_select<2>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept);
+          float nub = cnt <= 128 ? cc_knn_select<2, 12>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<4, 12>(L.buf[jj], cnt, nnk, lane, kept);
           if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
                             // in the result -- order them and drop the rest, so that the buffer bound holds
             unsigned long long first;
@@ -1232,7 +1238,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
     if (cnt > 128) {  // ties aside, what is within the nnk-th distance fits the smaller sorting network
       int kept;
-      cc_knn_select<4>(L.buf[jj], cnt, nnk, lane, kept);
+      cc_knn_select<4, 12>(L.buf[jj], cnt, nnk, lane, kept);
       cnt = kept;
     }
     unsigned long long first;
@@ -1257,6 +1263,6 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   }
   CC_KNN_TICK(5)
 #undef CC_KNN_TICK
-  if (phase_clk && tid == 0)
+  if (PH && phase_clk && tid == 0)
     for (int i = 0; i < 8; i++) phase_clk[(size_t)blockIdx.x * 8 + i] = pc_[i];
 }

@@ -154,10 +154,30 @@ class ContourDB {
 // scores and records it; fineOptimize replays the recorded hints in call order through checks, proposal merge, tidy-up
 // and refinement.  Candidate scans live in a process-wide device store (one per cont_sim setting).  Hint levels: 1..4.
 class CandidateManager {
+  // Candidate scans live in a device store shared by the managers of one (grid, cont_sim) setting.  It is a cache: when it
+  // is full it is emptied and refilled with what the manager at hand needs, so no number of distinct candidates exhausts it.
   struct Store {
     cc_db *db = nullptr;
+    cc_db_cfg_t cfg;
+    cc_ctx *ctx = nullptr;
+    int cap = 1024;
     std::map<const ContourManager *, int> pos;
-    std::vector<std::shared_ptr<const ContourManager>> keep;  // as ContourDB::all_bevs_: scans stay alive
+    std::vector<std::shared_ptr<const ContourManager>> keep;  // position -> scan (kept alive while it is in the store)
+    void reset() {
+      cc_db_destroy(db);
+      db = nullptr;
+      pos.clear();
+      keep.clear();
+      if (cc_db_create(ctx, &cfg, cap, &db) != CC_OK) die();
+    }
+    bool has(const ContourManager *p) const { return pos.count(p) != 0; }
+    int add(const std::shared_ptr<const ContourManager> &cm) {
+      const int g = cc_db_size(db);
+      if (cc_db_add_scan_host(db, &cm->desc(), (double)g, g) != CC_OK) die();
+      pos[cm.get()] = g;
+      keep.push_back(cm);
+      return g;
+    }
   };
   static Store &store(const ContourManager &cm, const ContourSimThresConfig &cs) {
     static std::map<std::string, Store> pool;
@@ -165,17 +185,31 @@ class CandidateManager {
     key.append((const char *)&cs, sizeof(cs));
     Store &st = pool[key];
     if (!st.db) {
-      cc_db_cfg_t d;
-      cc_default_db_cfg(&d);
-      d.cont_sim.ta_cell_cnt = cs.ta_cell_cnt;
-      d.cont_sim.tp_cell_cnt = cs.tp_cell_cnt;
-      d.cont_sim.tp_eigval = cs.tp_eigval;
-      d.cont_sim.ta_h_bar = cs.ta_h_bar;
-      d.cont_sim.ta_rcom = cs.ta_rcom;
-      d.cont_sim.tp_rcom = cs.tp_rcom;
-      if (cc_db_create(cc_host::context(cm.ccfg()), &d, 4096, &st.db) != CC_OK) die();
+      cc_default_db_cfg(&st.cfg);
+      st.cfg.cont_sim.ta_cell_cnt = cs.ta_cell_cnt;
+      st.cfg.cont_sim.tp_cell_cnt = cs.tp_cell_cnt;
+      st.cfg.cont_sim.tp_eigval = cs.tp_eigval;
+      st.cfg.cont_sim.ta_h_bar = cs.ta_h_bar;
+      st.cfg.cont_sim.ta_rcom = cs.ta_rcom;
+      st.cfg.cont_sim.tp_rcom = cs.tp_rcom;
+      st.ctx = cc_host::context(cm.ccfg());
+      if (const char *e = getenv("CC_CAND_STORE_CAP")) st.cap = atoi(e) > 0 ? atoi(e) : st.cap;
+      if (cc_db_create(st.ctx, &st.cfg, st.cap, &st.db) != CC_OK) die();
     }
     return st;
+  }
+  // every candidate of THIS manager present in the store (positions may change when the store is recycled)
+  void ensureMine() {
+    Store &st = *st_;
+    bool all = true;
+    for (const auto &c : my_cands_) all = all && st.has(c.get());
+    if (all) return;
+    int missing = 0;
+    for (const auto &c : my_cands_) missing += st.has(c.get()) ? 0 : 1;
+    CC_CHECK((int)my_cands_.size() <= st.cap);  // one manager's candidates must fit (the reference has no bound; raise CC_CAND_STORE_CAP)
+    if (cc_db_size(st.db) + missing > st.cap) st.reset();
+    for (const auto &c : my_cands_)
+      if (!st.has(c.get())) st.add(c);
   }
   static void die() {
     fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
@@ -198,7 +232,9 @@ class CandidateManager {
   const CandidateScoreEnsemble sim_ub_;
   CandidateScoreEnsemble sim_var_;
   Store *st_ = nullptr;
-  std::vector<cc_hint_t> hints_;
+  std::vector<cc_hint_t> hints_;                                // cand_gidx = index into my_cands_ until the call is made
+  std::vector<std::shared_ptr<const ContourManager>> my_cands_;  // this manager's candidate scans, first-appearance order
+  std::map<int, int> id2local_;                                 // the reference keys candidates_ by getIntID() (contour_db.h:468-476)
   int flow_valve = 0;
 
  public:
@@ -218,15 +254,14 @@ class CandidateManager {
     Store &st = store(*cm_tgt_, cont_sim);
     CC_CHECK(st_ == nullptr || st_ == &st);  // one cont_sim setting per manager
     st_ = &st;
-    auto it = st.pos.find(cm_cand.get());
-    if (it == st.pos.end()) {
-      const int g = cc_db_size(st.db);
-      if (cc_db_add_scan_host(st.db, &cm_cand->desc(), (double)g, g) != CC_OK) die();
-      it = st.pos.insert({cm_cand.get(), g}).first;
-      st.keep.push_back(cm_cand);
+    auto it = id2local_.find(cm_cand->getIntID());
+    if (it == id2local_.end()) {
+      it = id2local_.insert({cm_cand->getIntID(), (int)my_cands_.size()}).first;
+      my_cands_.push_back(cm_cand);
     }
+    ensureMine();
     cc_hint_t h;
-    h.cand_gidx = it->second;
+    h.cand_gidx = st.pos[my_cands_[it->second].get()];
     h.level = anchor_pair.level;
     h.seq_src = anchor_pair.seq_src;
     h.seq_tgt = anchor_pair.seq_tgt;
@@ -235,6 +270,7 @@ class CandidateManager {
     cc_query_result_t r;
     cc_hint_score_t sc;
     if (cc_db_check_hints_host(st.db, &cm_tgt_->desc(), &h, 1, &lb, &ub, 1, &r, &sc) != CC_OK) die();
+    h.cand_gidx = it->second;  // recorded by the manager's own numbering
     hints_.push_back(h);
     cand_aft_check1 += r.cand_aft_check1;
     cand_aft_check2 += r.cand_aft_check2;
@@ -265,7 +301,10 @@ class CandidateManager {
     if (hints_.empty() || !st_) return 0;
     const cc_score_t lb = to_c(sim_var_), ub = to_c(sim_ub_);
     cc_query_result_t r;
-    if (cc_db_check_hints_host(st_->db, &cm_tgt_->desc(), hints_.data(), (int)hints_.size(), &lb, &ub, max_fine_opt, &r, nullptr) != CC_OK)
+    ensureMine();
+    std::vector<cc_hint_t> hs(hints_);
+    for (auto &h : hs) h.cand_gidx = st_->pos[my_cands_[h.cand_gidx].get()];
+    if (cc_db_check_hints_host(st_->db, &cm_tgt_->desc(), hs.data(), (int)hs.size(), &lb, &ub, max_fine_opt, &r, nullptr) != CC_OK)
       die();
     if (r.n_res > 0) {
       res_cand.push_back(st_->keep[r.cand_gidx]);

@@ -112,3 +112,29 @@ def test_capacities_are_flagged_never_silent(oracle):
     rc, res, sc = _check(api, L, db3, many, hints)
     assert rc == CC_ECAPACITY and (res["flags"] & CC_QF_GMM_CAP) and not (res["flags"] & CC_QF_CHECK_CAP), (rc, res["flags"])
     assert res["n_res"] == 1   # delivered all the same
+
+
+def test_hint_must_name_existing_contours_on_both_sides(oracle):
+    """cc_db_check_hints validates seq_src against the DB scan and seq_tgt against the (device-resident) query scan: a hint
+    naming a contour that does not exist is CC_EINVAL, not a comparison against zero-filled rows."""
+    from test_emu_query import _load_query_fixture
+    L = oracle.L
+    desc, ts, exp, d = _load_query_fixture(L)
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=2)
+    db = api.db_create(ctx, d, cap=4)
+    api.db_add(db, desc[:1], ts[:1], np.zeros(1, np.int32))
+    pick = None
+    for qi in range(1, len(desc)):
+        for lev in range(1, 5):
+            if 0 < desc["n_cont"][qi][lev] < L.NPIV and desc["n_cont"][0][lev] > 0:
+                pick = (qi, lev, int(desc["n_cont"][qi][lev]))
+                break
+        if pick:
+            break
+    assert pick, "the fixture should hold a scan with fewer than 6 contours on some level"
+    qi, lev, nc = pick
+    rc, _, _ = _check(api, L, db, desc[qi:qi + 1], [(lev, 0, nc - 1)])
+    assert rc == 0
+    rc, _, _ = _check(api, L, db, desc[qi:qi + 1], [(lev, 0, nc)])
+    assert rc == -1 and b"query scan" in api.lib.cc_last_error()
