@@ -517,17 +517,47 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
 // ------------------------------------------------------------------------------------------------
 #define CC_KNN_S 4
 #define CC_KNN_ORDER_CAP 4096  // searches of one layer in a chunk (QB * CC_NPIV = 3072), padded to a power of two
+#define CC_KNN_ORDER_GROUP 16  // searches per group of the tiled search (= CC_KNN_TQ)
+
+// block-wide inclusive scan of n_pow2 ints in LDS (Hillis-Steele, ping-pong between a and b); returns the buffer holding the result
+template <bool MAX>
+__device__ __forceinline__ int *cc_block_scan(int *a, int *b, int n_pow2, int tid, int nt) {
+  for (int o = 1; o < n_pow2; o <<= 1) {
+    for (int i = tid; i < n_pow2; i += nt) {
+      const int x = a[i], y = i >= o ? a[i - o] : (MAX ? 0 : 0);
+      b[i] = i >= o ? (MAX ? (x > y ? x : y) : x + y) : x;
+    }
+    __syncthreads();
+    int *t = a;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+// Layout of the per-chunk order buffer (ints): per layer the searches in key[0] order, the group starts of the tiled search,
+// then the counts.
+#define CC_KNN_ORD_ORDER(ll) ((ll) * CC_KNN_ORDER_CAP)
+#define CC_KNN_ORD_GSTART(ll) (CC_NQLEV * CC_KNN_ORDER_CAP + (ll) * (CC_KNN_ORDER_CAP + 1))
+#define CC_KNN_ORD_NVALID (CC_NQLEV * CC_KNN_ORDER_CAP + CC_NQLEV * (CC_KNN_ORDER_CAP + 1))
+#define CC_KNN_ORD_NGROUP (CC_KNN_ORD_NVALID + CC_NQLEV)
+#define CC_KNN_ORD_INTS (CC_KNN_ORD_NGROUP + CC_NQLEV)
 
 // grid = n_q_levels, block = 1024.  order[ll][i] = search (q * CC_NPIV + seq) with the i-th smallest key[0] among the
 // layer's searches that have a key (q_keys[seq].sum() != 0, contour_db.h:726); the others get their empty result here.
+// For the tiled search the ordered searches are also cut into GROUPS of at most 16 whose key[0] lie within ~4 % of each
+// other (a group walks the union of its searches' windows: where searches are sparse -- the large keys -- a fixed
+// sixteen would span a multiple of a window): gstart[ll][g] .. gstart[ll][g + 1] are group g's positions in `order`.
 __global__ void __launch_bounds__(1024)
-cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, int *__restrict__ order /*[CC_NQLEV][CC_KNN_ORDER_CAP]*/,
-               int *__restrict__ n_valid /*[CC_NQLEV]*/, int *__restrict__ hit_cnt) {
+cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, int *__restrict__ ord, int *__restrict__ hit_cnt) {
   __shared__ unsigned long long a[CC_KNN_ORDER_CAP];
+  __shared__ int sa[CC_KNN_ORDER_CAP];
   __shared__ int nv;
+  int *sb_ = (int *)a;  // second scan buffer: the sort keys are dead by then
   const int ll = blockIdx.x, tid = threadIdx.x;
   const int level = P.q_levels[ll];
   const int ns = nq * CC_NPIV;
+  int *order = ord + CC_KNN_ORD_ORDER(ll), *gstart = ord + CC_KNN_ORD_GSTART(ll);
   if (tid == 0) nv = 0;
   if (ll == 0)  // layers the configuration does not query: empty results
     for (int i = tid; i < nq * (CC_NQLEV - P.n_q_levels) * CC_NPIV; i += 1024) {
@@ -558,8 +588,32 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
   if (mine) atomicAdd(&nv, mine);
   __syncthreads();
   cc_bitonic_sort_u64(a, np2, tid, 1024);
-  for (int i = tid; i < nv; i += 1024) order[ll * CC_KNN_ORDER_CAP + i] = (int)(a[i] & 0xFFFFFFFFu);
-  if (tid == 0) n_valid[ll] = nv;
+  const int nvl = nv;
+  for (int i = tid; i < nvl; i += 1024) order[i] = (int)(a[i] & 0xFFFFFFFFu);
+  // groups: geometric key[0] buckets of ratio 1.04, each cut into runs of 16
+  for (int i = tid; i < np2; i += 1024) {
+    int head = 0;
+    if (i < nvl && i > 0) {
+      const float q0 = cc_funkey((unsigned)(a[i] >> 32)), qp = cc_funkey((unsigned)(a[i - 1] >> 32));
+      const int b0 = (int)floorf(log2f(q0 > 1e-3f ? q0 : 1e-3f) * 17.673f), bp = (int)floorf(log2f(qp > 1e-3f ? qp : 1e-3f) * 17.673f);
+      head = b0 != bp ? i : 0;
+    }
+    sa[i] = head;  // index of the bucket's first search where a bucket starts, else 0 (search 0 starts the first bucket)
+  }
+  __syncthreads();
+  int *hd = cc_block_scan<true>(sa, sb_, np2, tid, 1024);  // hd[i] = first search of i's bucket
+  int *fl = hd == sa ? sb_ : sa;
+  for (int i = tid; i < np2; i += 1024) fl[i] = (i < nvl && ((i - hd[i]) & (CC_KNN_ORDER_GROUP - 1)) == 0) ? 1 : 0;
+  __syncthreads();
+  int *gi = cc_block_scan<false>(fl, hd, np2, tid, 1024);  // gi[i] = groups started up to and including i
+  for (int i = tid; i < nvl; i += 1024)
+    if (i == 0 || gi[i] != gi[i - 1]) gstart[gi[i] - 1] = i;
+  if (tid == 0) {
+    const int ng = nvl > 0 ? gi[nvl - 1] : 0;
+    gstart[ng] = nvl;
+    ord[CC_KNN_ORD_NVALID + ll] = nvl;
+    ord[CC_KNN_ORD_NGROUP + ll] = ng;
+  }
 }
 
 struct cc_knn_sstate {  // per search of a wave, wave-uniform values
@@ -924,7 +978,7 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
 template <bool PH>
 __global__ void __launch_bounds__(64 * CC_KNN_TW)
 cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
-              const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt,
+              const int *__restrict__ ordbuf /*cc_k_knn_order's output*/, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt,
               long long *__restrict__ phase_clk /*tuning aid (CC_KNN_PHASES=1), else nullptr: [grid][8] ticks of 10 ns*/) {
   __shared__ cc_knn_tlds L;
   long long pc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup | step | barrier | pass | cut-back | results | rounds | passes
@@ -936,13 +990,13 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     pt_ = now_;                                \
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nblk = (nq * CC_NPIV + CC_KNN_TQ - 1) / CC_KNN_TQ;
+  const int nblk = nq * CC_NPIV;  // one workgroup slot per search: at most that many groups (most slots exit at once)
   const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
   if (ll >= P.n_q_levels) return;
-  const int nv = n_valid[ll];
-  const int base = w * CC_KNN_TQ;
-  if (base >= nv) return;
-  const int ns = nv - base < CC_KNN_TQ ? nv - base : CC_KNN_TQ;  // searches of this workgroup
+  if (w >= ordbuf[CC_KNN_ORD_NGROUP + ll]) return;
+  const int *order_l = ordbuf + CC_KNN_ORD_ORDER(ll);
+  const int base = ordbuf[CC_KNN_ORD_GSTART(ll) + w];
+  const int ns = ordbuf[CC_KNN_ORD_GSTART(ll) + w + 1] - base;  // searches of this workgroup, 1 .. CC_KNN_TQ
   const int level = P.q_levels[ll];
   const int n = P.n_sorted[ll];
   const float *K = P.skeys[ll];
@@ -954,7 +1008,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   const int dir = wave >> 1, sub = wave & 1;  // this wave's direction and which of the round's two steps it takes
 
   // ---- this lane's search: key, dist_ub, epoch, bucket thresholds (cc_k_knn); padding columns repeat search 0
-  const int srch = order[ll * CC_KNN_ORDER_CAP + base + (j < ns ? j : 0)];
+  const int srch = order_l[base + (j < ns ? j : 0)];
   const int q = srch / CC_NPIV, seq = srch - q * CC_NPIV;
   float k[CC_KEY_DIM];
   {
@@ -1035,7 +1089,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   }
   __syncthreads();
   const int L0 = L.qb[j][0], E1 = L.qb[j][1], S2 = L.qb[j][2], E2 = L.qb[j][3];
-  const int p0 = __builtin_amdgcn_readfirstlane(L.qb[0][5]);  // search 0's own position splits the walk
+  const int p0 = __builtin_amdgcn_readfirstlane(L.qb[ns >> 1][5]);  // the middle search's own position splits the walk
   const bool valid = j < ns;
   float ubj = ub0;
   int tightj = 0;
@@ -1246,7 +1300,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
     else
       cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
-    const int s_ = order[ll * CC_KNN_ORDER_CAP + base + jj];
+    const int s_ = order_l[base + jj];
     const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
     const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;
     const int mm = cnt < nnk ? cnt : nnk;

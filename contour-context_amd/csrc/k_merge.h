@@ -169,7 +169,19 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         const double itx = -(i00 * ptx + i01 * pty), ity = -(i10 * ptx + i11 * pty);
         const double d00 = i00 * p->c + i01 * p->s, d10 = i10 * p->c + i11 * p->s;
         const double dtx = i00 * p->tx + i01 * p->ty + itx, dty = i10 * p->tx + i11 * p->ty + ity;
-        if (sqrt(dtx * dtx + dty * dty) < 2.0 && fabs(atan2(d10, d00)) < 0.3) hit = pi;
+        // sqrt(n2) < 2.0 && |atan2(d10, d00)| < 0.3, decided without the f64 square root and arc tangent unless a value lies
+        // within 1e-9 (relative) of its bar -- then the reference's expressions decide (sqrt and atan2 are monotone, their
+        // rounding moves a result by an ulp, eight orders of magnitude inside that margin)
+        const double n2 = dtx * dtx + dty * dty;
+        bool near_t = n2 < 4.0 * (1.0 - 1e-9);
+        if (!near_t && n2 <= 4.0 * (1.0 + 1e-9)) near_t = sqrt(n2) < 2.0;
+        if (near_t) {
+          const double t03 = 0.30933624960962325;  // tan(0.3)
+          const double ay = fabs(d10), lim = d00 * t03;
+          bool near_r = d00 > 0.0 && ay < lim * (1.0 - 1e-9);
+          if (!near_r && d00 > 0.0 && ay <= lim * (1.0 + 1e-9)) near_r = fabs(atan2(d10, d00)) < 0.3;
+          if (near_r) hit = pi;
+        }
       }
       if (hit >= 0) {
         cc_dprop *p = &c->props[hit];

@@ -130,7 +130,7 @@ def test_component_and_key_capacities_are_flagged(cc, oracle):
 
 def test_pair_pool_overflow_is_reported(cc, monkeypatch):
     import torch
-    monkeypatch.setenv("CC_GMM_POOL_PER_QUERY", "2")                    # read at cc_db_create: 1 024 pairs per lane
+    monkeypatch.setenv("CC_GMM_POOL_PAIRS", "32")                       # read at cc_db_create: 32 pairs per lane
     scans = [real_shaped_scan(20 + s) for s in range(2)]
     ctx, d, _ = _ingest(cc, [scans[0], scans[0], scans[1]])
     db = cc.Database(ctx, capacity=8)
@@ -138,7 +138,7 @@ def test_pair_pool_overflow_is_reported(cc, monkeypatch):
     # the first scan against its own copy: every gate passes, the refinement wants hundreds of pairs
     with pytest.raises(cc.CCError, match="pool"):
         db.query(d[:1], np.full(1, 2, np.int32))
-    monkeypatch.delenv("CC_GMM_POOL_PER_QUERY")
+    monkeypatch.delenv("CC_GMM_POOL_PAIRS")
     db2 = cc.Database(ctx, capacity=8)
     db2.add_scans(d[:2], np.array([0.0, 0.1]), np.arange(2, dtype=np.int32))
     r = db2.query(d[:1], np.full(1, 2, np.int32))
