@@ -898,13 +898,13 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 // 11th row (cc_k_ksort_merge).
 // ------------------------------------------------------------------------------------------------
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
-#define CC_KNN_TW 4       // waves per workgroup
+#define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
+#define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
 #define CC_KNN_TPASS 128  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one
 #define CC_KNN_TCAP 256   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
 #define CC_KNN_TWL 1216   // queue per wave: < CC_KNN_TPASS left pending by the whole workgroup + 1024 pairs of one step
-// LDS: 32 KB of buffers + 19 KB of queues + 1.3 KB: three workgroups per CU, so the 576 workgroups of a 512-query chunk
-// (3 layers x 192) are resident at once
+// LDS: 32 KB of buffers + 38 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
 static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS - 1 + 1024 <= CC_KNN_TWL &&
                   CC_KNN_TPASS <= 64 * CC_KNN_TW, "cc_k_knn_tile: buffer bounds");
@@ -990,13 +990,17 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     pt_ = now_;                                \
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nblk = nq * CC_NPIV;  // one workgroup slot per search: at most that many groups (most slots exit at once)
-  const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
-  if (ll >= P.n_q_levels) return;
-  if (w >= ordbuf[CC_KNN_ORD_NGROUP + ll]) return;
+  // one workgroup slot per search and layer (at most that many groups; most slots exit at once), layers interleaved
+  const int ll = blockIdx.x % P.n_q_levels, w = blockIdx.x / P.n_q_levels;
+  (void)nq;
+  const int ng_ = ordbuf[CC_KNN_ORD_NGROUP + ll];
+  if (w >= ng_) return;
+  // the groups with the largest key[0] first: their windows are the widest (dist_ub grows with the key, the keys get
+  // sparse), they set the kernel's duration and must not start last
+  const int gsel = ng_ - 1 - w;
   const int *order_l = ordbuf + CC_KNN_ORD_ORDER(ll);
-  const int base = ordbuf[CC_KNN_ORD_GSTART(ll) + w];
-  const int ns = ordbuf[CC_KNN_ORD_GSTART(ll) + w + 1] - base;  // searches of this workgroup, 1 .. CC_KNN_TQ
+  const int base = ordbuf[CC_KNN_ORD_GSTART(ll) + gsel];
+  const int ns = ordbuf[CC_KNN_ORD_GSTART(ll) + gsel + 1] - base;  // searches of this workgroup, 1 .. CC_KNN_TQ
   const int level = P.q_levels[ll];
   const int n = P.n_sorted[ll];
   const float *K = P.skeys[ll];
@@ -1005,7 +1009,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   const size_t cap = (size_t)P.cap_k;
   const int nnk = P.nnk;
   const int j = lane & 15, kq = lane >> 4;  // this lane's search (column) and its k-slice of every 4-wide MFMA step
-  const int dir = wave >> 1, sub = wave & 1;  // this wave's direction and which of the round's two steps it takes
+  const int dir = wave / (CC_KNN_TW / 2), sub = wave % (CC_KNN_TW / 2);  // this wave's direction and which of the round's steps it takes
 
   // ---- this lane's search: key, dist_ub, epoch, bucket thresholds (cc_k_knn); padding columns repeat search 0
   const int srch = order_l[base + (j < ns ? j : 0)];
@@ -1101,7 +1105,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   // radius (or past its ranges) so does everything further out.  One barrier per round.
   bool open_d = valid && (dir == 0 ? (p0 < E2 && p0 < n) : (p0 > L0 && p0 > 0));  // this lane's search, this wave's direction
   int sb = dir == 0 ? p0 + 64 * sub : p0 - 64 * (sub + 1);  // first index of this wave's current step (ascending inside a step)
-  if (sub == 1) open_d = open_d && (dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0));
+  if (sub > 0) open_d = open_d && (dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0));
   bool mine = __ballot(open_d) != 0ull;  // wave-uniform
   int wn = 0;                            // pairs pending in this wave's queue (wave-uniform)
   float a[4][3];  // A operand of the fetched step: tile t = keys sb + 16 t + (lane & 15), element 4 s + kq
@@ -1137,7 +1141,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       // the step's outermost key[0] (row 0 lives in the lanes kq == 0, element s = 0): upwards the last key, downwards the first
       const float far0 = dir == 0 ? cc_lane_bcast(a[3][0], 15) : cc_lane_bcast(a[0][0], 0);
       // the wave's next step travels while this one's pairs are filtered
-      sb += dir == 0 ? 128 : -128;
+      sb += dir == 0 ? CC_KNN_TSTRIDE : -CC_KNN_TSTRIDE;
       CC_KNN_TFETCH()
       // filter: D[row = 4 kq + r of tile t][column j] <= radius + slack -> one bit per pair, this lane's sixteen
       unsigned m = 0u;
@@ -1199,8 +1203,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
             }
             tgt = __builtin_amdgcn_readfirstlane(tgt);
             if (tgt != 0x7fffffff && tgt >= 64) {
-              const int kk = (tgt - 63 + 127) / 128;  // steps of 128 until the wave's step reaches that index
-              sb += dir == 0 ? 128 * kk : -128 * kk;
+              const int kk = (tgt - 63 + CC_KNN_TSTRIDE - 1) / CC_KNN_TSTRIDE;  // of the wave's own steps until one reaches that index
+              sb += dir == 0 ? CC_KNN_TSTRIDE * kk : -CC_KNN_TSTRIDE * kk;
               CC_KNN_TFETCH()
             }
           }
@@ -1215,14 +1219,27 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     __syncthreads();
     CC_KNN_TICK(2)
     // ---- the queues: worked off once CC_KNN_TPASS pairs are pending, or when the walk is over
-    const int c0 = L.wn[par][0], c1 = L.wn[par][1], c2 = L.wn[par][2], c3 = L.wn[par][3];
-    const int tot = c0 + c1 + c2 + c3;
-    const bool walking = (L.go[par][0] | L.go[par][1] | L.go[par][2] | L.go[par][3]) != 0;
+    int cum[CC_KNN_TW + 1];  // queue w holds the pairs cum[w] .. cum[w + 1] of the round's list
+    cum[0] = 0;
+    int going = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < CC_KNN_TW; w_++) {
+      cum[w_ + 1] = cum[w_] + L.wn[par][w_];
+      going |= L.go[par][w_];
+    }
+    const int tot = cum[CC_KNN_TW];
+    const bool walking = going != 0;
     if (tot >= CC_KNN_TPASS || (!walking && tot > 0)) {
       for (int e0 = 0; e0 < tot; e0 += CC_KNN_TPASS) {
         const int e = e0 + tid;
         if (tid < CC_KNN_TPASS && e < tot) {
-          const unsigned ent = e < c0 ? L.wl[0][e] : e < c0 + c1 ? L.wl[1][e - c0] : e < c0 + c1 + c2 ? L.wl[2][e - c0 - c1] : L.wl[3][e - c0 - c1 - c2];
+          int qw = 0;
+#pragma unroll
+          for (int w_ = 1; w_ < CC_KNN_TW; w_++) qw += e >= cum[w_] ? 1 : 0;
+          int qoff = cum[0];
+#pragma unroll
+          for (int w_ = 1; w_ < CC_KNN_TW; w_++) qoff = qw == w_ ? cum[w_] : qoff;
+          const unsigned ent = L.wl[qw][e - qoff];
           const int js = (int)(ent >> 28);
           const unsigned u_ = ent & 0x0FFFFFFFu;
           const int act = sact[u_];
