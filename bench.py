@@ -386,6 +386,7 @@ def main():
         out["roofline"]["step_algorithmic_bytes"] = sum(alg.values())
         out["roofline"]["ingest_roofline_scans_per_s"] = HBM_PEAK_GBS * 1e9 / (P * 16)
         out["roofline"]["value_over_ingest_roofline"] = value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))
+        batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
             # the reference's online loop on the scans already resident: from an empty DB, per 256-scan sub-batch
             # ingest -> add -> query at the scan's own epoch; with the DB update inside the timed region and without
@@ -395,10 +396,25 @@ def main():
                 out["extra"]["dropin_loop"] = dropin_loop(batches[0], P, min(B, 1024))
             except Exception as e:  # the headline stands on its own
                 out["extra"]["dropin_loop"] = {"error": repr(e)}
+            # the other single-GPU configurations of BASELINE.json, 4 timed steps each (same pipeline as the headline)
+            if args.db_scans == 5000 and args.workload == "sparse":
+                try:
+                    del batches
+                    db.close()
+                    db = None
+                    torch.cuda.empty_cache()
+                    big, rec50 = measure_config(cc, ctx, dev, wld, 50000, B, 4, 1, P, first_query=60000)
+                    out["extra"]["db_50k_sparse"] = big
+                    out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, wld, 20000, B, 4, 1, P, first_query=60000, rec=rec50)[0]
+                    del rec50
+                    out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 4, 1, P)[0]
+                except Exception as e:
+                    out["extra"]["other_configs_error"] = repr(e)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W % len(batches)], P, min(args.cpu_sample, B))
+            out["cpu_baseline"] = cpu_baseline(cc, desc_keep.numpy(), n_db, batch_cpu, P, min(args.cpu_sample, B))
         print(json.dumps(out), flush=True)
-    db.close()
+    if db is not None:
+        db.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -571,6 +587,67 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=None):
+    """A short run of the headline step on another configuration (world, DB size), same pipeline as the headline: ingest of
+    batch s + 1 on its own stream while batch s is queried (cc_db_query_submit), every result collected inside the timed
+    region.  `rec` = packed records of a DB built earlier whose first n_db scans are used.  Returns (figures, records)."""
+    import torch
+    HB, FB = cc.packed_sizes()
+    if rec is None or rec.shape[0] < n_db:
+        rec = torch.empty((n_db, HB + FB), dtype=torch.uint8, device=dev)
+        tmp = torch.empty((256, cc.DESC_BYTES), dtype=torch.uint8, device=dev)
+        for c0 in range(0, n_db, 256):
+            c1 = min(c0 + 256, n_db)
+            x, _, _ = cc.synth.make_sequence(c1 - c0, world=wld, device=dev, start=c0)
+            d = ctx.ingest(x.reshape(-1, 4), np.arange(c1 - c0 + 1, dtype=np.int64) * P, out=tmp[:c1 - c0])
+            hot, feat = ctx.pack(d)
+            rec[c0:c1, :HB] = hot
+            rec[c0:c1, HB:] = feat
+    db = cc.Database(ctx, capacity=n_db + 16)
+    db.add_packed(rec[:n_db, :HB].contiguous(), rec[:n_db, HB:].contiguous(), np.arange(n_db) / 10.0, np.arange(n_db, dtype=np.int32))
+    q0 = n_db if first_query is None else first_query
+    batches = []
+    for s_ in range(W + K):
+        x, _, _ = cc.synth.make_sequence(B, world=wld, device=dev, start=q0 + s_ * B)
+        batches.append(x.reshape(-1, 4).contiguous())
+    offs = np.arange(B + 1, dtype=np.int64) * P
+    epochs = np.full(B, n_db, np.int32)
+    slots = [torch.empty((B, cc.DESC_BYTES), dtype=torch.uint8, device=dev) for _ in range(2)]
+    s_main, s_ing = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+
+    def ingest_async(k):
+        s_ing.wait_stream(s_main)
+        with torch.cuda.stream(s_ing):
+            ctx.ingest(batches[k], offs, out=slots[k & 1])
+            ev = torch.cuda.Event()
+            ev.record(s_ing)
+        return ev
+
+    def run(first, count):
+        res = []
+        ev = ingest_async(first)
+        for k in range(first, first + count):
+            s_main.wait_event(ev)
+            if k + 1 < first + count:
+                ev = ingest_async(k + 1)
+            res.append(db.query_submit(slots[k & 1], epochs))
+        db.query_wait()
+        return res
+    run(0, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(W, K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    found = int(sum((r["n_res"] > 0).sum() for r in res))
+    flags = int(sum((r["flags"] != 0).sum() for r in res))
+    d = cc.desc_to_numpy(slots[(W + K - 1) & 1][:64])
+    db.close()
+    return {"scans_per_s": K * B / dt, "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W, "db_scans": n_db, "batch": B,
+            "loop_closures": found, "queries": K * B, "flagged_queries": flags,
+            "occupied_cells_mean": round(float(d["n_pix"].mean()), 1), "contours_per_level_mean": [round(float(v), 1) for v in d["n_cont"].mean(0)]}, rec
 
 
 def dropin_loop(batch0, P, n):

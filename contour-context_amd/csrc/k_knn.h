@@ -897,6 +897,7 @@ cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 // the final order is (distance, key id): hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an
 // 11th row (cc_k_ksort_merge).
 // ------------------------------------------------------------------------------------------------
+#define CC_KNN_TILE_MIN_KEYS 60000  // cc_db picks the tiled search from this many keys in a layer on (~10 000 scans)
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
 #define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
 #define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round

@@ -172,3 +172,27 @@ def test_knn_shared_walk_equals_default(cc, world_db, monkeypatch):
     assert _same(r1, r2)
     db1.close()
     db2.close()
+
+
+def test_knn_tiled_equals_walk(cc, world_db, monkeypatch):
+    """CC_KNN_MODE=2 (what cc_db picks by itself for layers of 60 000+ keys): 16 searches per workgroup, squared distances
+    on v_mfma_f32_16x16x4_f32 as a PREFILTER, exact nanoflann-order distances for the pairs that pass.  Same hits, in the
+    same order, bit-identical distances, at mixed epochs."""
+    ctx, desc, xq, qdesc, P = world_db
+    monkeypatch.setenv("CC_KNN_MODE", "0")
+    db1 = _db(cc, ctx, desc, N_DB)
+    monkeypatch.setenv("CC_KNN_MODE", "2")
+    db2 = _db(cc, ctx, desc, N_DB)
+    monkeypatch.delenv("CC_KNN_MODE")
+    ep = np.full(N_Q, N_DB, np.int32)
+    ep[::3] = N_DB // 2
+    ep[1::7] = N_DB // 3
+    r1, knn1, cnt1 = db1.query(qdesc, ep, want_knn=True)
+    r2, knn2, cnt2 = db2.query(qdesc, ep, want_knn=True)
+    assert np.array_equal(cnt1, cnt2) and cnt1.sum() > 0
+    m = np.arange(knn1.shape[-1])[None, None, None, :] < cnt1[..., None]
+    for f in ("gidx", "level", "seq", "dist_sq"):
+        assert np.array_equal(knn1[f][m], knn2[f][m]), f
+    assert _same(r1, r2)
+    db1.close()
+    db2.close()

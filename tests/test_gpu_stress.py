@@ -129,20 +129,24 @@ def test_component_and_key_capacities_are_flagged(cc, oracle):
 
 
 def test_pair_pool_overflow_is_reported(cc, monkeypatch):
-    import torch
-    monkeypatch.setenv("CC_GMM_POOL_PAIRS", "32")                       # read at cc_db_create: 32 pairs per lane
-    scans = [real_shaped_scan(20 + s) for s in range(2)]
-    ctx, d, _ = _ingest(cc, [scans[0], scans[0], scans[1]])
+    """The pair lists of the refined correlation problems come from a pool; running out of it must be an error
+    (CC_ECAPACITY), never a shorter list.  Forced with a 32-pair pool (CC_GMM_POOL_PAIRS, read at cc_db_create) on a scan
+    checked against its own copy through explicit hints (no retrieval, no time gating)."""
+    L = cc.L
+    scan = real_shaped_scan(20)
+    ctx, d, _ = _ingest(cc, [scan])
+    hints = np.zeros(3, L.hint_dt)
+    hints["cand_gidx"], hints["level"], hints["seq_src"], hints["seq_tgt"] = 0, [1, 2, 3], 0, 0
+    monkeypatch.setenv("CC_GMM_POOL_PAIRS", "32")
     db = cc.Database(ctx, capacity=8)
-    db.add_scans(d[:2], np.array([0.0, 0.1]), np.arange(2, dtype=np.int32))
-    # the first scan against its own copy: every gate passes, the refinement wants hundreds of pairs
+    db.add_scans(d[:1], np.zeros(1), np.zeros(1, np.int32))
     with pytest.raises(cc.CCError, match="pool"):
-        db.query(d[:1], np.full(1, 2, np.int32))
+        db.check_hints(d[0], hints)
     monkeypatch.delenv("CC_GMM_POOL_PAIRS")
     db2 = cc.Database(ctx, capacity=8)
-    db2.add_scans(d[:2], np.array([0.0, 0.1]), np.arange(2, dtype=np.int32))
-    r = db2.query(d[:1], np.full(1, 2, np.int32))
-    assert r["n_res"][0] == 1 and r["flags"][0] == 0 and r["correlation"][0] > 0.9
+    db2.add_scans(d[:1], np.zeros(1), np.zeros(1, np.int32))
+    r, sc = db2.check_hints(d[0], hints)
+    assert r["n_res"] == 1 and r["flags"] == 0 and r["correlation"] > 0.9 and sc["passed"].all()
     db.close()
     db2.close()
     ctx.close()
