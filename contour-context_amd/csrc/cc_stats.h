@@ -168,3 +168,76 @@ __device__ __forceinline__ void cc_calc_stat_vals(const cc_dev_cfg &cfg, const c
     o->com_feat = (sqrtf(dx * dx + dy * dy) > cfg.com_bias_thres) ? 1 : 0;
   }
 }
+
+// std::atan2(float, float) of the BCI build (contour_mng.h:860: RelativePoint::theta) -- glibc's atan2f, i.e. fdlibm's
+// e_atan2f.c / s_atanf.c (argument reduction to four intervals, odd/even degree-11 polynomial, hi/lo table), restated
+// operation for operation in f32: the device library's atan2f is as accurate but not the same function, and one ulp of
+// theta can move a check across the pi/16 window of BCI::checkConstellSim.  Checked bit for bit against glibc 2.35's
+// atan2f on 2e8 arguments (1e8 of them differences of BEV coordinates), tests/test_atan2f_replica.py.
+__device__ __forceinline__ float cc_atanf_fdlibm(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float aT[11] = {3.3333334327e-01f,  -2.0000000298e-01f, 1.4285714924e-01f,  -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                        6.6610731184e-02f,  -5.8335702866e-02f, 4.9768779427e-02f,  -3.6531571299e-02f, 1.6285819933e-02f};
+  const int hx = __float_as_int(x), ix = hx & 0x7fffffff;
+  if (ix >= 0x4c000000) {  // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;
+    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+  }
+  int id;
+  if (ix < 0x3ee00000) {  // |x| < 0.4375
+    if (ix < 0x31000000) return x;  // |x| < 2^-29
+    id = -1;
+  } else {
+    x = fabsf(x);
+    if (ix < 0x3f980000) {  // |x| < 1.1875
+      if (ix < 0x3f300000) {
+        id = 0;
+        x = (2.0f * x - 1.0f) / (2.0f + x);
+      } else {
+        id = 1;
+        x = (x - 1.0f) / (x + 1.0f);
+      }
+    } else if (ix < 0x401c0000) {  // |x| < 2.4375
+      id = 2;
+      x = (x - 1.5f) / (1.0f + 1.5f * x);
+    } else {
+      id = 3;
+      x = -1.0f / x;
+    }
+  }
+  const float z = x * x, w = z * z;
+  const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];
+  const float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+  const float r = hi - ((x * (s1 + s2) - lo) - x);
+  return hx < 0 ? -r : r;
+}
+__device__ __forceinline__ float cc_atan2f_fdlibm(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int hx = __float_as_int(x), ix = hx & 0x7fffffff, hy = __float_as_int(y), iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+  if (hx == 0x3f800000) return cc_atanf_fdlibm(y);
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+  if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000 || iy == 0x7f800000) {  // an infinite coordinate difference: not reachable from BEV cells; fdlibm's table
+    if (ix == 0x7f800000 && iy == 0x7f800000) return m == 0 ? 0.78539818525f + tiny : m == 1 ? -0.78539818525f - tiny : m == 2 ? 3.0f * 0.78539818525f + tiny : -3.0f * 0.78539818525f - tiny;
+    if (ix == 0x7f800000) return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  }
+  const int k = (iy - ix) >> 23;
+  float z;
+  if (k > 60)
+    z = pi_o_2 + 0.5f * pi_lo;
+  else if (hx < 0 && k < -60)
+    z = 0.0f;
+  else
+    z = cc_atanf_fdlibm(fabsf(y / x));
+  if (m == 0) return z;
+  if (m == 1) return __int_as_float(__float_as_int(z) ^ (int)0x80000000);
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}

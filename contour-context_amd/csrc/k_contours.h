@@ -788,7 +788,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       const float dist = sqrtf(vx * vx + vy * vy);
       const double dd = (double)dist;
       if (!(dd > (CC_BITS_PER_LAYER - 1) * 1.01 + 5.43 - 1e-3 || dd <= 5.43)) {
-        const float orie = atan2f(vy, vx);
+        const float orie = cc_atan2f_fdlibm(vy, vx);  // glibc's atan2f, operation for operation (cc_stats.h)
         double fl = floor((dd - 5.43) / 1.01);
         if (fl > CC_BITS_PER_LAYER - 1.0) fl = CC_BITS_PER_LAYER - 1.0;
         o.ok = 1;

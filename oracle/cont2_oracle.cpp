@@ -305,6 +305,11 @@ int orc_ingest_batch(const float *xyzi, const int64_t *offsets, int n_scans, con
 }
 
 // ---- unit hooks for the parity tests ----
+// std::atan2(float, float) as the reference's BCI build calls it (contour_mng.h:860), on arrays: the yardstick of the
+// device's atan2f replica (tests/test_atan2f_replica.py)
+void orc_atan2f(const float *y, const float *x, float *out, long n) {
+  for (long i = 0; i < n; i++) out[i] = std::atan2(y[i], x[i]);
+}
 void orc_eigen2f(const float m[4] /*a00 a01 a10 a11*/, float evals[2], float evecs[4] /*row-major*/) {
   M2F mm, ev;
   mm.a[0][0] = m[0];

@@ -28,4 +28,8 @@ void emu_sort_asc_f(emu_fkey *arr, int n) {
   ccsort::std_sort(arr, n, [](const emu_fkey &x, const emu_fkey &y) { return x.k < y.k; });
 }
 void emu_eigen2f(const float m[3], float ev[2], float vec[4]) { cc_eigen2f(m[0], m[1], m[2], ev, vec); }
+// the atan2f replica on arrays (tests/test_atan2f_replica.py)
+void emu_atan2f(const float *y, const float *x, float *out, long n) {
+  for (long i = 0; i < n; i++) out[i] = cc_atan2f_fdlibm(y[i], x[i]);
+}
 }
