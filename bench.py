@@ -396,18 +396,18 @@ def main():
                 out["extra"]["dropin_loop"] = dropin_loop(batches[0], P, min(B, 1024))
             except Exception as e:  # the headline stands on its own
                 out["extra"]["dropin_loop"] = {"error": repr(e)}
-            # the other single-GPU configurations of BASELINE.json, 4 timed steps each (same pipeline as the headline)
+            # the other single-GPU configurations of BASELINE.json, 8 timed steps each (same pipeline as the headline)
             if args.db_scans == 5000 and args.workload == "sparse":
                 try:
                     del batches
                     db.close()
                     db = None
                     torch.cuda.empty_cache()
-                    big, rec50 = measure_config(cc, ctx, dev, wld, 50000, B, 4, 1, P, first_query=60000)
+                    big, rec50 = measure_config(cc, ctx, dev, wld, 50000, B, 8, 2, P, first_query=60000)
                     out["extra"]["db_50k_sparse"] = big
-                    out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, wld, 20000, B, 4, 1, P, first_query=60000, rec=rec50)[0]
+                    out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, wld, 20000, B, 8, 2, P, first_query=60000, rec=rec50)[0]
                     del rec50
-                    out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 4, 1, P)[0]
+                    out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 8, 2, P)[0]
                 except Exception as e:
                     out["extra"]["other_configs_error"] = repr(e)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
