@@ -437,17 +437,26 @@ def _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add):
         return ev
 
     pending = []
+    host = {"ingest_issue": 0.0, "add": 0.0, "submit": 0.0}   # host seconds inside the three calls (where the one thread waits)
     ev = ingest_async(0)
     for k in range(len(chunks)):
         s_main.wait_event(ev)
+        ta = time.perf_counter()
         if k + 1 < len(chunks):
             ev = ingest_async(k + 1)
         q = slots[k % 3]
         i0 = k * sub
+        tb = time.perf_counter()
         if add:
             db.add_scans(q, ts[i0:i0 + sub], np.arange(i0, i0 + sub, dtype=np.int32))
+        tc = time.perf_counter()
         pending.append(db.query_submit(q, np.arange(i0, i0 + sub, dtype=np.int32)))
+        td = time.perf_counter()
+        host["ingest_issue"] += tb - ta
+        host["add"] += tc - tb
+        host["submit"] += td - tc
     db.query_wait()
+    _replay_pass.host_ms = {k_: v * 1e3 / len(chunks) for k_, v in host.items()}
     return np.concatenate(pending)
 
 
@@ -483,6 +492,7 @@ def online_replay(cc, ctx, batches, B, P, n, sub, dev):
         if mode != "warmup":
             out["scans_per_s_" + mode] = n / dt
             out["ms_per_sub_batch_" + mode] = dt / len(chunks) * 1e3
+            out["host_ms_per_sub_batch_" + mode] = {k_: round(v, 4) for k_, v in _replay_pass.host_ms.items()}
         db.close()
     out["loop_closures"] = int((res["with_update"]["n_res"] > 0).sum())
     out["identical_results"] = bool(res["with_update"].tobytes() == res["without_update"].tobytes())
