@@ -522,6 +522,8 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
     out_modes = {}
     for mode in ("with_update", "without_update"):
         db = cc.Database(ctx, capacity=(W + K) * sub + 16)
+        if args.lanes:
+            db.set_lanes(args.lanes)
         if mode == "without_update":
             for k, c in enumerate(chunks):
                 d = ctx.ingest(c, offs)
