@@ -501,21 +501,10 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3, shared walk (cc_db: env CC_KNN_SHARE=4; off by default until it has been measured on the GPU).
-//
-// At large DBs cc_k_knn is bound by the key stream every wave pulls through L2 for its own window (48 B per key
-// evaluated).  Searches whose anchors have neighbouring first dimensions walk almost the same window, so here one wave
-// serves CC_KNN_S searches that are adjacent in the chunk's key[0] order (cc_k_knn_order) and scores each 64-key step it
-// loads against all of them:
-//   * one common walk, split at search 0's own position p: upwards over the indices >= p, downwards over those < p, so
-//     every key index is seen exactly once by every search of the wave;
-//   * per search: its visible index ranges and epoch mask, its radius, its candidate buffer -- as in cc_k_knn;
-//   * a search leaves a direction when the step's outermost key lies BEYOND its own key[0] on that side by more than
-//     its radius (the 1-D bound; keys on the near side of its key[0] keep it open), or past its visible ranges.
-// The result per search is the same set in the same order as cc_k_knn's: the filter radius is admissible at every
-// moment and the survivors are ordered by (distance, key id).
+// Ordering of a chunk's searches by key[0] and their grouping, for the tiled search below.  (Round 2's "shared walk" --
+// one wave scoring four neighbouring searches against each 64-key step -- lived here; measured at the 50 000-scan DB it
+// was written for it gained nothing (148.1 k vs 147.5 k scans/s, profiles/r3/d_knn_shared_walk_50k.txt) and was removed.)
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_S 4
 #define CC_KNN_ORDER_CAP 4096  // searches of one layer in a chunk (QB * CC_NPIV = 3072), padded to a power of two
 #define CC_KNN_ORDER_GROUP 16  // searches per group of the tiled search (= CC_KNN_TQ)
 
@@ -614,264 +603,6 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
     ord[CC_KNN_ORD_NVALID + ll] = nvl;
     ord[CC_KNN_ORD_NGROUP + ll] = ng;
   }
-}
-
-struct cc_knn_sstate {  // per search of a wave, wave-uniform values
-  float ub;
-  int cnt, tight;
-};
-
-// grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_S), block = 64
-__global__ void __launch_bounds__(64)
-cc_k_knn_shared(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta, int nq,
-                const int *__restrict__ order, const int *__restrict__ n_valid, cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
-  __shared__ unsigned long long buf[CC_KNN_S][CC_KNN_CAP];
-  __shared__ cc_knn_sstate st[CC_KNN_S];
-  __shared__ float tgt[CC_KNN_S * 5];
-  __shared__ int bnd[CC_KNN_S * 5];
-  const int lane = threadIdx.x;
-  const int nblk = (nq * CC_NPIV + CC_KNN_S - 1) / CC_KNN_S;
-  const int ll = blockIdx.x / nblk, w = blockIdx.x - ll * nblk;
-  if (ll >= P.n_q_levels) return;
-  const int nv = n_valid[ll];
-  const int base = w * CC_KNN_S;
-  if (base >= nv) return;
-  const int ns = nv - base < CC_KNN_S ? nv - base : CC_KNN_S;  // searches of this wave
-  const int level = P.q_levels[ll];
-  const int n = P.n_sorted[ll];
-  const float *K = P.skeys[ll];
-  const int *sid = P.sid[ll];
-  const int *sact = P.sact[ll];
-  const unsigned cap = (unsigned)P.cap_k;
-  const int nnk = P.nnk;
-
-  // ---- per search: key, dist_ub, epoch, and the five index boundaries (as in cc_k_knn) ----
-  int srch[CC_KNN_S], epoch[CC_KNN_S];
-  float kq[CC_KNN_S][CC_KEY_DIM];
-#pragma unroll
-  for (int j = 0; j < CC_KNN_S; j++) {
-    srch[j] = order[ll * CC_KNN_ORDER_CAP + base + (j < ns ? j : 0)];  // padding repeats search 0 (its copy is never written out)
-    const int q = srch[j] / CC_NPIV, seq = srch[j] - q * CC_NPIV;
-    const float *qk = &qhot[q].keys[level - 1][seq][0];
-#pragma unroll
-    for (int d = 0; d < CC_KEY_DIM; d++) kq[j][d] = qk[d];
-    const cc_query_meta *qm = qmeta + q;
-    epoch[j] = qm->epoch;
-    const float *k = kq[j];
-    // dist_ub (contour_db.h:733-749), f32 results of f64 products exactly as written there
-    const float b00 = (float)((double)k[0] * 0.8), b01 = (float)((double)k[0] / 0.8);
-    const float b10 = (float)((double)k[1] * 0.8), b11 = (float)((double)k[1] / 0.8);
-    const float b20 = (float)((double)k[2] * 0.8 * 0.75), b21 = (float)((double)k[2] / (0.8 * 0.75));
-    const float t0a = (k[0] - b00) * (k[0] - b00), t0b = (k[0] - b01) * (k[0] - b01);
-    const float t1a = (k[1] - b10) * (k[1] - b10), t1b = (k[1] - b11) * (k[1] - b11);
-    const float t2a = (k[2] - b20) * (k[2] - b20), t2b = (k[2] - b21) * (k[2] - b21);
-    const float ub0 = (t0a < t0b ? t0b : t0a) + (t1a < t1b ? t1b : t1a) + (t2a < t2b ? t2b : t2a);
-    float rg[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) rg[i] = qm->ranges[ll][i];
-    int mid = 0;
-    {
-      bool found = false;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-        if (!found && rg[i] <= k[0] && rg[i + 1] > k[0]) {
-          mid = i;
-          found = true;
-        }
-    }
-    float t_e1 = rg[6], t_s2 = rg[6];
-#pragma unroll
-    for (int i = 1; i < 7; i++) {
-      if (i == mid + 1) t_e1 = rg[i];
-      if (i == 2 * mid + 1) t_s2 = rg[i];
-    }
-    if (lane == 0) {
-      st[j].ub = ub0;
-      st[j].cnt = 0;
-      st[j].tight = 0;
-      tgt[j * 5 + 0] = rg[0];
-      tgt[j * 5 + 1] = t_e1;
-      tgt[j * 5 + 2] = t_s2;
-      tgt[j * 5 + 3] = rg[6];
-      tgt[j * 5 + 4] = k[0];
-    }
-  }
-  cc_wave_sync();
-  // lb(t) = number of keys with key[0] < t: 8 lanes per search target, 9-ary, eight targets per pass
-  for (int t0 = 0; t0 < CC_KNN_S * 5; t0 += 8) {
-    const int g = lane >> 3, sub = lane & 7;
-    const int t = t0 + g < CC_KNN_S * 5 ? t0 + g : CC_KNN_S * 5 - 1;
-    const float tg = tgt[t];
-    int lo = 0, hi = n;
-    while (__ballot(hi > lo) != 0ull) {
-      const int len = hi - lo;
-      const int wd = (len + 8) / 9;
-      int p = lo + (sub + 1) * wd - 1;
-      p = p < hi - 1 ? p : hi - 1;
-      const bool below = (len > 0) && (K[(unsigned)(p < 0 ? 0 : p)] < tg);
-      const int c = __popc((unsigned)(__ballot(below) >> (lane & 56)) & 0xFFu);
-      if (len > 0) {
-        int pl = lo + c * wd - 1;
-        pl = pl < hi - 1 ? pl : hi - 1;
-        int ph = lo + (c + 1) * wd - 1;
-        ph = ph < hi - 1 ? ph : hi - 1;
-        if (c < 8) hi = ph;
-        if (c > 0) lo = pl + 1;
-      }
-    }
-    if (sub == 0 && t0 + g < CC_KNN_S * 5) bnd[t0 + g] = lo;
-  }
-  cc_wave_sync();
-  int L0[CC_KNN_S], E1[CC_KNN_S], S2[CC_KNN_S], E2[CC_KNN_S];
-#pragma unroll
-  for (int j = 0; j < CC_KNN_S; j++) {
-    L0[j] = __builtin_amdgcn_readfirstlane(bnd[j * 5 + 0]);
-    E1[j] = __builtin_amdgcn_readfirstlane(bnd[j * 5 + 1]);
-    S2[j] = __builtin_amdgcn_readfirstlane(bnd[j * 5 + 2]);
-    E2[j] = __builtin_amdgcn_readfirstlane(bnd[j * 5 + 3]);
-  }
-  const int p0 = __builtin_amdgcn_readfirstlane(bnd[4]);  // search 0's own position splits the walk
-
-  // ---- the common walk ----
-  bool open[CC_KNN_S][2];
-#pragma unroll
-  for (int j = 0; j < CC_KNN_S; j++) {
-    open[j][0] = j < ns && p0 < E2[j] && p0 < n;  // something visible at or above p0
-    open[j][1] = j < ns && p0 > L0[j] && p0 > 0;  // something visible below p0
-  }
-  int idx[2] = {p0 + lane, p0 - 1 - lane};
-  float c[2][CC_KEY_DIM];
-  int act[2], kid[2];
-  bool inside[2];
-#define CC_KNN_FETCH2(dir)                                                                          \
-  {                                                                                                 \
-    inside[dir] = idx[dir] >= 0 && idx[dir] < n;                                                    \
-    const unsigned u_ = inside[dir] ? (unsigned)idx[dir] : 0u;                                      \
-    act[dir] = sact[u_];                                                                            \
-    kid[dir] = sid[u_];                                                                             \
-    _Pragma("unroll") for (int d = 0; d < CC_KEY_DIM; d++) c[dir][d] = K[(size_t)d * cap + u_];    \
-  }
-  bool any[2];
-#pragma unroll
-  for (int dir = 0; dir < 2; dir++) {
-    any[dir] = false;
-#pragma unroll
-    for (int j = 0; j < CC_KNN_S; j++) any[dir] = any[dir] || open[j][dir];
-    if (any[dir]) CC_KNN_FETCH2(dir)
-  }
-  bool final_pass = false;
-  bool last_in[2] = {false, false};
-  float c0_far[2] = {0.f, 0.f};
-  while (true) {
-    if (any[0] || any[1]) {
-      float ubj[CC_KNN_S];
-      int cntj[CC_KNN_S], tightj[CC_KNN_S];
-#pragma unroll
-      for (int j = 0; j < CC_KNN_S; j++) {
-        ubj[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st[j].ub)));
-        cntj[j] = __builtin_amdgcn_readfirstlane(st[j].cnt);
-        tightj[j] = __builtin_amdgcn_readfirstlane(st[j].tight);
-      }
-#pragma unroll
-      for (int dir = 0; dir < 2; dir++) {
-        if (!any[dir]) continue;  // wave-uniform
-        const int id = idx[dir];
-        const int a_ = act[dir], kd = kid[dir];
-        const bool in_ = inside[dir];
-        float cc[CC_KEY_DIM];
-#pragma unroll
-        for (int d = 0; d < CC_KEY_DIM; d++) cc[d] = c[dir][d];
-        last_in[dir] = __builtin_amdgcn_readlane((int)in_, 63) != 0;
-        c0_far[dir] = cc_lane_bcast(cc[0], 63);
-        // the next step's keys travel while this step's candidates are filed
-        idx[dir] += dir == 0 ? 64 : -64;
-        CC_KNN_FETCH2(dir)
-#pragma unroll
-        for (int j = 0; j < CC_KNN_S; j++) {
-          if (!open[j][dir]) continue;  // wave-uniform
-          const float *k = kq[j];
-          // L2_Adaptor::evalMetric accumulation order (nanoflann.hpp:427-461)
-          float r = 0.f;
-          float d0 = k[0] - cc[0], d1 = k[1] - cc[1], d2 = k[2] - cc[2], d3 = k[3] - cc[3];
-          r += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-          d0 = k[4] - cc[4];
-          d1 = k[5] - cc[5];
-          d2 = k[6] - cc[6];
-          d3 = k[7] - cc[7];
-          r += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-          d0 = k[8] - cc[8];
-          r += d0 * d0;
-          d0 = k[9] - cc[9];
-          r += d0 * d0;
-          const bool vis = in_ && a_ <= epoch[j] && ((id >= L0[j] && id < E1[j]) || (id >= S2[j] && id < E2[j]));
-          const bool pass = vis && (tightj[j] ? (r <= ubj[j]) : (r < ubj[j]));
-          const unsigned long long m = __ballot(pass);
-          if (pass) buf[j][cntj[j] + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned)kd;
-          cntj[j] += __popcll(m);
-        }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < CC_KNN_S; j++) st[j].cnt = cntj[j];
-      }
-    } else {
-      final_pass = true;
-    }
-    cc_wave_sync();
-    // keep the best nnk of a search whose buffer has filled up (every search, one last time, when the walk is over)
-    for (int j = 0; j < ns; j++) {
-      const int cnt = __builtin_amdgcn_readfirstlane(st[j].cnt);
-      const int tight = __builtin_amdgcn_readfirstlane(st[j].tight);
-      if (!(final_pass || cnt >= 2 * nnk || (!tight && cnt >= nnk))) continue;
-      unsigned long long first;
-      const float nub = cnt <= 128 ? cc_knn_reduce<2>(buf[j], cnt, nnk, lane, first) : cc_knn_reduce<4>(buf[j], cnt, nnk, lane, first);
-      if (final_pass) {
-        const int s = order[ll * CC_KNN_ORDER_CAP + base + j];
-        const int q = s / CC_NPIV, seq = s - q * CC_NPIV;
-        const int slot = q * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq;
-        const int mm = cnt < nnk ? cnt : nnk;
-        if (lane < mm) {
-          const unsigned id = (unsigned)(first & 0xFFFFFFFFu);
-          cc_knn_hit_t h;
-          h.gidx = P.kgidx[ll][id];
-          h.level = (int16_t)level;
-          h.seq = (int16_t)P.kseq[ll][id];
-          h.dist_sq = __uint_as_float((unsigned)(first >> 32));
-          hits[(size_t)slot * CC_KNN_MAX + lane] = h;
-        }
-        if (lane == 0) hit_cnt[slot] = mm;
-      } else if (lane == 0) {
-        st[j].ub = nub;
-        st[j].cnt = nnk;
-        st[j].tight = 1;
-      }
-    }
-    if (final_pass) break;
-    cc_wave_sync();
-    // who goes on, in which direction
-#pragma unroll
-    for (int dir = 0; dir < 2; dir++) {
-      if (!any[dir]) continue;
-      any[dir] = false;
-      // index the NEXT step of this direction starts at (idx was already advanced)
-      const int nxt = __builtin_amdgcn_readfirstlane(idx[dir]);  // lane 0: p0 + 64 t (up) / p0 - 1 - 64 t (down)
-#pragma unroll
-      for (int j = 0; j < CC_KNN_S; j++) {
-        if (!open[j][dir]) continue;
-        const float ubn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st[j].ub)));
-        const int tn = __builtin_amdgcn_readfirstlane(st[j].tight);
-        // e: the anchor's first dimension relative to the step's outermost key; beyond = that key lies past the anchor
-        const float e = kq[j][0] - c0_far[dir];
-        const float far2 = e * e;
-        const bool beyond = dir == 0 ? (e < 0.f) : (e > 0.f);
-        const bool out_of_radius = beyond && (tn ? (far2 > ubn) : (far2 >= ubn));
-        const bool more_visible = dir == 0 ? (nxt < E2[j]) : (nxt >= L0[j]);
-        open[j][dir] = last_in[dir] && !out_of_radius && more_visible;
-        any[dir] = any[dir] || open[j][dir];
-      }
-    }
-  }
-#undef CC_KNN_FETCH2
 }
 
 // ------------------------------------------------------------------------------------------------

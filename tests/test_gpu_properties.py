@@ -153,27 +153,6 @@ def test_query_batch_invariance_incremental_db_and_knn(cc, world_db):
     db2.close()
 
 
-def test_knn_shared_walk_equals_default(cc, world_db, monkeypatch):
-    """CC_KNN_SHARE=4 (read at cc_db_create): one wave serves four searches that are neighbours in key[0] and scores every
-    64-key step against all of them.  Same hits, in the same order, and therefore the same results."""
-    ctx, desc, xq, qdesc, P = world_db
-    db1 = _db(cc, ctx, desc, N_DB)
-    monkeypatch.setenv("CC_KNN_SHARE", "4")
-    db2 = _db(cc, ctx, desc, N_DB)
-    monkeypatch.delenv("CC_KNN_SHARE")
-    ep = np.full(N_Q, N_DB, np.int32)
-    ep[::3] = N_DB // 2          # mixed epochs inside one wave: visibility masks and bucket ranges differ per search
-    r1, knn1, cnt1 = db1.query(qdesc, ep, want_knn=True)
-    r2, knn2, cnt2 = db2.query(qdesc, ep, want_knn=True)
-    assert np.array_equal(cnt1, cnt2) and cnt1.sum() > 0
-    m = np.arange(knn1.shape[-1])[None, None, None, :] < cnt1[..., None]
-    for f in ("gidx", "level", "seq", "dist_sq"):
-        assert np.array_equal(knn1[f][m], knn2[f][m]), f
-    assert _same(r1, r2)
-    db1.close()
-    db2.close()
-
-
 def test_knn_tiled_equals_walk(cc, world_db, monkeypatch):
     """CC_KNN_MODE=2 (what cc_db picks by itself for layers of 60 000+ keys): 16 searches per workgroup, squared distances
     on v_mfma_f32_16x16x4_f32 as a PREFILTER, exact nanoflann-order distances for the pairs that pass.  Same hits, in the

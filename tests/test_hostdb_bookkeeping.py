@@ -49,7 +49,7 @@ def test_bucket_timeline_matches_oracle(oracle):
     assert (osz > 0).sum() >= 12, "the test should populate most buckets"
 
 
-@pytest.mark.parametrize("share", [0, 4, 16])  # K3: one wave per search | shared walk | tiled (matrix-core prefilter)
+@pytest.mark.parametrize("share", [0, 16])  # K3: one wave per search | tiled (matrix-core prefilter)
 def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
     """K3 through the C-ABI (CPU build) on a DB spread over several buckets, incl. the bucket-skip quirk of
     layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
@@ -59,8 +59,7 @@ def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
     desc = _fake_desc(L, rng, n, 3.0, 40.0)
     ts = np.arange(n) * 0.1
     seeds = np.arange(n, dtype=np.int32)
-    monkeypatch.setenv("CC_KNN_SHARE", str(share if share == 4 else 0))
-    monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")  # 4: the shared-walk form of K3 (read at cc_db_create)
+    monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=4)
     db = api.db_create(ctx, cap=n)
@@ -84,7 +83,7 @@ def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
                 assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
 
 
-@pytest.mark.parametrize("share", [0, 4, 16])  # K3: one wave per search | shared walk | tiled (matrix-core prefilter)
+@pytest.mark.parametrize("share", [0, 16])  # K3: one wave per search | tiled (matrix-core prefilter)
 def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
     """Thousands of near-identical keys: every 64-key step of a search passes the radius test, so the pending candidate
     list grows to 2 * nnk - 1 + 64 entries before it is tightened and the bitonic sort pads it to 256 (the LDS buffer
@@ -102,7 +101,6 @@ def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
     for nnk in (64,):  # the capacity case: 2 * 64 - 1 + 64 pending candidates before a tightening
         dcfg = L.default_db_cfg()
         dcfg.nnk = nnk
-        monkeypatch.setenv("CC_KNN_SHARE", str(share if share == 4 else 0))
         monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")
         api = emu_api.EmuApi(L)
         ctx = api.create(max_batch=4)
