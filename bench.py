@@ -293,6 +293,9 @@ def main():
             run_steps(W, K)
             torch.cuda.synchronize()
             print("ab-env [%s]: %.0f scans/s" % (spec, K * B / (time.perf_counter() - t1)), file=sys.stderr)
+            if "PROF" in dict(kv):
+                print("ab-env [%s] kernel ms per step: %s" % (spec, json.dumps({k: round(v, 3) for k, v in read_kernel_ms().items()})),
+                      file=sys.stderr)
             db = db_saved
             db2.close()
             for k_, _ in kv:

@@ -105,8 +105,8 @@ def _same_result(exp, got, tol):
         assert abs(exp["correlation"] - got["correlation"]) < tol and np.abs(exp["tf"] - got["tf"]).max() < tol
 
 
-@pytest.mark.parametrize("share", [0, 16])  # K3: one wave per search | tiled (matrix-core prefilter)
-def test_golden_query_fixture(oracle, share, monkeypatch):
+@pytest.mark.parametrize("knn_mode", [0, 2])  # K3: one wave per search | tiled (matrix-core prefilter)
+def test_golden_query_fixture(oracle, knn_mode, monkeypatch):
     """Committed descriptors + expected results (tests/golden/make_query_golden.py): the oracle, replaying the driver loop
     from the descriptors, still reproduces them, and the emulated query kernels match them."""
     L = oracle.L
@@ -119,7 +119,7 @@ def test_golden_query_fixture(oracle, share, monkeypatch):
         _same_result(exp[i], odb.query(s), 1e-12)
         odb.add_scan(s, ts[i])
         odb.push_and_balance(i, ts[i])
-    monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")
+    monkeypatch.setenv("CC_KNN_MODE", str(knn_mode))
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=8)
     db = api.db_create(ctx, d, cap=n)

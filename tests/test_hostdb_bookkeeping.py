@@ -49,8 +49,8 @@ def test_bucket_timeline_matches_oracle(oracle):
     assert (osz > 0).sum() >= 12, "the test should populate most buckets"
 
 
-@pytest.mark.parametrize("share", [0, 16])  # K3: one wave per search | tiled (matrix-core prefilter)
-def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
+@pytest.mark.parametrize("knn_mode", [0, 2])  # K3: one wave per search | tiled (matrix-core prefilter)
+def test_knn_with_buckets_matches_oracle(oracle, knn_mode, monkeypatch):
     """K3 through the C-ABI (CPU build) on a DB spread over several buckets, incl. the bucket-skip quirk of
     layerKNNSearch (src/cont2/contour_db.cpp:341-369)."""
     L = oracle.L
@@ -59,7 +59,7 @@ def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
     desc = _fake_desc(L, rng, n, 3.0, 40.0)
     ts = np.arange(n) * 0.1
     seeds = np.arange(n, dtype=np.int32)
-    monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")
+    monkeypatch.setenv("CC_KNN_MODE", str(knn_mode))
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=4)
     db = api.db_create(ctx, cap=n)
@@ -83,8 +83,8 @@ def test_knn_with_buckets_matches_oracle(oracle, share, monkeypatch):
                 assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
 
 
-@pytest.mark.parametrize("share", [0, 16])  # K3: one wave per search | tiled (matrix-core prefilter)
-def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
+@pytest.mark.parametrize("knn_mode", [0, 2])  # K3: one wave per search | tiled (matrix-core prefilter)
+def test_knn_crowded_layer_matches_oracle(oracle, knn_mode, monkeypatch):
     """Thousands of near-identical keys: every 64-key step of a search passes the radius test, so the pending candidate
     list grows to 2 * nnk - 1 + 64 entries before it is tightened and the bitonic sort pads it to 256 (the LDS buffer
     must hold the padded width; found by an ASAN run of this harness in round 1's review)."""
@@ -101,7 +101,7 @@ def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
     for nnk in (64,):  # the capacity case: 2 * 64 - 1 + 64 pending candidates before a tightening
         dcfg = L.default_db_cfg()
         dcfg.nnk = nnk
-        monkeypatch.setenv("CC_KNN_MODE", "2" if share == 16 else "0")
+        monkeypatch.setenv("CC_KNN_MODE", str(knn_mode))
         api = emu_api.EmuApi(L)
         ctx = api.create(max_batch=4)
         db = api.db_create(ctx, dcfg, cap=n)
@@ -122,3 +122,41 @@ def test_knn_crowded_layer_matches_oracle(oracle, share, monkeypatch):
                     a, b = oknn[ll, seq, :m], knn[kq, ll, seq, :m]
                     assert np.array_equal(a["dist_sq"], b["dist_sq"])
                     assert np.array_equal(a["gidx"], b["gidx"]) and np.array_equal(a["seq"], b["seq"])
+
+
+def test_knn_tile_full_group_every_pair_passes(oracle, monkeypatch):
+    """The tiled K3 with a FULL group of 16 searches over near-identical keys: until the first radius is set every
+    (search, key) pair of a 64-key step passes the prefilter -- 1024 pairs per wave and round, the most a wave's work list
+    ever has to take."""
+    knn_mode = 2
+    L = oracle.L
+    rng = np.random.default_rng(5)
+    n = 320
+    desc = _fake_desc(L, rng, n)
+    base = rng.uniform(8.0, 12.0, L.KEY_DIM).astype(np.float32)
+    desc["keys"] = (base[None, None, None, :] + rng.normal(0, 0.05, (n, L.NLEV, L.NPIV, L.KEY_DIM))).astype(np.float32)
+    ts = np.arange(n) * 0.1
+    cfg = L.default_manager_cfg()
+    dcfg = L.default_db_cfg()
+    dcfg.nnk = 50
+    monkeypatch.setenv("CC_KNN_MODE", str(knn_mode))
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=16)
+    db = api.db_create(ctx, dcfg, cap=n)
+    api.db_add(db, desc, ts, np.arange(n, dtype=np.int32))
+    odb = oracle.DB(dcfg)
+    for i in range(n):
+        odb.add_scan(oracle.Scan.from_desc(desc[i], cfg, int_id=i), ts[i])
+        odb.push_and_balance(i, ts[i])
+    qi = rng.choice(n, 16, replace=False)
+    q = desc[qi].copy()
+    q["keys"] += np.float32(0.01)
+    res, knn, cnt = api.db_query(db, q, np.full(16, n, np.int32), want_knn=True)
+    for kq in range(0, 16, 5):
+        ores, oknn, ocnt = odb.query(oracle.Scan.from_desc(q[kq], cfg, int_id=10000 + kq), want_knn=True)
+        assert np.array_equal(ocnt, cnt[kq]) and ocnt.min() == dcfg.nnk
+        for ll in range(3):
+            for seq in range(6):
+                m = ocnt[ll, seq]
+                a, b = oknn[ll, seq, :m], knn[kq, ll, seq, :m]
+                assert np.array_equal(a["dist_sq"], b["dist_sq"]) and np.array_equal(a["gidx"], b["gidx"])
