@@ -21,6 +21,11 @@
 #include "cc_sort.h"
 #include "cc_stats.h"
 
+// the value becomes opaque to the optimiser at this point (no instruction is emitted)
+#ifndef CC_OPAQUE_I
+#define CC_OPAQUE_I(x) asm volatile("" : "+v"(x))
+#endif
+
 #define CC_NC CC_MAXC          // kept components per level handled exactly
 #define CC_LAB_NONE 0xFFFFu
 
@@ -196,38 +201,59 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   // ---- level index of every cell; the ACTIVE cells (above the lowest level) as a raster-ordered list ----
   // Everything below works on that list (a few hundred to a few thousand cells of the 22 500): thread t owns entries
   // t, t + nt, ... and keeps its first CC_K2_OWN of them in registers; the list itself lives in the scan's scratch block.
-  const int chunk_len = (n_cell + nt - 1) / nt;
-  const int c_lo = tid * chunk_len < n_cell ? tid * chunk_len : n_cell;
-  const int c_hi = c_lo + chunk_len < n_cell ? c_lo + chunk_len : n_cell;
-  int my_act = 0;
-  for (int c = c_lo; c < c_hi; c++) {
-    const float h = bev[c];
-    int lv = 0;
-    for (int e = 0; e < CC_NLEV; e++) lv += (h > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
-    LV[c] = (unsigned char)lv;
-    LAB[c] = lv ? (uint16_t)c : (uint16_t)CC_LAB_NONE;  // an active cell starts as its own root
-    my_act += lv ? 1 : 0;
+  // The BEV is read once with coalesced 16-byte loads (n_row, n_col even: n_cell is a multiple of 4 and every scan's
+  // image starts on a 16-byte boundary), four cells per lane: level index as one 32-bit LDS store, initial labels as one
+  // 64-bit store.  The raster-ordered list then comes from the level image in LDS: every wave owns a contiguous range of
+  // cells, counts its active cells with ballots, and after one barrier writes them at its offset -- consecutive lanes
+  // write consecutive entries.
+  {
+    const float4 *bev4 = (const float4 *)bev;
+    const int n_quad = n_cell >> 2;
+#pragma unroll 4
+    for (int v = tid; v < n_quad; v += nt) {
+      const float4 h4 = bev4[v];
+      const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+      unsigned lv4 = 0;
+      unsigned lab[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int lv = 0;
+        for (int e = 0; e < CC_NLEV; e++) lv += (hh[u] > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+        lv4 |= (unsigned)lv << (8 * u);
+        lab[u] = lv ? (unsigned)(4 * v + u) : (unsigned)CC_LAB_NONE;  // an active cell starts as its own root
+      }
+      ((unsigned *)LV)[v] = lv4;
+      ((uint2 *)LAB)[v] = make_uint2(lab[0] | (lab[1] << 16), lab[2] | (lab[3] << 16));
+    }
   }
   if (tid < 40) sh[tid] = 0;
   __syncthreads();
   const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
   int n_act;
   {
-    int incl = my_act;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
+    const int per_wave = (((n_cell + n_waves - 1) / n_waves) + 63) & ~63;
+    const int w_lo = wave_id * per_wave < n_cell ? wave_id * per_wave : n_cell;
+    const int w_hi = w_lo + per_wave < n_cell ? w_lo + per_wave : n_cell;
+    int cnt = 0;
+    for (int b = w_lo; b < w_hi; b += 64) {
+      const int c = b + lane;
+      cnt += __popcll(__ballot(c < w_hi && LV[c] != 0));
     }
-    if (lane == 63) sh[24 + wave_id] = incl;
+    if (lane == 0) sh[24 + wave_id] = cnt;
     __syncthreads();
-    int off = incl - my_act;
+    int off = 0;
     n_act = 0;
     for (int w = 0; w < n_waves; w++) {
       if (w < wave_id) off += sh[24 + w];
       n_act += sh[24 + w];
     }
-    for (int c = c_lo; c < c_hi; c++)
-      if (LV[c]) scr->act[off++] = (uint16_t)c;
+    for (int b = w_lo; b < w_hi; b += 64) {
+      const int c = b + lane;
+      const bool on = c < w_hi && LV[c] != 0;
+      const unsigned long long m = __ballot(on);
+      if (on) scr->act[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)c;
+      off += __popcll(m);
+    }
   }
   if (labels_dbg)
     for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
@@ -269,6 +295,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     //     cells, lv_grads ascending): those components stay merged; cells new at this level (LV == l + 1) are still their
     //     own roots.  One union per adjacent pair (W, NW, N, NE of every cell) that involves a new cell -- two old
     //     neighbours already share a root.
+#pragma unroll
+    for (int u = 0; u < CC_K2_OWN; u++) CC_OPAQUE_I(mc[u]);  // keeps the neighbour offsets of the owned cells from being hoisted (and then spilled)
     for (int i = tid; i < n_w; i += nt) CNT2[i] = 0;
     if (tid == 0) sh[1] = 0;
     CC_K2_FOR_ACTIVE({
@@ -469,9 +497,21 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
       rec.vol3 = 0.f;
       int poi_i = -1;
+      // the index image comes from the scratch block (L2): four 64-entry stretches are fetched at a time so that their
+      // round trips overlap
+      unsigned cv[4] = {CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE};
       for (int ib = i0; ib <= i1; ib += 64) {
+        const int u4 = ((ib - i0) >> 6) & 3;
+        if (u4 == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int iu = ib + 64 * u + lane;
+            cv[u] = iu <= i1 ? (unsigned)cidx[iu] : CC_COMP_NONE;
+          }
+        }
         const int i = ib + lane;
-        const bool mem = i <= i1 && cidx[i] == (unsigned)k;
+        const unsigned cme = u4 == 0 ? cv[0] : (u4 == 1 ? cv[1] : (u4 == 2 ? cv[2] : cv[3]));
+        const bool mem = cme == (unsigned)k;
         unsigned long long mask = __ballot(mem);
         if (!mask) continue;
         float h = 0.f, px = 0.f, py = 0.f;

@@ -10,8 +10,7 @@
 // candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
 // ------------------------------------------------------------------------------------------------
 #define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
-#define CC_MERGE_BLOCK 128
-#define CC_MERGE_PER_T (CC_CHK_STRIDE / CC_MERGE_BLOCK)  // consecutive check slots scanned by one thread
+#define CC_MERGE_BLOCK 64   // one wave per query: no cross-wave hand-offs, 39 KB of LDS (four queries per CU)
 
 struct cc_gmm_problem {
   int q;          // index into qdesc (tgt)
@@ -22,6 +21,7 @@ struct cc_gmm_problem {
 struct cc_dprop {  // CandidateAnchorProp (contour_db.h:267-274); constell_ kept as a 400-bit set in key order
   unsigned long long bits[7];
   double c, s, tx, ty;  // T_delta_ = [c -s tx; s c ty]
+  double ang;           // atan2(s, c), carried along instead of being re-derived from the matrix at every merge
   int vote_cnt;
   float area_perc;
 };
@@ -42,13 +42,13 @@ struct cc_merge_lds {
   unsigned short ord[CC_CHK_STRIDE];       // its check slot
   short next[CC_CHK_STRIDE];               // next passing check naming the same scan, -1 = none
   unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
-  int wsum[CC_MERGE_BLOCK / 64];
   int base;
   unsigned char want[CC_CHK_STRIDE];       // candidate k goes on to the correlation
   float tperc[CC_HOT_LEVELS][CC_NDIST];    // cont_perc_ of the query's top contours: cell_cnt * 1.0f / layer_cell_cnt
 };
 
 static_assert(CC_CHK_STRIDE % CC_MERGE_BLOCK == 0, "merge scan split");
+static_assert(CC_MERGE_BLOCK == 64, "the list building below uses wave ballots");
 
 // grid = nq, block = CC_MERGE_BLOCK
 __global__ void __launch_bounds__(CC_MERGE_BLOCK)
@@ -58,46 +58,34 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
            cc_gmm_problem *__restrict__ probs /*[nq][CC_MAXCAND]: problem of candidate k of query q*/,
            int *__restrict__ prob_list /*dense list of the problems that exist*/, int *__restrict__ n_prob) {
   __shared__ cc_merge_lds L;
-  const int q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (q >= nq) return;
   const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
   const cc_pass_rec *recs = pass + (size_t)q * CC_CHK_STRIDE;
-  if (tid < CC_HOT_LEVELS * CC_NDIST) {  // visible after the barriers of the list building below
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (tid < CC_HOT_LEVELS * CC_NDIST) {  // visible after the barrier of the list building below
     const int l = tid / CC_NDIST, t_ = tid - l * CC_NDIST;
     const cc_hot_desc_t *tq = qdesc + q;
     L.tperc[l][t_] = (float)tq->cont[l][t_].cell_cnt * 1.0f / (float)tq->layer_cell_cnt[l];
   }
-  // ---- ordered list of the passing checks (slot order = the reference's iteration order)
-  int n;
+  // ---- ordered list of the passing checks (slot order = the reference's iteration order): 64 slots per round, the
+  //      flags of all rounds fetched up front (coalesced byte loads), positions from ballots
+  int n = 0;
   {
-    unsigned okm = 0;
-    int cnt = 0;
-    for (int u = 0; u < CC_MERGE_PER_T; u++) {
-      const int ok = okp[tid * CC_MERGE_PER_T + u] != 0;
-      okm |= (unsigned)ok << u;
-      cnt += ok;
-    }
-    int incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) L.wsum[wave] = incl;
-    __syncthreads();
-    int off = incl - cnt;
-    n = 0;
-    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
-      if (w < wave) off += L.wsum[w];
-      n += L.wsum[w];
-    }
-    for (int u = 0; u < CC_MERGE_PER_T; u++) {
-      if ((okm >> u) & 1u) {
-        const int t = tid * CC_MERGE_PER_T + u;
+    unsigned char okv[CC_CHK_STRIDE / 64];
+#pragma unroll
+    for (int u = 0; u < CC_CHK_STRIDE / 64; u++) okv[u] = okp[u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < CC_CHK_STRIDE / 64; u++) {
+      const bool ok = okv[u] != 0;
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        const int t = u * 64 + lane, off = n + __popcll(m & lt_mask);
         L.ord[off] = (unsigned short)t;
         L.gid[off] = recs[t].gidx;
         L.next[off] = -1;
-        off++;
       }
+      n += __popcll(m);
     }
   }
   __syncthreads();
@@ -116,18 +104,10 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         first = true;
     }
     const unsigned long long m = __ballot(first);
-    if (lane == 0) L.wsum[wave] = __popcll(m);
-    __syncthreads();
-    int off = nc + __popcll(m & ((1ull << lane) - 1ull));
-    int tot = 0;
-    for (int w = 0; w < CC_MERGE_BLOCK / 64; w++) {
-      if (w < wave) off += L.wsum[w];
-      tot += L.wsum[w];
-    }
-    if (first) L.firstrec[off] = (unsigned short)i;
-    nc += tot;
-    __syncthreads();
+    if (first) L.firstrec[nc + __popcll(m & lt_mask)] = (unsigned short)i;
+    nc += __popcll(m);
   }
+  __syncthreads();
   if (tid == 0) {
     cc_qstate st;
     st.n_cand = nc;
@@ -189,13 +169,23 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         p->vote_cnt += np;
         const int w1 = p->vote_cnt, w2 = np;
         const double bx = (p->tx * w1 + ptx * w2) / (w1 + w2), by = (p->ty * w1 + pty * w2) / (w1 + w2);
-        const double ang1 = atan2(p->s, p->c), ang2 = ang2_cur;
+        // ang1 = atan2(T_delta(1,0), T_delta(0,0)) (contour_db.h:310): the matrix holds (cos, sin) of an angle this lane
+        // produced itself, so that angle -- brought back into (-pi, pi] -- is carried along instead of an f64 atan2 per
+        // merge; equal to the recomputed value up to the rounding of sin/cos/atan2 (1e-16, as the device's own
+        // transcendental functions differ from glibc's anyway; the pose tolerance is 1e-4)
+        const double ang1 = p->ang, ang2 = ang2_cur;
         double diff = ang2 - ang1;
         if (diff < 0) diff += 2 * 3.14159265358979323846;
         if (diff > 3.14159265358979323846) diff -= 2 * 3.14159265358979323846;
         const double ang_bl = diff * w2 / (w1 + w2) + ang1;
-        p->c = cos(ang_bl);
-        p->s = sin(ang_bl);
+        double sn, cs;
+        sincos(ang_bl, &sn, &cs);
+        p->c = cs;
+        p->s = sn;
+        double aw = ang_bl;
+        if (aw > 3.14159265358979323846) aw -= 2 * 3.14159265358979323846;
+        if (aw <= -3.14159265358979323846) aw += 2 * 3.14159265358979323846;
+        p->ang = aw;
         p->tx = bx;
         p->ty = by;
       } else if (nprops <= 3) {
@@ -203,6 +193,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         for (int w = 0; w < 7; w++) p->bits[w] = rec->bits[w];
         p->c = pc;
         p->s = ps;
+        p->ang = ang2_cur;
         p->tx = ptx;
         p->ty = pty;
         p->vote_cnt = np;
@@ -251,7 +242,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
         pb.gidx = c->gidx;
         pb.tf[0] = p0->tx;
         pb.tf[1] = p0->ty;
-        pb.tf[2] = atan2(p0->s, p0->c);
+        pb.tf[2] = p0->ang;
         probs[gi] = pb;
       }
     }
@@ -270,17 +261,8 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     const int k = b0 + tid;
     const bool w = k < nc && L.want[k];
     const unsigned long long m = __ballot(w);
-    if (lane == 0) L.wsum[wave] = __popcll(m);
-    __syncthreads();
-    int off = n_want + __popcll(m & ((1ull << lane) - 1ull));
-    int tot = 0;
-    for (int wv = 0; wv < CC_MERGE_BLOCK / 64; wv++) {
-      if (wv < wave) off += L.wsum[wv];
-      tot += L.wsum[wv];
-    }
-    if (w) L.ord[off] = (unsigned short)k;  // ord (the check slots) is dead by now
-    n_want += tot;
-    __syncthreads();
+    if (w) L.ord[n_want + __popcll(m & lt_mask)] = (unsigned short)k;  // ord (the check slots) is dead by now
+    n_want += __popcll(m);
   }
   if (tid == 0) L.base = n_want ? atomicAdd(n_prob, n_want) : 0;
   __syncthreads();

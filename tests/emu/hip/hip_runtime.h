@@ -8,6 +8,7 @@
 // nothing under contour-context_amd/ includes or links it.
 #pragma once
 #define CC_EMU 1  // selects the shuffle-based forms of the 16-lane group collectives (csrc/cc_group.h)
+#define CC_OPAQUE_I(x) asm volatile("" : "+r"(x))  // csrc/k_contours.h: the optimiser barrier, host constraint
 #include <pthread.h>
 #include <algorithm>
 #include <cmath>
