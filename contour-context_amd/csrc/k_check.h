@@ -360,41 +360,55 @@ __device__ __forceinline__ void cc_b1_sort(cc_b1_lds<PPM> &L, int npp, int ntp, 
     cc_group_sync();
     return;
   }
-  if (npp <= G) {  // one pair per lane: stable rank through group broadcasts, no LDS traffic
-    const float f = sl < npp ? CC_B1_KEY(L.pp[sl]) : 0.f;
+  // Stable rank = #(smaller keys) + #(equal keys at earlier positions): one 64-bit unsigned comparison of
+  // (order-preserving key << 32 | position) per pair of elements.
+  if (npp <= G) {  // one pair per lane: through group broadcasts, no LDS traffic
+    const unsigned kme = sl < npp ? CC_B1_UKEY(L.pp[sl]) : 0xFFFFFFFFu;
+    const unsigned long long me = ((unsigned long long)kme << 32) | (unsigned)sl;
     int rank = 0;
     for (int j = 0; j < npp; j++) {
-      const float fj = cc_group_bcast(f, j);
-      rank += (fj < f || (fj == f && j < sl)) ? 1 : 0;
+      const unsigned long long oj = ((unsigned long long)cc_group_bcast(kme, j) << 32) | (unsigned)j;
+      rank += oj < me ? 1 : 0;
     }
     cc_group_sync();  // every lane has read its pp before skey (same storage as the point tables, not as pp) is written
     if (sl < npp) {
       L.sidx[rank] = (unsigned char)sl;
-      L.skey[rank] = f;
+      L.skey[rank] = cc_funkey(kme);
     }
     cc_group_sync();
     return;
   }
   if (npp <= 48 || PPM <= 64) {
-    float fv[(PPM <= 64 ? 64 : 48) / CC_G];
-    int rk[(PPM <= 64 ? 64 : 48) / CC_G];
+    constexpr int NU = (PPM <= 64 ? 64 : 48) / CC_G;
+    unsigned kv[NU];
+    unsigned long long me[NU];
+    int rk[NU];
 #pragma unroll
-    for (int u = 0; u < (PPM <= 64 ? 64 : 48) / CC_G; u++) {
+    for (int u = 0; u < NU; u++) {
       const int p = sl + u * G;
-      fv[u] = p < npp ? CC_B1_KEY(L.pp[p]) : 0.f;
+      kv[u] = p < npp ? CC_B1_UKEY(L.pp[p]) : 0xFFFFFFFFu;
+      me[u] = ((unsigned long long)kv[u] << 32) | (unsigned)p;
       rk[u] = 0;
     }
-    for (int j = 0; j < npp; j++) {
-      const float fj = CC_B1_KEY(L.pp[j]);
+    if (npp <= 2 * G) {
+      for (int j = 0; j < npp; j++) {
+        const unsigned long long oj = ((unsigned long long)CC_B1_UKEY(L.pp[j]) << 32) | (unsigned)j;
+        rk[0] += oj < me[0] ? 1 : 0;
+        rk[1] += oj < me[1] ? 1 : 0;
+      }
+    } else {
+      for (int j = 0; j < npp; j++) {
+        const unsigned long long oj = ((unsigned long long)CC_B1_UKEY(L.pp[j]) << 32) | (unsigned)j;
 #pragma unroll
-      for (int u = 0; u < (PPM <= 64 ? 64 : 48) / CC_G; u++) rk[u] += (fj < fv[u] || (fj == fv[u] && j < sl + u * G)) ? 1 : 0;
+        for (int u = 0; u < NU; u++) rk[u] += oj < me[u] ? 1 : 0;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < (PPM <= 64 ? 64 : 48) / CC_G; u++) {
+    for (int u = 0; u < NU; u++) {
       const int p = sl + u * G;
       if (p < npp) {
         L.sidx[rk[u]] = (unsigned char)p;
-        L.skey[rk[u]] = fv[u];
+        L.skey[rk[u]] = cc_funkey(kv[u]);
       }
     }
     cc_group_sync();

@@ -484,74 +484,97 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       n_tot += sh[8 + l];
     }
     lev_base[CC_NLEV] = n_tot;
-    for (int w = wave_id; w < n_tot; w += n_waves) {
-      int l = 0;
-      for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
-      int kbase = 0;
-      for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
-      const int k = w - kbase;
-      const int i0 = scr->wfirst[l][k], i1 = scr->wlast[l][k];
-      const uint16_t *cidx = scr->compidx[l];
+    // The sums of a batch of components go to LDS; calcStatVals (a lane-serial stretch of ~500 instructions with the 2x2
+    // eigen-solver) then runs for all of them side by side, one thread per component, instead of on lane 0 of each wave.
+    struct walk_rec {
       cc_running_stat rec;
-      rec.cnt = 0;
-      rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
-      rec.vol3 = 0.f;
-      int poi_i = -1;
-      // the index image comes from the scratch block (L2): four 64-entry stretches are fetched at a time so that their
-      // round trips overlap
-      unsigned cv[4] = {CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE};
-      for (int ib = i0; ib <= i1; ib += 64) {
-        const int u4 = ((ib - i0) >> 6) & 3;
-        if (u4 == 0) {
+      int poi_i, lk;  // last cell of the component (list position); level << 16 | component index
+    };
+    static_assert(sizeof(walk_rec) == 80, "walk batch size");
+    walk_rec *wrec = (walk_rec *)(R + CC_K2_CACHE * 12);  // between the staged heights / positions and sh[]
+    const int WB = (int)(((char *)sh - (R + CC_K2_CACHE * 12)) / (long)sizeof(walk_rec));  // 239: up to the scalars in sh[], which live on
+    for (int w0 = 0; w0 < n_tot; w0 += WB) {
+      const int w1 = w0 + WB < n_tot ? w0 + WB : n_tot;
+      for (int w = w0 + wave_id; w < w1; w += n_waves) {
+        int l = 0;
+        for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
+        int kbase = 0;
+        for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
+        const int k = w - kbase;
+        const int i0 = scr->wfirst[l][k], i1 = scr->wlast[l][k];
+        const uint16_t *cidx = scr->compidx[l];
+        cc_running_stat rec;
+        rec.cnt = 0;
+        rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
+        rec.vol3 = 0.f;
+        int poi_i = -1;
+        // the index image comes from the scratch block (L2): four 64-entry stretches are fetched at a time so that their
+        // round trips overlap
+        unsigned cv[4] = {CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE};
+        for (int ib = i0; ib <= i1; ib += 64) {
+          const int u4 = ((ib - i0) >> 6) & 3;
+          if (u4 == 0) {
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int iu = ib + 64 * u + lane;
-            cv[u] = iu <= i1 ? (unsigned)cidx[iu] : CC_COMP_NONE;
+            for (int u = 0; u < 4; u++) {
+              const int iu = ib + 64 * u + lane;
+              cv[u] = iu <= i1 ? (unsigned)cidx[iu] : CC_COMP_NONE;
+            }
+          }
+          const int i = ib + lane;
+          const unsigned cme = u4 == 0 ? cv[0] : (u4 == 1 ? cv[1] : (u4 == 2 ? cv[2] : cv[3]));
+          const bool mem = cme == (unsigned)k;
+          unsigned long long mask = __ballot(mem);
+          if (!mask) continue;
+          float h = 0.f, px = 0.f, py = 0.f;
+          if (mem) {
+            if (i < n_cache) {
+              h = cbev[i];
+              const float2 rc = cpix[i];
+              px = rc.x;
+              py = rc.y;
+            } else {
+              const int c = (int)scr->act[i];
+              h = bev[c];
+              const float2 rc = pix[c];
+              px = rc.x;
+              py = rc.y;
+            }
+          }
+          while (mask) {
+            const int src = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            const float hh = cc_lane_bcast(h, src);
+            const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
+            rec.cnt += 1;
+            rec.ps_x += vr;
+            rec.ps_y += vc;
+            rec.t_xx += vr * vr;
+            rec.t_xy += vr * vc;
+            rec.t_yy += vc * vc;
+            rec.vol3 += hh;
+            rec.tq_x += (double)hh * vr;
+            rec.tq_y += (double)hh * vc;
+            poi_i = ib + src;
           }
         }
-        const int i = ib + lane;
-        const unsigned cme = u4 == 0 ? cv[0] : (u4 == 1 ? cv[1] : (u4 == 2 ? cv[2] : cv[3]));
-        const bool mem = cme == (unsigned)k;
-        unsigned long long mask = __ballot(mem);
-        if (!mask) continue;
-        float h = 0.f, px = 0.f, py = 0.f;
-        if (mem) {
-          if (i < n_cache) {
-            h = cbev[i];
-            const float2 rc = cpix[i];
-            px = rc.x;
-            py = rc.y;
-          } else {
-            const int c = (int)scr->act[i];
-            h = bev[c];
-            const float2 rc = pix[c];
-            px = rc.x;
-            py = rc.y;
-          }
-        }
-        while (mask) {
-          const int src = __ffsll((unsigned long long)mask) - 1;
-          mask &= mask - 1;
-          const float hh = cc_lane_bcast(h, src);
-          const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
-          rec.cnt += 1;
-          rec.ps_x += vr;
-          rec.ps_y += vc;
-          rec.t_xx += vr * vr;
-          rec.t_xy += vr * vc;
-          rec.t_yy += vc * vc;
-          rec.vol3 += hh;
-          rec.tq_x += (double)hh * vr;
-          rec.tq_y += (double)hh * vc;
-          poi_i = ib + src;
+        if (lane == 0) {
+          walk_rec o;
+          o.rec = rec;
+          o.poi_i = poi_i;
+          o.lk = (l << 16) | k;
+          wrec[w - w0] = o;
         }
       }
-      if (lane == 0) {
-        const int pc = poi_i >= 0 ? (int)scr->act[poi_i] : 0;
-        cc_contour_t cv;
-        cc_calc_stat_vals(cfg, rec, l, poi_i >= 0 ? pc / n_col : -1, poi_i >= 0 ? pc % n_col : -1, &cv);
-        scr->cont[l][k] = cv;
+      __syncthreads();
+      for (int s_ = tid; s_ < w1 - w0; s_ += nt) {
+        const walk_rec o = wrec[s_];
+        const int l = o.lk >> 16, k = o.lk & 0xFFFF;
+        const int pc = o.poi_i >= 0 ? (int)scr->act[o.poi_i] : 0;
+        cc_contour_t cvw;
+        cc_calc_stat_vals(cfg, o.rec, l, o.poi_i >= 0 ? pc / n_col : -1, o.poi_i >= 0 ? pc % n_col : -1, &cvw);
+        scr->cont[l][k] = cvw;
       }
+      __syncthreads();
     }
   }
   CC_K2_LAP(acc_walk);
@@ -725,31 +748,44 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
           const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
           const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
-          for (int base = 0; base < tot; base += 64) {
-            const int idx = base + lane;
-            bool q = false;
-            float dist = 0.f;
-            int lv = 0;
-            if (idx < tot) {
-              const int ro = idx / W;
-              const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
-              // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
-              // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
-              lv = LV[cell];
-              if (lv >= 2) {
-                const float2 rc = pix[cell];
-                const float dx = rc.x - vcx, dy = rc.y - vcy;
+          // nine 64-cell stretches (a 23 x 23 window) at a time: their level bytes and positions are fetched before any
+          // of them is compacted, so the L2 round trips of the positions overlap
+          const int KB = 9;
+          for (int base0 = 0; base0 < tot; base0 += 64 * KB) {
+            int lvv[KB];
+            float2 rcv[KB];
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              const int idx = base0 + 64 * u + lane;
+              lvv[u] = 0;
+              rcv[u] = make_float2(0.f, 0.f);
+              if (idx < tot) {
+                const int ro = idx / W;
+                const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
+                // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
+                // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
+                lvv[u] = LV[cell];
+                if (lvv[u] >= 2) rcv[u] = pix[cell];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              if (base0 + 64 * u >= tot) break;  // uniform
+              bool q = false;
+              float dist = 0.f;
+              if (lvv[u] >= 2) {
+                const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
                 dist = sqrtf(dx * dx + dy * dy);
                 q = (double)dist < r_lim;
               }
+              const unsigned long long m = __ballot(q);
+              const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+              if (q && pos < CAP) {
+                ldist[(a - g0) * CAP + pos] = dist;
+                lhi[(a - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+              }
+              n += __popcll(m);
             }
-            const unsigned long long m = __ballot(q);
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (q && pos < CAP) {
-              ldist[(a - g0) * CAP + pos] = dist;
-              lhi[(a - g0) * CAP + pos] = (unsigned char)(lv - 1);
-            }
-            n += __popcll(m);
           }
           if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
         }
@@ -845,8 +881,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   // RelativePoint records would.
   unsigned *bkey = (unsigned *)(R + 0);                            // [36][40] (T is dead now)
   int *bcnt = (int *)(R + 5760);                                   // [36] points per anchor
-  if (tid < NA) {
-    const int a = tid;
+  // one lane per anchor, the anchors dealt out over the waves (anchor a -> wave a % n_waves, lane a / n_waves): the
+  // lane-serial sort replay diverges between lanes, so the fewer anchors share a wave the less each waits for the others
+  if (lane * n_waves + wave_id < NA && lane < (NA + n_waves - 1) / n_waves) {
+    const int a = lane * n_waves + wave_id;
     const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
     unsigned *p = bkey + a * CC_BCI_MAXPTS;
     int n = 0;

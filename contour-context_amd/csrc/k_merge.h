@@ -79,13 +79,26 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     for (int u = 0; u < CC_CHK_STRIDE / 64; u++) {
       const bool ok = okv[u] != 0;
       const unsigned long long m = __ballot(ok);
-      if (ok) {
-        const int t = u * 64 + lane, off = n + __popcll(m & lt_mask);
-        L.ord[off] = (unsigned short)t;
-        L.gid[off] = recs[t].gidx;
-        L.next[off] = -1;
-      }
+      if (ok) L.ord[n + __popcll(m & lt_mask)] = (unsigned short)(u * 64 + lane);
       n += __popcll(m);
+    }
+  }
+  __syncthreads();
+  // the candidate scans of the listed checks: gathers from the pass records, four per lane in flight
+  for (int i0 = 0; i0 < n; i0 += 4 * CC_MERGE_BLOCK) {
+    int g[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * CC_MERGE_BLOCK + lane;
+      g[u] = i < n ? recs[L.ord[i]].gidx : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * CC_MERGE_BLOCK + lane;
+      if (i < n) {
+        L.gid[i] = g[u];
+        L.next[i] = -1;
+      }
     }
   }
   __syncthreads();

@@ -221,6 +221,24 @@ class ContourManager {
     str_id_ = !str_id.empty() ? std::move(str_id) : std::to_string(ptr_gapc->header.stamp);
   }
 
+  // Mirror-only: the evaluator's .bin reader (tools/pointcloud_util.h:9-47: at most 1 000 000 floats, x y z i records,
+  // intensity dropped) without the intermediate cloud.  A KITTI record IS a staging record (the kernels never read the
+  // fourth float), so the file is read straight into the context's pinned buffer.  Returns the number of points.
+  size_t makeBEVFromKittiBin(FILE *f, std::string str_id) {
+    CC_CHECK(f);
+    CC_CHECK(!scan_);
+    cc_ctx *ctx = cc_host::context(ccfg_);
+    const size_t cap = 1000000 / 4;
+    float *dst = cc_stage_points(ctx, (int64_t)cap);
+    if (!dst) die();
+    const size_t n = fread(dst, 4 * sizeof(float), cap, f);
+    CC_CHECK(n > 10);
+    want_images_ = keepImages();
+    if (cc_scan_ingest(ctx, dst, (int64_t)n, want_images_ ? 1 : 0, &scan_) != CC_OK) die();
+    str_id_ = std::move(str_id);
+    return n;
+  }
+
   // contour_mng.h:588: the work was queued by makeBEV; results are waited for where they are read
   void makeContoursRecurs() { CC_CHECK(scan_); }
   void clearImage() {}  // the dense image is never kept here (see bev_cells_)

@@ -178,21 +178,15 @@ class ContLCDEvaluator {
   std::shared_ptr<ContourManager> getCurrContourManager(const ContourManagerConfig &config) const {
     const LaserScanInfo &info = getCurrScanInfo();
     std::shared_ptr<ContourManager> cm(new ContourManager(config, info.seq));
-    auto cloud = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
     FILE *f = fopen(info.fpath.c_str(), "rb");
     if (!f) {
       printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
       exit(-1);
     }
-    std::vector<float> buf(1000000);
-    const size_t n = fread(buf.data(), sizeof(float), buf.size(), f) / 4;
-    fclose(f);
-    cloud->reserve(n);
-    for (size_t i = 0; i < n; i++) cloud->push_back(pcl::PointXYZ{buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], 0.f});
     std::string str_id = std::to_string(info.seq);
     str_id = "assigned_id_" + std::string(8 - str_id.length(), '0') + str_id;
-    pcl::PointCloud<pcl::PointXYZ>::ConstPtr cptr = cloud;
-    cm->makeBEV<pcl::PointXYZ>(cptr, str_id);
+    cm->makeBEVFromKittiBin(f, str_id);  // readKITTIPointCloudBin + makeBEV in one step: the records go straight to the staging buffer
+    fclose(f);
     cm->makeContoursRecurs();
     return cm;
   }
