@@ -36,9 +36,9 @@ struct cc_qstate {
   int n_cand;  // candidates_.size() before tidyUpCandidates
   int flags;
 };
-struct cc_merge_lds {
+struct alignas(16) cc_merge_lds {
   cc_dcand st[CC_MERGE_BLOCK];             // lane-private candidate state
-  int gid[CC_CHK_STRIDE];                  // candidate scan of the i-th passing check
+  alignas(16) int gid[CC_CHK_STRIDE];      // candidate scan of the i-th passing check (read four at a time)
   unsigned short ord[CC_CHK_STRIDE];       // its check slot
   short next[CC_CHK_STRIDE];               // next passing check naming the same scan, -1 = none
   unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
@@ -56,8 +56,14 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
            const cc_hot_desc_t *__restrict__ db_desc, const cc_pass_rec *__restrict__ pass, const unsigned char *__restrict__ pass_ok,
            const int *__restrict__ pass_cnt, cc_cand_out *__restrict__ cands_all, cc_qstate *__restrict__ qstate,
            cc_gmm_problem *__restrict__ probs /*[nq][CC_MAXCAND]: problem of candidate k of query q*/,
-           int *__restrict__ prob_list /*dense list of the problems that exist*/, int *__restrict__ n_prob) {
+           int *__restrict__ prob_list /*dense list of the problems that exist*/, int *__restrict__ n_prob,
+           long long *__restrict__ phase /*tuning aid (CC_MERGE_PHASES=1): [nq][8] ticks per stage, else nullptr*/) {
   __shared__ cc_merge_lds L;
+#define CC_MERGE_STAMP(i)                                                                                   \
+  do {                                                                                                      \
+    if (phase && threadIdx.x == 0) phase[(size_t)blockIdx.x * 8 + (i)] = (long long)wall_clock64();          \
+  } while (0)
+  CC_MERGE_STAMP(0);
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (q >= nq) return;
   const unsigned char *okp = pass_ok + (size_t)q * CC_CHK_STRIDE;
@@ -84,6 +90,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     }
   }
   __syncthreads();
+  CC_MERGE_STAMP(1);
   // the candidate scans of the listed checks: gathers from the pass records, four per lane in flight
   for (int i0 = 0; i0 < n; i0 += 4 * CC_MERGE_BLOCK) {
     int g[4];
@@ -102,15 +109,26 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     }
   }
   __syncthreads();
+  CC_MERGE_STAMP(2);
   // ---- thread the checks of one scan together; number the candidates in first-appearance order
   int nc = 0;
   for (int b0 = 0; b0 < n; b0 += CC_MERGE_BLOCK) {
     const int i = b0 + tid;
     bool first = false;
     if (i < n) {
+      // the nearest earlier check of the same scan: a backwards scan whose every step waits for an LDS read, so it takes
+      // four entries per read (a check that opens a new candidate scans everything before it)
       const int g = L.gid[i];
       int j = i - 1;
-      while (j >= 0 && L.gid[j] != g) j--;
+      while (j >= 0 && (j & 3) != 3 && L.gid[j] != g) j--;
+      if (j >= 0 && (j & 3) == 3 && L.gid[j] != g) {
+        int hit = -1;
+        for (; j >= 3 && hit < 0; j -= 4) {
+          const int4 v = *(const int4 *)&L.gid[j - 3];
+          hit = v.w == g ? j : (v.z == g ? j - 1 : (v.y == g ? j - 2 : (v.x == g ? j - 3 : -1)));
+        }
+        j = hit;
+      }
       if (j >= 0)
         L.next[j] = (short)i;  // j is the immediately preceding check of this scan: written by exactly one i
       else
@@ -127,6 +145,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
     st.flags = 0;
     qstate[q] = st;
   }
+  CC_MERGE_STAMP(3);
   // ---- one lane per candidate
   cc_dcand *c = &L.st[tid];
   for (int k = tid; k < nc; k += CC_MERGE_BLOCK) {
@@ -269,6 +288,7 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
   }
   // ---- dense problem list: ordered ranks within the query, one global atomic per query
   __syncthreads();
+  CC_MERGE_STAMP(4);
   int n_want = 0;
   for (int b0 = 0; b0 < nc; b0 += CC_MERGE_BLOCK) {
     const int k = b0 + tid;
@@ -280,5 +300,11 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
   if (tid == 0) L.base = n_want ? atomicAdd(n_prob, n_want) : 0;
   __syncthreads();
   for (int i = tid; i < n_want; i += CC_MERGE_BLOCK) prob_list[L.base + i] = q * CC_MAXCAND + (int)L.ord[i];
+  CC_MERGE_STAMP(5);
+  if (phase && tid == 0) {
+    phase[(size_t)blockIdx.x * 8 + 6] = n;
+    phase[(size_t)blockIdx.x * 8 + 7] = nc;
+  }
+#undef CC_MERGE_STAMP
 }
 

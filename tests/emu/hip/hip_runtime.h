@@ -45,6 +45,9 @@ struct int2 {
 struct uint2 {
   unsigned x, y;
 };
+struct int4 {
+  int x, y, z, w;
+};
 static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
 struct double2 {
   double x, y;
