@@ -49,6 +49,8 @@ struct cc_pass_rec {
 struct cc_check_params {
   cc_sim_cfg_t sim;
   cc_score_t lb;
+  int size_class[3];  // stage A: overlap counts that separate the four size classes of the check list (CC_A_CLASSES)
+  int cstl_class[3];  // compaction: constellation lengths that separate the four size classes of stage B2's list (CC_B2_CLASSES)
 };
 
 struct cc_chk_item {  // a check that passed stage A
@@ -152,28 +154,40 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
     sc[2] = sc[3] = sc[4] = 0;
   }
   // list append: one global atomic per workgroup (a single counter would otherwise see an atomic per wave, and
-  // same-address atomics are served one after the other)
-  __shared__ int s_wcnt[4], s_base;
-  const unsigned long long mk = __ballot(keep), ma = __ballot(anchor_ok);
+  // same-address atomics are served one after the other).  Inside the workgroup's stretch of the list the checks are
+  // grouped by expected work: stage B1 gives four consecutive checks to the four 16-lane groups of a wave, which advance
+  // together, so a wave takes as long as its largest check -- the potential pairs grow with the overlap count, and
+  // checks of one size class sit side by side (the order of the list never shows: results are slot-indexed).
+  __shared__ int s_bcnt[4][4], s_base;  // [size class][wave]
+  const int bk = !keep ? -1 : (sc_sum < P.size_class[0] ? 0 : (sc_sum < P.size_class[1] ? 1 : (sc_sum < P.size_class[2] ? 2 : 3)));
+  const unsigned long long ma = __ballot(anchor_ok);
+  const unsigned long long mb0 = __ballot(bk == 0), mb1 = __ballot(bk == 1), mb2 = __ballot(bk == 2), mb3 = __ballot(bk == 3);
   const int wave = threadIdx.x >> 6;
   if (lane == 0) {
-    s_wcnt[wave] = __popcll(mk);
+    s_bcnt[0][wave] = __popcll(mb0);
+    s_bcnt[1][wave] = __popcll(mb1);
+    s_bcnt[2][wave] = __popcll(mb2);
+    s_bcnt[3][wave] = __popcll(mb3);
     if (ma) atomicAdd(&pass_cnt[q * 4 + 1], __popcll(ma));
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    int tot = 0;
+    for (int b = 0; b < 4; b++)
+      for (int w = 0; w < 4; w++) tot += s_bcnt[b][w];
     s_base = tot ? atomicAdd(&cnt[CC_CNT_CHK], tot) : 0;
   }
   __syncthreads();
-  int base = s_base;
-  for (int w = 0; w < wave; w++) base += s_wcnt[w];
   if (keep) {
+    int pos = s_base;
+    for (int b = 0; b < 4; b++)
+      for (int w = 0; w < 4; w++) pos += (b < bk || (b == bk && w < wave)) ? s_bcnt[b][w] : 0;
+    const unsigned long long mine = bk == 0 ? mb0 : (bk == 1 ? mb1 : (bk == 2 ? mb2 : mb3));
     cc_chk_item it;
     it.q = q;
     it.t = t;
     it.h = h;
-    items[base + __popcll(mk & ((1ull << lane) - 1ull))] = it;
+    items[pos + __popcll(mine & ((1ull << lane) - 1ull))] = it;
   }
 }
 
@@ -633,22 +647,35 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 // The constellations that passed, as a dense index list for stage B2 (order irrelevant: results are slot-indexed).
 // One global atomic per workgroup.  grid = ceil(n_chk_max / 256) (device-side bound check), block = 256
 __global__ void __launch_bounds__(256)
-cc_k_compact_cstl(const cc_cstl_item *__restrict__ cstl, int *__restrict__ cnt, int *__restrict__ cstl_idx) {
-  __shared__ int s_wcnt[4], s_base;
+cc_k_compact_cstl(cc_check_params P, const cc_cstl_item *__restrict__ cstl, int *__restrict__ cnt, int *__restrict__ cstl_idx) {
+  __shared__ int s_bcnt[4][4], s_base;  // [size class][wave]: stage B2's groups advance four to a wave, like stage B1's
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool ok = i < cnt[CC_CNT_CHK] && cstl[i].n_in != 0;
-  const unsigned long long m = __ballot(ok);
-  if (lane == 0) s_wcnt[wave] = __popcll(m);
+  const int n_in = i < cnt[CC_CNT_CHK] ? (int)cstl[i].n_in : 0;
+  const bool ok = n_in != 0;
+  const int bk = !ok ? -1 : (n_in < P.cstl_class[0] ? 0 : (n_in < P.cstl_class[1] ? 1 : (n_in < P.cstl_class[2] ? 2 : 3)));
+  const unsigned long long mb0 = __ballot(bk == 0), mb1 = __ballot(bk == 1), mb2 = __ballot(bk == 2), mb3 = __ballot(bk == 3);
+  if (lane == 0) {
+    s_bcnt[0][wave] = __popcll(mb0);
+    s_bcnt[1][wave] = __popcll(mb1);
+    s_bcnt[2][wave] = __popcll(mb2);
+    s_bcnt[3][wave] = __popcll(mb3);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    int tot = 0;
+    for (int b = 0; b < 4; b++)
+      for (int w = 0; w < 4; w++) tot += s_bcnt[b][w];
     s_base = tot ? atomicAdd(&cnt[CC_CNT_CSTL], tot) : 0;
   }
   __syncthreads();
-  int base = s_base;
-  for (int w = 0; w < wave; w++) base += s_wcnt[w];
-  if (ok) cstl_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  if (ok) {
+    int pos = s_base;
+    for (int b = 0; b < 4; b++)
+      for (int w = 0; w < 4; w++) pos += (b < bk || (b == bk && w < wave)) ? s_bcnt[b][w] : 0;
+    const unsigned long long mine = bk == 0 ? mb0 : (bk == 1 ? mb1 : (bk == 2 ? mb2 : mb3));
+    cstl_idx[pos + __popcll(mine & ((1ull << lane) - 1ull))] = i;
+  }
 }
 
 // ---- stage B2 -------------------------------------------------------------------------------------------------------
