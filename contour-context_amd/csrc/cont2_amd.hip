@@ -181,6 +181,10 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
+  {
+    const char *e = getenv("CC_K2_LDS_PAD");  // tuning aid, read once: extra bytes asked for (above 80 KB one scan per CU instead of two)
+    if (e && atoi(e) > 0 && atoi(e) <= 65536) c->lds2 += (size_t)atoi(e);
+  }
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   {

@@ -51,7 +51,15 @@ struct cc_check_params {
   cc_score_t lb;
   int size_class[3];  // stage A: overlap counts that separate the four size classes of the check list (CC_A_CLASSES)
   int cstl_class[3];  // compaction: constellation lengths that separate the four size classes of stage B2's list (CC_B2_CLASSES)
+#ifdef CC_TUNE
+  int ablate;  // tuning aid (CC_ABLATE): stage B1 stops after its n-th part (1..5), stage B2 after part n - 10 (11..13)
+#endif
 };
+#ifdef CC_TUNE
+#define CC_ABLATE_AT(n) if (P.ablate == (n)) continue
+#else
+#define CC_ABLATE_AT(n)
+#endif
 
 struct cc_chk_item {  // a check that passed stage A
   int q, t;
@@ -528,6 +536,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       }
     }
     cc_group_sync();
+    CC_ABLATE_AT(1);
     // src points are sorted by bit_pos: the partners of a tgt point are the contiguous range [lo, hi)
     int npp_all = 0;
     for (int r0 = 0; r0 < ntp; r0 += G) {
@@ -560,6 +569,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       if (k < ntp) L.g.off[k] = (unsigned short)(npp_all + incl - cnt_k);
       npp_all += cc_group_sum_i(cnt_k);
     }
+    CC_ABLATE_AT(2);
     int flags = 0;
     int npp = npp_all;
     if (npp > PPM) {
@@ -577,7 +587,9 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       continue;
     }
     cc_b1_gen_pairs<PPM>(L, ntp, sl);
+    CC_ABLATE_AT(3);
     cc_b1_sort<PPM>(L, npp, ntp, sl);
+    CC_ABLATE_AT(4);
     // circular window of width pi/16 (contour_mng.h:344-357): for each start p1 the furthest p2, then the first start
     // that attains the maximum length (what the two-pointer loop records)
     const float angular_range = (float)(3.14159265358979323846 / 16);
@@ -611,6 +623,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       beg = 0;
     }
     if (sc && sl == 0) sc[2] = longest;
+    CC_ABLATE_AT(5);
     if (longest < P.lb.i_in_ang_rng) continue;
     // hand the constellation over to stage B2: the window pairs in sorted order, then the anchors (cstl_in order)
     int n_in = longest + 1;
@@ -752,6 +765,7 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       flags |= 1;
     }
     if (sc && sl == 0) sc[3] = ncs;
+    CC_ABLATE_AT(11);
     if (ncs < P.lb.i_indiv_sim) continue;
     cc_group_sync();
     // part 2: the "shaft" (contour_mng.h:1173-1184).  The reference scans the (i, j<i) pairs of the first <=10 entries in
@@ -823,6 +837,7 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
         }
       }
     }
+    CC_ABLATE_AT(12);
     // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
     unsigned long long rmm = 0ull;
     for (int r0 = 0; r0 < ncs; r0 += G) {
@@ -862,6 +877,7 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       ncs = L.misc[0];
     }
     if (sc && sl == 0) sc[4] = ncs;
+    CC_ABLATE_AT(13);
     if (ncs < P.lb.i_orie_sim) continue;
     // (4/4) getTFFromConstell: 2-D umeyama without scaling, closed form.  The sums run over the list in parallel
     // (partial sums per lane, then a fixed butterfly): the same terms as the reference's sequential sums in another
