@@ -435,6 +435,8 @@ def _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add):
         s_ing.wait_stream(s_main)
         with torch.cuda.stream(s_ing):
             ctx.ingest(chunks[k], offs, out=slots[k % 3])
+            if add:  # the device half of the append rides behind the ingest (cc_db_add_scans_prepare)
+                db.add_scans_prepare(slots[k % 3])
             ev = torch.cuda.Event()
             ev.record(s_ing)
         return ev
@@ -540,6 +542,8 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
             s_ing.wait_stream(s_main)
             with torch.cuda.stream(s_ing):
                 ctx.ingest(chunks[k], offs, out=slots[k % 3])
+                if mode == "with_update":  # the device half of the append rides behind the ingest (cc_db_add_scans_prepare)
+                    db.add_scans_prepare(slots[k % 3])
                 ev = torch.cuda.Event()
                 ev.record(s_ing)
             return ev

@@ -44,7 +44,7 @@ _lib = None
 # every symbol include/cont2_amd.h declares
 EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_db_cfg", "cc_default_thresholds",
            "cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_ingest_host_bev", "cc_db_create", "cc_db_destroy", "cc_db_size",
-           "cc_db_add_scans", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
+           "cc_db_add_scans", "cc_db_add_scans_prepare", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_hot_ptr", "cc_db_feat_ptr", "cc_pack_scans", "cc_db_add_packed",
            "cc_packed_sizes", "cc_db_bucket_state", "cc_est_sens_tf",
            "cc_profile_enable", "cc_profile_read", "cc_db_profile_enable", "cc_db_profile_read",
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
@@ -69,6 +69,7 @@ def lib():
         _lib.cc_db_destroy.argtypes = [C.c_void_p]
         _lib.cc_db_size.argtypes = [C.c_void_p]
         _lib.cc_db_add_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cc_db_add_scans_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib.cc_db_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
         _lib.cc_db_query_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
         _lib.cc_db_query_wait.argtypes = [C.c_void_p]
@@ -222,6 +223,13 @@ class Database:
         assert desc.is_cuda and desc.dtype == torch.uint8 and desc.is_contiguous() and len(ts) == n and len(seeds) == n
         stream = torch.cuda.current_stream(desc.device).cuda_stream
         _chk(lib().cc_db_add_scans(self.h, desc.data_ptr(), n, ts.ctypes.data, seeds.ctypes.data, stream), "cc_db_add_scans")
+
+    def add_scans_prepare(self, desc):
+        """Queue the device half of add_scans(desc, ...) on the current stream without waiting (cc_db_add_scans_prepare)."""
+        import torch
+        assert desc.is_cuda and desc.dtype == torch.uint8 and desc.is_contiguous()
+        stream = torch.cuda.current_stream(desc.device).cuda_stream
+        _chk(lib().cc_db_add_scans_prepare(self.h, desc.data_ptr(), desc.shape[0], stream), "cc_db_add_scans_prepare")
 
     def query(self, qdesc, epochs, lb=None, ub=None, want_knn=False):
         """qdesc: torch uint8 CUDA [nq, DESC_BYTES]; epochs int32 [nq] (DB state each query sees).

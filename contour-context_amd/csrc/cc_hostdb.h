@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <numeric>
 #include <vector>
 
@@ -115,13 +116,22 @@ struct LayerBook {
     int to_move_max = int((szb - szs + imba_diff_ratio_ * szs) / (2 - imba_diff_ratio_));
     int to_move_mid = int((szb - szs) / 2.0);
     int to_move_min = std::max(0, int((szb - szs - imba_diff_ratio_ * szb) / (2 - imba_diff_ratio_)));
-    std::vector<int> sort_permu(szb);
-    std::iota(sort_permu.begin(), sort_permu.end(), 0);
-    if (from1)
-      std::sort(sort_permu.begin(), sort_permu.end(), [&](const int &x, const int &y) { return k0(big.tree[x]) < k0(big.tree[y]); });
-    else
-      std::sort(sort_permu.begin(), sort_permu.end(), [&](const int &x, const int &y) { return k0(big.tree[x]) > k0(big.tree[y]); });
-    auto val = [&](int pos) { return k0(big.tree[sort_permu[pos]]); };
+    // The reference sorts the whole big tree by key dimension 0 (std::sort of an index permutation, ascending when the
+    // first bucket gives, descending otherwise).  Everything that follows only reads the sorted values at positions
+    // >= szb - to_move_max - 1, and which elements move is decided by their VALUES (the cut is placed at a value change),
+    // so only that tail is put in order here: a selection plus a sort of the tail, on the values themselves.  The order
+    // of the ids inside a tree never shows (membership, sizes and ranges do).
+    const int m_tail = std::min(szb, std::max(to_move_max, to_move_mid + 1) + 1);
+    std::vector<float> vals(szb);
+    for (int i = 0; i < szb; i++) vals[i] = k0(big.tree[i]);
+    if (from1) {
+      std::nth_element(vals.begin(), vals.begin() + (szb - m_tail), vals.end());
+      std::sort(vals.begin() + (szb - m_tail), vals.end());
+    } else {
+      std::nth_element(vals.begin(), vals.begin() + (szb - m_tail), vals.end(), std::greater<float>());
+      std::sort(vals.begin() + (szb - m_tail), vals.end(), std::greater<float>());
+    }
+    auto val = [&](int pos) { return vals[pos]; };  // pos >= szb - m_tail
     int num_to_move = 0;
     float split_val = tr1.buc_end;
     if (to_move_mid <= 0 || to_move_mid >= szb) {
@@ -161,19 +171,18 @@ struct LayerBook {
       }
       return;
     }
-    for (int i = 0; i < num_to_move; i++) small.tree.push_back(big.tree[sort_permu[szb - i - 1]]);
-    // keep in `big` the elements on its side of split_val (tr1: < split, tr2: >= split)
+    // the num_to_move extreme elements change trees: exactly the ones on the far side of split_val
     {
       auto moved = [&](int id) { return from1 ? (k0(id) >= split_val) : (k0(id) < split_val); };
-      int p_dat = szb - 1, p_perm = szb - 1;
-      for (; p_perm >= szb - num_to_move; p_perm--) {
-        while (moved(big.tree[p_dat])) p_dat--;
-        if (sort_permu[p_perm] < p_dat) {
-          std::swap(big.tree[p_dat], big.tree[sort_permu[p_perm]]);
-          p_dat--;
-        }
+      size_t keep = 0;
+      for (size_t i = 0; i < big.tree.size(); i++) {
+        const int id = big.tree[i];
+        if (moved(id))
+          small.tree.push_back(id);
+        else
+          big.tree[keep++] = id;
       }
-      big.tree.resize(p_dat + 1);
+      big.tree.resize(keep);
     }
     {
       auto moved = [&](int id) { return from1 ? (k0(id) >= split_val) : (k0(id) < split_val); };

@@ -305,10 +305,22 @@ int cc_db_size(const cc_db *db);
  * An append does NOT wait for query chunks in flight (cc_db_query_submit): they were submitted against an earlier epoch
  * and keep reading the state they were submitted with (the sorted key view is double-buffered and a buffer is rewritten
  * only after its readers have finished -- a device-side wait; everything else is append-only).  So the online loop
- * ingest -> add -> submit(query at its own epoch) streams batch after batch without draining the GPU.  The call itself
- * returns when its own device work is done (it synchronises `stream`). */
+ * ingest -> add -> submit(query at its own epoch) streams batch after batch without draining the GPU.  The call returns
+ * once the host bookkeeping is done and its device work (key upload, sorted-view merge) is QUEUED on `stream`: queries
+ * submitted afterwards wait for it on the device, whatever stream they come from; d_desc may be overwritten by work
+ * queued on `stream` after the call. */
 int cc_db_add_scans(cc_db *db, const cc_scan_desc_t *d_desc, int n, const double *h_ts,
                     const int32_t *h_seed, void *stream);
+
+/* Optional first half of cc_db_add_scans for callers that stream batch after batch (the online loop of bench.py
+ * --workload seq): queues, on `stream` and without waiting, what an append needs from the device before the host
+ * bookkeeping can run -- the batch's compact records packed into the rows they will occupy, the retrieval keys
+ * (key dimension 0 decides the bucket, contour_db.h:184-192) extracted and copied to pinned host memory.  Issued right
+ * behind the batch's ingest, the copy travels while the previous batch is being queried; cc_db_add_scans on the same
+ * (d_desc, n) then finds the keys on the host instead of waiting for a round trip.  The database is not changed.
+ * At most two batches (<= 4096 scans each) may be prepared ahead; they must be added in the order they were prepared and
+ * before anything else is added (CC_EINVAL otherwise).  d_desc must not be overwritten before the add. */
+int cc_db_add_scans_prepare(cc_db *db, const cc_scan_desc_t *d_desc, int n, void *stream);
 
 /* Replaces ContourDB::queryRangedKNN (contour_db.h:698-811) for a batch of query scans.
  * Query i is answered against DB epoch h_epoch[i] (use cc_db_size() for "now"); in the

@@ -32,7 +32,7 @@ class EmuApi:
         self.lib.cc_last_error.restype = C.c_char_p
         self.lib.cc_packed_sizes.restype = None
         for f in ("cc_create", "cc_destroy", "cc_ingest_batch", "cc_ingest_host", "cc_db_create", "cc_db_destroy", "cc_db_size",
-                  "cc_db_add_scans", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_bucket_state", "cc_db_check_hints", "cc_pack_scans", "cc_db_add_packed"):
+                  "cc_db_add_scans", "cc_db_add_scans_prepare", "cc_db_query_batch", "cc_db_query_submit", "cc_db_query_wait", "cc_db_bucket_state", "cc_db_check_hints", "cc_pack_scans", "cc_db_add_packed"):
             getattr(self.lib, f).restype = C.c_int
 
     def chk(self, rc, what):
@@ -85,6 +85,15 @@ class EmuApi:
         desc = np.ascontiguousarray(desc)
         ts = np.ascontiguousarray(ts, np.float64)
         seeds = np.ascontiguousarray(seeds, np.int32)
+        self.chk(self.lib.cc_db_add_scans(db, C.c_void_p(desc.ctypes.data), len(desc), C.c_void_p(ts.ctypes.data),
+                                          C.c_void_p(seeds.ctypes.data), None), "cc_db_add_scans")
+
+    def db_add_prepared(self, db, desc, ts, seeds):
+        """cc_db_add_scans_prepare + cc_db_add_scans on the same (pointer, n): the streamed form of db_add."""
+        desc = np.ascontiguousarray(desc)
+        ts = np.ascontiguousarray(ts, np.float64)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        self.chk(self.lib.cc_db_add_scans_prepare(db, C.c_void_p(desc.ctypes.data), len(desc), None), "cc_db_add_scans_prepare")
         self.chk(self.lib.cc_db_add_scans(db, C.c_void_p(desc.ctypes.data), len(desc), C.c_void_p(ts.ctypes.data),
                                           C.c_void_p(seeds.ctypes.data), None), "cc_db_add_scans")
 
