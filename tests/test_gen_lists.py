@@ -11,9 +11,15 @@ REF = "/root/reference/scripts/gen_batch_bin_configs.py"
 
 
 def _mod(path, name):
+    """Import a script by path without leaving a __pycache__ next to it (the reference tree is read-only for this build)."""
     spec = importlib.util.spec_from_file_location(name, path)
     m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True
+    try:
+        spec.loader.exec_module(m)
+    finally:
+        sys.dont_write_bytecode = old
     return m
 
 
