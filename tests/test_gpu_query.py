@@ -296,3 +296,58 @@ def test_full_sequence_online_replay(cc, oracle, tmp_path):
           % (n, int(hit.sum()), pr_o["max_f1"], pr_o["sim_thres"], pr_o["tp_count"], n_desc_checked, n_key_diff, n_key_vals))
     db.close()
     ctx.close()
+
+
+def test_prepared_appends_equal_plain_appends(cc, loop_sequence):
+    """cc_db_add_scans_prepare (the asynchronous first half of an append, queued behind the ingest on another stream, two
+    batches ahead) followed by cc_db_add_scans, with queries submitted in between and nothing drained: the same results,
+    bit for bit, as plain appends followed by one batched query (every scan at its own epoch)."""
+    import torch
+    xyzi, poses, ts = loop_sequence
+    n, P, sub = 384, xyzi.shape[1], 64
+    dev = xyzi.device
+    offs_all = np.arange(n + 1, dtype=np.int64) * P
+    seeds = np.arange(n, dtype=np.int32)
+    ctx = cc.Context(0, max_batch=128)
+    desc = ctx.ingest(xyzi[:n].reshape(-1, 4), offs_all)
+    db_a = cc.Database(ctx, capacity=512)
+    db_a.add_scans(desc, ts[:n], seeds)
+    ref = db_a.query(desc, seeds)
+    # streamed form
+    db_b = cc.Database(ctx, capacity=512)
+    db_b.set_lanes(4)
+    s_ing = torch.cuda.Stream(device=dev)
+    s_main = torch.cuda.current_stream(dev)
+    offs = np.arange(sub + 1, dtype=np.int64) * P
+    slots = [torch.empty((sub, cc.DESC_BYTES), dtype=torch.uint8, device=dev) for _ in range(3)]
+    nb = n // sub
+
+    def ingest_async(k):
+        s_ing.wait_stream(s_main)
+        with torch.cuda.stream(s_ing):
+            ctx.ingest(xyzi[k * sub:(k + 1) * sub].reshape(-1, 4), offs, out=slots[k % 3])
+            db_b.add_scans_prepare(slots[k % 3])
+            ev = torch.cuda.Event()
+            ev.record(s_ing)
+        return ev
+
+    evs = [ingest_async(0), ingest_async(1)]   # two batches prepared ahead
+    out = []
+    for k in range(nb):
+        s_main.wait_event(evs[k])
+        idx = np.arange(k * sub, (k + 1) * sub, dtype=np.int32)
+        db_b.add_scans(slots[k % 3], ts[k * sub:(k + 1) * sub], idx)
+        out.append(db_b.query_submit(slots[k % 3], idx))
+        if k + 2 < nb:
+            evs.append(ingest_async(k + 2))
+    db_b.query_wait()
+    torch.cuda.synchronize()
+    got = np.concatenate(out)
+    assert (ref["n_res"] > 0).sum() > 30
+    assert got.tobytes() == ref.tobytes()
+    sa, ra = db_a.bucket_state()
+    sb, rb = db_b.bucket_state()
+    assert np.array_equal(sa, sb) and np.array_equal(ra, rb)
+    db_a.close()
+    db_b.close()
+    ctx.close()
