@@ -10,7 +10,7 @@
 // candidate and every candidate is replayed by its own lane.  candidates_ keeps first-appearance order.
 // ------------------------------------------------------------------------------------------------
 #define CC_MAXCAND CC_CHK_STRIDE  // every passing check may name a different scan: no cap to overflow
-#define CC_MERGE_BLOCK 64   // one wave per query: no cross-wave hand-offs, 39 KB of LDS (four queries per CU)
+#define CC_MERGE_BLOCK 64   // one wave per query: no cross-wave hand-offs, 46 KB of LDS (three queries per CU)
 
 struct cc_gmm_problem {
   int q;          // index into qdesc (tgt)
@@ -42,6 +42,8 @@ struct alignas(16) cc_merge_lds {
   unsigned short ord[CC_CHK_STRIDE];       // its check slot
   short next[CC_CHK_STRIDE];               // next passing check naming the same scan, -1 = none
   unsigned short firstrec[CC_CHK_STRIDE];  // first passing check of candidate k (candidates in first-appearance order)
+  alignas(16) int cg[CC_CHK_STRIDE + 4];   // candidate k's scan (+ four sentinels behind the last one)
+  unsigned short clast[CC_CHK_STRIDE];     // candidate k's last check so far
   int base;
   unsigned char want[CC_CHK_STRIDE];       // candidate k goes on to the correlation
   float tperc[CC_HOT_LEVELS][CC_NDIST];    // cont_perc_ of the query's top contours: cell_cnt * 1.0f / layer_cell_cnt
@@ -110,33 +112,60 @@ cc_k_merge(int nq, cc_score_t lb, int n_row, int n_col, const cc_hot_desc_t *__r
   }
   __syncthreads();
   CC_MERGE_STAMP(2);
-  // ---- thread the checks of one scan together; number the candidates in first-appearance order
+  // ---- thread the checks of one scan together; number the candidates in first-appearance order.  64 checks per round:
+  //      (1) each lane looks its scan up among the candidates of the earlier rounds (four per LDS read; ~60 candidates per
+  //      query, against a backwards scan over up to all the ~270 earlier checks), (2) the round's checks of the same scan
+  //      find each other through ballots, one scan per step, (3) scans seen for the first time are numbered in lane order.
   int nc = 0;
+  if (lane < 4) L.cg[lane] = -1;  // behind the last candidate: a value no scan has
+  __syncthreads();
   for (int b0 = 0; b0 < n; b0 += CC_MERGE_BLOCK) {
-    const int i = b0 + tid;
-    bool first = false;
-    if (i < n) {
-      // the nearest earlier check of the same scan: a backwards scan whose every step waits for an LDS read, so it takes
-      // four entries per read (a check that opens a new candidate scans everything before it)
-      const int g = L.gid[i];
-      int j = i - 1;
-      while (j >= 0 && (j & 3) != 3 && L.gid[j] != g) j--;
-      if (j >= 0 && (j & 3) == 3 && L.gid[j] != g) {
-        int hit = -1;
-        for (; j >= 3 && hit < 0; j -= 4) {
-          const int4 v = *(const int4 *)&L.gid[j - 3];
-          hit = v.w == g ? j : (v.z == g ? j - 1 : (v.y == g ? j - 2 : (v.x == g ? j - 3 : -1)));
-        }
-        j = hit;
-      }
-      if (j >= 0)
-        L.next[j] = (short)i;  // j is the immediately preceding check of this scan: written by exactly one i
-      else
-        first = true;
+    const int i = b0 + lane;
+    const bool valid = i < n;
+    const int g = valid ? L.gid[i] : 0;
+    int k = -1;
+    for (int j0 = 0; j0 < nc; j0 += 4) {
+      const int4 v = *(const int4 *)&L.cg[j0];
+      k = v.x == g ? j0 : (v.y == g ? j0 + 1 : (v.z == g ? j0 + 2 : (v.w == g ? j0 + 3 : k)));
     }
-    const unsigned long long m = __ballot(first);
-    if (first) L.firstrec[nc + __popcll(m & lt_mask)] = (unsigned short)i;
-    nc += __popcll(m);
+    if (!valid) k = -1;
+    const int before = k >= 0 ? (int)L.clast[k] : -1;  // the scan's last check of the earlier rounds (read before this round moves it)
+    unsigned long long rem = __ballot(valid);
+    int prev_lane = -1, lead_lane = lane;
+    bool last_in_round = false;
+    while (rem) {
+      const int lead = __ffsll(rem) - 1;
+      const int g_lead = __builtin_amdgcn_readlane(g, lead);
+      const bool mine = valid && g == g_lead;
+      const unsigned long long same = __ballot(mine);
+      if (mine) {
+        const unsigned long long lower = same & lt_mask;
+        prev_lane = lower ? 63 - __builtin_clzll(lower) : -1;
+        lead_lane = lead;
+        last_in_round = (same >> lane) == 1ull;
+      }
+      rem &= ~same;
+    }
+    const bool opens = valid && k < 0 && prev_lane < 0;
+    const unsigned long long mo = __ballot(opens);
+    int kk = k;
+    if (opens) {
+      kk = nc + __popcll(mo & lt_mask);
+      L.cg[kk] = g;
+      L.firstrec[kk] = (unsigned short)i;
+    }
+    const int k_lead = __shfl(kk, lead_lane);  // a scan opened in this round: its later checks take the number from the first
+    if (valid && kk < 0) kk = k_lead;
+    if (valid) {
+      if (prev_lane >= 0)
+        L.next[b0 + prev_lane] = (short)i;
+      else if (before >= 0)
+        L.next[before] = (short)i;
+      if (last_in_round) L.clast[kk] = (unsigned short)i;
+    }
+    nc += __popcll(mo);
+    if (lane < 4) L.cg[nc + lane] = -1;
+    __syncthreads();  // the next round reads this round's candidates
   }
   __syncthreads();
   if (tid == 0) {

@@ -319,7 +319,8 @@ int cc_db_add_scans(cc_db *db, const cc_scan_desc_t *d_desc, int n, const double
  * behind the batch's ingest, the copy travels while the previous batch is being queried; cc_db_add_scans on the same
  * (d_desc, n) then finds the keys on the host instead of waiting for a round trip.  The database is not changed.
  * At most two batches (<= 4096 scans each) may be prepared ahead; they must be added in the order they were prepared and
- * before anything else is added (CC_EINVAL otherwise).  d_desc must not be overwritten before the add. */
+ * before anything else is added (CC_EINVAL otherwise); if the add of a prepared batch fails (CC_ECAPACITY: a scan flagged
+ * inexact), a batch prepared behind it is dropped with it.  d_desc must not be overwritten before the add. */
 int cc_db_add_scans_prepare(cc_db *db, const cc_scan_desc_t *d_desc, int n, void *stream);
 
 /* Replaces ContourDB::queryRangedKNN (contour_db.h:698-811) for a batch of query scans.
