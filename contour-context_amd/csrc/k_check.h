@@ -7,9 +7,10 @@
 // lanes of a wave stay on the same stage and the load is balanced over the chip no matter how the survivors are spread
 // over the queries:
 //   A   one lane per hit slot: anchor checkSim + the popcount bars of checkConstellSim          -> list of checks
-//   B1  16 lanes per check: neighbour pairing, exact replay of std::sort, rotation window       -> list of constellations
+//   B1  16 lanes per check: neighbour pairing, exact replay of std::sort, rotation window,
+//       pairwise checkSim of the window's pairs                                                  -> list of constellations
 //       (+ a large-capacity instance for the rare checks with more than 64 potential pairs)
-//   B2  16 lanes per constellation: pairwise checkSim, shaft / orientation filter, 2-D umeyama  -> pass records
+//   B2  16 lanes per constellation: shaft / orientation filter, 2-D umeyama                      -> pass records
 //   C   one lane per pass record: the pose's angle and rotation entries
 // Results land in slot-indexed arrays (slot = the reference's candidate iteration order), so the order in which the lists
 // were filled never shows.  Both scans of a check are read through their 18 KB "hot" records (cc_hot_desc_t).
@@ -65,7 +66,8 @@ struct cc_chk_item {  // a check that passed stage A
   int q, t;
   cc_knn_hit_t h;
 };
-struct cc_cstl_item {  // a check that passed the rotation-window test: its constellation in cstl_in order
+struct cc_cstl_item {  // a check that passed the rotation-window test and kept enough pairs in the individual similarity:
+                       // those pairs in cstl_in order (n_in of them; 0 = the check did not get this far)
   int q, t, gidx;
   unsigned char level, seq_src, seq_tgt, n_in;
   int flags;
@@ -633,17 +635,33 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       if (sl == 0) atomicOr((unsigned *)&pass_cnt[q * 4 + 0], (unsigned)CC_QF_CHECK_CAP);
     }
     if (sl == 0) atomicAdd(&pass_cnt[q * 4 + 2], 1);
-    for (int e = sl; e < n_in; e += G) {
-      unsigned short v;
-      if (e < longest && e < n_in - 1) {
-        const int pe = beg + e;  // < 2 * npp
-        const unsigned w = (unsigned)L.pp[L.sidx[pe >= npp ? pe - npp : pe]];
-        v = (unsigned short)(((w & 0xFF) << 8) | (((w >> 8) & 0xF) << 4) | ((w >> 16) & 0xF));
-      } else {
-        v = (unsigned short)((level << 8) | (seq_src << 4) | seq_tgt);
+    // (3/4, first part) the individual similarity of the window pairs and the anchors (contour_mng.h:1138-1160) is
+    // decided here, where the pairs are at hand: a check that keeps too few pairs ends without a record (a third of those
+    // that reach this point), and stage B2 is handed the pairs that passed, in cstl_in order, instead of reading the
+    // window back and gathering both contour rows of every pair only to drop it
+    const cc_hot_desc_t *src_d = db_hot + h.gidx, *tgt_d = qhot + q;
+    int ncs = 0;
+    for (int r0 = 0; r0 < n_in; r0 += G) {
+      const int e = r0 + sl;
+      unsigned v = 0;
+      bool sim = false;
+      if (e < n_in) {
+        if (e < longest && e < n_in - 1) {
+          const int pe = beg + e;  // < 2 * npp
+          const unsigned w = (unsigned)L.pp[L.sidx[pe >= npp ? pe - npp : pe]];
+          v = ((w & 0xFF) << 8) | (((w >> 8) & 0xF) << 4) | ((w >> 16) & 0xF);
+        } else {
+          v = (unsigned)((level << 8) | (seq_src << 4) | seq_tgt);
+        }
+        sim = cc_check_sim(src_d->cont[(v >> 8) - 1][(v >> 4) & 0xF], tgt_d->cont[(v >> 8) - 1][v & 0xF], P.sim);
       }
-      out->cs[e] = v;
+      const unsigned ms = cc_group_ballot(sim);
+      if (sim) out->cs[ncs + __popc(ms & ((1u << sl) - 1u))] = (unsigned short)v;  // <= n_in <= CC_CSTL_MAX entries
+      ncs += __popc(ms);
     }
+    if (sc && sl == 0) sc[3] = ncs;
+    CC_ABLATE_AT(6);
+    if (ncs < P.lb.i_indiv_sim) continue;
     if (sl == 0) {
       out->q = q;
       out->t = t;
@@ -651,7 +669,7 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       out->level = (unsigned char)level;
       out->seq_src = (unsigned char)seq_src;
       out->seq_tgt = (unsigned char)seq_tgt;
-      out->n_in = (unsigned char)n_in;
+      out->n_in = (unsigned char)ncs;  // the pairs that passed the individual similarity (>= i_indiv_sim >= 1: never 0 here)
       out->flags = flags;
     }
   }
@@ -729,44 +747,21 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
     const cc_hot_desc_t *src = db_hot + gidx, *tgt = qhot + q;
     cc_group_sync();  // the previous constellation's reads of the group's LDS are done
-    // (3/4) individual similarity of the window pairs + the anchors, in cstl_in order
-    int ncs = 0;
-    for (int r0 = 0; r0 < n_in; r0 += G) {
-      const int e = r0 + sl;
-      unsigned v = 0;
-      bool sim = false;
-      float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
-      if (e < n_in) {
-        v = it->cs[e];
-        const int l = (int)(v >> 8), s_ = (int)((v >> 4) & 0xF), t_ = (int)(v & 0xF);
-        const cc_contour_t &scv = src->cont[l - 1][s_];
-        const cc_contour_t &tcv = tgt->cont[l - 1][t_];
-        sim = cc_check_sim(scv, tcv, P.sim);
-        s0 = scv.pos_mean[0];
-        s1 = scv.pos_mean[1];
-        t0 = tcv.pos_mean[0];
-        t1 = tcv.pos_mean[1];
-      }
-      const unsigned ms = cc_group_ballot(sim);
-      if (sim) {
-        const int o = ncs + __popc(ms & ((1u << sl) - 1u));
-        if (o < CC_CSTL_MAX) {
-          L.cs[o] = (unsigned short)v;
-          L.spm[o][0] = s0;
-          L.spm[o][1] = s1;
-          L.tpm[o][0] = t0;
-          L.tpm[o][1] = t1;
-        }
-      }
-      ncs += __popc(ms);
+    // (3/4) the pairs that passed the individual similarity (stage B1's tail), in cstl_in order: their centres into LDS
+    const int ncs_in = n_in;
+    for (int e = sl; e < ncs_in; e += G) {
+      const unsigned v = it->cs[e];
+      const int l = (int)(v >> 8), s_ = (int)((v >> 4) & 0xF), t_ = (int)(v & 0xF);
+      const cc_contour_t &scv = src->cont[l - 1][s_];
+      const cc_contour_t &tcv = tgt->cont[l - 1][t_];
+      L.cs[e] = (unsigned short)v;
+      L.spm[e][0] = scv.pos_mean[0];
+      L.spm[e][1] = scv.pos_mean[1];
+      L.tpm[e][0] = tcv.pos_mean[0];
+      L.tpm[e][1] = tcv.pos_mean[1];
     }
-    if (ncs > CC_CSTL_MAX) {
-      ncs = CC_CSTL_MAX;
-      flags |= 1;
-    }
-    if (sc && sl == 0) sc[3] = ncs;
+    int ncs = ncs_in;
     CC_ABLATE_AT(11);
-    if (ncs < P.lb.i_indiv_sim) continue;
     cc_group_sync();
     // part 2: the "shaft" (contour_mng.h:1173-1184).  The reference scans the (i, j<i) pairs of the first <=10 entries in
     // order, replacing the running (normalised) src vector whenever the candidate is LONGER THAN THE RUNNING VECTOR'S NORM
