@@ -63,7 +63,7 @@ struct cc_check_params {
 #endif
 
 struct cc_chk_item {  // a check that passed stage A
-  int q, t;
+  int q, t;  // t: slot * CC_KNN_MAX + j in the low 16 bits, the two point tables' sizes above (see cc_k_check_a)
   cc_knn_hit_t h;
 };
 struct cc_cstl_item {  // a check that passed the rotation-window test and kept enough pairs in the individual similarity:
@@ -120,7 +120,7 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
   const int lane = threadIdx.x & 63;
   const int slot = t / CC_KNN_MAX, j = t - slot * CC_KNN_MAX;
   bool anchor_ok = false, keep = false;
-  int sc_sum = 0, sc_max = 0;
+  int sc_sum = 0, sc_max = 0, npts = 0;
   cc_knn_hit_t h;
   h.gidx = 0;
   h.level = h.seq = 0;
@@ -138,6 +138,7 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
       S[w] = bs->dist_bin[w];
       T[w] = bt->dist_bin[w];
     }
+    npts = (int)bs->n_pts | ((int)bt->n_pts << 8);  // same 64 bytes as the rings: stage B1 sizes its table loads with them
     anchor_ok = cc_check_sim(src->cont[li][h.seq], tgt->cont[li][seq_tgt], P.sim);
     if (anchor_ok) {
       int ov1 = 0, ov2 = 0, ov3 = 0;
@@ -195,7 +196,7 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
     const unsigned long long mine = bk == 0 ? mb0 : (bk == 1 ? mb1 : (bk == 2 ? mb2 : mb3));
     cc_chk_item it;
     it.q = q;
-    it.t = t;
+    it.t = t | (npts << 16);  // slot position (11 bits) | points of the src table << 16 | of the tgt table << 24
     it.h = h;
     items[pos + __popcll(mine & ((1ull << lane) - 1ull))] = it;
   }
@@ -507,7 +508,8 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
   for (int i = i0; i < n_items; i += stride) {
     const cc_chk_item it = it_nxt;
     if (i + stride < n_items) it_nxt = items[REDO ? redo_idx[i + stride] : i + stride];
-    const int q = it.q, t = it.t;
+    const int q = it.q, t = it.t & 0xFFFF;
+    const int nsp = (it.t >> 16) & 0xFF, ntp = (it.t >> 24) & 0xFF;
     const cc_knn_hit_t h = it.h;
     // the check's constellation record sits at the check's own list position; n_in = 0 until (unless) it passes
     cc_cstl_item *out = cstl + (REDO ? redo_idx[i] : i);
@@ -517,17 +519,17 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     int *sc = scores ? scores + ((size_t)q * CC_CHK_STRIDE + t) * CC_NSCORE : nullptr;
     const cc_bci_t *bs = &db_hot[h.gidx].bcis[level - 1][seq_src];
     const cc_bci_t *bt = &qhot[q].bcis[level - 1][seq_tgt];
-    // point tables and their sizes are fetched together (no dependent round trip), as 8-byte words: a table is
-    // 40 x 12 B = 60 words at an 8-byte aligned offset, four words per lane
+    // point tables as 8-byte words: a table is 40 x 12 B = 60 words at an 8-byte aligned offset, four words per lane; only
+    // the words that hold points are fetched (the sizes came with the item: ~22 of the 40 entries are in use)
     uint2 ps[4], pt[4];
     const uint2 *gs = (const uint2 *)bs->pts, *gt = (const uint2 *)bt->pts;
+    const int nws = (nsp * 12 + 7) >> 3, nwt = (ntp * 12 + 7) >> 3;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int k = sl + u * G;
-      ps[u] = k < 60 ? gs[k] : make_uint2(0u, 0u);
-      pt[u] = k < 60 ? gt[k] : make_uint2(0u, 0u);
+      ps[u] = k < nws ? gs[k] : make_uint2(0u, 0u);
+      pt[u] = k < nwt ? gt[k] : make_uint2(0u, 0u);
     }
-    const int nsp = bs->n_pts, ntp = bt->n_pts;
     cc_group_sync();  // the previous check's reads of the shared storage are done
 #pragma unroll
     for (int u = 0; u < 4; u++) {
