@@ -920,6 +920,63 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     if (sl == 0) results[pidx] = R;
   }
 }
+// tidyUpCandidates' order-changing compaction (contour_db.h:580-592) followed by fineOptimize's std::sort on the
+// still-all-zero correlation_ (contour_db.h:604-610), for one wave.
+//   compaction: the sequential two-pointer loop swaps the k-th candidate without an estimate, counted from the front,
+//     with the k-th candidate with one, counted from the back, until the pointers cross -- so the first n positions
+//     (n = candidates with an estimate) end up holding: the candidate itself where it has one, else the matching one
+//     from the back part.  Found with ballots, 64 positions per round.
+//   sort: a comparator that is always false makes libstdc++'s introsort a fixed permutation of its n inputs (median and
+//     partition swaps that never look at the values; the final insertion sort moves nothing): perm_tab holds it for
+//     every n (built on the host with std::sort itself, cc_db_create), row n at offset n (n - 1) / 2.
+// idx[0..n) = the candidates in the order fineOptimize sees them; returns n.  scr: CC_MAXCAND u16 of LDS scratch.
+__device__ __forceinline__ int cc_tidy_order(int nc, const unsigned char *has, unsigned short *idx, unsigned short *scr,
+                                             const unsigned short *__restrict__ perm_tab, int lane) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int n = 0;
+  for (int k0 = 0; k0 < nc; k0 += 64) n += __popcll(__ballot(k0 + lane < nc && has[k0 + lane]));
+  // front part: positions < n without an estimate, ascending -> scr[0..nf); back part: positions >= n with one,
+  // ascending -> scr[CC_MAXCAND - 1 - j] (read back descending)
+  int nf = 0, nb = 0;
+  for (int k0 = 0; k0 < nc; k0 += 64) {
+    const int k = k0 + lane;
+    const bool fr = k < n && !has[k], bk = k >= n && k < nc && has[k];
+    const unsigned long long mf = __ballot(fr), mb = __ballot(bk);
+    if (fr) scr[nf + __popcll(mf & lt)] = (unsigned short)k;
+    if (bk) scr[CC_MAXCAND - 1 - (nb + __popcll(mb & lt))] = (unsigned short)k;
+    nf += __popcll(mf);
+    nb += __popcll(mb);
+  }
+  __syncthreads();
+  // nf == nb; the a-th front gap takes the a-th estimate from the back, i.e. the (nb - 1 - a)-th in ascending order
+  unsigned short mine[CC_MAXCAND / 64];
+#pragma unroll
+  for (int u = 0; u < CC_MAXCAND / 64; u++) {
+    const int i = u * 64 + lane;
+    mine[u] = 0;
+    if (i < n) {
+      const int p = (int)perm_tab[(size_t)n * (n - 1) / 2 + i];  // position (after the compaction) that the sort puts at i
+      mine[u] = (unsigned short)p;
+    }
+  }
+  __syncthreads();
+  for (int a = lane; a < nf; a += 64) idx[scr[a]] = scr[CC_MAXCAND - 1 - (nb - 1 - a)];  // idx was the identity
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CC_MAXCAND / 64; u++) {
+    const int i = u * 64 + lane;
+    if (i < n) mine[u] = idx[mine[u]];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CC_MAXCAND / 64; u++) {
+    const int i = u * 64 + lane;
+    if (i < n) idx[i] = mine[u];
+  }
+  __syncthreads();
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5s: which candidates of a query get refined -- the first max_fine_opt_ of candidates_ after tidyUpCandidates'
 // compaction and fineOptimize's sort on the still-all-zero correlation_ (the same replay as in K6; contour_db.h:560-616).
@@ -928,11 +985,12 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
 __global__ void __launch_bounds__(64)
 cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
             const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[2][sel_stride]*/, int sel_stride,
-            int *__restrict__ n_sel /*[2]*/) {
-  __shared__ unsigned stk[CC_SORT_STACK];
+            int *__restrict__ n_sel /*[2]*/, const unsigned short *__restrict__ perm_tab) {
   __shared__ unsigned short idx[CC_MAXCAND];
+  __shared__ unsigned short scr[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
   __shared__ int gm[CC_MAXCAND];
+  __shared__ int s_off[2];
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
@@ -944,36 +1002,33 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
     has[k] = (g >= 0 && !((float)gres[g].corr_init < corr_lb)) ? 1 : 0;
   }
   __syncthreads();
-  if (lane != 0) return;
-  int p1 = 0, p2 = nc - 1;
-  while (p1 <= p2) {
-    if (!has[idx[p1]] && has[idx[p2]]) {
-      const unsigned short t = idx[p1];
-      idx[p1] = idx[p2];
-      idx[p2] = t;
-      p1++;
-      p2--;
-    } else {
-      if (has[idx[p1]]) p1++;
-      if (!has[idx[p2]]) p2--;
-    }
-  }
-  const int n = p2 + 1;
+  const int n = cc_tidy_order(nc, has, idx, scr, perm_tab, lane);
   if (n <= 0) return;
-  ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; }, stk);
   const int pre = max_fine_opt < n ? max_fine_opt : n;
   // two lists: short pair lists go to the 16-lane refinement instance, long ones to the 64-lane instance
   // (two atomics per query, not one per problem: same-address atomics are served one after the other)
-  int n_big = 0;
-  for (int i = 0; i < pre; i++) n_big += gres[gm[idx[i]]].n_pairs > CC_GMM_G16_MAX_PAIRS ? 1 : 0;
-  int o_small = (pre - n_big) ? atomicAdd(&n_sel[0], pre - n_big) : 0;
-  int o_big = n_big ? atomicAdd(&n_sel[1], n_big) : 0;
-  for (int i = 0; i < pre; i++) {
-    const int g = gm[idx[i]];
-    if (gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS)
-      sel_list[(size_t)sel_stride + o_big++] = g;
-    else
-      sel_list[o_small++] = g;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int n_big = 0, n_small = 0;
+  for (int i0 = 0; i0 < pre; i0 += 64) {
+    const int i = i0 + lane;
+    n_big += __popcll(__ballot(i < pre && gres[gm[idx[i < pre ? i : 0]]].n_pairs > CC_GMM_G16_MAX_PAIRS));
+  }
+  n_small = pre - n_big;
+  if (lane == 0) {
+    s_off[0] = n_small ? atomicAdd(&n_sel[0], n_small) : 0;
+    s_off[1] = n_big ? atomicAdd(&n_sel[1], n_big) : 0;
+  }
+  __syncthreads();
+  int o_small = s_off[0], o_big = s_off[1];
+  for (int i0 = 0; i0 < pre; i0 += 64) {
+    const int i = i0 + lane;
+    const int g = i < pre ? gm[idx[i]] : 0;
+    const bool big = i < pre && gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS, small = i < pre && !big;
+    const unsigned long long mbig = __ballot(big), msm = __ballot(small);
+    if (big) sel_list[(size_t)sel_stride + o_big + __popcll(mbig & lt)] = g;
+    if (small) sel_list[o_small + __popcll(msm & lt)] = g;
+    o_big += __popcll(mbig);
+    o_small += __popcll(msm);
   }
 }
 
@@ -985,9 +1040,11 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
 __global__ void __launch_bounds__(64)
 cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
            const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
-           const cc_hot_desc_t *__restrict__ qhot, cc_query_result_t *__restrict__ out) {
-  // one wave per query: lanes fetch the per-candidate inputs in parallel, lane 0 replays the order-dependent part on LDS
+           const cc_hot_desc_t *__restrict__ qhot, cc_query_result_t *__restrict__ out, const unsigned short *__restrict__ perm_tab) {
+  // one wave per query: lanes fetch the per-candidate inputs and order the candidates in parallel (cc_tidy_order), lane 0
+  // replays the short order-dependent rest on LDS
   __shared__ unsigned short idx[CC_MAXCAND];
+  __shared__ unsigned short scr[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
   __shared__ float corr_o[CC_MAXCAND];
   __shared__ int gm[CC_MAXCAND];
@@ -997,6 +1054,9 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   if (q >= nq) return;
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
   const int nc = qstate[q].n_cand;
+  // what lane 0 needs of the query's counters, fetched up front (every load it would issue later is a round trip)
+  const int pc0 = pass_cnt[q * 4 + 0], pc1 = pass_cnt[q * 4 + 1], pc2 = pass_cnt[q * 4 + 2], pc3 = pass_cnt[q * 4 + 3];
+  const int qflags = qhot[q].flags;
   int gfl = 0;  // capacity flags of the query's correlation problems (every one of them gates or ranks a candidate)
   for (int k = lane; k < nc; k += 64) {
     const int g = cands[k].gmm_idx;
@@ -1018,39 +1078,25 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   if (lane == 0) s_tot = tot;
   __syncthreads();
+  // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592, and the first std::sort:
+  // every anch_props_[0].correlation_ is still 0 -> the comparator is always false
+  const int n = cc_tidy_order(nc, has, idx, scr, perm_tab, lane);
   if (lane != 0) return;
   cc_query_result_t r;
   r.n_res = 0;
   r.cand_gidx = -1;
   r.correlation = 0;
   r.tf[0] = r.tf[1] = r.tf[2] = 0;
-  r.cand_aft_check1 = pass_cnt[q * 4 + 1];
-  r.cand_aft_check2 = pass_cnt[q * 4 + 2];
-  r.cand_aft_check3 = pass_cnt[q * 4 + 3];
+  r.cand_aft_check1 = pc1;
+  r.cand_aft_check2 = pc2;
+  r.cand_aft_check3 = pc3;
   r.n_cand_pose = nc;
   r.n_knn_hits = s_tot;
-  r.flags = (pass_cnt[q * 4 + 0] & CC_QF_CHECK_CAP) | ((gfl & 1) ? CC_QF_GMM_CAP : 0) | ((gfl & 4) ? CC_QF_DESC_CAP : 0) |
-            ((qhot[q].flags & (CC_DESC_INEXACT_COMPONENTS | CC_DESC_INEXACT_KEYS)) ? CC_QF_QUERY_INEXACT : 0);
+  r.flags = (pc0 & CC_QF_CHECK_CAP) | ((gfl & 1) ? CC_QF_GMM_CAP : 0) | ((gfl & 4) ? CC_QF_DESC_CAP : 0) |
+            ((qflags & (CC_DESC_INEXACT_COMPONENTS | CC_DESC_INEXACT_KEYS)) ? CC_QF_QUERY_INEXACT : 0);
   r.pad_ = 0;
-  // two-pointer compaction of candidates_ (has = corr_est_ != nullptr), contour_db.h:580-592
-  int p1 = 0, p2 = nc - 1;
-  while (p1 <= p2) {
-    if (!has[idx[p1]] && has[idx[p2]]) {
-      const unsigned short t = idx[p1];
-      idx[p1] = idx[p2];
-      idx[p2] = t;
-      p1++;
-      p2--;
-    } else {
-      if (has[idx[p1]]) p1++;
-      if (!has[idx[p2]]) p2--;
-    }
-  }
-  const int n = p2 + 1;
   r.n_cand_tidy = n;
   if (n > 0) {
-    // first std::sort: every anch_props_[0].correlation_ is still 0 -> comparator is always false
-    ccsort::std_sort(idx, n, [](unsigned short, unsigned short) { return false; }, stk);
     const int pre = max_fine_opt < n ? max_fine_opt : n;
     // candidates beyond `pre` keep correlation_ = 0
     ccsort::std_sort(idx, pre, [&](unsigned short a, unsigned short b) { return corr_o[a] > corr_o[b]; }, stk);
@@ -1068,5 +1114,3 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   }
   out[q] = r;
 }
-
-
