@@ -424,8 +424,9 @@ const void *cc_db_feat_ptr(const cc_db *db);
 int cc_db_profile_enable(cc_db *db, int on);
 int cc_db_profile_read(cc_db *db, double ms_out[5], int *n_launches);
 
-/* cc_db_query_batch cuts a batch into chunks of <= 512 queries (two per batch when it is smaller than 1024) and keeps
- * up to two of them in flight on internal streams
+/* cc_db_query_batch cuts a batch into one chunk per lane (<= 1024 queries each; a streamed cc_db_query_submit of 1024
+ * queries or more goes out in chunks of 1024, batch after batch on alternating lanes) and keeps up to two chunks in
+ * flight on internal streams
  * (the f64-bound correlation of one chunk overlaps the latency-bound retrieval/checks of the next).  n = 1 runs the
  * chunks one after the other (per-kernel timing, debugging); default 2.  No reference counterpart. */
 int cc_db_set_lanes(cc_db *db, int n);
