@@ -12,8 +12,8 @@ HEAD=$(cat .git_head 2>/dev/null || echo unknown)
 grep '^{' $OUT/bench_default.out > $OUT/bench_line_default.json
 if [ "$2" != "quick" ]; then
   timeout 600 python bench.py --workload seq 2> $OUT/bench_seq.err | grep '^{' > $OUT/bench_line_seq.json
-  timeout 600 python bench.py --no-cpu --no-extra --db-scans 50000 --steps 4 --warmup 1 2> $OUT/bench_db50k.err | grep '^{' > $OUT/bench_line_db50k.json
-  timeout 600 python bench.py --no-cpu --no-extra --db-scans 20000 --steps 4 --warmup 1 2> $OUT/bench_db20k.err | grep '^{' > $OUT/bench_line_db20k.json
+  timeout 600 python bench.py --no-cpu --no-extra --db-scans 50000 --steps 8 --warmup 2 2> $OUT/bench_db50k.err | grep '^{' > $OUT/bench_line_db50k.json
+  timeout 600 python bench.py --no-cpu --no-extra --db-scans 20000 --steps 8 --warmup 2 2> $OUT/bench_db20k.err | grep '^{' > $OUT/bench_line_db20k.json
   timeout 600 python bench.py --no-cpu --no-extra --workload dense --steps 6 --warmup 2 2> $OUT/bench_dense.err | grep '^{' > $OUT/bench_line_dense.json
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5
