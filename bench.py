@@ -393,7 +393,7 @@ def main():
         out["roofline"]["value_over_ingest_roofline"] = value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))
         batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
-            # the reference's online loop on the scans already resident: from an empty DB, per 256-scan sub-batch
+            # the reference's online loop on the scans already resident: from an empty DB, per 512-scan sub-batch
             # ingest -> add -> query at the scan's own epoch; with the DB update inside the timed region and without
             nrep = min(4, len(batches)) * B
             out["extra"] = {"online_replay": online_replay(cc, ctx, [b for b in batches[:min(4, len(batches))]], B, P, nrep, 512, dev)}
