@@ -39,6 +39,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 PROF_EVERY = 3  # the library's stage events ride on every 3rd chunk launch of the timed region (they cost throughput)
+ISO_STEPS = 4   # extra untimed steps, everything on one stream, for the isolated per-kernel times
+# what the path computes in, as the reference does: f32 for the BEV, moments, keys' sums, kNN distances and gates; f64 for
+# gaussPDF's exp, umeyama, the GMM-L2 cost / gradient and the L-BFGS refinement
+DTYPE = "f32+f64"
+DTYPE_NOTE = "as the reference: f32 raster / moments / key sums / kNN distances / gates, f64 gaussPDF exp, umeyama, GMM-L2 cost and L-BFGS"
 
 
 def main():
@@ -60,9 +65,12 @@ def main():
     ap.add_argument("--sync-query", action="store_true",
                     help="cc_db_query_batch per step (collects every batch before the next one is queued) instead of cc_db_query_submit + one cc_db_query_wait")
     ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
-    ap.add_argument("--workload", choices=("sparse", "dense", "seq"), default="sparse",
+    ap.add_argument("--workload", choices=("sparse", "dense", "kitti", "seq"), default="sparse",
                     help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
                          "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level; "
+                         "kitti: the KITTI-shaped town (street grid, porous vegetation, rough ground: 4-6 k occupied cells, ~100 "
+                         "contours on the low levels, 18 valid keys per scan) driven as a random walk, so that ~10 % of the query "
+                         "scans revisit a DB place and the others end without a candidate; "
                          "seq: BASELINE config 2's shape -- the reference's ONLINE loop (test/batch_bin_test.cpp:131-237) over one "
                          "long sequence of the dense world from an empty DB: per sub-batch ingest -> addScan/pushAndBalance -> query "
                          "(scan i against epoch i), the DB update INSIDE the timed region; a step = one sub-batch of --seq-batch scans")
@@ -123,7 +131,7 @@ def main():
 
     n_db, B, K, W = args.db_scans, args.batch, args.steps, args.warmup
     P = 64 * 1875
-    wld = cc.synth.World(dense=(args.workload in ("dense", "seq")))
+    wld = cc.synth.World(kitti=True) if args.workload == "kitti" else cc.synth.World(dense=(args.workload in ("dense", "seq")))
     if args.workload == "seq":
         return bench_seq(cc, args, dev, local_rank, world, rank, dist)
     ctx = cc.Context(local_rank, max_batch=max(B, 256))
@@ -261,15 +269,7 @@ def main():
     import ctypes as C
 
     def read_kernel_ms():
-        ms2 = (C.c_double * 2)()
-        nl = C.c_int()
-        cc.lib().cc_profile_read(ctx.h, ms2, C.byref(nl))
-        ms5 = (C.c_double * 5)()
-        nl2 = C.c_int()
-        cc.lib().cc_db_profile_read(db.h, ms5, C.byref(nl2))
-        a, b = max(nl.value, 1), max(nl2.value, 1) / float(B)   # ingest launches (one per step) | queries -> steps
-        return {"cc_k_rasterize": ms2[0] / a, "cc_k_contours": ms2[1] / a, "cc_k_knn": ms5[0] / b, "cc_k_check": ms5[1] / b,
-                "cc_k_merge": ms5[2] / b, "cc_k_gmm": ms5[3] / b, "cc_k_final": ms5[4] / b}
+        return _read_kernel_ms(cc, ctx, db, B)
 
     # HIP events over the timed region: per step, the summed durations of the kernel's launches (one per
     # chunk of <= 512 queries on the query side).  Launches of different streams overlap each other, so these are durations of
@@ -308,7 +308,7 @@ def main():
         args.no_overlap = True
         db.set_lanes(1)
         cc.lib().cc_db_profile_enable(db.h, 1)
-        run_steps(W, min(2, K))
+        run_steps(W, min(ISO_STEPS, K))
         torch.cuda.synchronize()
         kms_iso = read_kernel_ms()
 
@@ -338,59 +338,39 @@ def main():
     if rank == 0:
         total_scans = K * B * world
         value = total_scans / elapsed
-        # ---- roofline of the dominant kernel (HIP-event timed on its launch stream inside the timed region) ----
+        # ---- roofline (kernel groups HIP-event timed on their launch streams; dominant group by isolated time) ----
         d = cc.desc_to_numpy(qdesc2[(K - 1) & 1][:64])
         n_pix = float(d["n_pix"].mean())
         wl_stats = {"occupied_cells_mean": round(n_pix, 1), "contours_per_level_mean": [round(float(v), 1) for v in d["n_cont"].mean(0)],
                     "cells_above_level_mean": [round(float(v), 1) for v in d["layer_cell_cnt"].mean(0)],
-                    "inexact_descriptors": int((d["flags"] & 6).astype(bool).sum())}
-        # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"): what the step has to move, independent of how.
-        #  K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions;
-        #  K2 reads those and emits the descriptor used downstream;
-        #  K3 reads the layers' key matrices once and, per anchor key, the 40 B key and <= nnk 12-B hits;
-        #  K4 reads, per KNN hit, the hit and two contour records, per anchor-similar pair the two 256-bit rings, per
-        #     check that reaches the pairing the two 600-B BCIs, and writes a 104-B record per pass;
-        #  merge reads those records; K5 reads two ellipse tables (32 B/ellipse) per problem and writes 64 B.
-        desc_emit = float(np.mean(72 + 16 + 1440 + 36 * 600 + d["n_stored"].sum(1) * 76))
-        f = {k: float(res[k].mean()) for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check3", "n_cand_tidy")}
-        n_keys_db = 3 * 6 * n_db
-        alg = {"cc_k_rasterize": B * (P * 16 + 22500 * 4 + n_pix * 8),
-               "cc_k_contours": B * (22500 * 4 + n_pix * 8 + desc_emit),
-               "cc_k_knn": n_keys_db * 44 + B * 18 * 40 + B * f["n_knn_hits"] * 12,
-               "cc_k_check": B * (f["n_knn_hits"] * (12 + 2 * 76) + f["cand_aft_check1"] * (64 + 2 * 600) + f["cand_aft_check3"] * 104),
-               "cc_k_merge": B * f["cand_aft_check3"] * 104,
-               "cc_k_gmm": B * f["n_cand_tidy"] * (2 * 45 * 32 + 64),
-               "cc_k_final": B * 64}
-        dom = max(kms, key=lambda k: kms[k])
-        dom_ms, dom_bytes = kms[dom], alg[dom]
-        k1_ms, k1_bytes = kms["cc_k_rasterize"], alg["cc_k_rasterize"]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+                    "valid_db_keys_per_scan_mean": round(float((np.abs(d["keys"].reshape(len(d), 6, 6, 10)[:, 1:4]).sum(-1) > 0).sum((1, 2)).mean()), 2),
+                    "inexact_descriptors": int((d["flags"] & 6).astype(bool).sum()),
+                    "queries_with_a_loop_closure": round(n_found / float(K * B), 4),
+                    "checks_per_query_mean": round(float(res["cand_aft_check1"].mean()), 1),
+                    "correlation_problems_per_query_mean": round(float(res["n_cand_tidy"].mean()), 2)}
+        alg, split = algorithmic_bytes(d, res, B, P, n_db)
+        roof = roofline_object(alg, split, kms, kms_iso, B, n_db, args.workload, elapsed / K * 1e3, P)
+        roof.update({"streams": 1 if kms_iso is None else 3,
+                     "event_sampling": "query-side stage events on every %d. chunk launch of the timed region, ingest events on every step; "
+                                       "isolated: %d extra untimed steps, one stream, every launch" % (PROF_EVERY, ISO_STEPS),
+                     "query_protocol": "cc_db_query_batch per step" if (args.sync_query or kms_iso is None) else "cc_db_query_submit per step, one cc_db_query_wait inside the timed region",
+                     "value_over_ingest_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))})
         out = {
             "metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "synthetic Velodyne-64 scans (64x1875=120000 pts), %s world, %d-scan DB, %d query scans/step/GPU, "
-                                   "queries revisit DB places (loop closures found: %d of %d on rank 0); a step = ingest + query of "
+                                   "%s (loop closures found: %d of %d on rank 0); a step = ingest + query of "
                                    "the batch, the DB update (addScan/pushAndBalance) is outside the timed step"
-                                   % (args.workload, n_db, B, n_found, K * B),
-                       "world": args.workload, "workload_stats": wl_stats,
+                                   % (args.workload, n_db, B, "the drive goes on through the town: about a tenth of the query scans revisit a DB place"
+                                      if args.workload == "kitti" else "queries revisit DB places", n_found, K * B),
+                       "world": args.workload, "workload_stats": wl_stats, "dtype_note": DTYPE_NOTE,
                        "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10, <= 320 contours/level (flagged otherwise)",
                        "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B, n_db, args.workload)[0], "traffic_source": pmc_traffic(dom, B, n_db, args.workload)[1],
-                         "algorithmic_bytes_per_launch": dom_bytes,
-                         "kernels_ms_per_launch": kms, "kernels_ms_per_launch_isolated": kms_iso,
-                         "streams": 1 if kms_iso is None else 3,
-                         "event_sampling": "query-side stage events on every %d. chunk launch of the timed region, ingest events on every step" % PROF_EVERY,
-                         "query_protocol": "cc_db_query_batch per step" if (args.sync_query or kms_iso is None) else "cc_db_query_submit per step, one cc_db_query_wait inside the timed region",
-                         "rasterize_GBs": k1_bytes / ((kms_iso or kms)["cc_k_rasterize"] * 1e-3) / 1e9 if k1_ms > 0 else None},
+            "roofline": roof,
             "setup_s": setup_s,
         }
-        out["roofline"]["step_hbm_frac"] = sum(alg.values()) / (elapsed / K) / 1e9 / HBM_PEAK_GBS
-        out["roofline"]["step_algorithmic_bytes"] = sum(alg.values())
-        out["roofline"]["ingest_roofline_scans_per_s"] = HBM_PEAK_GBS * 1e9 / (P * 16)
-        out["roofline"]["value_over_ingest_roofline"] = value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))
         batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
             # the reference's online loop on the scans already resident: from an empty DB, per 512-scan sub-batch
@@ -413,6 +393,9 @@ def main():
                     out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, wld, 20000, B, 8, 2, P, first_query=60000, rec=rec50)[0]
                     del rec50
                     out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 8, 2, P)[0]
+                    # SURVEY.md 8(d)'s value distributions on a drive with a realistic revisit rate (the KITTI-shaped town)
+                    out["extra"]["db_5k_kitti_shaped"] = measure_config(cc, ctx, dev, cc.synth.World(kitti=True), 5000, B, 16, 2, P,
+                                                                         kernels=True, workload="kitti")[0]
                 except Exception as e:
                     out["extra"]["other_configs_error"] = repr(e)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
@@ -602,7 +585,7 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
         value = K * sub * world / dt
         out = {"metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
                "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                "config": {"workload": "online replay of one synthetic Velodyne-64 sequence (64x1875=120000 pts, dense world, 10 Hz, "
                                       "%d scans per rank from an empty DB): per %d-scan sub-batch ingest -> addScan/pushAndBalance -> query, "
                                       "scan i at epoch i; the DB update is INSIDE the timed step (BASELINE config 2's loop, "
@@ -623,7 +606,87 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
         dist.destroy_process_group()
 
 
-def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=None):
+def _read_kernel_ms(cc, ctx, db, B):
+    """HIP-event sums of the library's profiling hooks since the last read, per step of B scans: ingest kernels per launch
+    (one launch per step), query-side kernel groups per B queries (a group = the kernels of one stage of a chunk's chain)."""
+    import ctypes as C
+    ms2 = (C.c_double * 2)()
+    nl = C.c_int()
+    cc.lib().cc_profile_read(ctx.h, ms2, C.byref(nl))
+    ms5 = (C.c_double * 5)()
+    nl2 = C.c_int()
+    cc.lib().cc_db_profile_read(db.h, ms5, C.byref(nl2))
+    a, b = max(nl.value, 1), max(nl2.value, 1) / float(B)   # ingest launches (one per step) | queries -> steps
+    return {"cc_k_rasterize": ms2[0] / a, "cc_k_contours": ms2[1] / a, "cc_k_knn": ms5[0] / b, "cc_k_check": ms5[1] / b,
+            "cc_k_merge": ms5[2] / b, "cc_k_gmm": ms5[3] / b, "cc_k_final": ms5[4] / b}
+
+
+def algorithmic_bytes(d, res, B, P, n_db):
+    """ALGORITHMIC bytes per step and kernel group (DESIGN.md "Kernels"): what the step has to move, independent of how.
+    d = descriptors of (a sample of) the step's scans, res = the step's query results.
+      K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions;
+      K2 reads those and emits the descriptor used downstream;
+      K3 reads the layers' key matrices once and, per anchor key, the 40-B key and <= nnk 12-B hits;
+      K4 reads, per KNN hit, the hit and two contour records, per anchor-similar pair the two 256-bit rings, per check that
+         reaches the pairing the two 600-B BCIs, and writes a 104-B record per pass;
+      merge reads those records; K5 reads two ellipse tables (32 B/ellipse) per problem and writes 64 B.
+    Returns (per-group bytes, split): the split sorts the same bytes into `compulsory` (point stream in, descriptors out, the
+    key matrices and query keys once, results out), `intermediate` (the BEV that goes from K1 to K2 through HBM) and
+    `logical_gather` (per-hit / per-check / per-problem reads of DB records, mostly served by L2 / Infinity Cache)."""
+    n_pix = float(d["n_pix"].mean())
+    desc_emit = float(np.mean(72 + 16 + 1440 + 36 * 600 + d["n_stored"].sum(1) * 76))
+    f = {k: float(res[k].mean()) for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check3", "n_cand_tidy")}
+    n_keys_db = 3 * 6 * n_db
+    bev = 22500 * 4 + n_pix * 8
+    alg = {"cc_k_rasterize": B * (P * 16 + bev),
+           "cc_k_contours": B * (bev + desc_emit),
+           "cc_k_knn": n_keys_db * 44 + B * 18 * 40 + B * f["n_knn_hits"] * 12,
+           "cc_k_check": B * (f["n_knn_hits"] * (12 + 2 * 76) + f["cand_aft_check1"] * (64 + 2 * 600) + f["cand_aft_check3"] * 104),
+           "cc_k_merge": B * f["cand_aft_check3"] * 104,
+           "cc_k_gmm": B * f["n_cand_tidy"] * (2 * 45 * 32 + 64),
+           "cc_k_final": B * 64}
+    compulsory = B * P * 16 + B * desc_emit + n_keys_db * 44 + B * 18 * 40 + B * 64
+    intermediate = 2 * B * bev
+    split = {"compulsory": compulsory, "intermediate": intermediate, "logical_gather": sum(alg.values()) - compulsory - intermediate}
+    return alg, split
+
+
+def roofline_object(alg, split, kms, kms_iso, B, n_db, workload, ms_per_step, P):
+    """The `roofline` object of a JSON line.  Dominant kernel group = largest ISOLATED time per step (stable from run to run;
+    in the timed region kernels of three streams share the GPU and their event times move with the overlap).  `achieved` /
+    `frac` = algorithmic bytes / the group's HIP-event time in the timed region (the contract's definition);
+    `*_isolated` = the same bytes over the group's time with the GPU to itself; `kernels` lists every group both ways next
+    to its PMC traffic (profiles/*_pmc_summary.json of this same configuration, null otherwise)."""
+    iso = kms_iso or kms
+    dom = max(iso, key=lambda k: iso[k])
+    rows = []
+    for k in kms:
+        tr, _src = pmc_traffic(k, B, n_db, workload)
+        rows.append({"kernel": k, "algorithmic_bytes": alg[k], "ms_isolated": iso[k], "ms_in_step": kms[k],
+                     "frac_isolated": alg[k] / (iso[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if iso[k] > 0 else None,
+                     "frac_in_step": alg[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if kms[k] > 0 else None,
+                     "pmc_bytes": tr, "traffic_ratio": (tr / alg[k]) if tr else None})
+    ach = alg[dom] / (kms[dom] * 1e-3) / 1e9
+    ach_iso = alg[dom] / (iso[dom] * 1e-3) / 1e9
+    tr, src = pmc_traffic(dom, B, n_db, workload)
+    k1 = "cc_k_rasterize"
+    total = sum(alg.values())
+    return {"bound": "hbm", "kernel": dom, "dominant_by": "isolated HIP-event time per step",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "achieved_isolated": ach_iso, "frac_isolated": ach_iso / HBM_PEAK_GBS,
+            "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg[dom],
+            "kernels": rows, "kernels_ms_per_launch": kms, "kernels_ms_per_launch_isolated": kms_iso,
+            "isolated_sum_ms": sum(iso.values()),
+            "rasterize_GBs": alg[k1] / (iso[k1] * 1e-3) / 1e9 if iso[k1] > 0 else None,
+            "rasterize_frac_isolated": alg[k1] / (iso[k1] * 1e-3) / 1e9 / HBM_PEAK_GBS if iso[k1] > 0 else None,
+            "step_algorithmic_bytes": total, "step_bytes_split": split,
+            "step_hbm_frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "step_hbm_frac_compulsory": split["compulsory"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "step_hbm_frac_logical_gather": split["logical_gather"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ingest_roofline_scans_per_s": HBM_PEAK_GBS * 1e9 / (P * 16)}
+
+
+def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=None, kernels=False, workload=None):
     """A short run of the headline step on another configuration (world, DB size), same pipeline as the headline: ingest of
     batch s + 1 on its own stream while batch s is queried (cc_db_query_submit), every result collected inside the timed
     region.  `rec` = packed records of a DB built earlier whose first n_db scans are used.  Returns (figures, records)."""
@@ -671,6 +734,10 @@ def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=No
         return res
     run(0, W)
     torch.cuda.synchronize()
+    if kernels:
+        cc.lib().cc_profile_enable(ctx.h, 1)
+        cc.lib().cc_db_profile_enable(db.h, PROF_EVERY)
+        _read_kernel_ms(cc, ctx, db, B)
     t0 = time.perf_counter()
     res = run(W, K)
     torch.cuda.synchronize()
@@ -678,10 +745,31 @@ def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=No
     found = int(sum((r["n_res"] > 0).sum() for r in res))
     flags = int(sum((r["flags"] != 0).sum() for r in res))
     d = cc.desc_to_numpy(slots[(W + K - 1) & 1][:64])
+    out = {"scans_per_s": K * B / dt, "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W, "db_scans": n_db, "batch": B,
+           "loop_closures": found, "queries": K * B, "flagged_queries": flags,
+           "occupied_cells_mean": round(float(d["n_pix"].mean()), 1), "contours_per_level_mean": [round(float(v), 1) for v in d["n_cont"].mean(0)],
+           "valid_db_keys_per_scan_mean": round(float((np.abs(d["keys"].reshape(len(d), 6, 6, 10)[:, 1:4]).sum(-1) > 0).sum((1, 2)).mean()), 2)}
+    if kernels:   # per-kernel-group times: in the timed region and with the GPU to itself (ISO_STEPS extra steps on one stream)
+        kms = _read_kernel_ms(cc, ctx, db, B)
+        db.set_lanes(1)
+        cc.lib().cc_db_profile_enable(db.h, 1)
+        s_main.synchronize()
+        for k in range(W, W + min(ISO_STEPS, K)):
+            ctx.ingest(batches[k], offs, out=slots[0])
+            last = db.query(slots[0], epochs)
+        torch.cuda.synchronize()
+        kms_iso = _read_kernel_ms(cc, ctx, db, B)
+        cc.lib().cc_profile_enable(ctx.h, 0)
+        alg, split = algorithmic_bytes(d, res[-1], B, P, n_db)
+        roof = roofline_object(alg, split, kms, kms_iso, B, n_db, workload, dt / K * 1e3, P)
+        out["roofline"] = {k_: roof[k_] for k_ in ("kernel", "frac", "frac_isolated", "kernels", "isolated_sum_ms", "rasterize_frac_isolated",
+                                                   "step_hbm_frac", "step_hbm_frac_compulsory", "step_bytes_split")}
+        out["queries_with_a_loop_closure"] = round(found / float(K * B), 4)
+        out["checks_per_query_mean"] = round(float(np.mean([r["cand_aft_check1"].mean() for r in res])), 1)
+        out["knn_hits_per_query_mean"] = round(float(np.mean([r["n_knn_hits"].mean() for r in res])), 1)
+        out["correlation_problems_per_query_mean"] = round(float(np.mean([r["n_cand_tidy"].mean() for r in res])), 2)
     db.close()
-    return {"scans_per_s": K * B / dt, "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W, "db_scans": n_db, "batch": B,
-            "loop_closures": found, "queries": K * B, "flagged_queries": flags,
-            "occupied_cells_mean": round(float(d["n_pix"].mean()), 1), "contours_per_level_mean": [round(float(v), 1) for v in d["n_cont"].mean(0)]}, rec
+    return out, rec
 
 
 def dropin_loop(batch0, P, n):

@@ -22,9 +22,11 @@ struct sc_params {
   const int *cyl_off;     // [n_scans + 1]
   const long long *seeds; // [n_scans]
   float *out;             // [n_scans][n_rays][4]
-  int n_rays, n_scans, relief;
+  int n_rays, n_scans, relief;   // relief: 0 flat ground, 1 terrain relief (march), 2 flat + rough ground (kitti world)
   float noise_sigma;
-  float wave[6][5];       // terrain relief: amplitude, fx, phase x, fy, phase y
+  float wave[6][5];       // terrain relief / roughness: amplitude, fx, phase x, fy, phase y
+  const float *vols;      // porous cylinders, concatenated per scan: x y r z0 z1 extinction id (id as float bits) pad
+  const int *vol_off;     // [n_scans + 1] or NULL
 };
 
 __device__ __forceinline__ float sc_ground(const sc_params &P, float x, float y) {
@@ -62,8 +64,14 @@ __global__ void __launch_bounds__(256) sc_cast(sc_params P) {
   const float ox = px, oy = py, oz = gz + SC_SENSOR_H;
   float tb = __builtin_inff();
   // ---- ground
-  if (!P.relief) {
-    if (dz < -1e-6f) tb = -SC_SENSOR_H / dz;
+  if (P.relief != 1) {
+    if (dz < -1e-6f) {
+      tb = -SC_SENSOR_H / dz;
+      if (P.relief == 2) {  // rough ground: the height under the flat-plane hit shifts the hit along the ray (synth.cast_scan)
+        const float tq = fminf(tb, 2.f * SC_MAX_RANGE);
+        tb = -(SC_SENSOR_H - sc_ground(P, ox + tq * dx, oy + tq * dy)) / dz;
+      }
+    }
   } else if (live) {
     // 0.5 m march, first sample below the terrain, linear interpolation, two secant refinements (synth.cast_scan)
     float fprev = SC_SENSOR_H;
@@ -117,7 +125,7 @@ __global__ void __launch_bounds__(256) sc_cast(sc_params P) {
       const float tc = (-b - sqrtf(fmaxf(disc, 0.f))) / (2.f * a + 1e-12f);
       const float z = oz + tc * dz;
       bool ok = disc > 0.f && tc > 0.f;
-      if (!P.relief) {
+      if (P.relief != 1) {
         ok = ok && z >= 0.f && z <= h;
       } else {
         ok = ok && z >= base - 1.5f && z <= base + h;
@@ -130,9 +138,43 @@ __global__ void __launch_bounds__(256) sc_cast(sc_params P) {
       if (ok) tb = fminf(tb, tc);
     }
   }
+  const unsigned sd = (unsigned)(P.seeds[scan] & 0xFFFFFFFFll) ^ (unsigned)(P.seeds[scan] >> 32);
+  // ---- porous cylinders (crowns, bushes): the ray ends inside with probability 1 - exp(-extinction * chord), at a uniform
+  //      depth along the chord; both draws from one hash of (ray, object, scan) -- synth._vol_hash
+  if (P.vol_off) {
+    const float izv = 1.f / (fabsf(dz) < 1e-9f ? 1e-9f : dz);
+    for (int v0 = P.vol_off[scan]; v0 < P.vol_off[scan + 1]; v0 += SC_TILE * 6 / 8) {
+      const int nv = min(SC_TILE * 6 / 8, P.vol_off[scan + 1] - v0);
+      float(*vo)[8] = (float(*)[8]) & obj[0][0];
+      __syncthreads();
+      for (int i = threadIdx.x; i < nv * 8; i += blockDim.x) vo[i / 8][i % 8] = P.vols[(size_t)v0 * 8 + i];
+      __syncthreads();
+      for (int i = 0; i < nv; i++) {
+        const float qx = ox - vo[i][0], qy = oy - vo[i][1], r = vo[i][2];
+        const float b = 2.f * (qx * dx + qy * dy);
+        const float cc = qx * qx + qy * qy - r * r;
+        const float disc = b * b - 4.f * a * cc;
+        if (!(disc > 0.f)) continue;
+        const float sq = sqrtf(disc), ia = 1.f / (2.f * a + 1e-12f);
+        const float t_in = (-b - sq) * ia, t_out = (-b + sq) * ia;
+        const float tz0 = (vo[i][3] - oz) * izv, tz1 = (vo[i][4] - oz) * izv;
+        const float lo = fmaxf(fmaxf(t_in, fminf(tz0, tz1)), 0.f), hi = fminf(t_out, fmaxf(tz0, tz1));
+        const float ln = hi - lo;
+        if (!(ln > 0.f) || lo >= tb) continue;
+        const unsigned vid = (unsigned)__float_as_int(vo[i][6]);
+        unsigned h = ((unsigned)ray * 0x9E3779B1u) ^ ((vid + 0x7F4A7C15u) * 0x85EBCA77u) ^ ((sd + 0x165667B1u) * 0xC2B2AE3Du);
+        h ^= h >> 15;
+        h *= 0x2C1B3C6Du;
+        h ^= h >> 12;
+        h *= 0x297A2D39u;
+        h ^= h >> 15;
+        const float u1 = (float)(h & 0xFFFFu) * (1.f / 65536.f), u2 = (float)(h >> 16) * (1.f / 65536.f);
+        if (u1 < 1.f - expf(-vo[i][5] * ln)) tb = fminf(tb, lo + u2 * ln);
+      }
+    }
+  }
   if (!live) return;
   const bool hit = tb < SC_MAX_RANGE;
-  const unsigned sd = (unsigned)(P.seeds[scan] & 0xFFFFFFFFll) ^ (unsigned)(P.seeds[scan] >> 32);
   const unsigned h1 = sc_hash(sd, (unsigned)ray, 1u), h2 = sc_hash(sd, (unsigned)ray, 2u), h3 = sc_hash(sd, (unsigned)ray, 3u);
   const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(h2 >> 8) + 0.5f) * (1.f / 16777216.f);
   const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
@@ -147,8 +189,10 @@ __global__ void __launch_bounds__(256) sc_cast(sc_params P) {
 
 extern "C" int sc_cast_scans(const float *d_dirs, int n_rays, int n_scans, const float *d_poses, const float *d_boxes, const int *d_box_off,
                              const float *d_cyls, const int *d_cyl_off, const long long *d_seeds, int relief, const float *h_wave /*[30] or NULL*/,
-                             float noise_sigma, float *d_out, void *stream) {
+                             float noise_sigma, float *d_out, void *stream, const float *d_vols, const int *d_vol_off) {
   sc_params P;
+  P.vols = d_vols;
+  P.vol_off = d_vol_off;
   P.dirs = d_dirs;
   P.poses = d_poses;
   P.boxes = d_boxes;
@@ -161,7 +205,7 @@ extern "C" int sc_cast_scans(const float *d_dirs, int n_rays, int n_scans, const
   P.n_scans = n_scans;
   P.relief = relief;
   P.noise_sigma = noise_sigma;
-  for (int i = 0; i < 30; i++) (&P.wave[0][0])[i] = (relief && h_wave) ? h_wave[i] : 0.f;
+  for (int i = 0; i < 30; i++) (&P.wave[0][0])[i] = (relief && h_wave) ? h_wave[i] : 0.f;  // relief 1: terrain, 2: roughness
   if (n_scans <= 0) return 0;
   hipLaunchKernelGGL(sc_cast, dim3((n_rays + 255) / 256, n_scans), dim3(256), 0, (hipStream_t)stream, P);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -128,7 +128,7 @@ def test_golden_query_fixture(cc):
         assert r.tobytes() == got[a:b].tobytes()
 
 
-def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10):
+def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10, check_desc=False):
     import torch
     n, P = xyzi.shape[0], xyzi.shape[1]
     offs = np.arange(n + 1, dtype=np.int64) * P
@@ -141,9 +141,16 @@ def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10):
     torch.cuda.synchronize()
     d = cc.desc_to_numpy(desc)
     assert (d["flags"] == 0).all()
+    assert (res["flags"] == 0).all(), "capacity flags on %d queries" % int((res["flags"] != 0).sum())
     ores, _, odesc = oracle.run_sequence(xyzi.cpu().numpy().reshape(-1, 4), offs, ts, seeds, mcfg=mcfg, dcfg=dcfg, want_desc=True)
     assert (ores["n_res"] > 0).sum() >= min_hits, "sequence should contain loop closures (%d)" % (ores["n_res"] > 0).sum()
     bad = []
+    if check_desc:  # every descriptor: integers, contour rows and BCIs bit-exact, keys to the last bits of the f64 exp
+        from parity import compare_desc
+        for i in range(n):
+            b = compare_desc(odesc[i], d[i], float_exact=False)
+            if b:
+                bad.append("scan %d: %s" % (i, b[:4]))
     for i in range(n):
         for f in INT_FIELDS:
             if ores[f][i] != res[f][i]:
@@ -156,6 +163,7 @@ def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10):
     assert not bad, "%d mismatches\n" % len(bad) + "\n".join(bad[:40])
     db.close()
     ctx.close()
+    _seq_vs_oracle.desc = d
     return ores, res
 
 
@@ -180,6 +188,31 @@ def test_sequence_dense_world(cc, oracle):
     w = cc.synth.World(dense=True, loop_len=150.0)
     xyzi, poses, ts = cc.synth.make_sequence(330, world=w, device="cuda")
     _seq_vs_oracle(cc, oracle, xyzi, ts)
+
+
+def test_sequence_kitti_shaped(cc, oracle):
+    """SURVEY.md 8(d)'s value distributions on a revisiting drive: the KITTI-shaped town (synth.World(kitti=True): street
+    grid, porous tree crowns and bushes, rough ground) gives 4-6 k occupied cells, ~100 contours on the low levels and 18
+    valid DB keys per scan.  370 full-size scans of the 4 071-scan drive: 200 of the first pass along a street (no earlier
+    scan of the same place: these queries end without a result) and the 170 scans that drive it again 118 s later (loop
+    closures).  Every descriptor bit-exact (keys to the f64 exp's last bits), every integer of every query result equal
+    to the oracle's replay of the driver loop, correlation and pose within 1e-4."""
+    w = cc.synth.World(kitti=True)
+    idx = np.concatenate([np.arange(1484, 1684), np.arange(2667, 2837)])
+    xyzi, poses, ts = cc.synth.make_sequence(0, world=w, device="cuda", indices=idx)
+    ores, res = _seq_vs_oracle(cc, oracle, xyzi, ts, min_hits=40, check_desc=True)
+    d = _seq_vs_oracle.desc
+    n_pix, n_cont = d["n_pix"].mean(), d["n_cont"].mean(0)
+    valid = (np.abs(d["keys"].reshape(len(d), 6, 6, 10)[:, 1:4]).sum(-1) > 0).sum((1, 2)).mean()
+    print("kitti-shaped: %.0f occupied cells, contours per level %s, %.1f valid DB keys per scan, %d loop closures of %d queries; "
+          "per query: %.0f kNN hits, %.0f checks, %.1f correlation problems"
+          % (n_pix, np.round(n_cont, 1).tolist(), valid, int((ores["n_res"] > 0).sum()), len(idx), res["n_knn_hits"].mean(),
+             res["cand_aft_check1"].mean(), res["n_cand_tidy"].mean()))
+    assert 4000 <= n_pix <= 9000 and 50 <= n_cont[0] <= 150 and 50 <= n_cont[1] <= 150 and valid > 17.0
+    assert (ores["n_res"][:200] > 0).sum() <= 5          # the first pass has nothing to find
+    hit = np.nonzero(res["n_res"] > 0)[0]
+    dd = np.hypot(poses[hit, 0] - poses[res["cand_gidx"][hit], 0], poses[hit, 1] - poses[res["cand_gidx"][hit], 1])
+    assert (dd < 5.0).mean() > 0.9                       # and what the second pass finds is the same place
 
 
 def _write_eval_files(tmp_path, poses, ts):
