@@ -95,12 +95,18 @@ def lib():
 
 
 class CCError(RuntimeError):
-    pass
+    rc = 0
 
 
-def _chk(rc, what):
-    if rc != 0:
-        raise CCError("%s failed (%d): %s" % (what, rc, lib().cc_last_error().decode()))
+CC_ECAPACITY = -4
+
+
+def _chk(rc, what, tolerate=()):
+    if rc != 0 and rc not in tolerate:
+        e = CCError("%s failed (%d): %s" % (what, rc, lib().cc_last_error().decode()))
+        e.rc = rc
+        raise e
+    return rc
 
 
 class IngestDebug(C.Structure):
@@ -231,9 +237,11 @@ class Database:
         stream = torch.cuda.current_stream(desc.device).cuda_stream
         _chk(lib().cc_db_add_scans_prepare(self.h, desc.data_ptr(), desc.shape[0], stream), "cc_db_add_scans_prepare")
 
-    def query(self, qdesc, epochs, lb=None, ub=None, want_knn=False):
+    def query(self, qdesc, epochs, lb=None, ub=None, want_knn=False, allow_flagged=False):
         """qdesc: torch uint8 CUDA [nq, DESC_BYTES]; epochs int32 [nq] (DB state each query sees).
-        Returns numpy structured array of cc_query_result_t (+ knn hits / counts as torch tensors)."""
+        Returns numpy structured array of cc_query_result_t (+ knn hits / counts as torch tensors).
+        allow_flagged: a query that met an internal capacity (cc_query_result_t.flags != 0) makes the library return
+        CC_ECAPACITY with every result delivered; True hands the results back (the caller looks at `flags`) instead of raising."""
         import torch
         if lb is None:
             lb, ub = L.default_thresholds()
@@ -248,7 +256,8 @@ class Database:
         stream = torch.cuda.current_stream(qdesc.device).cuda_stream
         _chk(lib().cc_db_query_batch(self.h, qdesc.data_ptr(), nq, epochs.ctypes.data, C.addressof(lb), C.addressof(ub),
                                      res.ctypes.data, knn.data_ptr() if want_knn else None,
-                                     cnt.data_ptr() if want_knn else None, stream), "cc_db_query_batch")
+                                     cnt.data_ptr() if want_knn else None, stream), "cc_db_query_batch",
+             tolerate=(CC_ECAPACITY,) if allow_flagged else ())
         if want_knn:
             return res, knn.cpu().numpy().view(L.knn_hit_dt).reshape(nq, L.NQLEV, L.NPIV, L.KNN_MAX), cnt.cpu().numpy()
         return res

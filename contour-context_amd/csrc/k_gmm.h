@@ -16,7 +16,9 @@
 #include "cc_sort.h"
 #include "k_merge.h"
 
-#define CC_GMM_ECAP_L 128  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat)
+#define CC_GMM_ECAP_L CC_MAXC  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat): as many as the descriptor
+                               // stores contours, so the correlation has no capacity of its own (round 3: 128 -- a street scene
+                               // with ~100 contours on a level keeps up to ~150 ellipses, the KITTI-shaped world showed it)
 #define CC_GMM_G16_MAX_PAIRS 96  // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above
 
 struct cc_gmm_result {
@@ -26,7 +28,7 @@ struct cc_gmm_result {
   int optimized;   // 0: init correlation below the bar (no refinement)
   int iterations;
   int termination;
-  int flags;       // bit0: a scan kept only its first CC_GMM_ECAP_L ellipses of a level, bit1: the pair pool was full,
+  int flags;       // bit0: a scan kept only its first CC_GMM_ECAP_L ellipses of a level (cannot happen while CC_GMM_ECAP_L == CC_MAXC), bit1: the pair pool was full,
                    // bit2: contour table truncated (CC_MAXC)
   int n_pairs;     // selected (src, tgt) ellipse pairs
   int pad;
@@ -237,9 +239,9 @@ __device__ __forceinline__ void cc_gsync() {
 #define CC_GMM_LIST_CAP 256
 struct cc_gmm_scan_lds {
   float4 T[CC_GMM_TCHUNK];  // (mx, my, maj, -) of the current tgt chunk
-  unsigned short code[CC_GMM_LIST_CAP];
+  unsigned code[CC_GMM_LIST_CAP];
 };
-static_assert(CC_GMM_ECAP_L <= 128 && CC_GMM_LEVELS <= 4, "pair codes are level:2 | src:7 | tgt:7 bits");
+static_assert(CC_GMM_ECAP_L <= 512 && CC_GMM_LEVELS <= 4, "pair codes are level:2 | src:9 | tgt:9 bits");
 
 template <int G>
 __device__ __forceinline__ unsigned long long cc_gballot(bool pred) {
@@ -279,7 +281,7 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
           const float4 t = L.T[tj];
           const bool sel = valid && cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z);
           const unsigned long long m = cc_gballot<G>(sel);
-          if (sel) L.code[cnt + __popcll(m & ((1ull << sl) - 1ull))] = (unsigned short)((li << 14) | (si << 7) | (t0 + tj));
+          if (sel) L.code[cnt + __popcll(m & ((1ull << sl) - 1ull))] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
           cnt += __popcll(m);
           if (cnt > CC_GMM_LIST_CAP - G) {
             flush(cnt);
@@ -315,8 +317,8 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
     const int np = cc_gmm_scan_pairs<CC_G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
       cc_gsync<CC_G>();
       for (int e = sl; e < n; e += CC_G) {
-        const int code = L.code[e];
-        const int li = code >> 14, si = (code >> 7) & 127, ti = code & 127;
+        const int code = (int)L.code[e];
+        const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
         const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
         acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
       }
@@ -789,8 +791,8 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
       cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
         cc_gsync<G>();
         for (int e = sl; e < n; e += G) {
-          const int code = L.code[e];
-          const int li = code >> 14, si = (code >> 7) & 127, ti = code & 127;
+          const int code = (int)L.code[e];
+          const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
           pool[off + done + e] = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
         }
         done += n;
