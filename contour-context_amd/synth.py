@@ -156,26 +156,30 @@ def _world_ground(self, x, y):
 # poles, trunks, and -- what gives a real scan its thousands of occupied cells -- VOLUMETRIC vegetation: bushes and tree
 # crowns are cylinders of a porous medium in which a ray ends at a random depth (Beer-Lambert, hash of (scan, ray,
 # object)), so the upper beams fill a crown's whole footprint instead of drawing its outline.
-KITTI_DEFAULTS = dict(tile=2000.0, block=150.0, lane=1.5, fillet=8.0, road_half=4.6,
+KITTI_DEFAULTS = dict(tile=2000.0, block=150.0, explore=1.0, lane=1.5, fillet=8.0, road_half=4.6,
                       house=0.0012, car=1.0 / 420.0, hedge=0.002, pole=1.0 / 700.0, tree=0.02, bush=0.008,
                       crown_dens=0.1, bush_dens=1.2, rough=0.12)
 
 
-def street_walk(n_edges, nodes, seed):
-    """Seeded random walk over an nodes x nodes street grid from its centre: list of (i, j) nodes, prefix-stable."""
+def street_walk(n_edges, nodes, seed, explore=1.0):
+    """Seeded random walk over an nodes x nodes street grid from its centre: list of (i, j) nodes, prefix-stable.
+    explore > 1 prefers streets not driven yet by that factor (a driver who is going somewhere, not circling the block)."""
     rng = np.random.Generator(np.random.PCG64(seed + 77))
     i = j = nodes // 2
     di, dj = 1, 0
     out = [(i, j)]
+    seen = set()
     for _ in range(n_edges):
         opts = [(di, dj, 0.5), (-dj, di, 0.25), (dj, -di, 0.25)]  # straight, left, right
-        opts = [(a, b, w) for a, b, w in opts if 0 <= i + a < nodes and 0 <= j + b < nodes]
+        opts = [(a, b, w * (1.0 if frozenset(((i, j), (i + a, j + b))) in seen else explore))
+                for a, b, w in opts if 0 <= i + a < nodes and 0 <= j + b < nodes]
         u = rng.random() * sum(w for _, _, w in opts)  # one draw per edge whatever the options: prefix-stable
         for a, b, w in opts:
             u -= w
             if u <= 0:
                 break
         di, dj = a, b
+        seen.add(frozenset(((i, j), (i + di, j + dj))))
         i, j = i + di, j + dj
         out.append((i, j))
     return out
@@ -298,7 +302,7 @@ def _world_path(self, n_scans, step=1.0):
     if self._path is None or self._path[0][-1] < need:
         n_edges = int(need / g["block"]) + 64
         n_edges = ((n_edges + 255) // 256) * 256
-        walk = street_walk(n_edges, self.nodes, self.seed)
+        walk = street_walk(n_edges, self.nodes, self.seed, g["explore"])
         P = np.asarray([(self.street_xy[i], self.street_xy[j]) for i, j in walk])
         rng = np.random.Generator(np.random.PCG64(self.seed + 78))
         lane = g["lane"] + rng.normal(0, 0.25, len(P))              # lateral offset at every node, interpolated along the edge

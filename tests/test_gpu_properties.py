@@ -175,3 +175,45 @@ def test_knn_tiled_equals_walk(cc, world_db, monkeypatch):
     assert _same(r1, r2)
     db1.close()
     db2.close()
+
+
+def test_knn_tiled_near_ties_large_norms(cc, world_db, monkeypatch):
+    """The tiled search's matrix-core value is only a filter; it must never drop a true neighbour (k_knn.h
+    cc_knn_tile_slack).  Hand-made keys where that is hardest: large norms (|k| ~ 1000, so the f32 chain's absolute error is
+    at its largest) and, around every query key, hundreds of DB keys whose distances differ by a few ulps -- far more
+    than nnk_ of them within the radius, tied or nearly tied at the nnk-th distance.  Hit lists of CC_KNN_MODE=0 (one wave
+    per search, exact) and CC_KNN_MODE=2 (tiled, prefiltered) must be identical."""
+    import torch
+    ctx, desc, xq, qdesc, P = world_db
+    n = 600
+    d = cc.desc_to_numpy(desc[:n]).copy()
+    rng = np.random.default_rng(11)
+    keys = d["keys"].reshape(n, 6, 6, 10)
+    base = rng.uniform(150.0, 420.0, (6, 6, 10)).astype(np.float32)       # one place in key space per (level, anchor)
+    for i in range(n):
+        # a shell around the base key: radius r0 (1 + j 2^-21) along a random direction, j small: distances a few ulps apart
+        u = rng.normal(size=(6, 6, 10))
+        u /= np.linalg.norm(u, axis=-1, keepdims=True)
+        r0 = 3.0 * (1.0 + rng.integers(0, 6, (6, 6, 1)) * 2.0 ** -21)
+        keys[i] = (base + (u * r0).astype(np.float32)).astype(np.float32)
+    keys[::7] = keys[1::7][:len(keys[::7])]                                # and exact duplicates (ties broken by key id)
+    d["keys"] = keys.reshape(d["keys"].shape)
+    q = d[:48].copy()
+    qk = q["keys"].reshape(48, 6, 6, 10)
+    qk[:] = base[None] + rng.normal(0, 0.02, qk.shape).astype(np.float32)
+    q["keys"] = qk.reshape(q["keys"].shape)
+    dd = torch.from_numpy(np.frombuffer(d.tobytes(), np.uint8).reshape(n, cc.DESC_BYTES).copy()).cuda()
+    dq = torch.from_numpy(np.frombuffer(q.tobytes(), np.uint8).reshape(48, cc.DESC_BYTES).copy()).cuda()
+    out = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CC_KNN_MODE", mode)
+        db = cc.Database(ctx, capacity=n + 8)
+        db.add_scans(dd, np.arange(n) / 10.0, np.arange(n, dtype=np.int32))
+        out.append(db.query(dq, np.full(48, n, np.int32), want_knn=True, allow_flagged=True))
+        db.close()
+    monkeypatch.delenv("CC_KNN_MODE")
+    (r1, knn1, cnt1), (r2, knn2, cnt2) = out
+    assert np.array_equal(cnt1, cnt2) and cnt1.min() == 50, (cnt1.min(), cnt1.max())   # every search is full: the radius tightened
+    m = np.arange(knn1.shape[-1])[None, None, None, :] < cnt1[..., None]
+    for f in ("gidx", "level", "seq", "dist_sq"):
+        assert np.array_equal(knn1[f][m], knn2[f][m]), f
