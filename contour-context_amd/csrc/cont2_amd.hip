@@ -435,10 +435,10 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
     for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
   }
   if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
-  cc_scan *sc = new cc_scan();
+  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
+  cc_scan *sc = new cc_scan();  // from here on every failure path gives the handle (and, once taken, the descriptor slot) back
   sc->ctx = c;
   sc->d_desc = c->slot_free.back();
-  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
   const int64_t off[2] = {0, n_points};
   cc_ingest_debug_t dbg;
   dbg.d_bev = want_bev ? c->d_loop_bev : nullptr;
@@ -457,7 +457,13 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
       delete sc;
       return set_err(CC_ENOMEM, "cc_scan_ingest: out of host memory");
     }
-    HIPCHK(hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_loop));
+    const hipError_t e_ = hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_loop);
+    if (e_ != hipSuccess) {
+      c->slot_free.push_back(sc->d_desc);
+      free(sc->h_bev);
+      delete sc;
+      return set_err(CC_EHIP, "cc_scan_ingest: copy of the BEV image", e_);
+    }
     sc->bev_pending = true;
   }
   *out = sc;
