@@ -78,6 +78,11 @@ def main():
     ap.add_argument("--seq-batch", type=int, default=512, help="--workload seq: scans per ingest/add/query sub-batch (with four query "
                     "lanes, the online loop's default, two sub-batches are in flight while the host books the next append)")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` measurements of the default run (online replay)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every rank ingests + queries --batch scans per step (per-GPU work fixed, the default); "
+                         "strong = the --batch scans of a step are split over the ranks (total work fixed)")
+    ap.add_argument("--beams", type=int, default=64, help="rays of the synthetic sensor: beams x azim (the metric is quoted on 64 x 1875 = 120 000 points)")
+    ap.add_argument("--azim", type=int, default=1875)
     ap.add_argument("--tune-sweep", default="",
                     help="tuning aid (library built with -DCC_TUNE): 'VAR=v1,v2;VAR2=...': after the timed run, rebuild the DB "
                          "handle under each setting and print the isolated per-kernel ms of two steps to stderr")
@@ -118,23 +123,42 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    # CC_BENCH_HARNESS=emu (tests only, no GPU): the same launcher, sharding, DB exchange, step loop, timing protocol and JSON
+    # assembly with the C-ABI's CPU-harness build (tests/emu) underneath and gloo as the backend, so that the whole N > 1
+    # path has been executed before a multi-GPU node exists.  Its numbers mean nothing and the line says so.
+    harness = os.environ.get("CC_BENCH_HARNESS") == "emu"
     dist = None
+    backend = os.environ.get("CC_BENCH_BACKEND", "gloo" if harness else "nccl")  # "nccl" IS RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        backend = os.environ.get("CC_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
-        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        if harness:
+            dist.init_process_group(backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()  # n_gpus in the JSON line = the ranks the process group really has
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if harness else torch.device("cuda", local_rank)
+    if not harness:
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if not harness:
+            torch.cuda.synchronize()
 
     n_db, B, K, W = args.db_scans, args.batch, args.steps, args.warmup
-    P = 64 * 1875
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit("bench.py --scaling strong: --batch %d is not divisible by %d ranks" % (B, world))
+        B = B // world    # a step's --batch scans are split over the ranks
+    P = args.beams * args.azim
+    if harness:
+        args.no_overlap = args.no_cpu = args.no_extra = True
     wld = cc.synth.World(kitti=True) if args.workload == "kitti" else cc.synth.World(dense=(args.workload in ("dense", "seq")))
     if args.workload == "seq":
         return bench_seq(cc, args, dev, local_rank, world, rank, dist)
-    ctx = cc.Context(local_rank, max_batch=max(B, 256))
+    ctx = _HarnessCtx(cc, max(B, 8)) if harness else cc.Context(local_rank, max_batch=max(B, 256))
+    mk = dict(beams=args.beams, azim=args.azim)
 
     # ---------------- DB build (untimed): scan-sharded ingest, pack, ONE all-gather of the compact records ----------------
     t_setup = time.time()
@@ -149,19 +173,21 @@ def main():
     CH = 128
     for c0 in range(0, len(mine), CH):
         c1 = min(c0 + CH, len(mine))
-        xyzi, _, _ = cc.synth.make_sequence(0, world=wld, device=dev, indices=mine[c0:c1])
+        xyzi, _, _ = cc.synth.make_sequence(0, world=wld, device=dev, indices=mine[c0:c1], **mk)
         d = ctx.ingest(xyzi.reshape(-1, 4), np.arange(c1 - c0 + 1, dtype=np.int64) * P, out=desc_tmp[:c1 - c0])
         hot, feat = ctx.pack(d)
         rec_local[c0:c1, :HB] = hot
         rec_local[c0:c1, HB:] = feat
         if keep_desc:
             desc_keep[c0:c1].copy_(d)   # world == 1: mine == all scans in order
-    torch.cuda.synchronize()
+    sync()
+    if world > 1:
+        dist.barrier()
     t_x = time.perf_counter()
-    rec_db, exchange_bytes = SH.gather_records(rec_local, n_db, world, dist)   # RCCL over xGMI: 35 KB per scan (the descriptor is 169 KB)
-    torch.cuda.synchronize()
+    rec_db, exchange_bytes = SH.gather_records(rec_local, n_db, world, dist)   # RCCL over xGMI: 59 KB per scan (the descriptor is 169 KB)
+    sync()
     exchange_ms = (time.perf_counter() - t_x) * 1e3 if world > 1 else 0.0
-    db = cc.Database(ctx, capacity=n_db + 16)
+    db = _HarnessDb(ctx, n_db + 16) if harness else cc.Database(ctx, capacity=n_db + 16)
     if args.no_overlap:
         db.set_lanes(1)
     elif args.lanes:
@@ -178,8 +204,8 @@ def main():
     n_steps_total = min(W + K, 48)
     batches = []
     for s in range(n_steps_total):
-        start = n_db + (s * world + rank) * B
-        xyzi, _, _ = cc.synth.make_sequence(B, world=wld, device=dev, start=start)
+        start = n_db + (s * world + rank) * B   # weak: rank r's own batch; strong: rank r's slice of the step's global batch
+        xyzi, _, _ = cc.synth.make_sequence(B, world=wld, device=dev, start=start, **mk)
         batches.append(xyzi.reshape(-1, 4).contiguous())
     offs = np.arange(B + 1, dtype=np.int64) * P
     epochs = np.full(B, n_db, np.int32)
@@ -188,14 +214,14 @@ def main():
     gathered = torch.empty((world * B, HB + FB), dtype=torch.uint8, device=dev) if share else None
     rec_q = torch.empty((B, HB + FB), dtype=torch.uint8, device=dev) if share else None
     share_ev = []  # (start, end) events around the per-step all-gather
-    torch.cuda.synchronize()
+    sync()
     setup_s = time.time() - t_setup
 
     # Two HIP streams: while the query chain of batch s runs on the main stream, the ingest kernels of batch s+1 run on
     # a second one (double-buffered descriptors).  Every batch is ingested AND queried inside the timed region.
     qdesc2 = [qdesc, torch.empty_like(qdesc)]
-    s_ing = torch.cuda.Stream(device=dev)
-    s_main = torch.cuda.current_stream(dev)
+    s_ing = None if harness else torch.cuda.Stream(device=dev)
+    s_main = None if harness else torch.cuda.current_stream(dev)
 
     def ingest_async(x, slot):
         s_ing.wait_stream(s_main)  # the slot's previous query has been issued on the main stream
@@ -225,11 +251,16 @@ def main():
                 hq, fq = ctx.pack(q)
                 rec_q[:, :HB] = hq
                 rec_q[:, HB:] = fq
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                dist.all_gather_into_tensor(gathered, rec_q)
-                e1.record()
-                share_ev.append((e0, e1))
+                if harness:
+                    t_s = time.perf_counter()
+                    dist.all_gather_into_tensor(gathered, rec_q)
+                    share_ev.append((time.perf_counter() - t_s) * 1e3)
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    dist.all_gather_into_tensor(gathered, rec_q)
+                    e1.record()
+                    share_ev.append((e0, e1))
             if args.sync_query or args.no_overlap:
                 res = db.query(q, epochs)
             else:  # queue the batch; its chunks are collected when their lanes are needed again, the last ones below
@@ -242,16 +273,18 @@ def main():
         return found
 
     run_steps(0, W)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    cc.lib().cc_profile_enable(ctx.h, 1)
-    cc.lib().cc_db_profile_enable(db.h, PROF_EVERY)  # stage events on every 3rd chunk launch (alternating lanes)
-    torch.cuda.synchronize()
+    if not harness:
+        cc.lib().cc_profile_enable(ctx.h, 1)
+        cc.lib().cc_db_profile_enable(db.h, PROF_EVERY)  # stage events on every 3rd chunk launch (alternating lanes)
+    share_ev.clear()
+    sync()
     t0 = time.perf_counter()
     n_found = run_steps(W, K)
     res = run_steps.last
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -269,6 +302,8 @@ def main():
     import ctypes as C
 
     def read_kernel_ms():
+        if harness:
+            return {k_: 0.0 for k_ in ("cc_k_rasterize", "cc_k_contours", "cc_k_knn", "cc_k_check", "cc_k_merge", "cc_k_gmm", "cc_k_final")}
         return _read_kernel_ms(cc, ctx, db, B)
 
     # HIP events over the timed region: per step, the summed durations of the kernel's launches (one per
@@ -303,6 +338,9 @@ def main():
             for k_, _ in kv:
                 os.environ.pop(k_, None)
         read_kernel_ms()  # drop what these runs added to the profiling sums
+    share_ms = None
+    if share_ev:  # per-step time of the batch-record all-gather (--share-descriptors), this rank
+        share_ms = float(np.mean([e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in share_ev]))
     kms_iso = None
     if not args.no_overlap:         # the same kernels strictly one after the other (2 extra, untimed steps): isolated durations
         args.no_overlap = True
@@ -358,19 +396,37 @@ def main():
         out = {
             "metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": "synthetic Velodyne-64 scans (64x1875=120000 pts), %s world, %d-scan DB, %d query scans/step/GPU, "
+            "config": {"workload": "synthetic Velodyne-64 scans (%dx%d=%d pts), %s world, %d-scan DB, %d query scans/step/GPU, "
                                    "%s (loop closures found: %d of %d on rank 0); a step = ingest + query of "
                                    "the batch, the DB update (addScan/pushAndBalance) is outside the timed step"
-                                   % (args.workload, n_db, B, "the drive goes on through the town: about a tenth of the query scans revisit a DB place"
+                                   % (args.beams, args.azim, P, args.workload, n_db, B, "the drive goes on through the town: about a tenth of the query scans revisit a DB place"
                                       if args.workload == "kitti" else "queries revisit DB places", n_found, K * B),
                        "world": args.workload, "workload_stats": wl_stats, "dtype_note": DTYPE_NOTE,
                        "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10, <= 320 contours/level (flagged otherwise)",
-                       "db_scans": n_db, "batch": B, "points_per_scan": P, "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
+                       "db_scans": n_db, "batch": B, "global_batch": B * world, "points_per_scan": P,
+                       "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
             "roofline": roof,
             "setup_s": setup_s,
         }
+        if harness:
+            out["harness"] = "CPU harness build of the C-ABI (tests/emu), backend %s: a test of the launcher / sharding / JSON path, NOT a measurement" % backend
+        if world > 1:
+            # what the multi-GPU run did, as seen by the process group itself
+            HBq, FBq = cc.packed_sizes() if not harness else ctx.api.packed_sizes()
+            out["multi_gpu"] = {
+                "ranks_seen": dist.get_world_size(), "backend": backend, "scaling": args.scaling,
+                "per_rank_scans_per_s": per_rank,
+                "db_exchange": {"collective": "all_gather_into_tensor of the packed per-scan records (hot record + correlation inputs)",
+                                "bytes_per_scan": HBq + FBq, "bytes_gathered_per_rank": exchange_bytes, "ms": exchange_ms,
+                                "achieved_GBs": exchange_bytes * (world - 1) / world / (exchange_ms * 1e-3) / 1e9 if exchange_ms > 0 else None,
+                                "note": "bytes each rank receives from its peers / wall time of the collective (includes its launch and the first-use set-up of the communicator)"},
+                "per_step_exchange": ({"what": "--share-descriptors: all-gather of the step's packed records", "bytes_gathered_per_rank": int(gathered.numel()),
+                                       "ms": share_ms,
+                                       "achieved_GBs": gathered.numel() * (world - 1) / world / (share_ms * 1e-3) / 1e9 if share_ms else None}
+                                      if share else None),
+                "data_path_collectives_in_timed_step": 1 if share else 0}
         batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
             # the reference's online loop on the scans already resident: from an empty DB, per 512-scan sub-batch
@@ -606,6 +662,56 @@ def bench_seq(cc, args, dev, local_rank, world, rank, dist):
         dist.destroy_process_group()
 
 
+class _HarnessCtx:
+    """CC_BENCH_HARNESS=emu: cc.Context on the C-ABI's CPU-harness build (tests/emu_api.py), CPU torch tensors in and out."""
+
+    def __init__(self, cc, max_batch):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_api
+        self.L = cc.L
+        self.api = emu_api.EmuApi(cc.L)
+        self.h = self.api.create(max_batch=max_batch)
+
+    def ingest(self, x, offs, out=None):
+        import torch
+        d = self.api.ingest(self.h, x.numpy().reshape(-1, 4), offs)
+        t = torch.from_numpy(d.view(np.uint8).reshape(len(d), -1))
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+    def pack(self, d):
+        import torch
+        hot, feat = self.api.pack(self.h, d.numpy().view(self.L.scan_desc_dt).reshape(-1))
+        return torch.from_numpy(hot), torch.from_numpy(feat)
+
+    def close(self):
+        pass
+
+
+class _HarnessDb:
+    def __init__(self, ctx, capacity):
+        self.ctx, self.h = ctx, ctx.api.db_create(ctx.h, cap=capacity)
+
+    def add_packed(self, hot, feat, ts, seeds):
+        self.ctx.api.db_add_packed(self.h, hot.numpy(), feat.numpy(), ts, seeds)
+
+    def query(self, q, epochs):
+        return self.ctx.api.db_query(self.h, q.numpy().view(self.ctx.L.scan_desc_dt).reshape(-1), np.ascontiguousarray(epochs, np.int32))
+
+    query_submit = query
+
+    def query_wait(self):
+        pass
+
+    def set_lanes(self, n):
+        pass
+
+    def close(self):
+        pass
+
+
 def _read_kernel_ms(cc, ctx, db, B):
     """HIP-event sums of the library's profiling hooks since the last read, per step of B scans: ingest kernels per launch
     (one launch per step), query-side kernel groups per B queries (a group = the kernels of one stage of a chunk's chain)."""
@@ -666,6 +772,9 @@ def roofline_object(alg, split, kms, kms_iso, B, n_db, workload, ms_per_step, P)
                      "frac_isolated": alg[k] / (iso[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if iso[k] > 0 else None,
                      "frac_in_step": alg[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if kms[k] > 0 else None,
                      "pmc_bytes": tr, "traffic_ratio": (tr / alg[k]) if tr else None})
+    if not kms[dom] > 0 or not iso[dom] > 0:   # no device timers (the CPU-harness launcher test)
+        return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernels": rows, "step_algorithmic_bytes": sum(alg.values()), "step_bytes_split": split}
     ach = alg[dom] / (kms[dom] * 1e-3) / 1e9
     ach_iso = alg[dom] / (iso[dom] * 1e-3) / 1e9
     tr, src = pmc_traffic(dom, B, n_db, workload)

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, n=48, q_from=40):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -29,7 +29,6 @@ def _worker(rank, world, port, tmpdir):
     dcfg = L.default_db_cfg()
     dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
     w = cc.synth.World(loop_len=40.0)
-    n = 48
     SH = cc.sharding                                       # the same helpers bench.py builds its replicas with
     mine = SH.my_scans(n, rank, world)                     # scan-sharded ingest: rank r takes scans r, r + world, ...
     shard = SH.shard_len(n, world)
@@ -49,7 +48,7 @@ def _worker(rank, world, port, tmpdir):
     db = api.db_create(ctx, dcfg, cap=n)
     api.db_add_packed(db, rec[:, :hb], rec[:, hb:], ts, np.arange(n, dtype=np.int32))
     sizes, ranges = api.bucket_state(db)
-    qs = mine[mine >= 40].astype(np.int32)                 # query-sharded: a rank's queries are scans it ingested
+    qs = mine[mine >= q_from].astype(np.int32)             # query-sharded: a rank's queries are scans it ingested
     res = api.db_query(db, local[(qs - rank) // world], qs)
     np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), sizes=sizes, ranges=ranges, qs=qs, res=res.view(np.uint8),
              rec=rec, desc=local.view(np.uint8).reshape(len(mine), -1), bytes_per_scan=rec_all.shape[1])
@@ -63,7 +62,7 @@ def test_sharded_ingest_allgather_query(tmp_path, cc, oracle):
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["rec"], r1["rec"]), "all-gathered DB must be identical on every rank"
-    assert int(r0["bytes_per_scan"]) < 40000, "the exchange ships compact records, not 169 KB descriptors"
+    assert int(r0["bytes_per_scan"]) < 60000, "the exchange ships compact records, not 169 KB descriptors"
     assert np.array_equal(r0["sizes"], r1["sizes"]) and np.array_equal(r0["ranges"], r1["ranges"])
     # single-process oracle replay of the same sequence
     L = cc.L
@@ -84,6 +83,79 @@ def test_sharded_ingest_allgather_query(tmp_path, cc, oracle):
         for k, qi in enumerate(r["qs"]):
             for f in ["n_res", "cand_gidx", "cand_aft_check3", "n_knn_hits"]:
                 assert ores[f][qi] == res[f][k], (qi, f)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_query_at_world_sizes_that_do_not_divide_the_block(tmp_path, cc, oracle, world):
+    """The same DB build + query-sharded scoring at 4 and 8 ranks with 42 scans (neither divides: the last ranks' shards are
+    padded): identical replicas on every rank, every rank's descriptors and results equal to the single-process oracle."""
+    n, q_from = 42, 34
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n, q_from), nprocs=world, join=True)
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["rec"], r["rec"]) and np.array_equal(rs[0]["sizes"], r["sizes"]) and np.array_equal(rs[0]["ranges"], r["ranges"])
+    L = cc.L
+    dcfg = L.default_db_cfg()
+    dcfg.max_elapse, dcfg.min_elapse = 2.5, 1.5
+    w = cc.synth.World(loop_len=40.0)
+    x, _, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+    ores, _, odesc = oracle.run_sequence(x.numpy().reshape(-1, 4), np.arange(n + 1, dtype=np.int64) * x.shape[1], ts,
+                                         np.arange(n, dtype=np.int32), dcfg=dcfg, want_desc=True)
+    from parity import compare_desc
+    seen = set()
+    for r, rr in enumerate(rs):
+        got = rr["desc"].view(L.scan_desc_dt).reshape(-1)
+        mine = np.arange(r, n, world)
+        assert len(got) == len(mine)
+        for k, gi in enumerate(mine):
+            assert not compare_desc(odesc[gi], got[k], float_exact=True), (r, gi)
+        res = rr["res"].view(L.query_result_dt).reshape(-1)
+        for k, qi in enumerate(rr["qs"]):
+            seen.add(int(qi))
+            for f in ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check3", "n_knn_hits"]:
+                assert ores[f][qi] == res[f][k], (qi, f)
+    assert seen == set(range(q_from, n))
+
+
+def _bench_on_harness(world, extra):
+    import json
+    import subprocess
+    env = dict(os.environ, CC_BENCH_HARNESS="emu", CC_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1", "--db-scans", "13",
+           "--beams", "16", "--azim", "450"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]     # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_runs_end_to_end_on_the_cpu_harness_weak_shared():
+    """`python bench.py --gpus 4 --share-descriptors` with CC_BENCH_HARNESS=emu / gloo: self-launch under torch.distributed.run,
+    scan-sharded DB build (13 scans over 4 ranks: padded shards), the all-gather, replicated add, the timed step with the
+    per-step exchange, max over ranks, and the JSON line with its multi_gpu object -- the path the driver runs at N = 2, 4, 8."""
+    d = _bench_on_harness(4, ["--batch", "2", "--share-descriptors"])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["steps"] == 1 and d["value"] > 0
+    assert d["config"]["batch"] == 2 and d["config"]["global_batch"] == 8
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == 4 and m["backend"] == "gloo" and len(m["per_rank_scans_per_s"]) == 4
+    assert m["db_exchange"]["bytes_gathered_per_rank"] == 4 * 4 * m["db_exchange"]["bytes_per_scan"]   # 4 ranks x shard_len(13, 4) = 4 records
+    assert m["per_step_exchange"]["bytes_gathered_per_rank"] == 4 * 2 * m["db_exchange"]["bytes_per_scan"] and m["per_step_exchange"]["ms"] > 0
+    assert m["data_path_collectives_in_timed_step"] == 1
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]                     # whole-job scans / max-over-ranks time
+    assert "harness" in d and d["roofline"]["frac"] is None
+
+
+def test_bench_runs_end_to_end_on_the_cpu_harness_strong():
+    """--scaling strong: the step's --batch scans are split over the ranks (2 x 2 here), no collective in the timed step."""
+    d = _bench_on_harness(2, ["--batch", "4", "--scaling", "strong"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch"] == 2 and d["config"]["global_batch"] == 4
+    assert d["multi_gpu"]["ranks_seen"] == 2 and d["multi_gpu"]["per_step_exchange"] is None
+    assert d["multi_gpu"]["data_path_collectives_in_timed_step"] == 0
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
 def _online_worker(rank, world, port, tmpdir):
