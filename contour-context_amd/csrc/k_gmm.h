@@ -231,14 +231,20 @@ __device__ __forceinline__ void cc_gsync() {
 
 // ---- the selected (src, tgt) ellipse pairs of one problem -------------------------------------------------------------
 // G lanes own G src ellipses of a level at a time and walk the level's tgt ellipses, whose (mean, major axis) sit in LDS
-// (64 at a time, one broadcast ds_read per test); the pairs that pass GMMPair's test are filed in an LDS list as
-// (level, src, tgt) codes, compacted with a group ballot, and handed to `flush` whenever the list is nearly full and at
-// the end -- so the expensive per-pair work (term evaluation, pool record) runs on full lanes instead of the ~1 % of the
-// (src, tgt) grid that is selected.
+// (64 at a time, one broadcast ds_read per test).  ~1 % of the (src, tgt) grid passes GMMPair's test, so the grid is
+// swept with a CONSERVATIVE f32 test first -- |d_f32| <= 3 (maj_s + maj_t) + 0.01, four f32 operations per pair; the f32
+// image of the f64 expression is off by < 1e-4 for the coordinates the tidyUp gates let through, and a lane whose
+// transformed mean is beyond 4096 skips the shortcut -- and only its survivors take the exact f64 test (the reference's
+// expression decides, cc_gmm_pair_near).  A lane collects its hits of a 64-tgt chunk in a bit mask: no cross-lane traffic
+// in the sweep; per chunk one prefix sum over the group files the (level, src, tgt) codes in an LDS list in (src, tgt)
+// order, which is handed to `flush` whenever it is nearly full and at the end -- so the expensive per-pair work (term
+// evaluation, pool record) runs on full lanes.  Round 3 tested every pair in f64 and balloted once per tgt: K5's largest
+// part on contour-rich scans (0.66 ms of cc_k_gmm_init per 1 024 KITTI-shaped queries).
 #define CC_GMM_TCHUNK 64
 #define CC_GMM_LIST_CAP 256
+#define CC_GMM_PRE_MARGIN 0.01f
 struct cc_gmm_scan_lds {
-  float4 T[CC_GMM_TCHUNK];  // (mx, my, maj, -) of the current tgt chunk
+  float4 T[CC_GMM_TCHUNK];  // (mx, my, maj, 3 maj + margin) of the current tgt chunk
   unsigned code[CC_GMM_LIST_CAP];
 };
 static_assert(CC_GMM_ECAP_L <= 512 && CC_GMM_LEVELS <= 4, "pair codes are level:2 | src:9 | tgt:9 bits");
@@ -247,6 +253,21 @@ template <int G>
 __device__ __forceinline__ unsigned long long cc_gballot(bool pred) {
   if (G == 64) return __ballot(pred);
   return (unsigned long long)cc_group_ballot(pred);
+}
+template <int G>
+__device__ __forceinline__ int cc_gscan_incl(int v, int sl) {
+  if (G == 64) {
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o);
+      if (sl >= o) v += t;
+    }
+    return v;
+  }
+  return cc_group_scan_incl(v);
+}
+template <int G>
+__device__ __forceinline__ int cc_gbcast_i(int v, int src) {
+  return G == 64 ? __shfl(v, src) : cc_group_bcast(v, src);
 }
 
 // returns the number of selected pairs; flush(n) consumes L.code[0..n)
@@ -262,31 +283,63 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
       cc_gsync<G>();  // the previous chunk is no longer read
       for (int j = sl; j < tn; j += G) {
         const cc_ell *pt = &ftgt->ell[li][t0 + j];
-        L.T[j] = make_float4(pt->mx, pt->my, pt->maj, 0.f);
+        L.T[j] = make_float4(pt->mx, pt->my, pt->maj, 3.f * pt->maj + CC_GMM_PRE_MARGIN);
       }
       cc_gsync<G>();
       for (int s0 = 0; s0 < ns; s0 += G) {
         const int si = s0 + sl;
-        const bool valid = si < ns;
-        double sx = 0.0, sy = 0.0;
-        float smaj = 0.f;
-        if (valid) {
+        unsigned long long mask = 0ull;
+        if (si < ns) {
           const cc_ell *ps = &fsrc->ell[li][si];
           const double mx = (double)ps->mx, my = (double)ps->my;
-          sx = ct0 * mx + (-st0) * my + tx;  // T_init applied to the src mean, as written at correlation.h:87-90
-          sy = st0 * mx + ct0 * my + ty;
-          smaj = ps->maj;
+          const double sx = ct0 * mx + (-st0) * my + tx;  // T_init applied to the src mean, as written at correlation.h:87-90
+          const double sy = st0 * mx + ct0 * my + ty;
+          const float smaj = ps->maj;
+          const float sxf = (float)sx, syf = (float)sy, s3 = 3.f * smaj;
+          const bool pre_ok = fabsf(sxf) < 4096.f && fabsf(syf) < 4096.f;
+          for (int tj = 0; tj < tn; tj++) {
+            const float4 t = L.T[tj];
+            const float dxf = sxf - t.x, dyf = syf - t.y, r = s3 + t.w;
+            if (!pre_ok || dxf * dxf + dyf * dyf <= r * r) {
+              if (cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
+            }
+          }
         }
-        for (int tj = 0; tj < tn; tj++) {
-          const float4 t = L.T[tj];
-          const bool sel = valid && cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z);
-          const unsigned long long m = cc_gballot<G>(sel);
-          if (sel) L.code[cnt + __popcll(m & ((1ull << sl) - 1ull))] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
-          cnt += __popcll(m);
-          if (cnt > CC_GMM_LIST_CAP - G) {
-            flush(cnt);
-            total += cnt;
-            cnt = 0;
+        const int c = __popcll(mask);
+        const int incl = cc_gscan_incl<G>(c, sl);
+        const int tot = cc_gbcast_i<G>(incl, G - 1);
+        if (tot == 0) continue;
+        if (cnt + tot > CC_GMM_LIST_CAP) {
+          flush(cnt);
+          total += cnt;
+          cnt = 0;
+        }
+        if (tot <= CC_GMM_LIST_CAP) {
+          int pos = cnt + incl - c;
+          while (mask) {
+            const int tj = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
+          }
+          cnt += tot;
+        } else {  // one (src chunk, tgt chunk) block with more hits than the list holds: lane by lane (a lane has <= 64)
+          for (int l = 0; l < G; l++) {
+            const int cl = cc_gbcast_i<G>(c, l);
+            if (cl == 0) continue;
+            if (cnt + cl > CC_GMM_LIST_CAP) {
+              flush(cnt);
+              total += cnt;
+              cnt = 0;
+            }
+            if (sl == l) {
+              int pos = cnt;
+              while (mask) {
+                const int tj = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
+              }
+            }
+            cnt += cl;
           }
         }
       }
