@@ -19,7 +19,8 @@
 #define CC_GMM_ECAP_L CC_MAXC  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat): as many as the descriptor
                                // stores contours, so the correlation has no capacity of its own (round 3: 128 -- a street scene
                                // with ~100 contours on a level keeps up to ~150 ellipses, the KITTI-shaped world showed it)
-#define CC_GMM_G16_MAX_PAIRS 96  // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above
+#define CC_GMM_G16_MAX_PAIRS 96   // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above,
+#define CC_GMM_G64_MAX_PAIRS 511  // by the 256-lane instance (a workgroup per problem) beyond this many
 
 struct cc_gmm_result {
   double corr_init;
@@ -140,11 +141,37 @@ static_assert(sizeof(cc_gpair) == 64, "four 16-byte loads per pair");
 // sum over the lanes of a problem, result in every lane
 template <int G>
 __device__ __forceinline__ double cc_gsum(double v) {
-  if (G == 64) {
+  if (G >= 64) {
     v += __shfl_xor(v, 32);
     v += __shfl_xor(v, 16);
   }
   return cc_group_sum_d(v);
+}
+// the four sums of an evaluation (cost, gradient).  G = 256: a problem owns a whole workgroup of four waves; the waves'
+// partial sums meet in LDS and every lane adds them in the same order, so all 256 lanes hold bit-identical results and
+// take the same branches of the line search (two barriers per evaluation of several thousand cycles).
+template <int G>
+__device__ __forceinline__ void cc_gsum4(double &a, double &b, double &c, double &d) {
+  a = cc_gsum<G>(a);
+  b = cc_gsum<G>(b);
+  c = cc_gsum<G>(c);
+  d = cc_gsum<G>(d);
+  if (G == 256) {
+    __shared__ double part[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      part[w][0] = a;
+      part[w][1] = b;
+      part[w][2] = c;
+      part[w][3] = d;
+    }
+    __syncthreads();
+    a = ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0];
+    b = ((part[0][1] + part[1][1]) + part[2][1]) + part[3][1];
+    c = ((part[0][2] + part[1][2]) + part[2][2]) + part[3][2];
+    d = ((part[0][3] + part[1][3]) + part[2][3]) + part[3][3];
+    __syncthreads();
+  }
 }
 
 // One term of GMMPair::operator() (correlation.h:123-160) and its gradient, in closed form.  The reference builds the
@@ -219,7 +246,9 @@ __device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_
 // needs its threads to meet)
 template <int G>
 __device__ __forceinline__ void cc_gsync() {
-  if (G == 64) {
+  if (G == 256) {
+    __syncthreads();
+  } else if (G == 64) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #ifdef CC_EMU
     (void)__shfl(0, 0);
@@ -297,12 +326,28 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
           const float smaj = ps->maj;
           const float sxf = (float)sx, syf = (float)sy, s3 = 3.f * smaj;
           const bool pre_ok = fabsf(sxf) < 4096.f && fabsf(syf) < 4096.f;
-          for (int tj = 0; tj < tn; tj++) {
+          // four LDS reads in flight per step (a lone wave has nothing else to hide their latency behind)
+          int tj = 0;
+          for (; tj + 4 <= tn; tj += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = L.T[tj + u];
+            bool near[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const float dxf = sxf - t[u].x, dyf = syf - t[u].y, r = s3 + t[u].w;
+              near[u] = !pre_ok || dxf * dxf + dyf * dyf <= r * r;
+            }
+            if (near[0] | near[1] | near[2] | near[3]) {
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if (near[u] && cc_gmm_pair_near(sx - (double)t[u].x, sy - (double)t[u].y, smaj, t[u].z)) mask |= 1ull << (tj + u);
+            }
+          }
+          for (; tj < tn; tj++) {
             const float4 t = L.T[tj];
             const float dxf = sxf - t.x, dyf = syf - t.y, r = s3 + t.w;
-            if (!pre_ok || dxf * dxf + dyf * dyf <= r * r) {
-              if (cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
-            }
+            if ((!pre_ok || dxf * dxf + dyf * dyf <= r * r) && cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
           }
         }
         const int c = __popcll(mask);
@@ -349,51 +394,60 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
   return total + cnt;
 }
 
-// K5a: initial correlation of every problem (tryProblem, correlation.h:196-202).  16 lanes per problem; the selected pairs'
-// terms are evaluated from the compacted list, 16 pairs at a time.
+// K5a: initial correlation of every problem (tryProblem, correlation.h:196-202).  The selected pairs' terms are evaluated
+// from the compacted list, G pairs at a time.  16 lanes per problem (four problems per wave) when the chunk has more
+// problems than the launch has waves; a whole wave per problem otherwise (contour-rich scans with few candidates: ~1 100
+// problems of ~30 000 grid cells each per 1 024 KITTI-shaped queries -- with 16 lanes each they occupied 290 waves of a GPU
+// that holds thousands, and the kernel lasted as long as the largest grid).
+template <int G>
+__device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
+                                                const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl) {
+  const cc_gmm_problem pb = probs[pidx];
+  const cc_gmm_feat *fsrc = db_feat + pb.gidx;
+  const cc_gmm_feat *ftgt = qfeat + pb.q;
+  const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
+  const double c2 = ct0 * ct0 - st0 * st0, s2 = 2.0 * st0 * ct0;
+  double acc = 0.0;
+  const int np = cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
+    cc_gsync<G>();
+    for (int e = sl; e < n; e += G) {
+      const int code = (int)L.code[e];
+      const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
+      const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
+      acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
+    }
+    cc_gsync<G>();
+  });
+  const double cost = cc_gsum<G>(acc);
+  if (sl == 0) {
+    cc_gmm_result R;
+    R.corr_init = -cost / sqrt(fsrc->ac * ftgt->ac);
+    R.corr_opt = R.corr_init;
+    R.tf_opt[0] = pb.tf[0];
+    R.tf_opt[1] = pb.tf[1];
+    R.tf_opt[2] = pb.tf[2];
+    R.optimized = 0;
+    R.iterations = 0;
+    R.termination = 0;
+    R.flags = (fsrc->flags | ftgt->flags) & 5;
+    R.n_pairs = np;
+    R.pad = 0;
+    results[pidx] = R;
+  }
+}
 // grid = any (grid-stride over the device-side problem count), block = 64
 __global__ void __launch_bounds__(64)
 cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
               const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
   __shared__ cc_gmm_scan_lds lds[64 / CC_G];
-  const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
-  cc_gmm_scan_lds &L = lds[sub];
   const int n_prob = *n_prob_p;
-  for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G)) {
-    const int pidx = prob_list[pi];
-    const cc_gmm_problem pb = probs[pidx];
-    const cc_gmm_feat *fsrc = db_feat + pb.gidx;
-    const cc_gmm_feat *ftgt = qfeat + pb.q;
-    const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
-    const double c2 = ct0 * ct0 - st0 * st0, s2 = 2.0 * st0 * ct0;
-    double acc = 0.0;
-    const int np = cc_gmm_scan_pairs<CC_G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
-      cc_gsync<CC_G>();
-      for (int e = sl; e < n; e += CC_G) {
-        const int code = (int)L.code[e];
-        const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
-        const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
-        acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
-      }
-      cc_gsync<CC_G>();
-    });
-    const double cost = cc_group_sum_d(acc);
-    if (sl == 0) {
-      cc_gmm_result R;
-      R.corr_init = -cost / sqrt(fsrc->ac * ftgt->ac);
-      R.corr_opt = R.corr_init;
-      R.tf_opt[0] = pb.tf[0];
-      R.tf_opt[1] = pb.tf[1];
-      R.tf_opt[2] = pb.tf[2];
-      R.optimized = 0;
-      R.iterations = 0;
-      R.termination = 0;
-      R.flags = (fsrc->flags | ftgt->flags) & 5;
-      R.n_pairs = np;
-      R.pad = 0;
-      results[pidx] = R;
-    }
+  if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
+    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x);
+    return;
   }
+  const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
+  for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
+    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl);
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes
@@ -428,10 +482,11 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
     ay += t.gy;
     at += t.gt;
   }
-  *cost = cc_gsum<G>(a);
-  grad[0] = cc_gsum<G>(ax);
-  grad[1] = cc_gsum<G>(ay);
-  grad[2] = cc_gsum<G>(at);
+  cc_gsum4<G>(a, ax, ay, at);
+  *cost = a;
+  grad[0] = ax;
+  grad[1] = ay;
+  grad[2] = at;
 }
 
 struct cc_gmm_ctx {  // what a line-search evaluation needs
@@ -811,18 +866,23 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 // K5b: calcCorrelation (correlation.h:206-238) for the problems cc_k_select listed: LineSearchMinimizer, LBFGS rank 20,
 // Wolfe / cubic interpolation, <= 10 iterations.  G lanes per problem.
 // grid = any (grid-stride over the device-side list), block = 64
+// G = 16: four problems per wave; 64: one wave per problem; 256: one workgroup of four waves per problem (the long pair
+// lists of contour-rich scans -- ~1 500 pairs per problem on KITTI-shaped input, where a chunk has only ~1 000 problems to
+// refine: one wave each left three quarters of the SIMDs idle and the kernel lasted as long as its longest chain).
 template <int G>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(G == 256 ? 256 : 64)
 cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
                 cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
-  __shared__ double hist_all[64 / G][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
-  __shared__ cc_gmm_scan_lds scan_lds[64 / G];
+  constexpr int NP = G >= 64 ? 1 : 64 / G;  // problems per workgroup
+  __shared__ double hist_all[NP][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
+  __shared__ cc_gmm_scan_lds scan_lds[NP];
+  __shared__ int s_off;
   const int sub = threadIdx.x / G, sl = threadIdx.x % G;
   double *hist = hist_all[sub];
   cc_gmm_scan_lds &L = scan_lds[sub];
   const int n_sel = *n_sel_p;
-  for (int k = blockIdx.x * (64 / G) + sub; k < n_sel; k += gridDim.x * (64 / G)) {
+  for (int k = blockIdx.x * NP + sub; k < n_sel; k += gridDim.x * NP) {
     const int pidx = sel_list[k];
     cc_gmm_result R = results[pidx];
     if ((float)R.corr_init < corr_lb) continue;
@@ -833,23 +893,31 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     const int np = R.n_pairs;
     int off = 0;
     if (sl == 0) off = atomicAdd(pool_head, np);
-    off = G == 64 ? __shfl(off, 0) : cc_group_bcast(off, 0);
+    if (G == 256) {
+      __syncthreads();  // the previous problem's s_off has been read by everyone
+      if (sl == 0) s_off = off;
+      __syncthreads();
+      off = s_off;
+    } else {
+      off = G == 64 ? __shfl(off, 0) : cc_group_bcast(off, 0);
+    }
     if (off + np > pool_cap) {
       if (sl == 0) results[pidx].flags = R.flags | 2;
       continue;
     }
-    {
+    if (G != 256 || threadIdx.x < 64) {  // G = 256: the first wave files the pairs, all four evaluate them
+      constexpr int GS = G == 256 ? 64 : G;
       const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
       int done = 0;
-      cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
-        cc_gsync<G>();
-        for (int e = sl; e < n; e += G) {
+      cc_gmm_scan_pairs<GS>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
+        cc_gsync<GS>();
+        for (int e = sl; e < n; e += GS) {
           const int code = (int)L.code[e];
           const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
           pool[off + done + e] = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
         }
         done += n;
-        cc_gsync<G>();
+        cc_gsync<GS>();
       });
     }
     __threadfence_block();  // the pairs are read back by all lanes of the problem
@@ -1039,13 +1107,13 @@ __device__ __forceinline__ int cc_tidy_order(int nc, const unsigned char *has, u
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
-            const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[2][sel_stride]*/, int sel_stride,
-            int *__restrict__ n_sel /*[2]*/, const unsigned short *__restrict__ perm_tab) {
+            const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[3][sel_stride]*/, int sel_stride,
+            int *__restrict__ n_sel /*[2]*/, int *__restrict__ n_sel_wide, const unsigned short *__restrict__ perm_tab) {
   __shared__ unsigned short idx[CC_MAXCAND];
   __shared__ unsigned short scr[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
   __shared__ int gm[CC_MAXCAND];
-  __shared__ int s_off[2];
+  __shared__ int s_off[3];
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
@@ -1060,28 +1128,34 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
   const int n = cc_tidy_order(nc, has, idx, scr, perm_tab, lane);
   if (n <= 0) return;
   const int pre = max_fine_opt < n ? max_fine_opt : n;
-  // two lists: short pair lists go to the 16-lane refinement instance, long ones to the 64-lane instance
-  // (two atomics per query, not one per problem: same-address atomics are served one after the other)
+  // three lists by pair count: the 16-lane refinement instance, the 64-lane one, the 256-lane one
+  // (one atomic per list and query, not one per problem: same-address atomics are served one after the other)
   const unsigned long long lt = (1ull << lane) - 1ull;
-  int n_big = 0, n_small = 0;
+  int n_big = 0, n_wide = 0;
   for (int i0 = 0; i0 < pre; i0 += 64) {
     const int i = i0 + lane;
-    n_big += __popcll(__ballot(i < pre && gres[gm[idx[i < pre ? i : 0]]].n_pairs > CC_GMM_G16_MAX_PAIRS));
+    const int np = i < pre ? gres[gm[idx[i]]].n_pairs : 0;
+    n_big += __popcll(__ballot(np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_G64_MAX_PAIRS));
+    n_wide += __popcll(__ballot(np > CC_GMM_G64_MAX_PAIRS));
   }
-  n_small = pre - n_big;
+  const int n_small = pre - n_big - n_wide;
   if (lane == 0) {
     s_off[0] = n_small ? atomicAdd(&n_sel[0], n_small) : 0;
     s_off[1] = n_big ? atomicAdd(&n_sel[1], n_big) : 0;
+    s_off[2] = n_wide ? atomicAdd(n_sel_wide, n_wide) : 0;
   }
   __syncthreads();
-  int o_small = s_off[0], o_big = s_off[1];
+  int o_small = s_off[0], o_big = s_off[1], o_wide = s_off[2];
   for (int i0 = 0; i0 < pre; i0 += 64) {
     const int i = i0 + lane;
     const int g = i < pre ? gm[idx[i]] : 0;
-    const bool big = i < pre && gres[g].n_pairs > CC_GMM_G16_MAX_PAIRS, small = i < pre && !big;
-    const unsigned long long mbig = __ballot(big), msm = __ballot(small);
+    const int np = i < pre ? gres[g].n_pairs : 0;
+    const bool wide = i < pre && np > CC_GMM_G64_MAX_PAIRS, big = i < pre && !wide && np > CC_GMM_G16_MAX_PAIRS, small = i < pre && !wide && !big;
+    const unsigned long long mw = __ballot(wide), mbig = __ballot(big), msm = __ballot(small);
+    if (wide) sel_list[2 * (size_t)sel_stride + o_wide + __popcll(mw & lt)] = g;
     if (big) sel_list[(size_t)sel_stride + o_big + __popcll(mbig & lt)] = g;
     if (small) sel_list[o_small + __popcll(msm & lt)] = g;
+    o_wide += __popcll(mw);
     o_big += __popcll(mbig);
     o_small += __popcll(msm);
   }
