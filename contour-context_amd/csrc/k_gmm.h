@@ -20,7 +20,10 @@
                                // stores contours, so the correlation has no capacity of its own (round 3: 128 -- a street scene
                                // with ~100 contours on a level keeps up to ~150 ellipses, the KITTI-shaped world showed it)
 #define CC_GMM_G16_MAX_PAIRS 96   // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above,
-#define CC_GMM_G64_MAX_PAIRS 511  // by the 256-lane instance (a workgroup per problem) beyond this many
+#define CC_GMM_G64_MAX_PAIRS 0x7FFFFFFF  // a 256-lane instance (a workgroup per problem, template value 256 below) exists for lists beyond
+                                         // this; measured on KITTI-shaped input (~3 000 pairs x ~40 evaluations per problem) it LOSES: the
+                                         // refinement is bound by f64 issue, not by one wave's latency, and four waves repeat the serial
+                                         // line-search code (cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk).  Not launched.
 
 struct cc_gmm_result {
   double corr_init;
@@ -326,28 +329,28 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
           const float smaj = ps->maj;
           const float sxf = (float)sx, syf = (float)sy, s3 = 3.f * smaj;
           const bool pre_ok = fabsf(sxf) < 4096.f && fabsf(syf) < 4096.f;
-          // four LDS reads in flight per step (a lone wave has nothing else to hide their latency behind)
-          int tj = 0;
-          for (; tj + 4 <= tn; tj += 4) {
-            float4 t[4];
+          // pass 1, branch-free: the f32 test of all tn tgts, eight per step (LDS reads in flight together), into a
+          // candidate mask.  A branch to the f64 test inside this loop would be taken by the WAVE whenever any of its
+          // 64 lanes has a candidate among the step's tgts -- nearly always -- although ~1 % of the pairs are candidates.
+          unsigned long long cand = 0ull;
+          for (int tb = 0; tb < tn; tb += 8) {
+            unsigned m8 = 0u;
 #pragma unroll
-            for (int u = 0; u < 4; u++) t[u] = L.T[tj + u];
-            bool near[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const float dxf = sxf - t[u].x, dyf = syf - t[u].y, r = s3 + t[u].w;
-              near[u] = !pre_ok || dxf * dxf + dyf * dyf <= r * r;
+            for (int u = 0; u < 8; u++) {
+              const float4 t = L.T[tb + u < tn ? tb + u : tn - 1];
+              const float dxf = sxf - t.x, dyf = syf - t.y, r = s3 + t.w;
+              m8 |= (dxf * dxf + dyf * dyf <= r * r) ? (1u << u) : 0u;
             }
-            if (near[0] | near[1] | near[2] | near[3]) {
-#pragma unroll
-              for (int u = 0; u < 4; u++)
-                if (near[u] && cc_gmm_pair_near(sx - (double)t[u].x, sy - (double)t[u].y, smaj, t[u].z)) mask |= 1ull << (tj + u);
-            }
+            if (tb + 8 > tn) m8 &= (1u << (tn - tb)) - 1u;
+            cand |= (unsigned long long)m8 << tb;
           }
-          for (; tj < tn; tj++) {
+          if (!pre_ok) cand = tn >= 64 ? ~0ull : (1ull << tn) - 1ull;
+          // pass 2: the reference's f64 expression on the candidates (a handful per lane)
+          while (cand) {
+            const int tj = __ffsll((unsigned long long)cand) - 1;
+            cand &= cand - 1;
             const float4 t = L.T[tj];
-            const float dxf = sxf - t.x, dyf = syf - t.y, r = s3 + t.w;
-            if ((!pre_ok || dxf * dxf + dyf * dyf <= r * r) && cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
+            if (cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
           }
         }
         const int c = __popcll(mask);
@@ -458,9 +461,19 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
   sincos(p[2], &s, &c);
   const double c2 = c * c - s * s, s2 = 2.0 * s * c;
   double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
+  // the next pair's record is requested before this pair's ~190 f64 instructions are issued: with one wave per SIMD (few,
+  // long problems) nothing else hides the L2 round trip
+  float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
+  if (sl < np) {
+    const float4 *g4 = (const float4 *)(pairs + sl);
+    w0 = g4[0], w1 = g4[1], w2 = g4[2], w3 = g4[3];
+  }
   for (int i = sl; i < np; i += G) {
-    const float4 *g4 = (const float4 *)(pairs + i);
-    const float4 w0 = g4[0], w1 = g4[1], w2 = g4[2], w3 = g4[3];
+    float4 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+    if (i + G < np) {
+      const float4 *g4 = (const float4 *)(pairs + i + G);
+      n0 = g4[0], n1 = g4[1], n2 = g4[2], n3 = g4[3];
+    }
     cc_gpair P;
     P.s00 = w0.x;
     P.s01 = w0.y;
@@ -481,6 +494,7 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
     ax += t.gx;
     ay += t.gy;
     at += t.gt;
+    w0 = n0, w1 = n1, w2 = n2, w3 = n3;
   }
   cc_gsum4<G>(a, ax, ay, at);
   *cost = a;
@@ -870,7 +884,7 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 // lists of contour-rich scans -- ~1 500 pairs per problem on KITTI-shaped input, where a chunk has only ~1 000 problems to
 // refine: one wave each left three quarters of the SIMDs idle and the kernel lasted as long as its longest chain).
 template <int G>
-__global__ void __launch_bounds__(G == 256 ? 256 : 64)
+__global__ void __launch_bounds__(G == 256 ? 256 : 64) __attribute__((amdgpu_waves_per_eu(2)))
 cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
                 cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
