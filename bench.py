@@ -908,7 +908,8 @@ def dropin_loop(batch0, P, n):
         cfg = cfg.replace("/path/to/outcome-kitti08.txt", os.path.join(tmp, "outcome.txt"))
         open(os.path.join(tmp, "cfg.yaml"), "w").write(cfg)
         t0 = time.perf_counter()
-        r = subprocess.run([exe, os.path.join(tmp, "cfg.yaml")], capture_output=True, text=True, timeout=600)
+        prefix = os.environ.get("CC_DROPIN_PREFIX", "").split()   # tuning aid: e.g. a rocprofv3 command line in front of the driver
+        r = subprocess.run(prefix + [exe, os.path.join(tmp, "cfg.yaml")], capture_output=True, text=True, timeout=600)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": "driver exit code %d: %s" % (r.returncode, r.stderr[-300:])}

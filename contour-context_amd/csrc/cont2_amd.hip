@@ -52,6 +52,7 @@ struct cc_ctx {
   float *d_bev = nullptr;
   float2 *d_pix = nullptr;
   cc_k1_scan_out *d_k1 = nullptr;
+  cc_k1_part k1_part;               // scratch of the split rasterisation (calls of <= CC_K1_SPLIT_MAX_SCANS scans), allocated at first use
   cc_k2_scratch *d_scr = nullptr;
   long long *d_offsets = nullptr;
   // pinned staging ring for the per-chunk point offsets: a slot is reused only after the copy that read it has finished
@@ -74,6 +75,7 @@ struct cc_ctx {
   float *d_loop_bev = nullptr;
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
+  int k1_nosplit = 0;  // CC_K1_NOSPLIT=1: one workgroup per scan also for calls of a few scans (A/B aid)
   // optional per-kernel timing (cc_profile_*)
   bool prof = false;
   std::vector<hipEvent_t> ev;  // triplets (before K1, between, after K2)
@@ -187,9 +189,13 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   }
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   {
     const char *e = getenv("CC_K1_DIV");  // tuning aid, read once
     c->k1_div = (e && atoi(e) == 1) ? 1 : 0;
+    const char *e2 = getenv("CC_K1_NOSPLIT");
+    c->k1_nosplit = (e2 && atoi(e2) == 1) ? 1 : 0;
   }
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
 #undef CREATE_CHK
@@ -245,6 +251,9 @@ int cc_destroy(cc_ctx *c) {
   hipFree(c->d_bev);
   hipFree(c->d_pix);
   hipFree(c->d_k1);
+  hipFree(c->k1_part.key);
+  hipFree(c->k1_part.idx);
+  hipFree(c->k1_part.red);
   hipFree(c->d_scr);
   hipFree(c->d_offsets);
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
@@ -302,12 +311,29 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
       c->ev_used += 3;
       HIPCHK(hipEventRecord(pe[0], stream));
     }
-    if (c->dcfg.reso_pow2 && !c->k1_div)
+    if (nb <= CC_K1_SPLIT_MAX_SCANS && !c->k1_nosplit) {
+      // a handful of scans (the per-scan loop brings one): CC_K1_SPLIT workgroups per scan sweep a range of its points each,
+      // a second small kernel combines the ranges (first range wins ties: file order)
+      if (!c->k1_part.key) {
+        const size_t np = (size_t)CC_K1_SPLIT_MAX_SCANS * CC_K1_SPLIT;
+        HIPCHK(hipMalloc(&c->k1_part.key, sizeof(unsigned) * np * nc));
+        HIPCHK(hipMalloc(&c->k1_part.idx, sizeof(int) * np * nc));
+        HIPCHK(hipMalloc(&c->k1_part.red, sizeof(unsigned) * np * 2));
+      }
+      if (c->dcfg.reso_pow2 && !c->k1_div)
+        hipLaunchKernelGGL((cc_k_rasterize<4, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
+                           (const long long *)c->d_offsets, c->d_bev, c->d_pix, c->d_k1, c->k1_part);
+      else
+        hipLaunchKernelGGL((cc_k_rasterize<4, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
+                           (const long long *)c->d_offsets, c->d_bev, c->d_pix, c->d_k1, c->k1_part);
+      hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)c->d_offsets, c->k1_part, c->d_bev,
+                         c->d_pix, c->d_k1);
+    } else if (c->dcfg.reso_pow2 && !c->k1_div)
       hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
-                         c->d_bev, c->d_pix, c->d_k1);
+                         c->d_bev, c->d_pix, c->d_k1, cc_k1_part());
     else
       hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
-                         c->d_bev, c->d_pix, c->d_k1);
+                         c->d_bev, c->d_pix, c->d_k1, cc_k1_part());
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,

@@ -64,11 +64,22 @@ __device__ __forceinline__ int cc_wave_sum(int v) {
   return v;
 }
 
-// grid = n_scans, block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
-template <int CC_K1_U, bool CC_K1_POW2>
+// Partial results of one point range of a scan (CC_K1_SPLIT ranges per scan when a call brings only a few scans: the
+// per-scan loop of the class mirror brings one, and one workgroup sweeping 120 000 points alone lasts ~100 us):
+// per cell the height key and the scan-relative index of the first point that reaches it, plus the range's max / min keys.
+#define CC_K1_SPLIT 8
+#define CC_K1_SPLIT_MAX_SCANS 8   // calls with up to this many scans take the split path
+struct cc_k1_part {
+  unsigned *key;   // [n_scans * CC_K1_SPLIT][n_cell]
+  int *idx;        // same
+  unsigned *red;   // [n_scans * CC_K1_SPLIT][2]: max key, min key
+};
+
+// grid = n_scans (PART: n_scans * CC_K1_SPLIT), block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
+template <int CC_K1_U, bool CC_K1_POW2, bool PART = false>
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
-               float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {
+               float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out, cc_k1_part part = cc_k1_part()) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int n_cell = cfg.n_cell;
   unsigned *hmax = (unsigned *)smem;
@@ -76,10 +87,17 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   unsigned long long *idx3 = (unsigned long long *)(smem + (((size_t)n_cell * 4 + 15) & ~(size_t)15));
   unsigned *red = (unsigned *)(idx3 + n_w3);  // [0]=max key [1]=min key [2]=n_pix
 
-  const int scan = blockIdx.x;
+  const int scan = PART ? (int)blockIdx.x / CC_K1_SPLIT : (int)blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const long long p0 = offsets[scan];
-  const int n_pts = (int)(offsets[scan + 1] - p0);
+  long long p0 = offsets[scan];
+  int n_pts = (int)(offsets[scan + 1] - p0);
+  int idx_base = 0;  // scan-relative index of this workgroup's first point
+  if (PART) {
+    const int per = (n_pts + CC_K1_SPLIT - 1) / CC_K1_SPLIT, pi = (int)blockIdx.x % CC_K1_SPLIT;
+    idx_base = pi * per < n_pts ? pi * per : n_pts;
+    n_pts = n_pts - idx_base < per ? n_pts - idx_base : per;
+    p0 += idx_base;
+  }
   const float4 *P = pts + p0;
 
   const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
@@ -170,7 +188,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
 #pragma unroll
     for (int u = 0; u < CC_K1_U; u++) {
       if (cell[u] >= 0 && key[u] == hmax[cell[u]] && key[u] != KEY_EMPTY) {
-        const unsigned long long j = (unsigned long long)(base + tid + u * nt);
+        const unsigned long long j = (unsigned long long)(idx_base + base + tid + u * nt);
         const int w = cell[u] / 3, sh = (cell[u] - 3 * w) * CC_K1_IDX_BITS;
         unsigned long long old = idx3[w];
         while (true) {
@@ -193,6 +211,21 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   }
   __syncthreads();
 
+  if (PART) {  // this range's grid to the scratch; cc_k_rasterize_merge combines the ranges
+    unsigned *pk = part.key + (size_t)blockIdx.x * n_cell;
+    int *pj = part.idx + (size_t)blockIdx.x * n_cell;
+    for (int c = tid; c < n_cell; c += nt) {
+      const unsigned k = hmax[c];
+      pk[c] = k;
+      const int w = c / 3, sh = (c - 3 * w) * CC_K1_IDX_BITS;
+      pj[c] = k != KEY_EMPTY ? (int)((idx3[w] >> sh) & CC_K1_IDX_MASK) : -1;
+    }
+    if (tid == 0) {
+      part.red[(size_t)blockIdx.x * 2] = red[0];
+      part.red[(size_t)blockIdx.x * 2 + 1] = red[1];
+    }
+    return;
+  }
   // ---- outputs ----
   float *bev = bev_out + (size_t)scan * n_cell;
   float2 *pix = pix_out + (size_t)scan * n_cell;
@@ -205,6 +238,68 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
       int j = (int)((idx3[w] >> sh) & CC_K1_IDX_MASK);
       float4 q = P[j];
       // pointToContRowCol: x / reso + n_row/2 - 0.5f, left to right in f32
+      float2 rc;
+      rc.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
+      rc.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;
+      pix[c] = rc;
+      npix++;
+    }
+  }
+  npix = cc_wave_sum(npix);
+  if ((tid & 63) == 0) atomicAdd(&red[2], (unsigned)npix);
+  __syncthreads();
+  if (tid == 0) {
+    cc_k1_scan_out o;
+    o.max_bin_val = cc_funkey(red[0]);
+    o.min_bin_val = cc_funkey(red[1]);
+    o.n_pix = (int)red[2];
+    o.pad = 0;
+    scan_out[scan] = o;
+  }
+}
+
+// The ranges of a scan combined: a cell's height is the largest of the ranges' keys and its point the one of the FIRST
+// range that reaches it -- ranges are in file order and each holds the first of its own points, so this is the first point
+// of the scan at that height: the reference's strict `bev < height` update (contour_mng.h:517) as in the one-sweep kernel.
+// grid = n_scans, block = multiple of 64
+__global__ void __launch_bounds__(1024)
+cc_k_rasterize_merge(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets, cc_k1_part part,
+                     float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {
+  __shared__ unsigned red[3];
+  const int scan = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, n_cell = cfg.n_cell;
+  const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
+  const float4 *P = pts + offsets[scan];
+  if (tid == 0) {
+    unsigned mx = cc_fkey(CC_BEV_EMPTY), mn = cc_fkey(-CC_BEV_EMPTY);
+    for (int p = 0; p < CC_K1_SPLIT; p++) {
+      const unsigned a = part.red[((size_t)scan * CC_K1_SPLIT + p) * 2], b = part.red[((size_t)scan * CC_K1_SPLIT + p) * 2 + 1];
+      mx = a > mx ? a : mx;
+      mn = b < mn ? b : mn;
+    }
+    red[0] = mx;
+    red[1] = mn;
+    red[2] = 0;
+  }
+  __syncthreads();
+  float *bev = bev_out + (size_t)scan * n_cell;
+  float2 *pix = pix_out + (size_t)scan * n_cell;
+  int npix = 0;
+  for (int c = tid; c < n_cell; c += nt) {
+    unsigned k[CC_K1_SPLIT];
+#pragma unroll
+    for (int p = 0; p < CC_K1_SPLIT; p++) k[p] = part.key[((size_t)scan * CC_K1_SPLIT + p) * n_cell + c];
+    unsigned best = KEY_EMPTY;
+    int bp = -1;
+#pragma unroll
+    for (int p = 0; p < CC_K1_SPLIT; p++)
+      if (k[p] != KEY_EMPTY && (bp < 0 || k[p] > best)) {
+        best = k[p];
+        bp = p;
+      }
+    bev[c] = cc_funkey(best);
+    if (bp >= 0) {
+      const int j = part.idx[((size_t)scan * CC_K1_SPLIT + bp) * n_cell + c];
+      const float4 q = P[j];
       float2 rc;
       rc.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
       rc.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;

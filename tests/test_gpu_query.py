@@ -97,12 +97,16 @@ def test_knn_matches_oracle_db(cc, oracle, loop_sequence):
     ctx.close()
 
 
-def test_golden_query_fixture(cc):
-    """Committed descriptors of a 64-scan looping sequence + the expected result of every query (tests/golden/
+@pytest.mark.parametrize("graph", [0, 8])
+def test_golden_query_fixture(cc, graph, monkeypatch):
+    """graph = 8: chunks of up to eight queries go out as one hipGraph launch (CC_QUERY_GRAPH, captured and updated in place
+    per call) -- the parts list below has batches of 24 / 16 / 24 queries cut per lane, and single-query calls at the end.
+    Committed descriptors of a 64-scan looping sequence + the expected result of every query (tests/golden/
     make_query_golden.py; checked against the oracle by the CPU suite): scan i queries the DB as it was after i scans."""
     import torch
     from test_emu_query import _load_query_fixture, _same_result
     L = cc.L
+    monkeypatch.setenv("CC_QUERY_GRAPH", str(graph))
     desc, ts, exp, d = _load_query_fixture(L)
     n = len(desc)
     ddesc = torch.from_numpy(np.frombuffer(desc.tobytes(), np.uint8).reshape(n, cc.DESC_BYTES).copy()).cuda()
@@ -126,6 +130,12 @@ def test_golden_query_fixture(cc):
     db.query_wait()
     for (a, b), r in zip(parts, outs):
         assert r.tobytes() == got[a:b].tobytes()
+    # one query per call (what the class mirror's per-scan loop does): with graph = 8 each call is one graph launch
+    for i in (5, 33, 47, 63, 20):
+        one = db.query(ddesc[i:i + 1], seeds[i:i + 1])
+        assert one.tobytes() == got[i:i + 1].tobytes()
+    db.close()
+    ctx.close()
 
 
 def _seq_vs_oracle(cc, oracle, xyzi, ts, mcfg=None, dcfg=None, min_hits=10, check_desc=False):
