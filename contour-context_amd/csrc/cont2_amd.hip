@@ -69,7 +69,11 @@ struct cc_ctx {
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   // the per-scan loop (cc_scan_*): own stream, pinned + device point staging, a pool of device descriptor slots
   hipStream_t s_loop = nullptr;
-  float *h_pts = nullptr, *d_pts = nullptr;
+  // per-scan loop: two pinned staging buffers (the caller may fill the second one -- e.g. read the next scan's file from
+  // another thread -- while the first one's scan is in flight), one device point buffer (the stream orders its reuse)
+  float *h_pts[2] = {nullptr, nullptr}, *d_pts = nullptr;
+  hipEvent_t pts_ev[2] = {nullptr, nullptr};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
+  bool pts_busy[2] = {false, false};
   int64_t pts_cap = 0;  // points
   std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
   float *d_loop_bev = nullptr;
@@ -266,7 +270,10 @@ int cc_destroy(cc_ctx *c) {
     hipStreamSynchronize(c->s_loop);
     hipStreamDestroy(c->s_loop);
   }
-  if (c->h_pts) hipHostFree(c->h_pts);
+  for (int i = 0; i < 2; i++) {
+    if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
+    if (c->pts_ev[i]) hipEventDestroy(c->pts_ev[i]);
+  }
   hipFree(c->d_pts);
   hipFree(c->d_loop_bev);
   for (auto *b : c->slot_blocks) hipFree(b);
@@ -420,36 +427,47 @@ struct cc_scan {
 
 static int loop_reserve_points(cc_ctx *c, int64_t n_points) {
   if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++)
+    if (!c->pts_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[i], hipEventDisableTiming));
   if (n_points <= c->pts_cap) return CC_OK;
   HIPCHK(hipStreamSynchronize(c->s_loop));
-  if (c->h_pts) hipHostFree(c->h_pts);
+  for (int i = 0; i < 2; i++) {
+    if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
+    c->h_pts[i] = nullptr;
+    c->pts_busy[i] = false;
+  }
   hipFree(c->d_pts);
-  c->h_pts = c->d_pts = nullptr;
+  c->d_pts = nullptr;
   c->pts_cap = 0;
   const int64_t cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
-  HIPCHK(hipHostMalloc((void **)&c->h_pts, sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
+  for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&c->h_pts[i], sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
   HIPCHK(hipMalloc(&c->d_pts, sizeof(float) * 4 * (size_t)cap));
   c->pts_cap = cap;
   return CC_OK;
 }
 
-float *cc_stage_points(cc_ctx *c, int64_t n_points) {
-  if (!c || n_points < 1) return nullptr;
+float *cc_stage_points_slot(cc_ctx *c, int64_t n_points, int slot) {
+  if (!c || n_points < 1 || slot < 0 || slot > 1) return nullptr;
   if (hipSetDevice(c->device) != hipSuccess) return nullptr;
-  // the previous scan's H2D copy may still read the buffer
-  if (c->s_loop && hipStreamSynchronize(c->s_loop) != hipSuccess) return nullptr;
   if (loop_reserve_points(c, n_points) != CC_OK) return nullptr;
-  return c->h_pts;
+  // the slot's last H2D copy may still read the buffer: wait for that copy, not for the stream
+  if (c->pts_busy[slot]) {
+    if (hipEventSynchronize(c->pts_ev[slot]) != hipSuccess) return nullptr;
+    c->pts_busy[slot] = false;
+  }
+  return c->h_pts[slot];
 }
+float *cc_stage_points(cc_ctx *c, int64_t n_points) { return cc_stage_points_slot(c, n_points, 0); }
 
 int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out) {
   if (!c || !h_xyzi || !out || n_points < 1) return set_err(CC_EINVAL, "cc_scan_ingest: bad argument");
   HIPCHK(hipSetDevice(c->device));
-  if (h_xyzi != c->h_pts) {
-    if (c->s_loop) HIPCHK(hipStreamSynchronize(c->s_loop));  // the staging buffer is about to be overwritten
-    int rc = loop_reserve_points(c, n_points);
-    if (rc != CC_OK) return rc;
-    memcpy(c->h_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_points);
+  int slot = (c->h_pts[1] && h_xyzi == c->h_pts[1]) ? 1 : 0;
+  if (!c->h_pts[0] || (h_xyzi != c->h_pts[0] && h_xyzi != c->h_pts[1])) {
+    float *dst = cc_stage_points_slot(c, n_points, 0);  // waits for slot 0's previous copy, grows the buffers if need be
+    if (!dst) return set_err(CC_EHIP, "cc_scan_ingest: staging buffer");
+    memcpy(dst, h_xyzi, sizeof(float) * 4 * (size_t)n_points);
+    slot = 0;
   } else if (n_points > c->pts_cap) {
     return set_err(CC_EINVAL, "cc_scan_ingest: more points than were staged");
   }
@@ -461,7 +479,9 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
     for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
   }
   if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
-  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
+  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts[slot], sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
+  HIPCHK(hipEventRecord(c->pts_ev[slot], c->s_loop));
+  c->pts_busy[slot] = true;
   cc_scan *sc = new cc_scan();  // from here on every failure path gives the handle (and, once taken, the descriptor slot) back
   sc->ctx = c;
   sc->d_desc = c->slot_free.back();

@@ -239,6 +239,20 @@ class ContourManager {
     return n;
   }
 
+  // Mirror-only: n KITTI records already sitting in one of the context's staging buffers (cc_stage_points_slot), e.g. read
+  // there ahead of time by the evaluator's prefetch thread.
+  void makeBEVFromStaged(const float *staged, size_t n, std::string str_id) {
+    CC_CHECK(staged);
+    CC_CHECK(n > 10);
+    CC_CHECK(!scan_);
+    cc_ctx *ctx = cc_host::context(ccfg_);
+    want_images_ = keepImages();
+    if (cc_scan_ingest(ctx, staged, (int64_t)n, want_images_ ? 1 : 0, &scan_) != CC_OK) die();
+    str_id_ = std::move(str_id);
+  }
+  // the context the scans of this configuration are ingested on (one per ContourManagerConfig)
+  static cc_ctx *contextOf(const ContourManagerConfig &config) { return cc_host::context(cc_host::to_c(config)); }
+
   // contour_mng.h:588: the work was queued by makeBEV; results are waited for where they are read
   void makeContoursRecurs() { CC_CHECK(scan_); }
   void clearImage() {}  // the dense image is never kept here (see bev_cells_)

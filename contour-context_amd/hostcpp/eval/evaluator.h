@@ -12,6 +12,7 @@
 #include <iostream>
 #include <numeric>
 #include <sstream>
+#include <thread>
 #include <type_traits>
 
 #include "../cont2/contour_db.h"
@@ -71,6 +72,15 @@ class ContLCDEvaluator {
   const double min_time_excl = 15.0;  // revisits younger than 15 s are not loops
   const double sim_thres;             // similarity at or above which a prediction counts as positive
   int p_lidar_curr = -1;
+  struct Prefetch {  // the next scan's file on its way into a staging buffer (getCurrContourManager)
+    std::thread th;
+    int addr = -1, slot = 0;
+    cc_ctx *ctx = nullptr;
+    float *buf = nullptr;
+    size_t n = 0;
+    bool opened = false;
+  };
+  mutable Prefetch pf_;
   SimpleRMSE<2> tp_trans_rmse, all_trans_rmse;
   SimpleRMSE<1> tp_rot_rmse, all_rot_rmse;
   std::vector<PredictionOutcome> pred_records;
@@ -174,21 +184,65 @@ class ContLCDEvaluator {
     return laser_info_[p_lidar_curr];
   }
 
-  // read the current scan's .bin (x,y,z,i f32; tools/pointcloud_util.h:9-47) and build its descriptor on the device
+  // read the current scan's .bin (x,y,z,i f32; tools/pointcloud_util.h:9-47) and build its descriptor on the device.
+  // readKITTIPointCloudBin + makeBEV in one step: the records go straight to one of the context's two pinned staging
+  // buffers.  While this scan is ingested and queried, a helper thread reads the NEXT scan's file into the other buffer
+  // (plain fopen / fread, no device call), so that the next call finds its points staged -- the driver's loop
+  // (test/batch_bin_test.cpp:131-237) is unchanged.
   std::shared_ptr<ContourManager> getCurrContourManager(const ContourManagerConfig &config) const {
     const LaserScanInfo &info = getCurrScanInfo();
     std::shared_ptr<ContourManager> cm(new ContourManager(config, info.seq));
-    FILE *f = fopen(info.fpath.c_str(), "rb");
-    if (!f) {
-      printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
-      exit(-1);
-    }
     std::string str_id = std::to_string(info.seq);
     str_id = "assigned_id_" + std::string(8 - str_id.length(), '0') + str_id;
-    cm->makeBEVFromKittiBin(f, str_id);  // readKITTIPointCloudBin + makeBEV in one step: the records go straight to the staging buffer
-    fclose(f);
+    cc_ctx *ctx = ContourManager::contextOf(config);
+    const size_t cap = 1000000 / 4;  // readKITTIPointCloudBin reads at most 1 000 000 floats
+    size_t n = 0;
+    const float *pts = nullptr;
+    if (pf_.th.joinable()) pf_.th.join();
+    if (pf_.addr == p_lidar_curr && pf_.ctx == ctx && pf_.buf) {  // staged ahead of time
+      if (!pf_.opened) {
+        printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
+        exit(-1);
+      }
+      n = pf_.n;
+      pts = pf_.buf;
+    } else {
+      pf_.slot = 0;
+      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, 0);
+      CC_CHECK(dst);
+      FILE *f = fopen(info.fpath.c_str(), "rb");
+      if (!f) {
+        printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
+        exit(-1);
+      }
+      n = fread(dst, 4 * sizeof(float), cap, f);
+      fclose(f);
+      pts = dst;
+    }
+    cm->makeBEVFromStaged(pts, n, str_id);
     cm->makeContoursRecurs();
+    pf_.addr = -1;
+    if (p_lidar_curr + 1 < (int)laser_info_.size()) {  // the next scan's file into the other buffer, behind the scenes
+      const int slot = pf_.slot ^ 1;
+      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, slot);  // waits for that buffer's last copy only
+      CC_CHECK(dst);
+      pf_.slot = slot;
+      pf_.addr = p_lidar_curr + 1;
+      pf_.ctx = ctx;
+      pf_.buf = dst;
+      const std::string path = laser_info_[p_lidar_curr + 1].fpath;
+      Prefetch *pf = &pf_;
+      pf_.th = std::thread([pf, path, dst, cap]() {
+        FILE *f = fopen(path.c_str(), "rb");
+        pf->opened = f != nullptr;
+        pf->n = f ? fread(dst, 4 * sizeof(float), cap, f) : 0;
+        if (f) fclose(f);
+      });
+    }
     return cm;
+  }
+  ~ContLCDEvaluator() {
+    if (pf_.th.joinable()) pf_.th.join();
   }
 
   // judge one query: `cand_mng` is the proposed loop candidate (nullptr: none), T_est_delta_2d its BEV-frame transform

@@ -273,7 +273,11 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  * of descriptor slots; the calls only queue work on the context's own stream, the host copy of the descriptor (and of the
  * max-height image, if asked for) is fetched when a getter needs it.
  *   cc_stage_points  : pinned buffer for n_points x (x,y,z,i) f32, valid until the next cc_scan_ingest (write the points
- *                      there to save a host copy), NULL on failure
+ *                      there to save a host copy), NULL on failure.  cc_stage_points_slot: the same for slot 0 or 1 -- two
+ *                      buffers, so that the next scan's file can be read (by another host thread; no cc_* call from it)
+ *                      into one while the other's scan is on its way to the device; a slot is handed out again once ITS last
+ *                      copy has passed (readKITTIPointCloudBin of scan i+1 next to queryRangedKNN of scan i,
+ *                      tools/pointcloud_util.h:9-47, evaluator.h:285-302)
  *   cc_scan_ingest   : makeBEV + makeContoursRecurs for the points at h_xyzi (may be the staging pointer); want_bev != 0
  *                      keeps the max-height image for cc_scan_bev.  Returns at once (work is queued).
  *   cc_scan_desc     : host copy of the descriptor (first call: one D2H copy + sync); CC_ECAPACITY if the scan exceeded a
@@ -283,6 +287,7 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  *   cc_scan_release  : free the handle */
 typedef struct cc_scan cc_scan;
 float *cc_stage_points(cc_ctx *ctx, int64_t n_points);
+float *cc_stage_points_slot(cc_ctx *ctx, int64_t n_points, int slot);
 int cc_scan_ingest(cc_ctx *ctx, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out);
 int cc_scan_desc(cc_scan *scan, const cc_scan_desc_t **h_desc);
 int cc_scan_bev(cc_scan *scan, const float **h_bev);

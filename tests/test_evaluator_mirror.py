@@ -18,7 +18,7 @@ def _build(cc, tmp_path):
     pkg = os.path.join(ROOT, "contour-context_amd")
     cc.build()
     exe = str(tmp_path / "eval_replay")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(pkg, "hostcpp", "examples", "eval_replay.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(pkg, "hostcpp", "examples", "eval_replay.cpp"),
                            "-I", os.path.join(pkg, "hostcpp"), "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcont2_amd",
                            "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe

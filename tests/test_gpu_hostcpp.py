@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_batch_bin_demo_matches_oracle(cc, oracle, tmp_path):
     pkg = os.path.join(ROOT, "contour-context_amd")
     exe = str(tmp_path / "batch_bin_demo")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(pkg, "hostcpp", "examples", "batch_bin_demo.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(pkg, "hostcpp", "examples", "batch_bin_demo.cpp"),
                            "-I", os.path.join(pkg, "hostcpp"), "-L", pkg, "-lcont2_amd", "-Wl,-rpath," + pkg,
                            "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
     w = cc.synth.World(loop_len=40.0)
@@ -68,7 +68,7 @@ def test_batch_bin_test_driver_end_to_end(cc, oracle, tmp_path):
     scores must equal the oracle's replay; TFPN labels must follow the ground truth; pr_eval reads the file back."""
     pkg = os.path.join(ROOT, "contour-context_amd")
     exe = str(tmp_path / "batch_bin_test")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(pkg, "hostcpp", "examples", "batch_bin_test.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(pkg, "hostcpp", "examples", "batch_bin_test.cpp"),
                            "-I", os.path.join(pkg, "hostcpp"), "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lcont2_amd",
                            "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
     w = cc.synth.World(loop_len=40.0)

@@ -15,7 +15,7 @@ def _run(cc, tmp_path, cfg):
     cc.build()
     exe = str(tmp_path / "batch_bin_test")
     if not os.path.exists(exe):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(PKG, "hostcpp", "examples", "batch_bin_test.cpp"),
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(PKG, "hostcpp", "examples", "batch_bin_test.cpp"),
                                "-I", os.path.join(PKG, "hostcpp"), "-I", os.path.join(ROOT, "include"), "-L", PKG, "-lcont2_amd",
                                "-Wl,-rpath," + PKG, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe, cfg], capture_output=True, text=True).stdout

@@ -102,7 +102,7 @@ def _run_and_compare(cc, oracle, exe, tmp_path, device=None, env=None):
 def test_pair_demo_on_cpu_harness(cc, oracle, tmp_path):
     emu_so = emu_api.build()
     exe = str(tmp_path / "pair_demo_emu")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(PKG, "hostcpp", "examples", "pair_demo.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(PKG, "hostcpp", "examples", "pair_demo.cpp"),
                            "-I", os.path.join(PKG, "hostcpp"), "-L", os.path.dirname(emu_so), "-lcc_emu",
                            "-Wl,-rpath," + os.path.dirname(emu_so), "-pthread", "-o", exe])
     _run_and_compare(cc, oracle, exe, tmp_path, env=dict(os.environ, **emu_api.SMALL_GRIDS))
@@ -111,7 +111,7 @@ def test_pair_demo_on_cpu_harness(cc, oracle, tmp_path):
 @pytest.mark.gpu
 def test_pair_demo_on_gpu(cc, oracle, tmp_path):
     exe = str(tmp_path / "pair_demo")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(PKG, "hostcpp", "examples", "pair_demo.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(PKG, "hostcpp", "examples", "pair_demo.cpp"),
                            "-I", os.path.join(PKG, "hostcpp"), "-L", PKG, "-lcont2_amd", "-Wl,-rpath," + PKG,
                            "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
     _run_and_compare(cc, oracle, exe, tmp_path, device="cuda")
