@@ -12,6 +12,18 @@
 
 #define CC_G 16
 
+// hand-off of LDS data between the lanes of ONE wave: LDS operations of a wave execute in issue order, only the compiler has
+// to be kept from reordering them.  The CPU harness runs the lanes as OS threads and needs a real rendezvous.
+__device__ __forceinline__ void cc_wave_sync() {
+#ifndef CC_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  (void)__ballot(1);  // rendezvous of the wave's 64 OS threads (a workgroup may hold several waves)
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+
 #ifndef CC_EMU
 // LDS hand-off between the lanes of one group: a wave's lanes run in lockstep and its LDS operations are executed in
 // issue order, so only the compiler has to be kept from moving LDS accesses across the hand-off (a wavefront-scope fence

@@ -18,6 +18,7 @@
 // per (anchor, division) in the same order.  Parallelism comes from contours x levels x anchors.
 #pragma once
 #include "cc_dev.h"
+#include "cc_group.h"
 #include "cc_sort.h"
 #include "cc_stats.h"
 
@@ -37,7 +38,8 @@ struct cc_comp_t {  // per kept component, spilled to global scratch between lev
 struct cc_k2_scratch {  // per scan of a launch
   cc_comp_t comp[CC_NLEV][CC_NC];
   cc_contour_t cont[CC_NLEV][CC_NC];
-  uint16_t wfirst[CC_NLEV][CC_NC], wlast[CC_NLEV][CC_NC];  // list positions of a component's first and last cell
+  alignas(16) uint16_t memb[CC_NLEV][((CC_MAX_CELLS + 7) & ~7) + 8 * CC_NC];  // per level: the components' member lists (positions in `act`, raster
+                                                              // order), every list starts on a 16-byte boundary
   uint16_t act[CC_MAX_CELLS];                               // active cells (above the lowest level), raster order
   uint16_t compidx[CC_NLEV][CC_MAX_CELLS];                  // per level: component index of list entry i, 0x7FFF = none
 };
@@ -287,8 +289,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       tmark = now_;                                        \
     }                                                      \
   } while (0)
-  unsigned *w_last = W, *w_minc = W + CC_NC, *w_maxc = W + 2 * CC_NC, *w_area = W + 3 * CC_NC, *w_cB = W + 4 * CC_NC,
-           *w_first = W + 5 * CC_NC;
+  unsigned *w_minc = W + CC_NC, *w_maxc = W + 2 * CC_NC, *w_area = W + 3 * CC_NC, *w_cB = W + 4 * CC_NC;
   const int n_w = (n_cell + 15) >> 4;
   for (int l = CC_NLEV - 1; l >= 0; --l) {
     // (a) 8-connected labelling of the level set LV > l.  LAB still holds the forest of level l+1 (a subset of this level's
@@ -367,12 +368,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       roots[rk] = (uint16_t)me;
       LAB[me] = (uint16_t)(0x8000u | (unsigned)rk);  // nothing reads LAB in this loop
       // working arrays of the kept components (W aliases CNT2: the kept test above is done)
-      w_last[k] = 0;
       w_minc[k] = 0xFFFFu;
       w_maxc[k] = 0;
       w_area[k] = 0;
       w_cB[k] = 255;
-      w_first[k] = 0;
     }
     __syncthreads();
     // (d) per component: area, column range, last cell of the raster order, first member column of the second row
@@ -393,12 +392,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           if (v & 0x8000u) {  // else: unmarked root, component with < 3 cells (or beyond the capacity)
             j = v & 0x7FFFu;
             const int rr = c / n_col, cc = c - rr * n_col;
-            atomicMax(&w_last[j], (unsigned)i);
             atomicMin(&w_minc[j], (unsigned)cc);
             atomicMax(&w_maxc[j], (unsigned)cc);
             atomicAdd(&w_area[j], 1u);
             if (rr == (int)(root_cell / (unsigned)n_col) + 1) atomicMin(&w_cB[j], (unsigned)cc);
-            if (root_cell == (unsigned)c) w_first[j] = (unsigned)i;
             if (ld) ld[c] = (int16_t)j;
           }
         }
@@ -448,8 +445,6 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       cp.cB = (uint8_t)w_cB[k];
       cp.pad[0] = cp.pad[1] = 0;
       scr->comp[l][k] = cp;
-      scr->wfirst[l][k] = (uint16_t)w_first[k];
-      scr->wlast[l][k] = (uint16_t)w_last[k];
     }
     __syncthreads();
     for (int k = tid; k < n_kept; k += nt) {
@@ -460,122 +455,132 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     prev_n = n_kept;
     __syncthreads();
   }
-  // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331), one WAVE
-  //      per component, all levels side by side.  The members of a component are the list entries between its first and
-  //      last cell whose index image says so; the 64 lanes test 64 entries at once, the members found (ballot) are then
-  //      accumulated one by one, in list = raster order, by all lanes redundantly -- the exact sequence of f32/f64
-  //      additions of the reference -- with lane broadcasts for the operands.  Height and continuous position of the
-  //      first CC_K2_CACHE active cells are staged in LDS (the label image is dead by now).
+  // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331): ONE LANE
+  //      per component.  The reference adds a component's cells one after the other (f32 cell_vol3_, f64 sums): that chain
+  //      is serial, but the ~100-600 components of a scan are independent, so each gets a lane and a wave works on 64 of
+  //      them at once.  (Round 3 gave a component a whole wave that found its members with ballots and then accumulated
+  //      them on all 64 lanes redundantly: the SIMDs were busy repeating one lane's arithmetic -- 190 of a KITTI-shaped
+  //      scan's 580 us.)  First the member lists: per level one wave sweeps the level's index image in list = raster order,
+  //      64 entries at a time, and gives every entry its rank inside its component (entries of one component meet through
+  //      ballots; a running count per component in LDS) -- a stable counting sort, so every list is in raster order.  Then
+  //      every lane walks its component's list, eight positions per 16-byte load (the next load in flight), heights and
+  //      continuous positions of the first CC_K2_CACHE active cells from LDS, and finishes with calcStatVals.
   __threadfence_block();
   __syncthreads();
   {
     float *cbev = (float *)R;                                      // [CC_K2_CACHE]
     float2 *cpix = (float2 *)(R + CC_K2_CACHE * 4);                // [CC_K2_CACHE]
+    uint16_t *moff = (uint16_t *)(R + CC_K2_CACHE * 12);           // [6][CC_NC] start of a component's list in memb[l], in units of 8
+    uint16_t *mcnt = moff + CC_NLEV * CC_NC;                       // [6][CC_NC] members filed so far
     const int n_cache = n_act < CC_K2_CACHE ? n_act : CC_K2_CACHE;
     for (int i = tid; i < n_cache; i += nt) {
       const int c = (int)scr->act[i];
       cbev[i] = bev[c];
       cpix[i] = pix[c];
     }
-    __syncthreads();
+    for (int i = tid; i < CC_NLEV * CC_NC; i += nt) mcnt[i] = 0;
     int n_tot = 0, lev_base[CC_NLEV + 1];
     for (int l = 0; l < CC_NLEV; l++) {
       lev_base[l] = n_tot;
       n_tot += sh[8 + l];
     }
     lev_base[CC_NLEV] = n_tot;
-    // The sums of a batch of components go to LDS; calcStatVals (a lane-serial stretch of ~500 instructions with the 2x2
-    // eigen-solver) then runs for all of them side by side, one thread per component, instead of on lane 0 of each wave.
-    struct walk_rec {
+    for (int l = wave_id; l < CC_NLEV; l += n_waves) {  // list starts: exclusive prefix sum of the areas, each rounded up to a multiple of 8
+      const int n = sh[8 + l];
+      int run = 0;
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const int a8 = k < n ? ((int)scr->comp[l][k].area + 7) >> 3 : 0;
+        int incl = a8;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
+        }
+        if (k < n) moff[l * CC_NC + k] = (uint16_t)(run + incl - a8);
+        run += __shfl(incl, 63);
+      }
+    }
+    __syncthreads();
+    for (int l = wave_id; l < CC_NLEV; l += n_waves) {  // member lists, a wave per level
+      const uint16_t *cidx = scr->compidx[l];
+      uint16_t *memb = scr->memb[l];
+      uint16_t *cnt_l = mcnt + l * CC_NC;
+      const uint16_t *off_l = moff + l * CC_NC;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      unsigned jn = lane < n_act ? (unsigned)cidx[lane] : CC_COMP_NONE;
+      for (int b0 = 0; b0 < n_act; b0 += 64) {
+        const unsigned j = jn;
+        const int i = b0 + lane;
+        jn = i + 64 < n_act ? (unsigned)cidx[i + 64] : CC_COMP_NONE;  // the next stretch travels while this one is filed
+        unsigned long long todo = __ballot(j != CC_COMP_NONE);
+        while (todo) {
+          const int src = __ffsll(todo) - 1;
+          const unsigned j0 = (unsigned)__builtin_amdgcn_readlane((int)j, src);  // src is wave-uniform
+          const unsigned long long m = __ballot(j == j0);
+          const int base = (int)cnt_l[j0];
+          if (j == j0) memb[(int)off_l[j0] * 8 + base + __popcll(m & lt)] = (uint16_t)i;
+          cc_wave_sync();  // every lane has read the count
+          if (lane == src) cnt_l[j0] = (uint16_t)(base + __popcll(m));
+          cc_wave_sync();
+          todo &= ~m;
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int w = tid; w < n_tot; w += nt) {
+      int l = 0;
+      for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
+      int kbase = 0;
+      for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
+      const int k = w - kbase;
+      const int area = (int)mcnt[l * CC_NC + k];  // == comp[l][k].area
+      const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
       cc_running_stat rec;
-      int poi_i, lk;  // last cell of the component (list position); level << 16 | component index
-    };
-    static_assert(sizeof(walk_rec) == 80, "walk batch size");
-    walk_rec *wrec = (walk_rec *)(R + CC_K2_CACHE * 12);  // between the staged heights / positions and sh[]
-    const int WB = (int)(((char *)sh - (R + CC_K2_CACHE * 12)) / (long)sizeof(walk_rec));  // 239: up to the scalars in sh[], which live on
-    for (int w0 = 0; w0 < n_tot; w0 += WB) {
-      const int w1 = w0 + WB < n_tot ? w0 + WB : n_tot;
-      for (int w = w0 + wave_id; w < w1; w += n_waves) {
-        int l = 0;
-        for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
-        int kbase = 0;
-        for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
-        const int k = w - kbase;
-        const int i0 = scr->wfirst[l][k], i1 = scr->wlast[l][k];
-        const uint16_t *cidx = scr->compidx[l];
-        cc_running_stat rec;
-        rec.cnt = 0;
-        rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
-        rec.vol3 = 0.f;
-        int poi_i = -1;
-        // the index image comes from the scratch block (L2): four 64-entry stretches are fetched at a time so that their
-        // round trips overlap
-        unsigned cv[4] = {CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE, CC_COMP_NONE};
-        for (int ib = i0; ib <= i1; ib += 64) {
-          const int u4 = ((ib - i0) >> 6) & 3;
-          if (u4 == 0) {
+      rec.cnt = 0;
+      rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
+      rec.vol3 = 0.f;
+      int poi_i = -1;
+      uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+      if (area > 0) nx = ml[0];
+      for (int m0 = 0; m0 < area; m0 += 8) {
+        const uint4 cur = nx;
+        if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+        const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int iu = ib + 64 * u + lane;
-              cv[u] = iu <= i1 ? (unsigned)cidx[iu] : CC_COMP_NONE;
-            }
-          }
-          const int i = ib + lane;
-          const unsigned cme = u4 == 0 ? cv[0] : (u4 == 1 ? cv[1] : (u4 == 2 ? cv[2] : cv[3]));
-          const bool mem = cme == (unsigned)k;
-          unsigned long long mask = __ballot(mem);
-          if (!mask) continue;
-          float h = 0.f, px = 0.f, py = 0.f;
-          if (mem) {
+        for (int u = 0; u < 8; u++) {
+          if (m0 + u < area) {
+            const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
+            float h;
+            float2 rc;
             if (i < n_cache) {
               h = cbev[i];
-              const float2 rc = cpix[i];
-              px = rc.x;
-              py = rc.y;
+              rc = cpix[i];
             } else {
               const int c = (int)scr->act[i];
               h = bev[c];
-              const float2 rc = pix[c];
-              px = rc.x;
-              py = rc.y;
+              rc = pix[c];
             }
-          }
-          while (mask) {
-            const int src = __ffsll((unsigned long long)mask) - 1;
-            mask &= mask - 1;
-            const float hh = cc_lane_bcast(h, src);
-            const double vr = (double)cc_lane_bcast(px, src), vc = (double)cc_lane_bcast(py, src);
+            const double vr = (double)rc.x, vc = (double)rc.y;
             rec.cnt += 1;
             rec.ps_x += vr;
             rec.ps_y += vc;
             rec.t_xx += vr * vr;
             rec.t_xy += vr * vc;
             rec.t_yy += vc * vc;
-            rec.vol3 += hh;
-            rec.tq_x += (double)hh * vr;
-            rec.tq_y += (double)hh * vc;
-            poi_i = ib + src;
+            rec.vol3 += h;
+            rec.tq_x += (double)h * vr;
+            rec.tq_y += (double)h * vc;
+            poi_i = i;
           }
         }
-        if (lane == 0) {
-          walk_rec o;
-          o.rec = rec;
-          o.poi_i = poi_i;
-          o.lk = (l << 16) | k;
-          wrec[w - w0] = o;
-        }
       }
-      __syncthreads();
-      for (int s_ = tid; s_ < w1 - w0; s_ += nt) {
-        const walk_rec o = wrec[s_];
-        const int l = o.lk >> 16, k = o.lk & 0xFFFF;
-        const int pc = o.poi_i >= 0 ? (int)scr->act[o.poi_i] : 0;
-        cc_contour_t cvw;
-        cc_calc_stat_vals(cfg, o.rec, l, o.poi_i >= 0 ? pc / n_col : -1, o.poi_i >= 0 ? pc % n_col : -1, &cvw);
-        scr->cont[l][k] = cvw;
-      }
-      __syncthreads();
+      const int pc = poi_i >= 0 ? (int)scr->act[poi_i] : 0;
+      cc_contour_t cvw;
+      cc_calc_stat_vals(cfg, rec, l, poi_i >= 0 ? pc / n_col : -1, poi_i >= 0 ? pc % n_col : -1, &cvw);
+      scr->cont[l][k] = cvw;
     }
+    __syncthreads();
   }
   CC_K2_LAP(acc_walk);
   if (phase_clk && tid == 0) {

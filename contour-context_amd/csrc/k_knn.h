@@ -47,18 +47,6 @@ struct cc_query_meta {  // per query scan, host-built
   float ranges[CC_NQLEV][7];       // LayerDB::bucket_ranges_ at this epoch
 };
 
-// hand-off of LDS data between the lanes of ONE wave (the searches run one wave per workgroup): LDS operations of a wave
-// execute in issue order, only the compiler has to be kept from reordering them.  The CPU harness runs the lanes as OS
-// threads and needs a real rendezvous.
-__device__ __forceinline__ void cc_wave_sync() {
-#ifndef CC_EMU
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#else
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  (void)__ballot(1);  // rendezvous of the wave's 64 OS threads (a workgroup may hold several waves)
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-#endif
-}
 
 // Ascending bitonic sort of 64 * R keys held R per lane: position p lives in v[p / 64] of lane p % 64.
 template <int R>

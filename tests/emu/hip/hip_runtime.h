@@ -49,6 +49,10 @@ struct int4 {
   int x, y, z, w;
 };
 static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
+struct uint4 {
+  unsigned x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
 struct double2 {
   double x, y;
 };
