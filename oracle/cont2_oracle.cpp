@@ -322,6 +322,20 @@ void orc_eigen2f(const float m[4] /*a00 a01 a10 a11*/, float evals[2], float eve
   evecs[2] = ev.a[1][0];
   evecs[3] = ev.a[1][1];
 }
+// the oracle's restatement of cv::connectedComponentsWithStats(img, labels, stats, centroids, 8, CV_32S) on one patch
+// (orc_contour.h:connectedComponentsWithStats8): label image out, returns the number of labels incl. background.  For
+// tests/test_oracle_ccl_second_restatement.py, which checks the numbering against an independent two-pass restatement.
+int orc_ccl8(const uint8_t *img, int rows, int cols, int32_t *labels_out, int32_t *stats_out /*[n][5] or null*/) {
+  std::vector<uint8_t> im(img, img + (size_t)rows * cols);
+  std::vector<int> labels;
+  std::vector<std::array<int, 5>> stats;
+  const int n = connectedComponentsWithStats8(im, rows, cols, labels, stats);
+  for (size_t i = 0; i < labels.size(); i++) labels_out[i] = labels[i];
+  if (stats_out)
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < 5; k++) stats_out[i * 5 + k] = stats[i][k];
+  return n;
+}
 // permutation produced by std::sort with comparator key[a] > key[b] (contour_mng.h:596-599)
 void orc_sort_desc_perm(const int32_t *keys, int n, int32_t *perm) {
   std::vector<std::pair<int32_t, int32_t>> v(n);

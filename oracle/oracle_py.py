@@ -71,6 +71,7 @@ def lib():
         _lib.orc_knn_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _lib.orc_eigen2f.argtypes = [C.c_void_p] * 3
         _lib.orc_sort_desc_perm.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.orc_ccl8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.orc_sort_asc_perm_f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     return _lib
 
@@ -276,6 +277,16 @@ def eigen2f(m):
     vec = np.zeros(4, np.float32)
     lib().orc_eigen2f(_p(m), _p(ev), _p(vec))
     return ev, vec.reshape(2, 2)
+
+
+def ccl8(img):
+    """The oracle's connectedComponentsWithStats (8-connectivity) on a uint8 patch -> (label image int32, stats [n][5])."""
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols = img.shape
+    lab = np.zeros((rows, cols), np.int32)
+    st = np.zeros((rows * cols + 1, 5), np.int32)
+    n = lib().orc_ccl8(_p(img), rows, cols, _p(lab), _p(st))
+    return lab, st[:n]
 
 
 def sort_desc_perm(keys):
