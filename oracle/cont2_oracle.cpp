@@ -458,6 +458,24 @@ void orc_gmm(void *src, void *tgt, const double tf_init[3], double *corr_init, d
     iters[2] = sum.n_eval;
   }
 }
+// the accepted points of the refinement (x_0 .. x_n, n = iterations), for tests/test_oracle_linesearch_properties.py
+int orc_gmm_trace(void *src, void *tgt, const double tf_init[3], double *xs /*[11][3]*/, int32_t *termination) {
+  ConstellCorrelation cc((GMMOptConfig()));
+  Iso2d T = Iso2d::fromAngTrans(tf_init[2], V2D(tf_init[0], tf_init[1]));
+  cc.initProblem(*((ScanH *)src)->cm, *((ScanH *)tgt)->cm, T);
+  ceres_like::SolveSummary sum;
+  cc.calcCorrelation(&sum);
+  int n = 0;
+  for (const auto &x : sum.iterates) {
+    if (n >= 11) break;
+    xs[n * 3] = x[0];
+    xs[n * 3 + 1] = x[1];
+    xs[n * 3 + 2] = x[2];
+    n++;
+  }
+  if (termination) *termination = sum.termination;
+  return n;
+}
 // cost + gradient of the GMM functor at p (autodiff restatement), for cross-checks against scipy
 void orc_gmm_eval(void *src, void *tgt, const double tf_init[3], const double p[3], double *cost, double grad[3],
                   double autocorr[2]) {

@@ -67,6 +67,7 @@ def lib():
                                          C.c_int, C.c_void_p, C.c_void_p]
         _lib.orc_gmm.argtypes = [C.c_void_p] * 7
         _lib.orc_gmm_eval.argtypes = [C.c_void_p] * 7
+        _lib.orc_gmm_trace.argtypes = [C.c_void_p] * 5
         _lib.orc_umeyama.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib.orc_knn_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _lib.orc_eigen2f.argtypes = [C.c_void_p] * 3
@@ -243,6 +244,15 @@ def gmm(src, tgt, tf_init):
     it = np.zeros(3, np.int32)
     lib().orc_gmm(src.h, tgt.h, _p(tf_init), C.byref(ci), C.byref(co), _p(tf), _p(it))
     return ci.value, co.value, tf, it
+
+
+def gmm_trace(src, tgt, tf_init):
+    """accepted points x_0 .. x_n of the L-BFGS refinement (n <= 10) and the termination code"""
+    tf_init = np.ascontiguousarray(tf_init, np.float64)
+    xs = np.zeros((11, 3), np.float64)
+    term = C.c_int32()
+    n = lib().orc_gmm_trace(src.h, tgt.h, _p(tf_init), _p(xs), C.byref(term))
+    return xs[:n].copy(), term.value
 
 
 def gmm_eval(src, tgt, tf_init, p):

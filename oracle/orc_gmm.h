@@ -7,6 +7,7 @@
 // reference: the restatement follows Ceres' published algorithm and defaults from memory of the
 // 2.x sources -- PARITY UNPINNED for this third-party part.
 #pragma once
+#include <array>
 #include <cmath>
 #include <deque>
 #include <vector>
@@ -610,6 +611,7 @@ struct SolveSummary {
   int iterations = 0;
   int termination = 0;  // 0 no-convergence(max iter) 1 gradient tol 2 function tol 3 parameter tol -1 failure
   int n_eval = 0;
+  std::vector<std::array<double, 3>> iterates;  // x_0 and the accepted point of every iteration (tests: Wolfe / L-BFGS properties)
 };
 
 // line_search_minimizer.cc LineSearchMinimizer::Minimize, options of correlation.h:213-217
@@ -636,6 +638,8 @@ inline void Solve(const GMMPair &prob, double *parameters, SolveSummary *summary
   summary->initial_cost = current_state.cost;
   summary->final_cost = current_state.cost;
   summary->iterations = 0;
+  summary->iterates.clear();
+  summary->iterates.push_back({x[0], x[1], x[2]});
   if (current_state.gradient_max_norm <= gradient_tolerance) {
     summary->termination = 1;
     return;
@@ -712,6 +716,7 @@ inline void Solve(const GMMPair &prob, double *parameters, SolveSummary *summary
     const double step_size_tolerance = parameter_tolerance * (x_norm + parameter_tolerance);
     const double cost_change = previous_state.cost - current_state.cost;
     for (int i = 0; i < 3; i++) x[i] = x_plus_delta[i];
+    summary->iterates.push_back({x[0], x[1], x[2]});
     summary->iterations = iteration;
     summary->final_cost = current_state.cost;
     if (step_norm <= step_size_tolerance) {
