@@ -252,10 +252,7 @@ __device__ __forceinline__ void cc_gsync() {
   if (G == 256) {
     __syncthreads();
   } else if (G == 64) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef CC_EMU
-    (void)__shfl(0, 0);
-#endif
+    cc_wave_sync();
   } else {
     cc_group_sync();
   }

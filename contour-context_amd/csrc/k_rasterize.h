@@ -13,31 +13,11 @@
 // Roofline: HBM.  Algorithmic bytes = 16 B x points = what the sweep reads.
 #pragma once
 #include "cc_dev.h"
+#include "cc_group.h"
 
 #define CC_K1_IDX_BITS 21
 #define CC_K1_IDX_MASK 0x1FFFFFull
 #define CC_K1_U_DEFAULT 4  // points per lane and chunk (8 measured equal: the sweep is bound by instruction issue, not by loads in flight)
-
-// value of the lane D places to the left / one place to the right inside the 16-lane row; 0 beyond the row's ends
-#ifndef CC_EMU
-template <int D>
-__device__ __forceinline__ int cc_row_shr(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xF, 0xF, true);
-}
-__device__ __forceinline__ int cc_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
-#else
-template <int D>
-__device__ __forceinline__ int cc_row_shr(int v) {
-  const int sl = threadIdx.x & 15;
-  const int o = __shfl(v, sl >= D ? sl - D : sl, 16);
-  return sl >= D ? o : 0;
-}
-__device__ __forceinline__ int cc_row_shl1(int v) {
-  const int sl = threadIdx.x & 15;
-  const int o = __shfl(v, sl < 15 ? sl + 1 : sl, 16);
-  return sl < 15 ? o : 0;
-}
-#endif
 
 struct cc_k1_scan_out {
   float max_bin_val, min_bin_val;

@@ -4,6 +4,15 @@
 #include "../tools/bm_util.h"
 #include "contour_mng.h"
 
+// The reference's DYNAMIC_THRES=1 build (CMakeLists.txt:13-21; contour_db.h:439-466, 566-574) raises the lower bars of a
+// query's checks from candidate to candidate inside CandidateManager -- a sequential dependence between the checks of one
+// query.  The device path evaluates a query's checks side by side with CONSTANT bars (the shipped DYNAMIC_THRES=0; the upper
+// ensemble is validated -- lb.strictSmaller(ub) -- and otherwise unused, as in that build).  A driver compiled for the
+// dynamic variant must not silently get the constant one:
+#if defined(DYNAMIC_THRES) && DYNAMIC_THRES
+#error "cont2_amd: DYNAMIC_THRES=1 is not supported (checks of a query run in parallel with constant thresholds); build with -DDYNAMIC_THRES=0"
+#endif
+
 // As in the reference (contour_db.h:23): the library records its stage timers ("KNN search", "Constell", "L2 opt") into a
 // profiler object that the EXECUTABLE defines.
 extern SequentialTimeProfiler stp;

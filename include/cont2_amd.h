@@ -334,7 +334,13 @@ int cc_db_add_scans_prepare(cc_db *db, const cc_scan_desc_t *d_desc, int n, void
  *   d_qdesc : [nq] query descriptors (device)
  *   h_res   : [nq] results (host)
  *   d_knn   : optional [nq][CC_NQLEV][CC_NPIV][CC_KNN_MAX] hits + d_knn_cnt [nq][3][6] i32
- *             (parity/debug; NULL to skip) */
+ *             (parity/debug; NULL to skip)
+ *   thres_lb: the bars of the four gates and of the post-checks (CandidateScoreEnsemble sim_lb, contour_db.h:374-596)
+ *   thres_ub: validated like CandidateManager's ctor does (lb.strictSmaller(ub), contour_db.h:365-367: CC_EINVAL otherwise)
+ *             and otherwise UNUSED: the bars stay constant during a query, which is the reference's shipped DYNAMIC_THRES=0
+ *             build (CMakeLists.txt:13-21).  The DYNAMIC_THRES=1 variant (contour_db.h:439-466, 566-574 raise the bars from
+ *             candidate to candidate, a sequential dependence between a query's checks) is NOT implemented; the class mirror
+ *             refuses to compile with that macro set (hostcpp/cont2/contour_db.h). */
 int cc_db_query_batch(cc_db *db, const cc_scan_desc_t *d_qdesc, int nq, const int32_t *h_epoch,
                       const cc_score_t *thres_lb, const cc_score_t *thres_ub,
                       cc_query_result_t *h_res, cc_knn_hit_t *d_knn, int32_t *d_knn_cnt,
