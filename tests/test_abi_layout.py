@@ -32,7 +32,7 @@ def test_layout_sizes(cc, oracle):
     hb, fb = C.c_size_t(), C.c_size_t()
     lib.cc_packed_sizes.restype = None
     lib.cc_packed_sizes(C.byref(hb), C.byref(fb))
-    assert hb.value == L.hot_desc_dt.itemsize == 18448 and fb.value == 16 + 16 + 8 + 4 * 128 * 32
+    assert hb.value == L.hot_desc_dt.itemsize == 18448 and fb.value == 16 + 16 + 8 + 4 * 320 * 32  # CC_MAXC ellipses per correlation level
 
 
 def test_hot_record_is_a_view_of_the_descriptor(cc, oracle):
