@@ -15,6 +15,7 @@ if [ "$2" != "quick" ]; then
   timeout 600 python bench.py --no-cpu --no-extra --db-scans 50000 --steps 8 --warmup 2 2> $OUT/bench_db50k.err | grep '^{' > $OUT/bench_line_db50k.json
   timeout 600 python bench.py --no-cpu --no-extra --db-scans 20000 --steps 8 --warmup 2 2> $OUT/bench_db20k.err | grep '^{' > $OUT/bench_line_db20k.json
   timeout 600 python bench.py --no-cpu --no-extra --workload dense --steps 6 --warmup 2 2> $OUT/bench_dense.err | grep '^{' > $OUT/bench_line_dense.json
+  timeout 600 python bench.py --no-cpu --no-extra --workload kitti --steps 16 --warmup 2 2> $OUT/bench_kitti.err | grep '^{' > $OUT/bench_line_kitti.json
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5
   timeout 600 rocprofv3 --kernel-include-regex "cc_k_" --kernel-trace --stats --output-format csv -d /tmp/p1 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra 2> $OUT/prof_trace.err | grep '^{' > $OUT/bench_line_under_rocprof.json
@@ -24,6 +25,16 @@ if [ "$2" != "quick" ]; then
   F=$(find /tmp/p2 -name "*counter_collection.csv" | head -1); W=$(find /tmp/p3 -name "*counter_collection.csv" | head -1)
   cd $GRAFT_REPO_ROOT
   python profiles/summarize.py ${TAG} $OUT/prof "$S" "$T" "$F" "$W" 1024 5000 sparse $HEAD > $OUT/summarize.log 2>&1
+  # the same three passes on the KITTI-shaped workload (5 k-scan DB): its kernel mix is a different one (K2 and K5 lead)
+  cd /tmp
+  rm -rf /tmp/k1 /tmp/k2 /tmp/k3
+  timeout 600 rocprofv3 --kernel-include-regex "cc_k_" --kernel-trace --stats --output-format csv -d /tmp/k1 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra --workload kitti > /dev/null 2> $OUT/prof_trace_kitti.err
+  timeout 600 rocprofv3 --kernel-include-regex "cc_k_" --pmc FETCH_SIZE --output-format csv -d /tmp/k2 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra --workload kitti --steps 2 --warmup 1 > /dev/null 2> $OUT/prof_fetch_kitti.err
+  timeout 600 rocprofv3 --kernel-include-regex "cc_k_" --pmc WRITE_SIZE --output-format csv -d /tmp/k3 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra --workload kitti --steps 2 --warmup 1 > /dev/null 2> $OUT/prof_write_kitti.err
+  S=$(find /tmp/k1 -name "*kernel_stats.csv" | head -1); T=$(find /tmp/k1 -name "*kernel_trace.csv" | head -1)
+  F=$(find /tmp/k2 -name "*counter_collection.csv" | head -1); W=$(find /tmp/k3 -name "*counter_collection.csv" | head -1)
+  cd $GRAFT_REPO_ROOT
+  python profiles/summarize.py ${TAG}_kitti $OUT/prof_kitti "$S" "$T" "$F" "$W" 1024 5000 kitti $HEAD > $OUT/summarize_kitti.log 2>&1
   if [ "$2" = "full" ]; then
     cd /tmp
     timeout 600 rocprofv3 --kernel-include-regex "cc_k_knn" --kernel-trace --stats --output-format csv -d /tmp/p6 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra --db-scans 50000 --steps 2 --warmup 1 > /dev/null 2> $OUT/prof_trace50k.err
