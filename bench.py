@@ -8,10 +8,10 @@ Contract (see the task statement):  python bench.py --gpus N --steps K --warmup 
     streamed: cc_db_query_submit per step (the lanes are not drained between batches) and one cc_db_query_wait before
     the timed region closes, so every result is on the host inside it (--sync-query: cc_db_query_batch per step);
   * N > 1: launched by torch.distributed.run, one rank per GPU.  The DB build is scan-sharded
-    (each rank ingests n_db/N scans and packs them into the 35 KB per-scan records the DB keeps) followed by ONE
+    (each rank ingests n_db/N scans and packs them into the 59 KB per-scan records the DB keeps) followed by ONE
     all-gather of those records over RCCL (the path's only exchange: every replica needs every DB scan); in the timed step every rank ingests + queries its own
     batch against its replica (weak scaling, no data-path collective: queries never need another rank's scans).
-    `--share-descriptors` additionally all-gathers each batch's compact records (35 KB/scan), which an online
+    `--share-descriptors` additionally all-gathers each batch's compact records (59 KB/scan), which an online
     deployment that appends the queried scans to every replica would do;
   * rank 0 prints ONE JSON line.  `value` is whole-job scans/s.
 Extra objects: `roofline` (dominant kernel, HIP-event timed inside the library) and `cpu_baseline`

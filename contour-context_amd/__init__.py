@@ -171,7 +171,7 @@ class Context:
 
     def pack(self, desc):
         """Full descriptors (torch uint8 CUDA [n, DESC_BYTES]) -> (hot [n, HOT_BYTES], feat [n, FEAT_BYTES]): the compact
-        per-scan records the database keeps and the ranks exchange (35 KB instead of 169 KB per scan)."""
+        per-scan records the database keeps and the ranks exchange (59 KB instead of 169 KB per scan)."""
         import torch
         n = desc.shape[0]
         hb, fb = packed_sizes()

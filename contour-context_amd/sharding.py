@@ -2,7 +2,7 @@
 
   * ingest is scan-sharded, interleaved: of a block of scans rank r takes r, r + G, r + 2 G, ... (consecutive scans take
     equally long, so every rank finishes together whatever the block length);
-  * each rank packs its scans into the two compact records the database keeps (cc_pack_scans: 18 KB hot record + 16 KB
+  * each rank packs its scans into the two compact records the database keeps (cc_pack_scans: 18 KB hot record + 41 KB
     correlation inputs, against 169 KB of descriptor) and the ranks all-gather them -- `torch.distributed` with the "nccl"
     backend, i.e. RCCL over xGMI (point to point, fully connected: every link carries one peer's shard); no all-reduce;
   * every rank re-orders the gathered records into scan order and appends them to its replica (cc_db_add_packed): the host

@@ -416,7 +416,7 @@ int cc_db_debug_passes(cc_db *db, cc_pass_dbg_t *h_out, int cap, int *n_out);
 /* ---- the compact per-scan records (multi-GPU exchange) ----
  * cc_pack_scans turns full descriptors into the two records the database keeps per scan: the hot record
  * (cc_hot_desc_t, 18 KB) and the correlation inputs (opaque, 16 KB; cc_packed_sizes gives both sizes).  A rank packs
- * the scans it ingested, the ranks all-gather the two arrays over RCCL (35 KB per scan instead of the 169 KB
+ * the scans it ingested, the ranks all-gather the two arrays over RCCL (59 KB per scan instead of the 169 KB
  * descriptor), and every rank appends the gathered scans to its replica with cc_db_add_packed -- the same effect as
  * cc_db_add_scans on the full descriptors (which is pack + add_packed).  d_hot_out / d_feat_out: device arrays of n
  * records each. */

@@ -1,5 +1,5 @@
 """Multi-GPU path on CPU (gloo, world_size 2): scan-sharded ingest -> pack -> ONE all-gather of the compact per-scan
-records (18 KB hot record + 16 KB correlation inputs instead of the 169 KB descriptor) -> replicated DB via
+records (18 KB hot record + 41 KB correlation inputs instead of the 169 KB descriptor) -> replicated DB via
 cc_db_add_packed -> query-sharded scoring; and the launcher path of `bench.py --gpus N`.  Compute runs through the product's C-ABI in its CPU build (tests/emu);
 the collective is torch.distributed exactly as bench.py uses it (nccl = RCCL on the GPU box)."""
 import os
