@@ -7,13 +7,43 @@
 #include "../../contour-context_amd/csrc/cont2_amd.hip"
 
 namespace emu {
-thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+thread_local dim3 t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx *t_block;
-thread_local WaveCtx *t_wave;
-thread_local int t_lane;
-thread_local unsigned t_coll;
-thread_local unsigned t_gcoll;
+thread_local Fiber *t_cur;
 }  // namespace emu
+
+// The context switch of the harness' fibers (x86-64 System V): push the callee-saved registers, swap the stack pointers,
+// pop the other side's registers, return into it.
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch, @function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch, .-emu_switch
+)");
+// where a new fiber starts: run the launch's kernel call for this HIP thread, then hand over to the scheduler for good
+extern "C" void emu_fiber_entry() {
+  emu::BlockCtx *blk = emu::t_block;
+  blk->run(blk->arg);
+  emu::t_cur->done = true;
+  emu::emu_switch(&emu::t_cur->sp, blk->sched_sp);
+  abort();  // a finished fiber is never resumed
+}
 
 extern "C" {
 // unit hooks for the std::sort replica and the 2x2 eigen solver

@@ -3,13 +3,17 @@
 // There is no GPU in the build container, so kernel *logic* is exercised on the CPU before a
 // GPU slot is spent: the kernel headers under contour-context_amd/csrc/ are compiled unchanged
 // with g++ against this stand-in for <hip/hip_runtime.h> (tests/emu is put first on the include
-// path).  One OS thread per HIP thread, pthread barriers for __syncthreads(), per-wave barriers
-// for the 64-lane cross-lane ops, __atomic builtins for atomics.  It is never part of the product:
-// nothing under contour-context_amd/ includes or links it.
+// path).  Every HIP thread of a workgroup is a FIBER (its own stack, a user-space context switch of six registers) of the
+// OS thread that runs the workgroup; __syncthreads(), the 64-lane cross-lane operations and the 16-lane group operations are
+// cooperative barriers (a fiber that has to wait hands over to the next one); the workgroups of a launch are spread over a
+// few OS threads, `__shared__` being thread-local statics; __atomic builtins for atomics (workgroups on different OS threads
+// really run side by side).  Round 3 used one OS thread per HIP thread and pthread barriers: the suite spent 40 of its 60
+// CPU-minutes in futex calls.  It is never part of the product: nothing under contour-context_amd/ includes or links it.
 #pragma once
 #define CC_EMU 1  // selects the shuffle-based forms of the 16-lane group collectives (csrc/cc_group.h)
 #define CC_OPAQUE_I(x) asm volatile("" : "+r"(x))  // csrc/k_contours.h: the optimiser barrier, host constraint
-#include <pthread.h>
+#include <sys/mman.h>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -26,7 +30,7 @@ using std::isfinite;
 #define __forceinline__ inline
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define __restrict__ __restrict
 
 struct dim3 {
@@ -61,45 +65,73 @@ static inline float4 make_float4(float a, float b, float c, float d) { return {a
 static inline int2 make_int2(int a, int b) { return {a, b}; }
 
 namespace emu {
+// A cooperative barrier: the last fiber to arrive releases the others; a waiting fiber hands over to the scheduler and
+// looks again when it is resumed.
+struct CoBarrier {
+  int arrived = 0;
+  unsigned gen = 0;
+};
 struct WaveCtx {
-  pthread_barrier_t bar;
+  CoBarrier bar;
   unsigned long long scratch64[2][64];  // ping-pong: one barrier per collective is enough
-  pthread_barrier_t gbar[4];            // sub-wave collectives of width 16 (4 groups)
+  CoBarrier gbar[4];                    // sub-wave collectives of width 16 (4 groups)
   unsigned long long gscratch[2][64];
 };
-struct BlockCtx {
-  pthread_barrier_t bar;
-  std::vector<WaveCtx> waves;
-  char *dyn_smem = nullptr;
+struct Fiber {
+  void *sp = nullptr;  // saved stack pointer while the fiber is not running
+  dim3 tidx;
+  WaveCtx *wave = nullptr;
+  int lane = 0;
+  unsigned coll = 0, gcoll = 0;  // per-fiber count of wave / group collectives (selects the ping-pong buffer)
+  bool done = false;
 };
-extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+struct BlockCtx {
+  CoBarrier bar;
+  std::vector<WaveCtx> waves;
+  std::vector<Fiber> fibers;
+  char *dyn_smem = nullptr;
+  void (*run)(void *) = nullptr;  // the kernel call of this launch
+  void *arg = nullptr;
+  void *sched_sp = nullptr;       // the scheduler's saved stack pointer
+};
+extern thread_local dim3 t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockCtx *t_block;
-extern thread_local WaveCtx *t_wave;
-extern thread_local int t_lane;
-extern thread_local unsigned t_coll;  // per-thread count of wave collectives (selects the ping-pong buffer)
-extern thread_local unsigned t_gcoll; // same for the width-16 collectives
+extern thread_local Fiber *t_cur;
+extern "C" void emu_switch(void **save_sp, void *load_sp);  // emu_main.cpp: swap callee-saved registers and stacks
+
+static inline void yield() { emu_switch(&t_cur->sp, t_block->sched_sp); }
+static inline void co_wait(CoBarrier &b, int n) {
+  const unsigned my = b.gen;
+  if (++b.arrived == n) {
+    b.arrived = 0;
+    b.gen++;
+    return;
+  }
+  while (b.gen == my) yield();
+}
 }  // namespace emu
 
-#define threadIdx (emu::t_threadIdx)
+#define threadIdx (emu::t_cur->tidx)
 #define blockIdx (emu::t_blockIdx)
 #define blockDim (emu::t_blockDim)
 #define gridDim (emu::t_gridDim)
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)emu::t_block->dyn_smem;
 
-static inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
+static inline void __syncthreads() { emu::co_wait(emu::t_block->bar, (int)emu::t_blockDim.x); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-static inline int __lane_id() { return emu::t_lane; }
+static inline int __lane_id() { return emu::t_cur->lane; }
 static inline long long wall_clock64() { return 0; }
 
 // ---- cross-lane (wave = 64).  All 64 lanes of the wave must call these together. ----
 // A lane can only reach its (n+2)-th collective (which reuses buffer n%2) after passing the barrier of collective
 // n+1, i.e. after every lane has finished reading buffer n%2 -- so no second barrier is needed.
 static inline unsigned long long __ballot(int pred) {
-  emu::WaveCtx *w = emu::t_wave;
-  unsigned long long *buf = w->scratch64[emu::t_coll++ & 1];
-  buf[emu::t_lane] = pred ? 1ull : 0ull;
-  pthread_barrier_wait(&w->bar);
+  emu::Fiber *f = emu::t_cur;
+  emu::WaveCtx *w = f->wave;
+  unsigned long long *buf = w->scratch64[f->coll++ & 1];
+  buf[f->lane] = pred ? 1ull : 0ull;
+  emu::co_wait(w->bar, 64);
   unsigned long long m = 0;
   for (int i = 0; i < 64; i++) m |= (buf[i] & 1ull) << i;
   return m;
@@ -107,12 +139,13 @@ static inline unsigned long long __ballot(int pred) {
 template <typename T>
 static inline T emu_shfl_any(T v, int src) {
   static_assert(sizeof(T) <= 8, "shfl payload");
-  emu::WaveCtx *w = emu::t_wave;
-  unsigned long long *buf = w->scratch64[emu::t_coll++ & 1];
+  emu::Fiber *f = emu::t_cur;
+  emu::WaveCtx *w = f->wave;
+  unsigned long long *buf = w->scratch64[f->coll++ & 1];
   unsigned long long raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
-  buf[emu::t_lane] = raw;
-  pthread_barrier_wait(&w->bar);
+  buf[f->lane] = raw;
+  emu::co_wait(w->bar, 64);
   unsigned long long r = buf[src & 63];
   T out;
   std::memcpy(&out, &r, sizeof(T));
@@ -121,13 +154,14 @@ static inline T emu_shfl_any(T v, int src) {
 // width-16 variant: only the 16 lanes of the caller's group rendezvous (groups of one wave may diverge)
 template <typename T>
 static inline T emu_shfl_g16(T v, int src_in_group) {
-  emu::WaveCtx *w = emu::t_wave;
-  const int g = emu::t_lane >> 4;
-  unsigned long long *buf = w->gscratch[emu::t_gcoll++ & 1];
+  emu::Fiber *f = emu::t_cur;
+  emu::WaveCtx *w = f->wave;
+  const int g = f->lane >> 4;
+  unsigned long long *buf = w->gscratch[f->gcoll++ & 1];
   unsigned long long raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
-  buf[emu::t_lane] = raw;
-  pthread_barrier_wait(&w->gbar[g]);
+  buf[f->lane] = raw;
+  emu::co_wait(w->gbar[g], 16);
   unsigned long long r = buf[g * 16 + (src_in_group & 15)];
   T out;
   std::memcpy(&out, &r, sizeof(T));
@@ -146,19 +180,19 @@ static inline T __shfl(T v, int src, int width = 64) {
 }
 template <typename T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
-  const int rel = emu::t_lane & (width - 1);
+  const int rel = emu::t_cur->lane & (width - 1);
   const int src = rel + (int)delta;
   return emu_shfl_w(v, src < width ? src : rel, width);
 }
 template <typename T>
 static inline T __shfl_up(T v, unsigned delta, int width = 64) {
-  const int rel = emu::t_lane & (width - 1);
+  const int rel = emu::t_cur->lane & (width - 1);
   const int src = rel - (int)delta;
   return emu_shfl_w(v, src >= 0 ? src : rel, width);
 }
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
-  const int rel = emu::t_lane & (width - 1);
+  const int rel = emu::t_cur->lane & (width - 1);
   return emu_shfl_w(v, (rel ^ mask) & (width - 1), width);
 }
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
@@ -168,14 +202,15 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl_any(v,
 // D[row 4 (l >> 4) + r][column l & 15], r = 0..3: a k-ordered fmaf chain on top of C (cdna_hip_programming.md section 3)
 typedef float emu_f32x4 __attribute__((__vector_size__(16)));
 static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
-  emu::WaveCtx *w = emu::t_wave;
-  unsigned long long *buf = w->scratch64[emu::t_coll++ & 1];
+  emu::Fiber *f = emu::t_cur;
+  emu::WaveCtx *w = f->wave;
+  unsigned long long *buf = w->scratch64[f->coll++ & 1];
   unsigned ua, ub_;
   std::memcpy(&ua, &a, 4);
   std::memcpy(&ub_, &b, 4);
-  buf[emu::t_lane] = ((unsigned long long)ub_ << 32) | ua;
-  pthread_barrier_wait(&w->bar);
-  const int col = emu::t_lane & 15, rq = emu::t_lane >> 4;
+  buf[f->lane] = ((unsigned long long)ub_ << 32) | ua;
+  emu::co_wait(w->bar, 64);
+  const int col = f->lane & 15, rq = f->lane >> 4;
   emu_f32x4 d = c;
   for (int r = 0; r < 4; r++) {
     const int row = 4 * rq + r;
@@ -307,14 +342,10 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) emu::launch(kernel, (grid).x, (block).x, (size_t)(smem), __VA_ARGS__)
 
 namespace emu {
-// Run `kernel(args...)` over grid x block (1-D), one block at a time.
-template <typename K, typename... Args>
-void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args);
-}  // namespace emu
-namespace emu {
-// One set of `block` OS threads per launch, reused for every workgroup of the grid (workgroups run one after the other:
-// `__shared__` variables are function-local statics shared by all threads).  A thread that returns early from the kernel
-// simply waits at the end-of-workgroup barrier.
+extern "C" void emu_fiber_entry();  // emu_main.cpp
+// Run `kernel(args...)` over grid x block (1-D).  The workgroups are dealt out to a few OS threads; an OS thread runs one
+// workgroup at a time, its HIP threads as fibers on stacks of its own, scheduled round-robin: a fiber runs until it has to
+// wait at a barrier / collective, or returns from the kernel.
 template <typename K, typename... Args>
 void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... args) {
   if (block % 64 != 0) {
@@ -322,44 +353,75 @@ void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... ar
     abort();
   }
   if (grid == 0) return;
-  BlockCtx ctx;
-  pthread_barrier_init(&ctx.bar, nullptr, block);
-  ctx.waves.resize(block / 64);
-  for (auto &w : ctx.waves) {
-    pthread_barrier_init(&w.bar, nullptr, 64);
-    for (auto &g : w.gbar) pthread_barrier_init(&g, nullptr, 16);
-  }
-  pthread_barrier_t next_bar;  // between workgroups (separate from ctx.bar: a kernel may leave threads at different phases)
-  pthread_barrier_init(&next_bar, nullptr, block);
-  std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
-  ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
-  std::vector<std::thread> th;
-  th.reserve(block);
-  for (unsigned t = 0; t < block; t++) {
-    th.emplace_back([&, t]() {
-      t_threadIdx = dim3(t);
-      t_blockDim = dim3(block);
-      t_gridDim = dim3(grid);
-      t_block = &ctx;
-      t_wave = &ctx.waves[t / 64];
-      t_lane = t % 64;
-      for (unsigned b = 0; b < grid; b++) {
-        t_blockIdx = dim3(b);
-        t_coll = 0;
-        t_gcoll = 0;
-        kernel(args...);
-        pthread_barrier_wait(&next_bar);
-        if (t == 0 && dyn_smem) memset(ctx.dyn_smem, 0x5a, dyn_smem);
-        if (dyn_smem) pthread_barrier_wait(&next_bar);
+  auto call = [&]() { kernel(args...); };
+  using Call = decltype(call);
+  const size_t STK = 256 * 1024;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  if (const char *e = getenv("CC_EMU_THREADS")) hw = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : hw;
+  const unsigned nworkers = grid < hw ? grid : hw;
+  std::atomic<unsigned> next{0};
+  auto worker = [&]() {
+    BlockCtx ctx;
+    ctx.waves.resize(block / 64);
+    ctx.fibers.resize(block);
+    ctx.run = [](void *p) { (*(Call *)p)(); };
+    ctx.arg = (void *)&call;
+    char *stacks = (char *)mmap(nullptr, STK * block, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == (char *)MAP_FAILED) {
+      fprintf(stderr, "emu: cannot map fiber stacks\n");
+      abort();
+    }
+    std::vector<char> smem(dyn_smem + 64, 0x5a);  // poison: kernels must initialise their LDS
+    ctx.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+    t_block = &ctx;
+    t_blockDim = dim3(block);
+    t_gridDim = dim3(grid);
+    for (unsigned b = next.fetch_add(1); b < grid; b = next.fetch_add(1)) {
+      t_blockIdx = dim3(b);
+      if (dyn_smem) memset(ctx.dyn_smem, 0x5a, dyn_smem);
+      ctx.bar = CoBarrier();
+      for (auto &w : ctx.waves) {
+        w.bar = CoBarrier();
+        for (auto &g : w.gbar) g = CoBarrier();
       }
-    });
-  }
-  for (auto &x : th) x.join();
-  pthread_barrier_destroy(&ctx.bar);
-  pthread_barrier_destroy(&next_bar);
-  for (auto &w : ctx.waves) {
-    pthread_barrier_destroy(&w.bar);
-    for (auto &g : w.gbar) pthread_barrier_destroy(&g);
+      for (unsigned t = 0; t < block; t++) {
+        Fiber &f = ctx.fibers[t];
+        f.tidx = dim3(t);
+        f.wave = &ctx.waves[t / 64];
+        f.lane = (int)(t % 64);
+        f.coll = f.gcoll = 0;
+        f.done = false;
+        // initial frame: six callee-saved registers (zero) and the entry point as the return address; at the entry the
+        // stack pointer must be 8 modulo 16, as after a call
+        uintptr_t top = ((uintptr_t)(stacks + STK * (t + 1)) & ~(uintptr_t)15) - 8;
+        void **sp = (void **)top;
+        *--sp = (void *)emu_fiber_entry;
+        for (int r = 0; r < 6; r++) *--sp = nullptr;
+        f.sp = (void *)sp;
+      }
+      unsigned live = block;
+      while (live) {
+        for (unsigned t = 0; t < block; t++) {
+          Fiber &f = ctx.fibers[t];
+          if (f.done) continue;
+          t_cur = &f;
+          emu_switch(&ctx.sched_sp, f.sp);
+          if (f.done) live--;
+        }
+      }
+    }
+    t_cur = nullptr;
+    t_block = nullptr;
+    munmap(stacks, STK * block);
+  };
+  if (nworkers <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    th.reserve(nworkers);
+    for (unsigned i = 0; i < nworkers; i++) th.emplace_back(worker);
+    for (auto &x : th) x.join();
   }
 }
 }  // namespace emu
