@@ -453,7 +453,8 @@ def main():
                     out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 8, 2, P)[0]
                     # SURVEY.md 8(d)'s value distributions on a drive with a realistic revisit rate (the KITTI-shaped town)
                     out["extra"]["db_5k_kitti_shaped"] = measure_config(cc, ctx, dev, cc.synth.World(kitti=True), 5000, B, 16, 2, P,
-                                                                         kernels=True, workload="kitti")[0]
+                                                                         kernels=True, workload="kitti",
+                                                                         cpu_sample=0 if (args.no_cpu or args.cpu_sample <= 0) else 96)[0]
                 except Exception as e:
                     out["extra"]["other_configs_error"] = repr(e)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
@@ -806,15 +807,18 @@ def roofline_object(alg, split, kms, kms_iso, B, n_db, workload, ms_per_step, P)
             "ingest_roofline_scans_per_s": HBM_PEAK_GBS * 1e9 / (P * 16)}
 
 
-def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=None, kernels=False, workload=None):
+def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=None, kernels=False, workload=None, cpu_sample=0):
     """A short run of the headline step on another configuration (world, DB size), same pipeline as the headline: ingest of
     batch s + 1 on its own stream while batch s is queried (cc_db_query_submit), every result collected inside the timed
     region.  `rec` = packed records of a DB built earlier whose first n_db scans are used.  Returns (figures, records)."""
     import torch
     HB, FB = cc.packed_sizes()
+    desc_keep = None
     if rec is None or rec.shape[0] < n_db:
         rec = torch.empty((n_db, HB + FB), dtype=torch.uint8, device=dev)
         tmp = torch.empty((256, cc.DESC_BYTES), dtype=torch.uint8, device=dev)
+        if cpu_sample:   # the CPU leg rebuilds its DB from the scans' descriptors
+            desc_keep = torch.empty((n_db, cc.DESC_BYTES), dtype=torch.uint8, device="cpu")
         for c0 in range(0, n_db, 256):
             c1 = min(c0 + 256, n_db)
             x, _, _ = cc.synth.make_sequence(c1 - c0, world=wld, device=dev, start=c0)
@@ -822,6 +826,8 @@ def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=No
             hot, feat = ctx.pack(d)
             rec[c0:c1, :HB] = hot
             rec[c0:c1, HB:] = feat
+            if desc_keep is not None:
+                desc_keep[c0:c1].copy_(d)
     db = cc.Database(ctx, capacity=n_db + 16)
     db.add_packed(rec[:n_db, :HB].contiguous(), rec[:n_db, HB:].contiguous(), np.arange(n_db) / 10.0, np.arange(n_db, dtype=np.int32))
     q0 = n_db if first_query is None else first_query
@@ -889,6 +895,15 @@ def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=No
         out["knn_hits_per_query_mean"] = round(float(np.mean([r["n_knn_hits"].mean() for r in res])), 1)
         out["correlation_problems_per_query_mean"] = round(float(np.mean([r["n_cand_tidy"].mean() for r in res])), 2)
     db.close()
+    if cpu_sample and desc_keep is not None:
+        # the oracle on the SAME workload (same DB, the first cpu_sample scans of the first timed batch), one thread like the
+        # reference: what north_star's "x times the CPU path on KITTI-08-shaped input" is measured against
+        try:
+            cb = cpu_baseline(cc, desc_keep.numpy(), n_db, batches[W], P, cpu_sample, all_cores=False)
+            out["cpu_baseline"] = cb
+            out["gpu_over_one_cpu_core"] = out["scans_per_s"] / cb["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     return out, rec
 
 
@@ -1042,7 +1057,7 @@ def _cpu_worker(shm_dir, wid, n_workers, n_db, P, n_q_total, repeats, barrier, o
     out_q.put((wid, done, t0, time.perf_counter()))
 
 
-def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q):
+def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q, all_cores=True):
     """The reference's single-threaded code path on the CPU restatement (oracle/, kd-tree = the reference's vendored
     nanoflann when oracle/_ref is built) on the SAME workload.  The DB is rebuilt on the CPU side from the descriptors of
     the DB scans (untimed: addScan + pushAndBalance per scan); then the first n_q scans of the first timed batch go
@@ -1092,6 +1107,8 @@ def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q):
                                 "L2 opt": tq["L2 opt"] / n_q, "Update database (outside `value`, like the GPU step)": t_upd / n_q},
            "online_loop_scans_per_s": n_q / (dt + t_upd),
            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
+    if not all_cores:
+        return out
     # ---- measured all-cores figure: N independent single-threaded copies on disjoint scans
     try:
         import multiprocessing as mp
