@@ -642,17 +642,23 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
     __syncthreads();
   }
-  // size sort, bigger first (contour_mng.h:596-599): one lane per level replays libstdc++ std::sort
-  {
-    const int lane_l = (nt >= 64 * CC_NLEV) ? ((tid & 63) == 0 ? (tid >> 6) : -1) : (tid < CC_NLEV ? tid : -1);
-    if (lane_l >= 0 && lane_l < CC_NLEV) {
-      unsigned *a = arr + lane_l * CC_NC;
-      ccsort::std_sort(a, CC_NLEV_AT(lane_l), [](unsigned x, unsigned y) { return (x >> 16) > (y >> 16); },
-                       (unsigned *)R2 + lane_l * CC_SORT_STACK);  // R2 is unused until the keys phase
-      int tot = 0;
-      for (int i = 0; i < CC_NLEV_AT(lane_l); i++) tot += (int)(a[i] >> 16);
-      sh2[lane_l] = tot;
-    }
+  // size sort, bigger first (contour_mng.h:596-599): libstdc++'s std::sort replayed by one WAVE per level (round 3: one
+  // lane per level, ~40 of a KITTI-shaped scan's 440 us): parallel partitions + stable rank, cc_sort.h.  The rank keys of
+  // the insertion order (skey) are dead by now: their rows hold the partitions' stopper lists, then the ranked copy.
+  for (int l = wave_id; l < CC_NLEV; l += n_waves) {
+    unsigned *a = arr + l * CC_NC;
+    const int n = CC_NLEV_AT(l);
+    unsigned short *lpos = (unsigned short *)(skey + l * CC_NC), *rasc = lpos + CC_NC;
+    ccsort::std_sort_wave(
+        a, n, [](unsigned x) { return 0xFFFFu - (x >> 16); },
+        [&]() {
+          for (int k = lane; k < n; k += 64) a[T[l * CC_NC + k].rank] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+        },
+        lane, lpos, rasc, skey + l * CC_NC, (unsigned *)R2 + l * CC_SORT_STACK);
+    int tot = 0;
+    for (int i = lane; i < n; i += 64) tot += (int)(a[i] >> 16);
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) sh2[l] = tot;
   }
   __syncthreads();
   CC_K2_STAMP(5);

@@ -45,7 +45,27 @@ extern "C" void emu_fiber_entry() {
   abort();  // a finished fiber is never resumed
 }
 
+// the wave-parallel std::sort replay (cc_sort.h: std_sort_wave) on one array, as K2's size sort uses it
+__global__ void emu_k_sort_wave(unsigned *arr, const unsigned *pristine, int n) {
+  __shared__ unsigned a[4096];
+  __shared__ unsigned short st[2 * 4096];
+  __shared__ unsigned seg[CC_SORT_STACK];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n; i += 64) a[i] = pristine[i];
+  ccsort::std_sort_wave(
+      a, n, [](unsigned x) { return 0xFFFFu - (x >> 16); },
+      [&]() {
+        for (int i = lane; i < n; i += 64) a[i] = pristine[i];
+      },
+      lane, st, st + 4096, (unsigned *)st, seg);
+  for (int i = lane; i < n; i += 64) arr[i] = a[i];
+}
+
 extern "C" {
+void emu_sort_desc_wave(unsigned *arr, int n) {
+  std::vector<unsigned> in(arr, arr + n);
+  hipLaunchKernelGGL(emu_k_sort_wave, dim3(1), dim3(64), 0, nullptr, arr, (const unsigned *)in.data(), n);
+}
 // unit hooks for the std::sort replica and the 2x2 eigen solver
 void emu_sort_desc(unsigned *arr, int n) {
   ccsort::std_sort(arr, n, [](unsigned x, unsigned y) { return (x >> 16) > (y >> 16); });

@@ -41,3 +41,39 @@ def test_float_asc_sort(oracle):
         arr["idx"] = np.arange(n)
         lib.emu_sort_asc_f(arr.ctypes.data_as(C.c_void_p), n)
         assert np.array_equal(arr["idx"], perm)
+
+
+def _killer(n):
+    """A sequence on which median-of-3 quicksort degenerates (Musser's construction), so that introsort's depth limit is
+    reached and the heapsort branch runs: the wave replay must hand such input to the serial replica."""
+    k = n // 2
+    a = np.zeros(n, np.int32)
+    for i in range(1, k + 1):
+        if i % 2 == 1:
+            a[i - 1] = i
+            a[i] = k + i
+        a[k + i - 1] = 2 * i
+    return a
+
+
+def test_wave_parallel_replay_matches_std_sort(oracle):
+    """std_sort_wave (one wave per array: parallel Hoare partitions + stable rank; K2's size sort) against the real
+    std::sort: random tie-heavy inputs of every length class, sorted / reversed / all-equal inputs, and inputs that drive
+    introsort into its heapsort branch."""
+    lib = C.CDLL(emu_api.build())
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 128, 129, 257, 320, 1000]:
+        for hi in (2, 5, 40, 5000):
+            cases.append(rng.integers(3, 3 + hi, n).astype(np.int32))
+    for n in (17, 33, 200, 320):
+        cases += [np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32)[::-1].copy(), np.full(n, 7, np.int32)]
+    for n in (64, 200, 320, 2000):
+        cases.append(_killer(n))
+        cases.append(-_killer(n) + 5000)
+    for keys in cases:
+        n = len(keys)
+        perm = oracle.sort_desc_perm(keys)
+        arr = ((keys.astype(np.uint32) << 16) | np.arange(n, dtype=np.uint32)).copy()
+        lib.emu_sort_desc_wave(arr.ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(arr & 0xFFFF, perm), (n, keys[:8])
