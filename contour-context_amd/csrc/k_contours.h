@@ -892,49 +892,59 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   // RelativePoint records would.
   unsigned *bkey = (unsigned *)(R + 0);                            // [36][40] (T is dead now)
   int *bcnt = (int *)(R + 5760);                                   // [36] points per anchor
-  // one lane per anchor, the anchors dealt out over the waves (anchor a -> wave a % n_waves, lane a / n_waves): the
-  // lane-serial sort replay diverges between lanes, so the fewer anchors share a wave the less each waits for the others
-  if (lane * n_waves + wave_id < NA && lane < (NA + n_waves - 1) / n_waves) {
-    const int a = lane * n_waves + wave_id;
-    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-    unsigned *p = bkey + a * CC_BCI_MAXPTS;
-    int n = 0;
-    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-    for (int q = 0; q < CC_BCI_MAXPTS; q++) {
-      const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
-      if (!o.ok) continue;
-      p[n++] = ((unsigned)o.bit << 8) | (unsigned)q;
-      const unsigned long long m = 1ull << (o.bit & 63);
-      const int w = o.bit >> 6;
-      b0 |= w == 0 ? m : 0ull;
-      b1 |= w == 1 ? m : 0ull;
-      b2 |= w == 2 ? m : 0ull;
-      b3 |= w == 3 ? m : 0ull;
+  // One WAVE per anchor (round 3: one lane per anchor, a lane-serial gather + sort replay + segment scan of dependent LDS
+  // reads, 26 us per scan whatever the scan): the <= 40 candidate neighbours sit one per lane, the valid ones are compacted
+  // with a ballot (slot order, as the serial loop appended them), sorted by the wave-parallel std::sort replay (cc_sort.h),
+  // segment starts found with a ballot.  Per-wave scratch behind the key tables in R2 (divs 5040 B + 3 x 36 ints end at 5488).
+  {
+    char *ws = R2 + 5504 + wave_id * 448;
+    unsigned short *lpos = (unsigned short *)ws, *rasc = lpos + CC_BCI_MAXPTS;   // 2 x 80 B
+    unsigned *tmp = (unsigned *)(ws + 160);                                        // 160 B
+    unsigned *seg = (unsigned *)(ws + 320);                                        // CC_SORT_STACK words = 104 B
+    static_assert(320 + CC_SORT_STACK * 4 <= 448 && CC_BCI_MAXPTS <= 64, "per-wave BCI scratch");
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int a = wave_id; a < NA; a += n_waves) {
+      const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+      unsigned *p = bkey + a * CC_BCI_MAXPTS;
+      bci_tmp o;
+      o.ok = 0;
+      o.bit = 0;
+      if (lane < CC_BCI_MAXPTS) o = btmp[a * CC_BCI_MAXPTS + lane];
+      const unsigned long long mok = __ballot(o.ok != 0);
+      const int n = __popcll(mok);
+      auto gather = [&]() {
+        if (o.ok) p[__popcll(mok & lt)] = ((unsigned)o.bit << 8) | (unsigned)lane;
+      };
+      gather();
+      // the 256-bit ring: word w = OR of the valid lanes' bits of that word
+      unsigned long long bw[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        unsigned long long v = (o.ok && (o.bit >> 6) == w) ? (1ull << (o.bit & 63)) : 0ull;
+        for (int sh_ = 32; sh_ > 0; sh_ >>= 1) v |= __shfl_xor(v, sh_);
+        bw[w] = v;
+      }
+      ccsort::std_sort_wave(p, n, [](unsigned x) { return x >> 8; }, gather, lane, lpos, rasc, tmp, seg);
+      cc_bci_t *ob = &desc->bcis[ll][seq];
+      // segment starts: positions where bit_pos changes, then n (contour_mng.h:871-883)
+      const bool head = lane < n && (lane == 0 || (p[lane] >> 8) != (p[lane - 1] >> 8));
+      const unsigned long long mh = __ballot(head);
+      const int nh = __popcll(mh), ns = n > 0 ? nh + 1 : 0;
+      if (head) ob->segs[__popcll(mh & lt)] = (uint16_t)lane;
+      if (lane == 0 && n > 0) ob->segs[nh] = (uint16_t)n;
+      if (lane >= ns && lane < CC_BCI_MAXPTS + 2) ob->segs[lane] = 0;
+      if (lane == 0) {
+        bcnt[a] = n;
+        ob->dist_bin[0] = bw[0];
+        ob->dist_bin[1] = bw[1];
+        ob->dist_bin[2] = bw[2];
+        ob->dist_bin[3] = bw[3];
+        ob->piv_seq = (int8_t)seq;
+        ob->level = (int8_t)ll;
+        ob->n_pts = (uint8_t)n;
+        ob->n_segs = (uint8_t)ns;
+      }
     }
-    // pending-halves stack of the sort replay: behind the key tables in R2 (divs 5040 B + 3 x 36 ints end at 5488)
-    ccsort::std_sort(p, n, [](unsigned x, unsigned y) { return (x >> 8) < (y >> 8); }, (unsigned *)(R2 + 5504) + a * CC_SORT_STACK);
-    bcnt[a] = n;
-    cc_bci_t *ob = &desc->bcis[ll][seq];
-    ob->dist_bin[0] = b0;
-    ob->dist_bin[1] = b1;
-    ob->dist_bin[2] = b2;
-    ob->dist_bin[3] = b3;
-    ob->piv_seq = (int8_t)seq;
-    ob->level = (int8_t)ll;
-    ob->n_pts = (uint8_t)n;
-    int ns = 0;
-    if (n > 0) {
-      ob->segs[ns++] = 0;
-      unsigned last = p[0] >> 8;
-      for (int i = 0; i < n; i++)
-        if (last != (p[i] >> 8)) {
-          ob->segs[ns++] = (uint16_t)i;
-          last = p[i] >> 8;
-        }
-      ob->segs[ns++] = (uint16_t)n;
-    }
-    ob->n_segs = (uint8_t)ns;
-    for (int i = ns; i < CC_BCI_MAXPTS + 2; i++) ob->segs[i] = 0;
   }
   __syncthreads();
   // the point records, all threads
