@@ -16,6 +16,9 @@ if [ "$2" != "quick" ]; then
   timeout 600 python bench.py --no-cpu --no-extra --db-scans 20000 --steps 8 --warmup 2 2> $OUT/bench_db20k.err | grep '^{' > $OUT/bench_line_db20k.json
   timeout 600 python bench.py --no-cpu --no-extra --workload dense --steps 6 --warmup 2 2> $OUT/bench_dense.err | grep '^{' > $OUT/bench_line_dense.json
   timeout 600 python bench.py --no-cpu --no-extra --workload kitti --steps 16 --warmup 2 2> $OUT/bench_kitti.err | grep '^{' > $OUT/bench_line_kitti.json
+  # a long timed region (100 steps = 102 400 scans, ~0.23 s): the figure that does not depend on where eight steps happen to end
+  timeout 600 python bench.py --no-cpu --no-extra --steps 100 --warmup 4 2> $OUT/bench_steps100.err | grep '^{' > $OUT/bench_line_steps100.json
+  timeout 600 python bench.py --no-cpu --no-extra --workload kitti --steps 100 --warmup 4 2> $OUT/bench_kitti100.err | grep '^{' > $OUT/bench_line_kitti_steps100.json
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5
   timeout 600 rocprofv3 --kernel-include-regex "cc_k_" --kernel-trace --stats --output-format csv -d /tmp/p1 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra 2> $OUT/prof_trace.err | grep '^{' > $OUT/bench_line_under_rocprof.json
