@@ -52,14 +52,42 @@ struct cc_gmm_feat {
   cc_ell ell[CC_GMM_LEVELS][CC_GMM_ECAP_L];
 };
 
-// grid = n scans, block = 64
-__global__ void __launch_bounds__(64)
+// One term of the auto-correlation sum (correlation.h:102-119): ellipses a, b of one level.
+__device__ __forceinline__ double cc_gmm_self_term(const cc_ell &a, const cc_ell &b) {
+  const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
+  const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
+  const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
+  const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
+  const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
+  const double h0 = -0.5 * mx, h1 = -0.5 * my;
+  const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
+  return (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+}
+
+// grid = n scans, block = CC_GMM_PREP_BLOCK (four waves per scan).
+// The auto-correlation term sums n^2 ordered pairs per level; a street scene has n ~ 140 on the low levels (80 000 f64
+// exp / sqrt / divisions per scan: on one wave that was a third of K2's own time on the KITTI-shaped workload).  Three facts
+// take most of it away without touching the value beyond the rounding of the sum:
+//   * term(i, j) == term(j, i) bit for bit (the sums of the covariances commute, the centre difference changes sign and
+//     enters twice): the upper triangle is evaluated, off-diagonal terms count twice (an exact doubling);
+//   * a term is at most exp(x) times the sum's own diagonal terms (prefactor <= geometric mean of the two self terms, by
+//     Minkowski's determinant inequality), x <= -|m|^2 / (2 tr N) for a positive definite N: pairs with |m|^2 > 200 tr N
+//     (x < -100, e^-100 = 4e-44) cannot reach the last bit of an f64 sum and are dropped by an f32 test -- only where N is
+//     safely positive definite in f32 (det > 1e-4 tr^2); degenerate ellipses go the exact way and keep whatever the reference
+//     makes of them;
+//   * the pairs that stay (a fifth on street scenes) are queued per wave in LDS and evaluated 64 at a time, so the f64
+//     code runs on full waves.
+#define CC_GMM_PREP_BLOCK 256
+__global__ void __launch_bounds__(CC_GMM_PREP_BLOCK)
 cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__restrict__ feat) {
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = CC_GMM_PREP_BLOCK / 64;
   if ((int)blockIdx.x >= n) return;
   const cc_scan_desc_t *d = desc + blockIdx.x;
   cc_gmm_feat *F = feat + blockIdx.x;
   __shared__ cc_ell E[CC_GMM_ECAP_L];
+  __shared__ unsigned s_q[NW][128];  // per wave: pairs waiting for the exact evaluation, (i << 16) | j, a ring
+  __shared__ double s_part[NW];
   int flags = 0;
   double acc = 0;
   for (int li = 0; li < CC_GMM_LEVELS; li++) {
@@ -67,6 +95,7 @@ cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__res
     const int full = d->layer_cell_cnt[lev];
     const int ncont = d->n_cont[lev], nst = d->n_stored[lev];
     // contours in sorted order until >= 95 % of the level's cells: contour j is used iff the cells before it are < 95 %
+    // (every wave works this out for itself: the same few loads, no hand-over)
     int n_use = 0, run = 0;
     for (int j0 = 0; j0 < ncont; j0 += 64) {
       const int j = j0 + lane;
@@ -89,8 +118,8 @@ cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__res
       n_use = CC_GMM_ECAP_L;
       flags |= 1;
     }
-    __syncthreads();
-    for (int j = lane; j < n_use; j += 64) {
+    __syncthreads();  // the previous level's reads of E are done
+    for (int j = tid; j < n_use; j += CC_GMM_PREP_BLOCK) {
       const cc_contour_t &cv = d->cont[lev][j];
       // getManualCov (contour.h:376-378) in f32; the reference then casts to double
       const float v00 = cv.eig_vecs[0], v10 = cv.eig_vecs[1], v01 = cv.eig_vecs[2], v11 = cv.eig_vecs[3];
@@ -109,23 +138,63 @@ cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__res
       F->ell[li][j] = e;
     }
     __syncthreads();
-    for (int idx = lane; idx < n_use * n_use; idx += 64) {
-      const int i = idx / n_use, j = idx - i * n_use;
-      const cc_ell a = E[i], b = E[j];
-      const double n00 = 2.0 * ((double)a.c00 + (double)b.c00), n01 = 2.0 * ((double)a.c01 + (double)b.c01);
-      const double n10 = 2.0 * ((double)a.c10 + (double)b.c10), n11 = 2.0 * ((double)a.c11 + (double)b.c11);
-      const double mx = (double)a.mx - (double)b.mx, my = (double)a.my - (double)b.my;
-      const double det = n00 * n11 - n10 * n01, invdet = 1.0 / det;
-      const double i00 = n11 * invdet, i10 = -n10 * invdet, i01 = -n01 * invdet, i11 = n00 * invdet;
-      const double h0 = -0.5 * mx, h1 = -0.5 * my;
-      const double r0 = h0 * i00 + h1 * i10, r1 = h0 * i01 + h1 * i11;
-      acc += (double)a.w * (double)b.w / sqrt(det) * exp(r0 * mx + r1 * my);
+    // upper triangle as a rectangle: rows r and n - 1 - r together hold n + 1 entries (j >= i)
+    const int nrow = (n_use + 1) >> 1, wid = n_use + 1, tot = nrow * wid;
+    int qh = 0, qn = 0;  // this wave's ring: head, entries (wave-uniform)
+    for (int i0 = wave * 64; i0 < tot; i0 += CC_GMM_PREP_BLOCK) {
+      const int idx = i0 + lane;
+      bool go = false;
+      int i = 0, j = 0;
+      if (idx < tot) {
+        const int r = idx / wid, c = idx - r * wid;
+        if (c < n_use - r) {
+          i = r;
+          j = r + c;
+          go = true;
+        } else if (n_use - 1 - r != r) {  // the middle row of an odd n has no partner
+          i = n_use - 1 - r;
+          j = i + (c - (n_use - r));
+          go = true;
+        }
+      }
+      if (go) {
+        const cc_ell a = E[i], b = E[j];
+        const float dx = a.mx - b.mx, dy = a.my - b.my;
+        const float t00 = a.c00 + b.c00, t11 = a.c11 + b.c11, t01 = a.c01 + b.c01, t10 = a.c10 + b.c10;
+        const float tr = t00 + t11, det = t00 * t11 - t01 * t10;  // of N / 2
+        // |m|^2 > 200 tr N = 400 tr(N / 2); NaN anywhere fails the comparisons and keeps the pair
+        if (dx * dx + dy * dy > 400.f * tr && det > 1e-4f * tr * tr) go = false;
+      }
+      const unsigned long long m = __ballot(go);
+      if (go) s_q[wave][(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & 127] = ((unsigned)i << 16) | (unsigned)j;
+      qn += __popcll(m);
+      cc_wave_sync();
+      if (qn >= 64) {
+        const unsigned e = s_q[wave][(qh + lane) & 127];
+        const int ei = (int)(e >> 16), ej = (int)(e & 0xFFFFu);
+        const double t = cc_gmm_self_term(E[ei], E[ej]);
+        acc += ei == ej ? t : 2.0 * t;
+        qh = (qh + 64) & 127;
+        qn -= 64;
+        cc_wave_sync();
+      }
     }
-    if (lane == 0) F->n_ell[li] = n_use;
+    if (lane < qn) {
+      const unsigned e = s_q[wave][(qh + lane) & 127];
+      const int ei = (int)(e >> 16), ej = (int)(e & 0xFFFFu);
+      const double t = cc_gmm_self_term(E[ei], E[ej]);
+      acc += ei == ej ? t : 2.0 * t;
+    }
+    cc_wave_sync();
+    if (tid == 0) F->n_ell[li] = n_use;
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) {
-    F->ac = acc;
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int w = 0; w < NW; w++) t += s_part[w];
+    F->ac = t;
     F->flags = flags;
   }
 }

@@ -71,3 +71,35 @@ def test_kernels_on_the_cpu_harness_match_the_kitti_shaped_record(oracle):
     out = api.db_query(db, desc[qs], qs)
     for k, qi in enumerate(qs):
         _same_result(res[qi], out[k], 1e-6)
+
+
+def test_auto_correlation_term_against_the_full_double_sum(oracle):
+    """cc_k_gmm_prep evaluates the upper triangle of the self term and drops far pairs by an f32 bound (k_gmm.h): the value
+    must equal the reference's full ordered double sum (correlation.h:102-119), here in numpy on the record's own ellipses,
+    to the rounding of an f64 sum."""
+    L = oracle.L
+    desc = _load(L)[0]
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=2)
+    _, feat = api.pack(ctx, desc[:6])
+    ecap = (feat.shape[1] - 40) // (4 * 32)   # cc_gmm_feat: n_ell[4], flags, pad[3], ac, ell[4][ecap] of 32 B
+    for k in range(len(feat)):
+        raw = feat[k].tobytes()
+        n_ell = np.frombuffer(raw, np.int32, 4, 0)
+        ac = np.frombuffer(raw, np.float64, 1, 32)[0]
+        ell = np.frombuffer(raw, np.float32, 4 * ecap * 8, 40).reshape(4, ecap, 8).astype(np.float64)
+        tot = 0.0
+        far = 0
+        for li in range(4):
+            e = ell[li, :n_ell[li]]
+            n00 = 2 * (e[:, None, 0] + e[None, :, 0]); n01 = 2 * (e[:, None, 1] + e[None, :, 1])
+            n10 = 2 * (e[:, None, 2] + e[None, :, 2]); n11 = 2 * (e[:, None, 3] + e[None, :, 3])
+            mx = e[:, None, 4] - e[None, :, 4]; my = e[:, None, 5] - e[None, :, 5]
+            det = n00 * n11 - n10 * n01
+            i00, i10, i01, i11 = n11 / det, -n10 / det, -n01 / det, n00 / det
+            r0 = -0.5 * mx * i00 - 0.5 * my * i10; r1 = -0.5 * mx * i01 - 0.5 * my * i11
+            x = r0 * mx + r1 * my
+            far += int((x < -100).sum())
+            tot += float((e[:, None, 6] * e[None, :, 6] / np.sqrt(det) * np.exp(x)).sum())
+        assert n_ell[:3].min() > 60 and far > 1000          # street-scene sized tables, and the far-pair bound has work to do
+        assert abs(ac - tot) <= 1e-13 * abs(tot), (k, ac, tot)
