@@ -955,6 +955,9 @@ def dropin_loop(batch0, P, n):
                 out["scans_per_s"] = n / float(p[3])
         if "seconds_per_call" in out:
             out["ms_per_scan_three_calls"] = 1e3 * sum(out["seconds_per_call"].values())
+        for line in r.stderr.splitlines():
+            if line.startswith("[evaluator helper"):     # CC_EVAL_TIMERS=1: what the prefetch thread spent per scan
+                out["helper_thread"] = line
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/cont2_amd.h"
@@ -68,7 +69,9 @@ struct cc_ctx {
   bool has_last = false;
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   // the per-scan loop (cc_scan_*): own stream, pinned + device point staging, a pool of device descriptor slots
-  hipStream_t s_loop = nullptr;
+  hipStream_t s_loop = nullptr;       // per-scan loop: descriptor fetches, cc_db_query_scan / cc_db_add_scan
+  hipStream_t s_ing = nullptr;        // per-scan loop: cc_scan_ingest (copy of the points, K1, K2); a scan's `ready` event is recorded here
+  std::mutex slot_mu;                 // slot_free: cc_scan_ingest may run on a helper thread next to cc_scan_offload / cc_scan_release
   // per-scan loop: two pinned staging buffers (the caller may fill the second one -- e.g. read the next scan's file from
   // another thread -- while the first one's scan is in flight), one device point buffer (the stream orders its reuse)
   float *h_pts[2] = {nullptr, nullptr}, *d_pts = nullptr;
@@ -266,6 +269,10 @@ int cc_destroy(cc_ctx *c) {
   }
   if (c->ev_last) hipEventDestroy(c->ev_last);
   hipFree(c->d_phase_clk);
+  if (c->s_ing) {
+    hipStreamSynchronize(c->s_ing);
+    hipStreamDestroy(c->s_ing);
+  }
   if (c->s_loop) {
     hipStreamSynchronize(c->s_loop);
     hipStreamDestroy(c->s_loop);
@@ -421,16 +428,18 @@ struct cc_scan {
   cc_ctx *ctx = nullptr;
   cc_scan_desc_t *d_desc = nullptr;  // device slot (nullptr once offloaded)
   cc_scan_desc_t *h_desc = nullptr;  // host copy (malloc), fetched on demand
+  hipEvent_t ready = nullptr;        // recorded on the ingest stream behind the scan's last kernel / copy
   float *h_bev = nullptr;            // host copy of the max-height image, if it was asked for
   bool bev_pending = false;
 };
 
 static int loop_reserve_points(cc_ctx *c, int64_t n_points) {
   if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
+  if (!c->s_ing) HIPCHK(hipStreamCreateWithFlags(&c->s_ing, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++)
     if (!c->pts_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[i], hipEventDisableTiming));
   if (n_points <= c->pts_cap) return CC_OK;
-  HIPCHK(hipStreamSynchronize(c->s_loop));
+  HIPCHK(hipStreamSynchronize(c->s_ing));
   for (int i = 0; i < 2; i++) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
     c->h_pts[i] = nullptr;
@@ -471,48 +480,80 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
   } else if (n_points > c->pts_cap) {
     return set_err(CC_EINVAL, "cc_scan_ingest: more points than were staged");
   }
-  if (c->slot_free.empty()) {
-    const int nblk = 64;
-    cc_scan_desc_t *blk = nullptr;
-    HIPCHK(hipMalloc(&blk, sizeof(cc_scan_desc_t) * nblk));
-    c->slot_blocks.push_back(blk);
-    for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
-  }
   if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
-  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts[slot], sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_loop));
-  HIPCHK(hipEventRecord(c->pts_ev[slot], c->s_loop));
+  // Everything of the ingest goes to its own stream: a caller may ingest scan i + 1 (from a helper thread, as the evaluator
+  // mirror does) while scan i is queried and added on the loop stream; whoever reads the descriptor waits for `ready`.
+  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts[slot], sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_ing));
+  HIPCHK(hipEventRecord(c->pts_ev[slot], c->s_ing));
   c->pts_busy[slot] = true;
   cc_scan *sc = new cc_scan();  // from here on every failure path gives the handle (and, once taken, the descriptor slot) back
   sc->ctx = c;
-  sc->d_desc = c->slot_free.back();
+  {
+    std::lock_guard<std::mutex> lk(c->slot_mu);
+    if (c->slot_free.empty()) {
+      const int nblk = 64;
+      cc_scan_desc_t *blk = nullptr;
+      const hipError_t e_ = hipMalloc(&blk, sizeof(cc_scan_desc_t) * nblk);
+      if (e_ != hipSuccess) {
+        delete sc;
+        return set_err(CC_EHIP, "cc_scan_ingest: descriptor slots", e_);
+      }
+      c->slot_blocks.push_back(blk);
+      for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
+    }
+    sc->d_desc = c->slot_free.back();
+    c->slot_free.pop_back();
+  }
+  auto give_back = [&](void) {
+    {
+      std::lock_guard<std::mutex> lk(c->slot_mu);
+      c->slot_free.push_back(sc->d_desc);
+    }
+    if (sc->ready) hipEventDestroy(sc->ready);
+    free(sc->h_bev);
+    delete sc;
+  };
   const int64_t off[2] = {0, n_points};
   cc_ingest_debug_t dbg;
   dbg.d_bev = want_bev ? c->d_loop_bev : nullptr;
   dbg.d_pix_rc = nullptr;
   dbg.d_labels = nullptr;
-  const int rc = cc_ingest_batch(c, c->d_pts, off, 1, sc->d_desc, want_bev ? &dbg : nullptr, c->s_loop);
+  const int rc = cc_ingest_batch(c, c->d_pts, off, 1, sc->d_desc, want_bev ? &dbg : nullptr, c->s_ing);
   if (rc != CC_OK) {
-    delete sc;
+    give_back();
     return rc;
   }
-  c->slot_free.pop_back();
   if (want_bev) {  // the image scratch is shared: bring it over now (asynchronously, into the handle's own buffer)
     sc->h_bev = (float *)malloc(sizeof(float) * (size_t)c->dcfg.n_cell);
     if (!sc->h_bev) {
-      c->slot_free.push_back(sc->d_desc);
-      delete sc;
+      give_back();
       return set_err(CC_ENOMEM, "cc_scan_ingest: out of host memory");
     }
-    const hipError_t e_ = hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_loop);
+    const hipError_t e_ = hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_ing);
     if (e_ != hipSuccess) {
-      c->slot_free.push_back(sc->d_desc);
-      free(sc->h_bev);
-      delete sc;
+      give_back();
       return set_err(CC_EHIP, "cc_scan_ingest: copy of the BEV image", e_);
     }
     sc->bev_pending = true;
   }
+  hipError_t e_ = hipEventCreateWithFlags(&sc->ready, hipEventDisableTiming);
+  if (e_ == hipSuccess) e_ = hipEventRecord(sc->ready, c->s_ing);
+  if (e_ != hipSuccess) {
+    hipStreamSynchronize(c->s_ing);  // the queued kernels write the slot
+    give_back();
+    return set_err(CC_EHIP, "cc_scan_ingest: ready event", e_);
+  }
   *out = sc;
+  return CC_OK;
+}
+
+// the loop stream (or the host) behind the scan's ingest
+static int scan_wait_ready(cc_scan *sc, bool host) {
+  if (!sc->ready) return CC_OK;
+  if (host)
+    HIPCHK(hipEventSynchronize(sc->ready));
+  else
+    HIPCHK(hipStreamWaitEvent(sc->ctx->s_loop, sc->ready, 0));
   return CC_OK;
 }
 
@@ -522,9 +563,11 @@ static int scan_fetch(cc_scan *sc) {
   sc->h_desc = (cc_scan_desc_t *)malloc(sizeof(cc_scan_desc_t));
   if (!sc->h_desc) return set_err(CC_ENOMEM, "cc_scan: out of host memory");
   HIPCHK(hipSetDevice(sc->ctx->device));
+  const int rcw = scan_wait_ready(sc, false);
+  if (rcw != CC_OK) return rcw;
   HIPCHK(hipMemcpyAsync(sc->h_desc, sc->d_desc, sizeof(cc_scan_desc_t), hipMemcpyDeviceToHost, sc->ctx->s_loop));
   HIPCHK(hipStreamSynchronize(sc->ctx->s_loop));
-  sc->bev_pending = false;
+  sc->bev_pending = false;  // the image copy was queued before `ready`
   return CC_OK;
 }
 
@@ -544,7 +587,8 @@ int cc_scan_bev(cc_scan *sc, const float **h_bev) {
   if (!sc->h_bev) return set_err(CC_EINVAL, "cc_scan_bev: the image was not asked for at cc_scan_ingest");
   if (sc->bev_pending) {
     HIPCHK(hipSetDevice(sc->ctx->device));
-    HIPCHK(hipStreamSynchronize(sc->ctx->s_loop));
+    const int rcw = scan_wait_ready(sc, true);
+    if (rcw != CC_OK) return rcw;
     sc->bev_pending = false;
   }
   *h_bev = sc->h_bev;
@@ -556,7 +600,10 @@ int cc_scan_offload(cc_scan *sc) {
   if (!sc->d_desc) return CC_OK;
   const int rc = scan_fetch(sc);
   if (rc != CC_OK) return rc;
-  sc->ctx->slot_free.push_back(sc->d_desc);  // reuse is ordered behind everything queued on the loop stream so far
+  {  // the fetch above synchronised the loop stream: nothing queued reads the slot any more
+    std::lock_guard<std::mutex> lk(sc->ctx->slot_mu);
+    sc->ctx->slot_free.push_back(sc->d_desc);
+  }
   sc->d_desc = nullptr;
   return CC_OK;
 }
@@ -567,9 +614,14 @@ int cc_scan_release(cc_scan *sc) {
   if (!sc) return CC_OK;
   if (sc->d_desc || sc->bev_pending) {
     hipSetDevice(sc->ctx->device);
-    if (sc->ctx->s_loop) hipStreamSynchronize(sc->ctx->s_loop);  // queued work may still read the slot / write the image
-    if (sc->d_desc) sc->ctx->slot_free.push_back(sc->d_desc);
+    if (sc->ready) hipEventSynchronize(sc->ready);               // the ingest may still write the slot / the image
+    if (sc->ctx->s_loop) hipStreamSynchronize(sc->ctx->s_loop);  // queued work may still read the slot
+    if (sc->d_desc) {
+      std::lock_guard<std::mutex> lk(sc->ctx->slot_mu);
+      sc->ctx->slot_free.push_back(sc->d_desc);
+    }
   }
+  if (sc->ready) hipEventDestroy(sc->ready);
   free(sc->h_desc);
   free(sc->h_bev);
   delete sc;

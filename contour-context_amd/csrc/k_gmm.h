@@ -1249,7 +1249,8 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
 __global__ void __launch_bounds__(64)
 cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
            const cc_gmm_result *__restrict__ gres, const int *__restrict__ pass_cnt, const int *__restrict__ hit_cnt,
-           const cc_hot_desc_t *__restrict__ qhot, cc_query_result_t *__restrict__ out, const unsigned short *__restrict__ perm_tab) {
+           const cc_hot_desc_t *__restrict__ qhot, cc_query_result_t *__restrict__ out, const unsigned short *__restrict__ perm_tab,
+           const int *__restrict__ nprob /*the chunk's problem counters and pool head*/, int *__restrict__ nprob_host /*or nullptr: copy them there*/) {
   // one wave per query: lanes fetch the per-candidate inputs and order the candidates in parallel (cc_tidy_order), lane 0
   // replays the short order-dependent rest on LDS
   __shared__ unsigned short idx[CC_MAXCAND];
@@ -1261,6 +1262,7 @@ cc_k_final(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restric
   __shared__ unsigned stk[CC_SORT_STACK];
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
+  if (nprob_host && q == 0 && lane < 4) nprob_host[lane] = nprob[lane];  // small chunks: no copy command behind the chain
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
   const int nc = qstate[q].n_cand;
   // what lane 0 needs of the query's counters, fetched up front (every load it would issue later is a round trip)

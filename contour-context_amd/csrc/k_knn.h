@@ -205,10 +205,25 @@ struct cc_kappend_params {
   int n_old[CC_NQLEV];
   int q_levels[CC_NQLEV];
   int cap_k;
+  // small appends only (else act_first[CC_NQLEV] == 0): the changed tails of the layers' activation arrays ride along --
+  // tail l = ent[act_src[l] .. act_src[l] + (act_first[l + 1] - act_first[l])) goes to act_dst[l][..]
+  int *act_dst[CC_NQLEV];
+  int act_src[CC_NQLEV];
+  int act_first[CC_NQLEV + 1];
 };
+// grid = ceil(max(entries, tail ints) / 256), block = 256.  `ent` is the append's staging buffer: device memory, or (small
+// appends) the pinned host buffer itself -- a few hundred bytes are not worth a copy command in front of the kernel.
 __global__ void __launch_bounds__(256)
 cc_k_keys_append(cc_kappend_params P, const cc_hot_desc_t *__restrict__ hot, const int *__restrict__ ent) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < P.act_first[CC_NQLEV]) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < CC_NQLEV; i++)
+      if (t >= P.act_first[i]) l = i;
+    const int j = t - P.act_first[l];
+    P.act_dst[l][j] = ent[P.act_src[l] + j];
+  }
   if (t >= P.first[CC_NQLEV]) return;
   int l = 0;
 #pragma unroll

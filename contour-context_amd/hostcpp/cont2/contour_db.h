@@ -1,6 +1,9 @@
 // Host mirror of include/cont2/contour_db.h (ContourDB, configs, CandidateScoreEnsemble) and of the two
 // ConstellCorrelation statics the drivers call (include/cont2/correlation.h:241-296), on top of the C-ABI.
 #pragma once
+#include <algorithm>
+#include <deque>
+
 #include "../tools/bm_util.h"
 #include "contour_mng.h"
 
@@ -141,19 +144,35 @@ class ContourDB {
       fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
       abort();
     }
-    // the DB keeps its own compact records of the scan: the descriptor moves to the host (the getters keep working) and its
-    // device slot goes back to the context's pool
-    if (h && cc_scan_offload(h) != CC_OK) {
-      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
-      abort();
+    // The DB keeps its own compact records of the scan.  The full descriptor (169 KB) stays in its device slot for now: its
+    // host copy is fetched when a getter first asks for it, and moving every scan to the host right here cost the loop a
+    // 169 KB copy + a stream synchronisation per scan.  Only the most recent residentScans() descriptors stay (1.4 GB at
+    // the default 8 192 -- a KITTI sequence fits); beyond that the oldest one moves to the host and its slot is reused.
+    if (h) on_device_.push_back(pending_);
+    while (on_device_.size() > residentScans()) {
+      cc_scan *old = on_device_.front()->scanHandle();
+      if (old && cc_scan_offload(old) != CC_OK) {
+        fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+        abort();
+      }
+      on_device_.pop_front();
     }
     all_bevs_.push_back(pending_);
     pending_.reset();
+  }
+  // how many added scans keep their full descriptor on the device (env CC_SCANS_ON_DEVICE; 0: none, as before round 4)
+  static size_t residentScans() {
+    static const size_t n = [] {
+      const char *e = getenv("CC_SCANS_ON_DEVICE");
+      return e ? (size_t)std::max(0L, atol(e)) : (size_t)8192;
+    }();
+    return n;
   }
 
  private:
   std::shared_ptr<ContourManager> pending_;
   double pending_ts_ = 0;
+  std::deque<std::shared_ptr<ContourManager>> on_device_;  // added scans whose descriptor still sits in a device slot, oldest first
 };
 
 // contour_db.h:264-656, the hint-driven use of CandidateManager (the single-pair flow of test/kitti_read_bin_test.cpp:226-291):

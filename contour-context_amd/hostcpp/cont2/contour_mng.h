@@ -250,6 +250,15 @@ class ContourManager {
     if (cc_scan_ingest(ctx, staged, (int64_t)n, want_images_ ? 1 : 0, &scan_) != CC_OK) die();
     str_id_ = std::move(str_id);
   }
+  // Mirror-only: a scan that was ingested ahead of time (cc_scan_ingest on the evaluator's helper thread, with
+  // want_bev = keepImages() at that moment); the handle is owned from here on.
+  void adoptIngested(cc_scan *scan, bool with_images, std::string str_id) {
+    CC_CHECK(scan);
+    CC_CHECK(!scan_);
+    scan_ = scan;
+    want_images_ = with_images;
+    str_id_ = std::move(str_id);
+  }
   // the context the scans of this configuration are ingested on (one per ContourManagerConfig)
   static cc_ctx *contextOf(const ContourManagerConfig &config) { return cc_host::context(cc_host::to_c(config)); }
 

@@ -12,6 +12,10 @@
 #include <iostream>
 #include <numeric>
 #include <sstream>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 
@@ -72,13 +76,31 @@ class ContLCDEvaluator {
   const double min_time_excl = 15.0;  // revisits younger than 15 s are not loops
   const double sim_thres;             // similarity at or above which a prediction counts as positive
   int p_lidar_curr = -1;
-  struct Prefetch {  // the next scan's file on its way into a staging buffer (getCurrContourManager)
+  // The scans ahead of the driver's position on their way: file -> pinned staging buffer -> device (getCurrContourManager).
+  // One helper thread for the evaluator's lifetime runs up to AHEAD scans ahead of the scan the driver holds; what it has
+  // finished waits in `ready`, in address order.
+  struct Prefetch {
+    static constexpr int AHEAD = 2;  // = the context's staging buffers (cc_stage_points_slot: scan `addr` goes through slot addr & 1)
+    struct Item {
+      int addr = -1;
+      size_t n = 0;
+      bool opened = false;
+      cc_scan *scan = nullptr;  // ingested ahead of time (nullptr: file missing, fewer than 11 points, or the ingest failed: `err`)
+      std::string err;
+    };
     std::thread th;
-    int addr = -1, slot = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    // all below: under `mu`
+    bool busy = false, quit = false;
+    int next = -1, limit = -1;  // the helper fetches address `next` while next < limit
     cc_ctx *ctx = nullptr;
-    float *buf = nullptr;
-    size_t n = 0;
-    bool opened = false;
+    bool with_images = false;
+    std::deque<Item> ready;
+    double t_stage = 0, t_read = 0, t_ingest = 0;  // helper seconds (CC_EVAL_TIMERS=1 prints them when the evaluator goes)
+    long n_done = 0;
+    double t_wait = 0, t_call = 0;  // driver thread: waiting for the helper's item / the whole getCurrContourManager call
+    long n_call = 0;
   };
   mutable Prefetch pf_;
   SimpleRMSE<2> tp_trans_rmse, all_trans_rmse;
@@ -186,28 +208,56 @@ class ContLCDEvaluator {
 
   // read the current scan's .bin (x,y,z,i f32; tools/pointcloud_util.h:9-47) and build its descriptor on the device.
   // readKITTIPointCloudBin + makeBEV in one step: the records go straight to one of the context's two pinned staging
-  // buffers.  While this scan is ingested and queried, a helper thread reads the NEXT scan's file into the other buffer
-  // (plain fopen / fread, no device call), so that the next call finds its points staged -- the driver's loop
-  // (test/batch_bin_test.cpp:131-237) is unchanged.
+  // buffers.  While this scan is queried and added, a helper thread reads the NEXT scans' files (plain fopen / fread) and
+  // queues their ingest on the context's ingest stream (cc_scan_ingest: copy of the points, rasterisation, contours --
+  // nothing of it is observable before the call that hands the scan out), so that the next call finds its descriptor on
+  // the way or done -- the driver's loop (test/batch_bin_test.cpp:131-237) is unchanged.
   std::shared_ptr<ContourManager> getCurrContourManager(const ContourManagerConfig &config) const {
+    const auto tc0 = std::chrono::steady_clock::now();
     const LaserScanInfo &info = getCurrScanInfo();
     std::shared_ptr<ContourManager> cm(new ContourManager(config, info.seq));
     std::string str_id = std::to_string(info.seq);
     str_id = "assigned_id_" + std::string(8 - str_id.length(), '0') + str_id;
-    cc_ctx *ctx = ContourManager::contextOf(config);
+    cc_ctx *ctx = ContourManager::contextOf(config);  // the first call creates the context (~60 ms, once)
     const size_t cap = 1000000 / 4;  // readKITTIPointCloudBin reads at most 1 000 000 floats
-    size_t n = 0;
-    const float *pts = nullptr;
-    if (pf_.th.joinable()) pf_.th.join();
-    if (pf_.addr == p_lidar_curr && pf_.ctx == ctx && pf_.buf) {  // staged ahead of time
-      if (!pf_.opened) {
-        printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
-        exit(-1);
+    const bool with_images = ContourManager::keepImages();
+    const int n_scans = (int)laser_info_.size();
+    bool adopted = false;
+    {
+      std::unique_lock<std::mutex> lk(pf_.mu);
+      // is this scan among the ones the helper has fetched or is fetching (in order, same context, same image switch)?
+      const bool coming = pf_.ctx == ctx && pf_.with_images == with_images && pf_.next >= 0 &&
+                          ((!pf_.ready.empty() && pf_.ready.front().addr == p_lidar_curr) ||
+                           (pf_.ready.empty() && pf_.next == p_lidar_curr && pf_.next < pf_.limit));
+      if (coming) {
+        const auto tw0 = std::chrono::steady_clock::now();
+        pf_.cv.wait(lk, [this] { return !pf_.ready.empty(); });
+        pf_.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        Prefetch::Item it = std::move(pf_.ready.front());
+        pf_.ready.pop_front();
+        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+        lk.unlock();
+        pf_.cv.notify_all();
+        if (!it.opened) {
+          printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
+          exit(-1);
+        }
+        CC_CHECK(it.n > 10);
+        if (!it.scan) {
+          fprintf(stderr, "cont2_amd: %s\n", it.err.c_str());
+          abort();
+        }
+        cm->adoptIngested(it.scan, with_images, str_id);
+        adopted = true;
+      } else {  // first scan, a jump, another configuration: the helper is parked and what it fetched is dropped
+        pf_.next = -1;
+        pf_.cv.wait(lk, [this] { return !pf_.busy; });
+        for (auto &it : pf_.ready)
+          if (it.scan) cc_scan_release(it.scan);
+        pf_.ready.clear();
       }
-      n = pf_.n;
-      pts = pf_.buf;
-    } else {
-      pf_.slot = 0;
+    }
+    if (!adopted) {
       float *dst = cc_stage_points_slot(ctx, (int64_t)cap, 0);
       CC_CHECK(dst);
       FILE *f = fopen(info.fpath.c_str(), "rb");
@@ -215,36 +265,95 @@ class ContLCDEvaluator {
         printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
         exit(-1);
       }
-      n = fread(dst, 4 * sizeof(float), cap, f);
+      const size_t n = fread(dst, 4 * sizeof(float), cap, f);
       fclose(f);
-      pts = dst;
+      cm->makeBEVFromStaged(dst, n, str_id);
+      {
+        std::lock_guard<std::mutex> lk(pf_.mu);
+        pf_.ctx = ctx;
+        pf_.with_images = with_images;
+        pf_.next = p_lidar_curr + 1;
+        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+      }
+      if (!pf_.th.joinable()) pf_.th = std::thread([this, cap] { prefetchLoop(cap); });
+      pf_.cv.notify_all();
     }
-    cm->makeBEVFromStaged(pts, n, str_id);
     cm->makeContoursRecurs();
-    pf_.addr = -1;
-    if (p_lidar_curr + 1 < (int)laser_info_.size()) {  // the next scan's file into the other buffer, behind the scenes
-      const int slot = pf_.slot ^ 1;
-      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, slot);  // waits for that buffer's last copy only
-      CC_CHECK(dst);
-      pf_.slot = slot;
-      pf_.addr = p_lidar_curr + 1;
-      pf_.ctx = ctx;
-      pf_.buf = dst;
-      const std::string path = laser_info_[p_lidar_curr + 1].fpath;
-      Prefetch *pf = &pf_;
-      pf_.th = std::thread([pf, path, dst, cap]() {
-        FILE *f = fopen(path.c_str(), "rb");
-        pf->opened = f != nullptr;
-        pf->n = f ? fread(dst, 4 * sizeof(float), cap, f) : 0;
-        if (f) fclose(f);
-      });
-    }
+    pf_.t_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+    pf_.n_call++;
     return cm;
   }
   ~ContLCDEvaluator() {
-    if (pf_.th.joinable()) pf_.th.join();
+    if (pf_.th.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(pf_.mu);
+        pf_.quit = true;
+      }
+      pf_.cv.notify_all();
+      pf_.th.join();
+    }
+    for (auto &it : pf_.ready)
+      if (it.scan) cc_scan_release(it.scan);
+    if (getenv("CC_EVAL_TIMERS") && pf_.n_done > 0)
+      fprintf(stderr, "[evaluator helper, mean us over %ld scans] staging buffer %.1f  file read %.1f  cc_scan_ingest %.1f | driver thread: wait for the helper %.1f of %.1f per getCurrContourManager (the first call creates the context)\n",
+              pf_.n_done, 1e6 * pf_.t_stage / pf_.n_done, 1e6 * pf_.t_read / pf_.n_done, 1e6 * pf_.t_ingest / pf_.n_done,
+              1e6 * pf_.t_wait / std::max(1L, pf_.n_call), 1e6 * pf_.t_call / std::max(1L, pf_.n_call));
   }
 
+ private:
+  void prefetchLoop(size_t cap) const {
+    Prefetch &pf = pf_;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(pf.mu);
+      pf.cv.wait(lk, [&pf] { return pf.quit || (pf.next >= 0 && pf.next < pf.limit && (int)pf.ready.size() < Prefetch::AHEAD); });
+      if (pf.quit) return;
+      Prefetch::Item it;
+      it.addr = pf.next;
+      cc_ctx *ctx = pf.ctx;
+      const bool with_images = pf.with_images;
+      pf.busy = true;
+      lk.unlock();
+      // the slot's previous occupant is scan addr - 2: its copy to the device was queued long ago and is waited for here
+      const auto t0 = std::chrono::steady_clock::now();
+      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, it.addr & 1);
+      const auto t1 = std::chrono::steady_clock::now();
+      auto t2 = t1, t3 = t1;
+      if (!dst) {
+        it.opened = true;
+        it.n = 11;
+        it.err = cc_last_error();  // the message is per thread
+      } else {
+        FILE *f = fopen(laser_info_[it.addr].fpath.c_str(), "rb");
+        it.opened = f != nullptr;
+        it.n = f ? fread(dst, 4 * sizeof(float), cap, f) : 0;
+        if (f) fclose(f);
+        t2 = std::chrono::steady_clock::now();
+        if (it.n > 10 && cc_scan_ingest(ctx, dst, (int64_t)it.n, with_images ? 1 : 0, &it.scan) != CC_OK) {
+          it.scan = nullptr;
+          it.err = cc_last_error();
+        }
+        t3 = std::chrono::steady_clock::now();
+      }
+      lk.lock();
+      pf.t_stage += std::chrono::duration<double>(t1 - t0).count();
+      pf.t_read += std::chrono::duration<double>(t2 - t1).count();
+      pf.t_ingest += std::chrono::duration<double>(t3 - t2).count();
+      pf.n_done++;
+      pf.busy = false;
+      if (pf.next == it.addr) {  // still wanted (the driver did not jump meanwhile)
+        pf.ready.push_back(std::move(it));
+        pf.next++;
+      } else if (it.scan) {
+        lk.unlock();
+        cc_scan_release(it.scan);
+        lk.lock();
+      }
+      lk.unlock();
+      pf.cv.notify_all();
+    }
+  }
+
+ public:
   // judge one query: `cand_mng` is the proposed loop candidate (nullptr: none), T_est_delta_2d its BEV-frame transform
   PredictionOutcome addPrediction(const std::shared_ptr<const ContourManager> &q_mng, double est_corr,
                                   const std::shared_ptr<const ContourManager> &cand_mng = nullptr,

@@ -74,3 +74,25 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
     timing = (proj / "log" / "timing_cont2.txt").read_text()
     for name in ("make bev", "KNN search", "Constell", "L2 opt", "Update database", "queryRangedKNN (wall)"):
         assert name in timing, timing
+
+
+def test_evaluator_read_ahead_paths_give_the_same_descriptors(cc, tmp_path):
+    """hostcpp/eval/evaluator.h reads and ingests up to two scans ahead on a helper thread; a scan asked for twice, or with
+    the image switch flipped in between, goes the direct way -- same descriptors either way (tests/evaluator_prefetch_check.cpp)."""
+    emu_so = emu_api.build()
+    exe = str(tmp_path / "prefetch_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "evaluator_prefetch_check.cpp"), "-I", os.path.join(PKG, "hostcpp"),
+                           "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so),
+                           "-pthread", "-o", exe])
+    n = 9
+    x, poses, ts = cc.synth.make_sequence(n, world=cc.synth.World(loop_len=40.0), beams=16, azim=450)
+    xs = x.numpy()
+    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
+    with open(lst, "w") as f, open(pos, "w") as g:
+        for i in range(n):
+            p = tmp_path / ("%06d.bin" % i)
+            xs[i].astype(np.float32).tofile(p)
+            f.write("%.6f %d %s\n" % (ts[i], i, p))
+            g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
+    out = subprocess.run([exe, str(pos), str(lst)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and ("OK %d" % n) in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
