@@ -269,22 +269,28 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
 /* ---- the per-scan loop (test/batch_bin_test.cpp:131-237 at sensor rate) ----
  * A cc_scan is ONE scan's descriptor kept on the device between ContourManager::makeContoursRecurs (contour_mng.h:588),
  * ContourDB::queryRangedKNN (contour_db.h:698) and ContourDB::addScan (:814): the class mirror's ContourManager holds one.
- * Nothing is allocated per scan: the context owns a pinned staging buffer for the points, a device point buffer and a pool
- * of descriptor slots; the calls only queue work on the context's own stream, the host copy of the descriptor (and of the
- * max-height image, if asked for) is fetched when a getter needs it.
+ * Nothing is allocated per scan: the context owns pinned staging buffers for the points, a device point buffer and a pool
+ * of descriptor slots; the calls only queue work, the host copy of the descriptor (and of the max-height image, if asked
+ * for) is fetched when a getter needs it.  TWO streams: cc_scan_ingest queues on the context's ingest stream and records
+ * the scan's `ready` event behind its last kernel; cc_scan_desc / cc_scan_offload / cc_db_query_scan / cc_db_add_scan work on
+ * the loop stream, which waits for `ready` first.  So scan i + 1 (and i + 2) can be ingested while scan i is queried and
+ * added -- also from ANOTHER host thread: ONE thread at a time may be inside cc_stage_points* / cc_scan_ingest, next to
+ * one thread in the other cc_scan_* / cc_db_* calls (the slot pool is locked, cc_last_error is per thread).  The class
+ * mirror's evaluator does exactly that (hostcpp/eval/evaluator.h: a helper thread reads the next files and ingests them).
  *   cc_stage_points  : pinned buffer for n_points x (x,y,z,i) f32, valid until the next cc_scan_ingest (write the points
  *                      there to save a host copy), NULL on failure.  cc_stage_points_slot: the same for slot 0 or 1 -- two
- *                      buffers, so that the next scan's file can be read (by another host thread; no cc_* call from it)
- *                      into one while the other's scan is on its way to the device; a slot is handed out again once ITS last
- *                      copy has passed (readKITTIPointCloudBin of scan i+1 next to queryRangedKNN of scan i,
- *                      tools/pointcloud_util.h:9-47, evaluator.h:285-302)
- *   cc_scan_ingest   : makeBEV + makeContoursRecurs for the points at h_xyzi (may be the staging pointer); want_bev != 0
- *                      keeps the max-height image for cc_scan_bev.  Returns at once (work is queued).
+ *                      buffers, so that the next scan's file can be read into one while the other's scan is on its way to
+ *                      the device; a slot is handed out again once ITS last copy has passed (readKITTIPointCloudBin of scan
+ *                      i+1 next to queryRangedKNN of scan i, tools/pointcloud_util.h:9-47, evaluator.h:285-302).  Asking
+ *                      for more points than the buffers hold re-allocates BOTH slots (after the ingest stream has drained)
+ *   cc_scan_ingest   : makeBEV + makeContoursRecurs for the points at h_xyzi (may be a staging pointer); want_bev != 0
+ *                      keeps the max-height image for cc_scan_bev.  Returns at once (work is queued on the ingest stream).
  *   cc_scan_desc     : host copy of the descriptor (first call: one D2H copy + sync); CC_ECAPACITY if the scan exceeded a
  *                      capacity of the contour kernel (flags CC_DESC_INEXACT_*), the copy is delivered all the same
- *   cc_scan_offload  : move the descriptor to the host and give the device slot back (the mirror does this once the scan
- *                      is in the DB, which keeps its own compact records); cc_scan_desc keeps working
- *   cc_scan_release  : free the handle */
+ *   cc_scan_offload  : move the descriptor to the host and give the device slot back; cc_scan_desc keeps working.  (The
+ *                      mirror keeps the descriptors of the last CC_SCANS_ON_DEVICE = 8 192 added scans on the device --
+ *                      169 KB each -- and offloads the oldest beyond that: a copy + sync per scan the loop does not need)
+ *   cc_scan_release  : free the handle (waits for the scan's ingest and for queued readers of its slot) */
 typedef struct cc_scan cc_scan;
 float *cc_stage_points(cc_ctx *ctx, int64_t n_points);
 float *cc_stage_points_slot(cc_ctx *ctx, int64_t n_points, int slot);
