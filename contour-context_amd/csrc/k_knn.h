@@ -508,23 +508,132 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
 // one wave scoring four neighbouring searches against each 64-key step -- lived here; measured at the 50 000-scan DB it
 // was written for it gained nothing (148.1 k vs 147.5 k scans/s, profiles/r3/d_knn_shared_walk_50k.txt) and was removed.)
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_ORDER_CAP 4096  // searches of one layer in a chunk (QB * CC_NPIV = 3072), padded to a power of two
+#define CC_KNN_ORDER_CAP 8192  // searches of one layer in a chunk (QB * CC_NPIV = 6144), padded to a power of two
 #define CC_KNN_ORDER_GROUP 16  // searches per group of the tiled search (= CC_KNN_TQ)
+#define CC_KNN_ORDER_LDS (12 * CC_KNN_ORDER_CAP)  // dynamic LDS of cc_k_knn_order: three 4-byte arrays per search
 
-// block-wide inclusive scan of n_pow2 ints in LDS (Hillis-Steele, ping-pong between a and b); returns the buffer holding the result
-template <bool MAX>
-__device__ __forceinline__ int *cc_block_scan(int *a, int *b, int n_pow2, int tid, int nt) {
-  for (int o = 1; o < n_pow2; o <<= 1) {
-    for (int i = tid; i < n_pow2; i += nt) {
-      const int x = a[i], y = i >= o ? a[i - o] : (MAX ? 0 : 0);
-      b[i] = i >= o ? (MAX ? (x > y ? x : y) : x + y) : x;
+// Ascending bitonic sort of 1024 * R 32-bit keys by a workgroup of 1024 threads, R keys per lane in registers: position
+// P = (wave * R + a) * 64 + lane lives in v[a].  Partners inside a lane are register moves, inside a wave shuffles; only
+// the log2(16) * (log2(16) + 1) / 2 = 10 stages whose partner sits in another wave go through LDS (xch, 1024 * R words) --
+// a sort of 8 192 keys with every stage in LDS (91 barriers over 64 KB) took 0.5 ms on the three workgroups this kernel
+// has, longer than the search it prepares.
+template <int R>
+__device__ __forceinline__ void cc_block_bitonic_u32(unsigned (&v)[R], unsigned *xch, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int N = 1024 * R;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * R) {  // partner in another wave
+#pragma unroll
+        for (int a = 0; a < R; a++) xch[(wave * R + a) * 64 + lane] = v[a];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+          const int P = (wave * R + a) * 64 + lane;
+          const unsigned o = xch[P ^ j];
+          const bool up = (P & k) == 0, lower = (P & j) == 0;
+          const unsigned mn = o < v[a] ? o : v[a], mx = o < v[a] ? v[a] : o;
+          v[a] = (lower == up) ? mn : mx;
+        }
+        __syncthreads();
+      } else if (j >= 64) {  // partner in the same lane
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+          const int b = a ^ (j >> 6);
+          if (b > a) {
+            const bool up = (((wave * R + a) * 64) & k) == 0;
+            const unsigned x = v[a], y = v[b];
+            const bool sw = (x > y) == up;
+            v[a] = sw ? y : x;
+            v[b] = sw ? x : y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+          const unsigned o = (unsigned)__shfl_xor((int)v[a], j);
+          const bool up = ((((wave * R + a) * 64 + lane) & k) == 0);
+          const bool lower = (lane & j) == 0;
+          const unsigned mn = o < v[a] ? o : v[a], mx = o < v[a] ? v[a] : o;
+          v[a] = (lower == up) ? mn : mx;
+        }
+      }
     }
-    __syncthreads();
-    int *t = a;
-    a = b;
-    b = t;
   }
-  return a;
+}
+
+// sort key of a search: (quantised log of key[0]) << 13 | search index; the top bits are the geometric bucket (ratio 1.04)
+#define CC_KNN_ORD_IDX_BITS 13
+#define CC_KNN_ORD_SUB_BITS 6
+static_assert((1 << CC_KNN_ORD_IDX_BITS) >= CC_KNN_ORDER_CAP, "search index bits of the order key");
+__device__ __forceinline__ unsigned cc_knn_order_key(float q0, int i) {
+  // floor(log2(q0) * 17.673 * 64) + 177 * 64: >= 0 for q0 >= 1e-3, < 2^19 for any float
+  int ql = (int)floorf(log2f(q0 > 1e-3f ? q0 : 1e-3f) * (17.673f * (1 << CC_KNN_ORD_SUB_BITS))) + (177 << CC_KNN_ORD_SUB_BITS);
+  ql = ql < 0 ? 0 : (ql > (1 << 18) ? (1 << 18) : ql);
+  return ((unsigned)ql << CC_KNN_ORD_IDX_BITS) | (unsigned)i;
+}
+template <int R>
+__device__ __forceinline__ void cc_knn_order_sort(const cc_knn_params &P, const cc_hot_desc_t *__restrict__ qhot, int ns, int ll, int level,
+                                                  int *__restrict__ hit_cnt, unsigned *sk, int tid, int *nv) {
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned v[R];
+  int mine = 0;
+#pragma unroll
+  for (int a = 0; a < R; a++) {
+    const int i = (wave * R + a) * 64 + lane;
+    v[a] = 0xFFFFFFFFu;
+    if (i < ns) {
+      const int q = i / CC_NPIV, seq = i - q * CC_NPIV;
+      const float *qk = &qhot[q].keys[level - 1][seq][0];
+      float sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < CC_KEY_DIM; d++) sum += qk[d];
+      if (sum != 0.f && P.n_sorted[ll] > 0) {
+        v[a] = cc_knn_order_key(qk[0], i);
+        mine++;
+      } else {
+        hit_cnt[q * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq] = 0;
+      }
+    }
+  }
+  if (mine) atomicAdd(nv, mine);
+  cc_block_bitonic_u32<R>(v, sk, tid);
+#pragma unroll
+  for (int a = 0; a < R; a++) sk[(wave * R + a) * 64 + lane] = v[a];
+  __syncthreads();
+}
+
+// block-wide inclusive scan (sum, or running maximum; values >= 0) of n_pow2 ints in LDS, in place: every thread takes a
+// stretch of consecutive entries, the stretches' totals are scanned inside the waves and across them.  block = 1024.
+template <bool MAX>
+__device__ __forceinline__ void cc_block_scan(int *a, int n_pow2, int tid, int *wsum /*[16]*/) {
+  const int E = n_pow2 >= 1024 ? n_pow2 / 1024 : 1;
+  const int base = tid * E, lane = tid & 63, wave = tid >> 6;
+  int run = 0;
+  if (base < n_pow2)
+    for (int e = 0; e < E; e++) {
+      const int v = a[base + e];
+      run = MAX ? (v > run ? v : run) : run + v;
+      a[base + e] = run;
+    }
+  int incl = run;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl = MAX ? (v > incl ? v : incl) : incl + v;
+  }
+  int excl = __shfl_up(incl, 1);  // of the lanes before this one
+  if (lane == 0) excl = 0;
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  for (int w = 0; w < wave; w++) excl = MAX ? (wsum[w] > excl ? wsum[w] : excl) : excl + wsum[w];
+  if (base < n_pow2)
+    for (int e = 0; e < E; e++) {
+      const int v = a[base + e];
+      a[base + e] = MAX ? (v > excl ? v : excl) : v + excl;
+    }
+  __syncthreads();
 }
 
 // Layout of the per-chunk order buffer (ints): per layer the searches in key[0] order, the group starts of the tiled search,
@@ -542,10 +651,12 @@ __device__ __forceinline__ int *cc_block_scan(int *a, int *b, int n_pow2, int ti
 // sixteen would span a multiple of a window): gstart[ll][g] .. gstart[ll][g + 1] are group g's positions in `order`.
 __global__ void __launch_bounds__(1024)
 cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, int *__restrict__ ord, int *__restrict__ hit_cnt) {
-  __shared__ unsigned long long a[CC_KNN_ORDER_CAP];
-  __shared__ int sa[CC_KNN_ORDER_CAP];
+  HIP_DYNAMIC_SHARED(char, smem)  // CC_KNN_ORDER_LDS bytes
+  unsigned *sk = (unsigned *)smem;                       // [CC_KNN_ORDER_CAP] sort exchange, then the sorted keys
+  int *sa = (int *)(smem + 4 * CC_KNN_ORDER_CAP);         // [CC_KNN_ORDER_CAP]
+  int *fl = (int *)(smem + 8 * CC_KNN_ORDER_CAP);         // [CC_KNN_ORDER_CAP]
   __shared__ int nv;
-  int *sb_ = (int *)a;  // second scan buffer: the sort keys are dead by then
+  __shared__ int wsum[16];
   const int ll = blockIdx.x, tid = threadIdx.x;
   const int level = P.q_levels[ll];
   const int ns = nq * CC_NPIV;
@@ -557,51 +668,38 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
       hit_cnt[q * (CC_NQLEV * CC_NPIV) + P.n_q_levels * CC_NPIV + r] = 0;
     }
   __syncthreads();
-  int np2 = 64;  // sort width: the chunk's searches of this layer, padded to a power of two
-  while (np2 < ns) np2 <<= 1;
-  int mine = 0;
-  for (int i = tid; i < np2; i += 1024) {
-    unsigned long long v = ~0ull;
-    if (i < ns) {
-      const int q = i / CC_NPIV, seq = i - q * CC_NPIV;
-      const float *qk = &qhot[q].keys[level - 1][seq][0];
-      float sum = 0.f;
-#pragma unroll
-      for (int d = 0; d < CC_KEY_DIM; d++) sum += qk[d];
-      if (sum != 0.f && P.n_sorted[ll] > 0) {
-        v = ((unsigned long long)cc_fkey(qk[0]) << 32) | (unsigned)i;
-        mine++;
-      } else {
-        hit_cnt[q * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq] = 0;
-      }
-    }
-    a[i] = v;
+  // the chunk's searches of this layer by (key[0], search), padded to the sort's width
+  int np2;
+  if (ns <= 1024) {
+    np2 = 1024;
+    cc_knn_order_sort<1>(P, qhot, ns, ll, level, hit_cnt, sk, tid, &nv);
+  } else if (ns <= 4096) {
+    np2 = 4096;
+    cc_knn_order_sort<4>(P, qhot, ns, ll, level, hit_cnt, sk, tid, &nv);
+  } else {
+    np2 = 8192;
+    cc_knn_order_sort<8>(P, qhot, ns, ll, level, hit_cnt, sk, tid, &nv);
   }
-  if (mine) atomicAdd(&nv, mine);
-  __syncthreads();
-  cc_bitonic_sort_u64(a, np2, tid, 1024);
   const int nvl = nv;
-  for (int i = tid; i < nvl; i += 1024) order[i] = (int)(a[i] & 0xFFFFFFFFu);
+  for (int i = tid; i < nvl; i += 1024) order[i] = (int)(sk[i] & ((1u << CC_KNN_ORD_IDX_BITS) - 1u));
   // groups: geometric key[0] buckets of ratio 1.04, each cut into runs of 16
   for (int i = tid; i < np2; i += 1024) {
     int head = 0;
     if (i < nvl && i > 0) {
-      const float q0 = cc_funkey((unsigned)(a[i] >> 32)), qp = cc_funkey((unsigned)(a[i - 1] >> 32));
-      const int b0 = (int)floorf(log2f(q0 > 1e-3f ? q0 : 1e-3f) * 17.673f), bp = (int)floorf(log2f(qp > 1e-3f ? qp : 1e-3f) * 17.673f);
+      const unsigned b0 = sk[i] >> (CC_KNN_ORD_IDX_BITS + CC_KNN_ORD_SUB_BITS), bp = sk[i - 1] >> (CC_KNN_ORD_IDX_BITS + CC_KNN_ORD_SUB_BITS);
       head = b0 != bp ? i : 0;
     }
     sa[i] = head;  // index of the bucket's first search where a bucket starts, else 0 (search 0 starts the first bucket)
   }
   __syncthreads();
-  int *hd = cc_block_scan<true>(sa, sb_, np2, tid, 1024);  // hd[i] = first search of i's bucket
-  int *fl = hd == sa ? sb_ : sa;
-  for (int i = tid; i < np2; i += 1024) fl[i] = (i < nvl && ((i - hd[i]) & (CC_KNN_ORDER_GROUP - 1)) == 0) ? 1 : 0;
+  cc_block_scan<true>(sa, np2, tid, wsum);  // sa[i] = first search of i's bucket
+  for (int i = tid; i < np2; i += 1024) fl[i] = (i < nvl && ((i - sa[i]) & (CC_KNN_ORDER_GROUP - 1)) == 0) ? 1 : 0;
   __syncthreads();
-  int *gi = cc_block_scan<false>(fl, hd, np2, tid, 1024);  // gi[i] = groups started up to and including i
+  cc_block_scan<false>(fl, np2, tid, wsum);  // fl[i] = groups started up to and including i
   for (int i = tid; i < nvl; i += 1024)
-    if (i == 0 || gi[i] != gi[i - 1]) gstart[gi[i] - 1] = i;
+    if (i == 0 || fl[i] != fl[i - 1]) gstart[fl[i] - 1] = i;
   if (tid == 0) {
-    const int ng = nvl > 0 ? gi[nvl - 1] : 0;
+    const int ng = nvl > 0 ? fl[nvl - 1] : 0;
     gstart[ng] = nvl;
     ord[CC_KNN_ORD_NVALID + ll] = nvl;
     ord[CC_KNN_ORD_NGROUP + ll] = ng;
@@ -636,13 +734,16 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
 #define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
 #define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
-#define CC_KNN_TPASS 128  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one
-#define CC_KNN_TCAP 256   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
-#define CC_KNN_TWL 1216   // queue per wave: < CC_KNN_TPASS left pending by the whole workgroup + 1024 pairs of one step
-// LDS: 32 KB of buffers + 38 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
+#define CC_KNN_TPASS 256  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one (round 3:
+                          // 128 -- a pass every 1.5 rounds, each one a round trip to the keys with the whole workgroup waiting)
+#define CC_KNN_TCAP 384   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
+#define CC_KNN_TWL 320    // queue per wave: a wave stops queueing once fewer than 64 places are left and carries the rest of its
+                          // step's pairs over to the next round -- by then a pass has run: a queue that full holds CC_KNN_TPASS pairs
+                          // (round 3 sized the queues for a step in which all 1 024 pairs pass: 38 KB that were never used)
+// LDS: 48 KB of buffers + 10 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
-static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS - 1 + 1024 <= CC_KNN_TWL &&
-                  CC_KNN_TPASS <= 64 * CC_KNN_TW, "cc_k_knn_tile: buffer bounds");
+static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS + 64 <= CC_KNN_TWL &&
+                  CC_KNN_TPASS <= 64 * CC_KNN_TW && CC_KNN_TCAP <= 384, "cc_k_knn_tile: buffer bounds");
 
 // |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
 // search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
@@ -709,6 +810,21 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
   }
   kept = off;
   return __uint_as_float(hi);
+}
+
+// A search's buffer of cnt <= CC_KNN_TCAP candidates cut back to those within its nnk-th smallest distance (a few more,
+// see cc_knn_select); returns that distance, `kept` candidates stay at buf[0..kept), kept <= 64.
+__device__ __forceinline__ float cc_knn_cut(unsigned long long *buf, int cnt, int nnk, int lane, int &kept) {
+  float nub = cnt <= 128 ? cc_knn_select<2, 12>(buf, cnt, nnk, lane, kept)
+                         : (cnt <= 256 ? cc_knn_select<4, 12>(buf, cnt, nnk, lane, kept) : cc_knn_select<6, 12>(buf, cnt, nnk, lane, kept));
+  if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
+                    // in the result -- order them and drop the rest, so that the buffer bound holds
+    unsigned long long first;
+    nub = kept <= 128 ? cc_knn_reduce<2>(buf, kept, nnk, lane, first)
+                      : (kept <= 256 ? cc_knn_reduce<4>(buf, kept, nnk, lane, first) : cc_knn_reduce<8>(buf, kept, nnk, lane, first));
+    kept = nnk;
+  }
+  return nub;
 }
 
 // grid = n_q_levels * ceil(nq * CC_NPIV / CC_KNN_TQ), block = 64 * CC_KNN_TW.  PH: the phase timers (tuning aid) are compiled in.
@@ -845,6 +961,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   if (sub > 0) open_d = open_d && (dir == 0 ? (sb < E2 && sb < n) : (sb + 64 > L0 && sb + 64 > 0));
   bool mine = __ballot(open_d) != 0ull;  // wave-uniform
   int wn = 0;                            // pairs pending in this wave's queue (wave-uniform)
+  unsigned m_left = 0u;                  // this lane's pairs of the wave's last step that found no room in the queue yet
+  int sb_left = 0;                       // ... and that step's first index
+  bool has_left = false;                 // wave-uniform: some lane has such pairs
   float a[4][3];  // A operand of the fetched step: tile t = keys sb + 16 t + (lane & 15), element 4 s + kq
   // this lane's three rows of the sorted view (0..9 key dims, 10 = |k|^2; row 11 is the constant 1: any readable row, not used)
   const float *Krow[3];
@@ -866,7 +985,19 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   CC_KNN_TICK(0)
   for (int par = 0;; par ^= 1) {
     if (PH) pc_[6]++;
-    if (mine) {
+    if (has_left) {  // the rest of the last step's pairs first (the pass in between has emptied the queue)
+      unsigned m = m_left;
+      while (__ballot(m != 0u) != 0ull && wn + 64 <= CC_KNN_TWL) {
+        const bool push = m != 0u;
+        const int bit = __ffs(m) - 1;
+        m &= m - 1u;
+        const unsigned long long mk = __ballot(push);
+        if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)(sb_left + 16 * (bit >> 2) + 4 * kq + (bit & 3));
+        wn += __popcll(mk);
+      }
+      m_left = m;
+      has_left = __ballot(m != 0u) != 0ull;
+    } else if (mine) {
       const int sb_cur = sb;
       cc_f32x4 acc[4];
 #pragma unroll
@@ -904,8 +1035,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           m &= vis;
         }
       }
-      // queue the pairs, one per lane and turn
-      while (__ballot(m != 0u) != 0ull) {
+      // queue the pairs, one per lane and turn; what finds no room waits for the next round
+      while (__ballot(m != 0u) != 0ull && wn + 64 <= CC_KNN_TWL) {
         const bool push = m != 0u;
         const int bit = __ffs(m) - 1;  // -1 when m == 0 (unused)
         m &= m - 1u;
@@ -913,6 +1044,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
         if (push) L.wl[wave][wn + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned)j << 28) | (unsigned)(sb_cur + 16 * (bit >> 2) + 4 * kq + (bit & 3));
         wn += __popcll(mk);
       }
+      m_left = m;
+      sb_left = sb_cur;
+      has_left = __ballot(m != 0u) != 0ull;
       // who goes on with this wave: a search leaves when the step's outermost key lies beyond its own key[0] on that side by
       // more than its radius (the radius may be a pass old: then it only leaves later), or when the wave's next step is past
       // its visible ranges
@@ -950,7 +1084,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     }
     if (lane == 0) {
       L.wn[par][wave] = wn;
-      L.go[par][wave] = mine ? 1 : 0;
+      L.go[par][wave] = (mine || has_left) ? 1 : 0;
     }
     CC_KNN_TICK(1)
     __syncthreads();
@@ -1017,13 +1151,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           due &= due - 1ull;
           const int cnt = __builtin_amdgcn_readlane(cnt_l, jj);
           int kept;
-          float nub = cnt <= 128 ? cc_knn_select<2, 12>(L.buf[jj], cnt, nnk, lane, kept) : cc_knn_select<4, 12>(L.buf[jj], cnt, nnk, lane, kept);
-          if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
-                            // in the result -- order them and drop the rest, so that the buffer bound holds
-            unsigned long long first;
-            nub = kept <= 128 ? cc_knn_reduce<2>(L.buf[jj], kept, nnk, lane, first) : cc_knn_reduce<4>(L.buf[jj], kept, nnk, lane, first);
-            kept = nnk;
-          }
+          const float nub = cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept);
           if (lane == 0) {
             L.st[jj].ub = nub;
             L.st[jj].cnt = kept;
@@ -1044,16 +1172,13 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   // ---- results: the nnk best by (distance, key id); wave w writes the searches w, w + 4, ...
   for (int jj = wave; jj < ns; jj += CC_KNN_TW) {
     int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
-    if (cnt > 128) {  // ties aside, what is within the nnk-th distance fits the smaller sorting network
+    if (cnt > 128) {  // what is within the nnk-th distance fits the smaller sorting network
       int kept;
-      cc_knn_select<4, 12>(L.buf[jj], cnt, nnk, lane, kept);
+      cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept);
       cnt = kept;
     }
     unsigned long long first;
-    if (cnt <= 128)
-      cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
-    else
-      cc_knn_reduce<4>(L.buf[jj], cnt, nnk, lane, first);
+    cc_knn_reduce<2>(L.buf[jj], cnt, nnk, lane, first);
     const int s_ = order_l[base + jj];
     const int q_ = s_ / CC_NPIV, seq_ = s_ - q_ * CC_NPIV;
     const int slot = q_ * (CC_NQLEV * CC_NPIV) + ll * CC_NPIV + seq_;

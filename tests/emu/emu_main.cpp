@@ -61,7 +61,37 @@ __global__ void emu_k_sort_wave(unsigned *arr, const unsigned *pristine, int n) 
   for (int i = lane; i < n; i += 64) arr[i] = a[i];
 }
 
+// the order kernel's workgroup sort (k_knn.h: cc_block_bitonic_u32), 1024 * R keys
+template <int R>
+__global__ void emu_k_block_bitonic(unsigned *arr) {
+  __shared__ unsigned xch[1024 * R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v[R];
+  for (int a = 0; a < R; a++) v[a] = arr[(wave * R + a) * 64 + lane];
+  cc_block_bitonic_u32<R>(v, xch, tid);
+  for (int a = 0; a < R; a++) arr[(wave * R + a) * 64 + lane] = v[a];
+}
+// and its in-place block scans (cc_block_scan), n a power of two <= 8192
+__global__ void emu_k_block_scan(int *arr, int n, int is_max) {
+  __shared__ int a[8192];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 1024) a[i] = arr[i];
+  __syncthreads();
+  if (is_max)
+    cc_block_scan<true>(a, n, tid, wsum);
+  else
+    cc_block_scan<false>(a, n, tid, wsum);
+  for (int i = tid; i < n; i += 1024) arr[i] = a[i];
+}
+
 extern "C" {
+void emu_block_bitonic(unsigned *arr, int r) {
+  if (r == 1) hipLaunchKernelGGL(emu_k_block_bitonic<1>, dim3(1), dim3(1024), 0, nullptr, arr);
+  if (r == 4) hipLaunchKernelGGL(emu_k_block_bitonic<4>, dim3(1), dim3(1024), 0, nullptr, arr);
+  if (r == 8) hipLaunchKernelGGL(emu_k_block_bitonic<8>, dim3(1), dim3(1024), 0, nullptr, arr);
+}
+void emu_block_scan(int *arr, int n, int is_max) { hipLaunchKernelGGL(emu_k_block_scan, dim3(1), dim3(1024), 0, nullptr, arr, n, is_max); }
 void emu_sort_desc_wave(unsigned *arr, int n) {
   std::vector<unsigned> in(arr, arr + n);
   hipLaunchKernelGGL(emu_k_sort_wave, dim3(1), dim3(64), 0, nullptr, arr, (const unsigned *)in.data(), n);

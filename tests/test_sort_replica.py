@@ -77,3 +77,30 @@ def test_wave_parallel_replay_matches_std_sort(oracle):
         arr = ((keys.astype(np.uint32) << 16) | np.arange(n, dtype=np.uint32)).copy()
         lib.emu_sort_desc_wave(arr.ctypes.data_as(C.c_void_p), n)
         assert np.array_equal(arr & 0xFFFF, perm), (n, keys[:8])
+
+
+def test_order_kernel_sort_and_scans():
+    """cc_k_knn_order's building blocks on the CPU harness: the workgroup bitonic sort that keeps 1024 x R keys in registers
+    (shuffles inside a wave, LDS only between waves; k_knn.h: cc_block_bitonic_u32) and the in-place block scans."""
+    lib = C.CDLL(emu_api.build())
+    rng = np.random.default_rng(11)
+    for r in (1, 4, 8):
+        for kind in range(3):
+            n = 1024 * r
+            a = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+            if kind == 1:
+                a[rng.integers(0, n, n // 2)] = 0xFFFFFFFF          # padding keys
+            if kind == 2:
+                a = (rng.integers(0, 50, n).astype(np.uint32) << 13) | np.arange(n, dtype=np.uint32)   # many equal buckets
+            exp = np.sort(a)
+            lib.emu_block_bitonic(a.ctypes.data_as(C.c_void_p), r)
+            assert np.array_equal(a, exp), (r, kind)
+    for n in (64, 1024, 2048, 8192):
+        v = rng.integers(0, 3, n).astype(np.int32)
+        s = v.copy()
+        lib.emu_block_scan(s.ctypes.data_as(C.c_void_p), n, 0)
+        assert np.array_equal(s, np.cumsum(v))
+        h = np.where(rng.random(n) < 0.05, np.arange(n), 0).astype(np.int32)
+        m = h.copy()
+        lib.emu_block_scan(m.ctypes.data_as(C.c_void_p), n, 1)
+        assert np.array_equal(m, np.maximum.accumulate(h))
