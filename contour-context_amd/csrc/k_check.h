@@ -750,17 +750,32 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     const cc_hot_desc_t *src = db_hot + gidx, *tgt = qhot + q;
     cc_group_sync();  // the previous constellation's reads of the group's LDS are done
     // (3/4) the pairs that passed the individual similarity (stage B1's tail), in cstl_in order: their centres into LDS
+    // What the orientation test below needs of the same two rows (the major axes, the eccentricity flags) comes along in
+    // this gather and waits in registers -- entry e = sl + 16 u is this lane's in both loops -- instead of a second dependent
+    // round trip to the rows.
     const int ncs_in = n_in;
-    for (int e = sl; e < ncs_in; e += G) {
-      const unsigned v = it->cs[e];
-      const int l = (int)(v >> 8), s_ = (int)((v >> 4) & 0xF), t_ = (int)(v & 0xF);
-      const cc_contour_t &scv = src->cont[l - 1][s_];
-      const cc_contour_t &tcv = tgt->cont[l - 1][t_];
-      L.cs[e] = (unsigned short)v;
-      L.spm[e][0] = scv.pos_mean[0];
-      L.spm[e][1] = scv.pos_mean[1];
-      L.tpm[e][0] = tcv.pos_mean[0];
-      L.tpm[e][1] = tcv.pos_mean[1];
+    float ax_s[CC_CSTL_MAX / CC_G][2], ax_t[CC_CSTL_MAX / CC_G][2];
+    unsigned ecc_both = 0u;  // bit u: both contours of entry sl + 16 u have ecc_feat
+#pragma unroll
+    for (int u = 0; u < CC_CSTL_MAX / CC_G; u++) {
+      const int e = sl + u * G;
+      ax_s[u][0] = ax_s[u][1] = ax_t[u][0] = ax_t[u][1] = 0.f;
+      if (e < ncs_in) {
+        const unsigned v = it->cs[e];
+        const int l = (int)(v >> 8), s_ = (int)((v >> 4) & 0xF), t_ = (int)(v & 0xF);
+        const cc_contour_t &scv = src->cont[l - 1][s_];
+        const cc_contour_t &tcv = tgt->cont[l - 1][t_];
+        L.cs[e] = (unsigned short)v;
+        L.spm[e][0] = scv.pos_mean[0];
+        L.spm[e][1] = scv.pos_mean[1];
+        L.tpm[e][0] = tcv.pos_mean[0];
+        L.tpm[e][1] = tcv.pos_mean[1];
+        ax_s[u][0] = scv.eig_vecs[2];
+        ax_s[u][1] = scv.eig_vecs[3];
+        ax_t[u][0] = tcv.eig_vecs[2];
+        ax_t[u][1] = tcv.eig_vecs[3];
+        ecc_both |= (scv.ecc_feat && tcv.ecc_feat) ? (1u << u) : 0u;
+      }
     }
     int ncs = ncs_in;
     CC_ABLATE_AT(11);
@@ -837,23 +852,23 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     CC_ABLATE_AT(12);
     // orientation test per pair (order-independent), then the order-dependent swap-to-back removal (contour_mng.h:1186-1201)
     unsigned long long rmm = 0ull;
-    for (int r0 = 0; r0 < ncs; r0 += G) {
-      const int e = r0 + sl;
-      bool rm = false;
-      if (e < ncs) {
-        const unsigned v = L.cs[e];
-        const cc_contour_t &scv = src->cont[(v >> 8) - 1][(v >> 4) & 0xF];
-        const cc_contour_t &tcv = tgt->cont[(v >> 8) - 1][v & 0xF];
-        if (scv.ecc_feat && tcv.ecc_feat) {
-          const float pi6 = (float)(3.14159265358979323846 / 6);
-          const float theta_s = acosf(shx * scv.eig_vecs[2] + shy * scv.eig_vecs[3]);
-          const float theta_t = acosf(thx * tcv.eig_vecs[2] + thy * tcv.eig_vecs[3]);
-          const float pms = (float)(3.14159265358979323846 - (double)theta_s);
-          rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
+#pragma unroll
+    for (int u = 0; u < CC_CSTL_MAX / CC_G; u++) {
+      const int r0 = u * G, e = r0 + sl;
+      if (r0 < ncs) {  // group-uniform
+        bool rm = false;
+        if (e < ncs) {
+          if ((ecc_both >> u) & 1u) {
+            const float pi6 = (float)(3.14159265358979323846 / 6);
+            const float theta_s = acosf(shx * ax_s[u][0] + shy * ax_s[u][1]);
+            const float theta_t = acosf(thx * ax_t[u][0] + thy * ax_t[u][1]);
+            const float pms = (float)(3.14159265358979323846 - (double)theta_s);
+            rm = fabsf(theta_s - theta_t) > pi6 && fabsf(pms - theta_t) > pi6;
+          }
+          L.keepf[e] = (unsigned char)e;  // position -> original index (identity when nothing is removed)
         }
-        L.keepf[e] = (unsigned char)e;  // position -> original index (identity when nothing is removed)
+        rmm |= (unsigned long long)cc_group_ballot(rm) << r0;
       }
-      rmm |= (unsigned long long)cc_group_ballot(rm) << r0;
     }
     cc_group_sync();
     if (rmm) {

@@ -45,6 +45,7 @@ struct cc_k2_scratch {  // per scan of a launch
 };
 #define CC_K2_OWN 4       // list entries a thread keeps in registers (beyond: read from the scratch block)
 #define CC_K2_CACHE 3072  // active cells whose height / position are staged in LDS for the walk
+#define CC_K2_BIG 128     // components with more cells than this are walked by eight lanes, one running sum each
 
 struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
   float pm[2];
@@ -472,7 +473,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     float2 *cpix = (float2 *)(R + CC_K2_CACHE * 4);                // [CC_K2_CACHE]
     uint16_t *moff = (uint16_t *)(R + CC_K2_CACHE * 12);           // [6][CC_NC] start of a component's list in memb[l], in units of 8
     uint16_t *mcnt = moff + CC_NLEV * CC_NC;                       // [6][CC_NC] members filed so far
+    uint16_t *big = (uint16_t *)(R + 45056);                       // [<= n_tot] components left to the eight-lane pass (the levels' working arrays are dead)
     const int n_cache = n_act < CC_K2_CACHE ? n_act : CC_K2_CACHE;
+    if (tid == 0) sh[3] = 0;
     for (int i = tid; i < n_cache; i += nt) {
       const int c = (int)scr->act[i];
       cbev[i] = bev[c];
@@ -512,18 +515,31 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
         const unsigned j = jn;
         const int i = b0 + lane;
         jn = i + 64 < n_act ? (unsigned)cidx[i + 64] : CC_COMP_NONE;  // the next stretch travels while this one is filed
+        // rank of every entry among the stretch's entries of its component, with ballots only (one turn per distinct
+        // component, no memory access in the loop); then ONE gather of the components' running counts, the list writes, and
+        // the last entry of every component moves its count on -- two LDS round trips per stretch, not per component
         unsigned long long todo = __ballot(j != CC_COMP_NONE);
+        int rank = 0, total = 0;
+        bool last = false;
         while (todo) {
           const int src = __ffsll(todo) - 1;
           const unsigned j0 = (unsigned)__builtin_amdgcn_readlane((int)j, src);  // src is wave-uniform
           const unsigned long long m = __ballot(j == j0);
-          const int base = (int)cnt_l[j0];
-          if (j == j0) memb[(int)off_l[j0] * 8 + base + __popcll(m & lt)] = (uint16_t)i;
-          cc_wave_sync();  // every lane has read the count
-          if (lane == src) cnt_l[j0] = (uint16_t)(base + __popcll(m));
-          cc_wave_sync();
+          if (j == j0) {
+            rank = __popcll(m & lt);
+            total = __popcll(m);
+            last = (m >> lane) == 1ull;
+          }
           todo &= ~m;
         }
+        int base = 0;
+        if (j != CC_COMP_NONE) {
+          base = (int)cnt_l[j];
+          memb[(int)off_l[j] * 8 + base + rank] = (uint16_t)i;
+        }
+        cc_wave_sync();  // every lane has read its count
+        if (j != CC_COMP_NONE && last) cnt_l[j] = (uint16_t)(base + total);
+        cc_wave_sync();
       }
     }
     __threadfence_block();
@@ -535,6 +551,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
       const int k = w - kbase;
       const int area = (int)mcnt[l * CC_NC + k];  // == comp[l][k].area
+      if (area > CC_K2_BIG) {  // left to the eight-lane pass below
+        big[atomicAdd(&sh[3], 1)] = (uint16_t)w;
+        continue;
+      }
       const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
       cc_running_stat rec;
       rec.cnt = 0;
@@ -579,6 +599,79 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       cc_contour_t cvw;
       cc_calc_stat_vals(cfg, rec, l, poi_i >= 0 ? pc / n_col : -1, poi_i >= 0 ? pc % n_col : -1, &cvw);
       scr->cont[l][k] = cvw;
+    }
+    __syncthreads();
+    // The large components (a street scene's ground-connected blob holds a few thousand cells): one lane adding nine running
+    // values per cell is ~75 cycles per cell whatever the other 63 lanes do, and the phase lasted as long as the largest
+    // component.  Every running sum is a sequential chain of its own, so EIGHT LANES share a component, one sum each
+    // (a product a * b with (a, b) picked per lane, 1.0 for the plain sums: the same values added in the same order), and
+    // the chain per cell shrinks to one f64 multiply and one add; lane 0 of the eight collects the sums and finishes.
+    {
+      const int n_big = sh[3];
+      const int role = tid & 7;
+      for (int g0 = 0; g0 < n_big; g0 += nt >> 3) {  // block-uniform trip count
+        const int g = g0 + (tid >> 3);
+        const bool on = g < n_big;
+        double acc = 0.0;
+        float vol3 = 0.f;
+        int poi_i = -1, cnt = 0, l = 0, k = 0;
+        if (on) {
+          const int w = (int)big[g];
+          for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
+          int kbase = 0;
+          for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
+          k = w - kbase;
+          const int area = (int)mcnt[l * CC_NC + k];
+          const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
+          uint4 nx = ml[0];
+          for (int m0 = 0; m0 < area; m0 += 8) {
+            const uint4 cur = nx;
+            if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+            const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (m0 + u < area) {
+                const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
+                float h;
+                float2 rc;
+                if (i < n_cache) {
+                  h = cbev[i];
+                  rc = cpix[i];
+                } else {
+                  const int c = (int)scr->act[i];
+                  h = bev[c];
+                  rc = pix[c];
+                }
+                const double vr = (double)rc.x, vc = (double)rc.y, hd = (double)h;
+                // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: the f32 height sum, which every lane keeps)
+                const double fa = role >= 5 ? hd : ((role == 1 || role == 4) ? vc : vr);
+                const double fb = role < 2 ? 1.0 : ((role == 2 || role == 5) ? vr : vc);
+                acc += fa * fb;
+                vol3 += h;
+                cnt += 1;
+                poi_i = i;
+              }
+            }
+          }
+        }
+        cc_running_stat rec;
+        const int b8 = (tid & 63) & ~7;
+        rec.ps_x = __shfl(acc, b8 + 0);
+        rec.ps_y = __shfl(acc, b8 + 1);
+        rec.t_xx = __shfl(acc, b8 + 2);
+        rec.t_xy = __shfl(acc, b8 + 3);
+        rec.t_yy = __shfl(acc, b8 + 4);
+        rec.tq_x = __shfl(acc, b8 + 5);
+        rec.tq_y = __shfl(acc, b8 + 6);
+        rec.vol3 = vol3;
+        rec.cnt = cnt;
+        if (on && role == 0) {
+          const int pc = poi_i >= 0 ? (int)scr->act[poi_i] : 0;
+          cc_contour_t cvw;
+          cc_calc_stat_vals(cfg, rec, l, poi_i >= 0 ? pc / n_col : -1, poi_i >= 0 ? pc % n_col : -1, &cvw);
+          scr->cont[l][k] = cvw;
+        }
+      }
     }
     __syncthreads();
   }

@@ -265,6 +265,9 @@ class ContourManager {
   // contour_mng.h:588: the work was queued by makeBEV; results are waited for where they are read
   void makeContoursRecurs() { CC_CHECK(scan_); }
   void clearImage() {}  // the dense image is never kept here (see bev_cells_)
+  // contour_mng.h:562-571 rebuilds bev_ from the pillar list after clearImage(); here getBevImage() reads the copy that came
+  // back from the device with the scan (keepImages() at makeBEV time), which clearImage() does not drop: nothing to rebuild
+  void resumeImage() {}
 
   // contour_mng.h:573-586: the dense max-height image, -VAL_ABS_INF_ where no point fell
   cc_host::Image<float> getBevImage() const {

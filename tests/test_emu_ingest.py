@@ -130,3 +130,21 @@ def test_resolutions_pow2_and_not(oracle):
         cfg.n_row, cfg.n_col = n, n
         d = _check(oracle, [s], cfg=cfg)
         assert d["n_pix"][0] > 500
+
+
+def test_large_components_go_through_the_eight_lane_walk(oracle):
+    """Components of more than CC_K2_BIG = 128 cells (a plateau of 45 x 40 cells with a tower on it, a long wall, next to small
+    clutter): their running sums are accumulated by eight lanes, one sum each (k_contours.h) -- the same values in the same
+    order, so the contour rows stay bit-exact."""
+    rng = np.random.default_rng(21)
+    pts = []
+    for (x0, x1, y0, y1, z0, z1, n) in ((-30, 15, -20, 20, 1.6, 2.4, 60000), (-10, 5, -5, 8, 3.1, 4.8, 15000), (20, 22, -60, 60, 2.2, 3.9, 9000),
+                                        (-70, 70, -70, 70, 0.0, 5.0, 1500)):
+        p = np.zeros((n, 4), np.float32)
+        p[:, 0] = rng.uniform(x0, x1, n)
+        p[:, 1] = rng.uniform(y0, y1, n)
+        p[:, 2] = rng.uniform(z0, z1, n) - 2.0      # the reference adds lidar_height_ = 2
+        pts.append(p)
+    scan = np.concatenate(pts)[rng.permutation(sum(len(p) for p in pts))]
+    d = _check(oracle, [scan])
+    assert d["cont"]["cell_cnt"][0, 0].max() > 1000 and (d["cont"]["cell_cnt"][0, :4].max(axis=1) > 128).all() and (d["flags"] == 0).all()
