@@ -733,6 +733,7 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
 #define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
 #define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round
+#define CC_KNN_TREP 2     // 64-key steps a wave takes per round
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
 #define CC_KNN_TPASS 256  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one (round 3:
                           // 128 -- a pass every 1.5 rounds, each one a round trip to the keys with the whole workgroup waiting)
@@ -997,7 +998,10 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       }
       m_left = m;
       has_left = __ballot(m != 0u) != 0ull;
-    } else if (mine) {
+    } else {
+      // a wave takes CC_KNN_TREP steps per round: the barrier, the look at the other waves' queues and the pass decision are
+      // paid once per 128 keys
+      for (int rep_ = 0; rep_ < CC_KNN_TREP && mine && !has_left; rep_++) {
       const int sb_cur = sb;
       cc_f32x4 acc[4];
 #pragma unroll
@@ -1080,6 +1084,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
             }
           }
         }
+      }
       }
     }
     if (lane == 0) {
