@@ -548,22 +548,24 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
       int cnt_k = 0;
       if (k < ntp) {
         const int tb = (int)L.g.tp[k].bit_pos;
+        // two lower-bound searches over <= 40 sorted entries with a FIXED trip count and predicated updates: the lanes of a
+        // wave (four checks in different states) stay on one instruction stream instead of peeling off through exec masks
         int a = 0, b = nsp;
-        while (a < b) {  // #(sb < tb - 1)
-          const int mid = (a + b) >> 1;
-          if ((int)L.g.sp[mid].bit_pos < tb - 1)
-            a = mid + 1;
-          else
-            b = mid;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {  // #(sb < tb - 1); 2^6 > CC_BCI_MAXPTS
+          const int mid = (a + b) >> 1;   // < nsp while a < b; == a == b <= nsp afterwards (clamped for the read)
+          const bool go = a < b, up = (int)L.g.sp[mid < CC_BCI_MAXPTS ? mid : CC_BCI_MAXPTS - 1].bit_pos < tb - 1;
+          a = (go && up) ? mid + 1 : a;
+          b = (go && !up) ? mid : b;
         }
         const int lo = a;
         b = nsp;
-        while (a < b) {  // #(sb <= tb + 1)
+#pragma unroll
+        for (int it = 0; it < 6; it++) {  // #(sb <= tb + 1)
           const int mid = (a + b) >> 1;
-          if ((int)L.g.sp[mid].bit_pos <= tb + 1)
-            a = mid + 1;
-          else
-            b = mid;
+          const bool go = a < b, up = (int)L.g.sp[mid < CC_BCI_MAXPTS ? mid : CC_BCI_MAXPTS - 1].bit_pos <= tb + 1;
+          a = (go && up) ? mid + 1 : a;
+          b = (go && !up) ? mid : b;
         }
         L.g.lo[k] = (unsigned char)lo;
         L.g.hi[k] = (unsigned char)a;
@@ -605,14 +607,15 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     for (int p1 = sl; p1 < npp; p1 += G) {
       const float v1 = L.skey[p1];
       int a = p1, b = p1 + npp - 1;  // window [p1, p2], p2 in [p1, p1+npp)
-      while (a < b) {                // largest p2 with valid(p2); valid is monotone in p2
-        const int mid = (a + b + 1) >> 1;
+      // largest p2 with valid(p2); valid is monotone in p2.  Fixed trip count (npp <= PPM), predicated updates: see above
+#pragma unroll
+      for (int it = 0; it < (PPM <= 64 ? 6 : 8); it++) {
+        const int mid = (a + b + 1) >> 1;  // in (a, b] while a < b; == a == b afterwards: a valid index either way
         const bool wr = mid >= npp;  // mid < 2 * npp: mid % npp and mid / npp without a division
         const float d = L.skey[mid - (wr ? npp : 0)] - v1;
-        if (wr ? d >= CC_B1_WRAP_T : d > angular_range)
-          b = mid - 1;
-        else
-          a = mid;
+        const bool go = a < b, out = wr ? d >= CC_B1_WRAP_T : d > angular_range;
+        b = (go && out) ? mid - 1 : b;
+        a = (go && !out) ? mid : a;
       }
       const int len = a - p1 + 1;
       if (len > bestL || (len == bestL && p1 < bestP)) {
