@@ -177,6 +177,32 @@ def test_knn_tiled_equals_walk(cc, world_db, monkeypatch):
     db2.close()
 
 
+@pytest.mark.parametrize("n_queries", [400, 1024])
+def test_knn_tiled_equals_walk_large_chunks(cc, world_db, monkeypatch, n_queries):
+    """The same comparison with chunks of 400 and 1 024 queries: cc_k_knn_order sorts 2 400 / 6 144 searches per layer with four /
+    eight keys per lane in registers (k_knn.h: cc_block_bitonic_u32), and a chunk is ONE launch of the tiled search."""
+    import torch
+    ctx, desc, xq, qdesc, P = world_db
+    reps = (n_queries + N_Q - 1) // N_Q
+    q = qdesc.repeat(reps, 1)[:n_queries].contiguous()
+    ep = np.full(n_queries, N_DB, np.int32)
+    ep[::3] = N_DB // 2
+    ep[1::7] = N_DB // 3
+    out = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CC_KNN_MODE", mode)
+        db = _db(cc, ctx, desc, N_DB)
+        out.append(db.query(q, ep, want_knn=True))
+        db.close()
+    monkeypatch.delenv("CC_KNN_MODE")
+    (r1, knn1, cnt1), (r2, knn2, cnt2) = out
+    assert np.array_equal(cnt1, cnt2) and cnt1.sum() > 0
+    m = np.arange(knn1.shape[-1])[None, None, None, :] < cnt1[..., None]
+    for f in ("gidx", "level", "seq", "dist_sq"):
+        assert np.array_equal(knn1[f][m], knn2[f][m]), f
+    assert _same(r1, r2)
+
+
 def test_knn_tiled_near_ties_large_norms(cc, world_db, monkeypatch):
     """The tiled search's matrix-core value is only a filter; it must never drop a true neighbour (k_knn.h
     cc_knn_tile_slack).  Hand-made keys where that is hardest: large norms (|k| ~ 1000, so the f32 chain's absolute error is
