@@ -1,0 +1,89 @@
+"""Randomised end-to-end parity campaign ON THE GPU (not collected by pytest; run by hand on the GPU box):
+    python tests/fuzz_gpu_query.py <seed0> <n_iter>
+The draws of tests/fuzz_emu_query.py (world, drive, DB configuration, gate thresholds), but the product's own path end to
+end -- points -> cc_ingest_batch -> cc_db_add_scans -> one batched cc_db_query_batch of EVERY scan at its own epoch -- against
+the oracle's replay of the reference loop on the same points: descriptors (integers, contour rows, BCIs bit-exact; keys to
+the f64 exp's last bits), every integer of every result record, correlation and pose within 1e-4.  Walk and tiled K3
+alternate; every third drive uses full-size scans."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE]
+import cc_amd  # noqa: E402
+import oracle_py as oracle  # noqa: E402
+from parity import compare_desc  # noqa: E402
+
+INT_FIELDS = ["n_res", "cand_gidx", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy", "n_knn_hits"]
+
+
+def one(cc, seed):
+    import torch
+    L = oracle.L
+    rng = np.random.default_rng(seed)
+    d = L.default_db_cfg()
+    d.min_elapse = float(rng.uniform(0.8, 2.0))
+    d.max_elapse = d.min_elapse + float(rng.uniform(0.5, 1.5))
+    d.nnk = int(rng.choice([10, 30, 50, 64]))
+    d.max_fine_opt = int(rng.choice([2, 5, 10]))
+    qlv = [(1, 2, 3), (2, 3), (2, 3, 4), (1, 2, 3)][int(rng.integers(4))]
+    d.n_q_levels = len(qlv)
+    for i, v in enumerate(qlv):
+        d.q_levels[i] = v
+    lb, ub = L.default_thresholds()
+    if rng.random() < 0.5:
+        lb.i_ovlp_sum, lb.i_ovlp_max_one, lb.i_in_ang_rng, lb.i_indiv_sim, lb.i_orie_sim = [int(v) for v in rng.integers(2, 5, 5)]
+        lb.correlation = float(rng.uniform(0.1, 0.5))
+    kind = int(rng.integers(3))
+    world = cc.synth.World(loop_len=float(rng.uniform(24, 36)), dense=(kind == 1), seed=int(rng.integers(1 << 20))) if kind < 2 else \
+        cc.synth.World(kitti=True, seed=int(rng.integers(1 << 20)), block=float(rng.uniform(36, 50)), tile=300.0)
+    n = int(rng.integers(56, 84))
+    full = seed % 3 == 0
+    x, poses, ts = cc.synth.make_sequence(n, world=world, device="cuda", step=(1.0 if kind < 2 else 3.0),
+                                          **({} if full else dict(beams=16, azim=450)))
+    P = x.shape[1]
+    offs = np.arange(n + 1, dtype=np.int64) * P
+    seeds = rng.integers(0, 1 << 20, n).astype(np.int32)
+    os.environ["CC_KNN_MODE"] = "2" if seed % 2 else "0"
+    ctx = cc.Context(0, None, max_batch=128)
+    desc = ctx.ingest(x.reshape(-1, 4), offs)
+    db = cc.Database(ctx, cfg=d, capacity=n)
+    db.add_scans(desc, ts, seeds)
+    res = db.query(desc, np.arange(n, dtype=np.int32), lb=lb, ub=ub, allow_flagged=True)
+    torch.cuda.synchronize()
+    dn = cc.desc_to_numpy(desc)
+    ores, _, odesc = oracle.run_sequence(x.cpu().numpy().reshape(-1, 4), offs, ts, seeds, dcfg=d, lb=lb, ub=ub, want_desc=True)
+    bad = 0
+    for i in range(n):
+        if dn["flags"][i] or res["flags"][i]:
+            continue  # a capacity was met and reported: not a parity case
+        b = compare_desc(odesc[i], dn[i], float_exact=False)
+        if b:
+            print("  MISMATCH seed %d scan %d descriptor: %s" % (seed, i, b[:3]))
+            bad += 1
+        for f in INT_FIELDS:
+            if ores[f][i] != res[f][i]:
+                print("  MISMATCH seed %d scan %d field %s: oracle %s kernels %s" % (seed, i, f, ores[f][i], res[f][i]))
+                bad += 1
+        if ores["n_res"][i] and res["n_res"][i]:
+            e = max(abs(ores["correlation"][i] - res["correlation"][i]), float(np.abs(ores["tf"][i] - res["tf"][i]).max()))
+            if e > 1e-4:
+                print("  MISMATCH seed %d scan %d float error %.3g" % (seed, i, e))
+                bad += 1
+    print("seed %d kind %d %s n %d nnk %d qlv %s hits %d flagged %d knn-mode %s: %s" % (
+        seed, kind, "full" if full else "16x450", n, d.nnk, qlv, int((ores["n_res"] > 0).sum()), int((dn["flags"] != 0).sum() + (res["flags"] != 0).sum()),
+        os.environ["CC_KNN_MODE"], "ok" if not bad else "%d MISMATCHES" % bad), flush=True)
+    db.close()
+    ctx.close()
+    return bad
+
+
+if __name__ == "__main__":
+    s0, it = int(sys.argv[1]), int(sys.argv[2])
+    cc = cc_amd.load()
+    tot = 0
+    for s in range(s0, s0 + it):
+        tot += one(cc, s)
+    print("done: %d mismatches" % tot)
