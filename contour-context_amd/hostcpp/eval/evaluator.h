@@ -268,15 +268,21 @@ class ContLCDEvaluator {
       const size_t n = fread(dst, 4 * sizeof(float), cap, f);
       fclose(f);
       cm->makeBEVFromStaged(dst, n, str_id);
-      {
-        std::lock_guard<std::mutex> lk(pf_.mu);
-        pf_.ctx = ctx;
-        pf_.with_images = with_images;
-        pf_.next = p_lidar_curr + 1;
-        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+      static const bool read_ahead = [] {  // CC_EVAL_READ_AHEAD=0: every scan is read and ingested by the call that asks for it
+        const char *e = getenv("CC_EVAL_READ_AHEAD");
+        return !(e && atoi(e) == 0);
+      }();
+      if (read_ahead) {
+        {
+          std::lock_guard<std::mutex> lk(pf_.mu);
+          pf_.ctx = ctx;
+          pf_.with_images = with_images;
+          pf_.next = p_lidar_curr + 1;
+          pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+        }
+        if (!pf_.th.joinable()) pf_.th = std::thread([this, cap] { prefetchLoop(cap); });
+        pf_.cv.notify_all();
       }
-      if (!pf_.th.joinable()) pf_.th = std::thread([this, cap] { prefetchLoop(cap); });
-      pf_.cv.notify_all();
     }
     cm->makeContoursRecurs();
     pf_.t_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();

@@ -92,6 +92,13 @@ def test_batch_bin_test_driver_end_to_end(cc, oracle, tmp_path):
     subprocess.check_output([exe, str(tmp_path / "cfg.yaml")], text=True)
     rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "outcome.txt")]
     assert len(rows) == n
+    # the evaluator reads and ingests two scans ahead on a helper thread (its own HIP stream); the same drive with every scan
+    # read and ingested by the call that asks for it must give the same file, byte for byte -- three times over (a race
+    # between the helper's ingest and the driver thread's query / update would not show on every run)
+    first = open(tmp_path / "outcome.txt", "rb").read()
+    for k in range(3):
+        subprocess.check_output([exe, str(tmp_path / "cfg.yaml")], text=True, env=dict(os.environ, CC_EVAL_READ_AHEAD=("0" if k == 0 else "1")))
+        assert open(tmp_path / "outcome.txt", "rb").read() == first, "outcome differs (run %d)" % k
     dcfg = cc.L.default_db_cfg()
     dcfg.max_elapse, dcfg.min_elapse = 10.0, 6.0
     P = xs.shape[1]
