@@ -43,7 +43,10 @@ def one(seed):
     P = x.shape[1]
     xs = x.numpy().reshape(-1, 4)
     offs = np.arange(n + 1, dtype=np.int64) * P
-    seeds = rng.integers(0, 1 << 20, n).astype(np.int32)
+    # the reference's drivers use a scan's sequence number as its id AND as the balance seed (batch_bin_test.cpp:131-237);
+    # CandidateManager keys candidates by that id (contour_db.h:476), the C-ABI by DB index -- the same thing as long as ids
+    # are unique, which the evaluator CHECKs: distinct values here (a duplicate merges two scans' candidates in the oracle)
+    seeds = rng.choice(1 << 20, n, replace=False).astype(np.int32)
     ores, _, odesc = oracle.run_sequence(xs, offs, ts, seeds, dcfg=d, lb=lb, ub=ub, want_desc=True)
     os.environ["CC_KNN_MODE"] = "2" if seed % 2 else "0"
     api = emu_api.EmuApi(L)

@@ -45,13 +45,44 @@ def one(cc, seed):
                                           **({} if full else dict(beams=16, azim=450)))
     P = x.shape[1]
     offs = np.arange(n + 1, dtype=np.int64) * P
-    seeds = rng.integers(0, 1 << 20, n).astype(np.int32)
+    # the reference's drivers use a scan's sequence number as its id AND as the balance seed (batch_bin_test.cpp:131-237);
+    # CandidateManager keys candidates by that id (contour_db.h:476), the C-ABI by DB index -- the same thing as long as ids
+    # are unique, which the evaluator CHECKs: distinct values here (a duplicate merges two scans' candidates in the oracle)
+    seeds = rng.choice(1 << 20, n, replace=False).astype(np.int32)
     os.environ["CC_KNN_MODE"] = "2" if seed % 2 else "0"
     ctx = cc.Context(0, None, max_batch=128)
     desc = ctx.ingest(x.reshape(-1, 4), offs)
     db = cc.Database(ctx, cfg=d, capacity=n)
-    db.add_scans(desc, ts, seeds)
-    res = db.query(desc, np.arange(n, dtype=np.int32), lb=lb, ub=ub, allow_flagged=True)
+    online = seed % 4 == 1
+    if not online:
+        db.add_scans(desc, ts, seeds)
+        res = db.query(desc, np.arange(n, dtype=np.int32), lb=lb, ub=ub, allow_flagged=True)
+    else:
+        # the online loop: sub-batch after sub-batch is added and queried at its own epochs with nothing collected in
+        # between (cc_db_add_scans[_prepare] / cc_db_query_submit, 1-4 lanes): appends run next to query chunks in flight
+        sub = int(rng.choice([1, 5, 16, 37]))
+        db.set_lanes(int(rng.choice([1, 2, 4])))
+        prep = bool(rng.integers(2))
+        parts = []
+        if prep:
+            db.add_scans_prepare(desc[0:min(sub, n)].contiguous())
+        for a0 in range(0, n, sub):
+            a1 = min(a0 + sub, n)
+            blk = desc[a0:a1].contiguous()
+            db.add_scans(blk, ts[a0:a1], seeds[a0:a1])
+            if prep and a1 < n:
+                db.add_scans_prepare(desc[a1:min(a1 + sub, n)].contiguous())
+            try:
+                parts.append(db.query_submit(blk, np.arange(a0, a1, dtype=np.int32), lb=lb, ub=ub))
+            except cc.CCError as e:
+                if e.rc != cc.CC_ECAPACITY:
+                    raise
+        try:
+            db.query_wait()
+        except cc.CCError as e:
+            if e.rc != cc.CC_ECAPACITY:
+                raise
+        res = np.concatenate(parts)
     torch.cuda.synchronize()
     dn = cc.desc_to_numpy(desc)
     ores, _, odesc = oracle.run_sequence(x.cpu().numpy().reshape(-1, 4), offs, ts, seeds, dcfg=d, lb=lb, ub=ub, want_desc=True)
@@ -72,9 +103,17 @@ def one(cc, seed):
             if e > 1e-4:
                 print("  MISMATCH seed %d scan %d float error %.3g" % (seed, i, e))
                 bad += 1
-    print("seed %d kind %d %s n %d nnk %d qlv %s hits %d flagged %d knn-mode %s: %s" % (
-        seed, kind, "full" if full else "16x450", n, d.nnk, qlv, int((ores["n_res"] > 0).sum()), int((dn["flags"] != 0).sum() + (res["flags"] != 0).sum()),
+    print("seed %d kind %d %s %s n %d nnk %d qlv %s hits %d flagged %d knn-mode %s: %s" % (
+        seed, kind, "full" if full else "16x450", "online" if online else "batch", n, d.nnk, qlv, int((ores["n_res"] > 0).sum()), int((dn["flags"] != 0).sum() + (res["flags"] != 0).sum()),
         os.environ["CC_KNN_MODE"], "ok" if not bad else "%d MISMATCHES" % bad), flush=True)
+    if bad and os.environ.get("CC_FUZZ_DUMP"):  # what a CPU-harness replay of the query side needs (tests/fuzz_emu_query.py --replay)
+        os.makedirs(os.environ["CC_FUZZ_DUMP"], exist_ok=True)
+        np.savez_compressed(os.path.join(os.environ["CC_FUZZ_DUMP"], "seed%d.npz" % seed), odesc=np.frombuffer(odesc.tobytes(), np.uint8),
+                            gdesc=np.frombuffer(dn.tobytes(), np.uint8), ts=ts, seeds=seeds, ores=np.frombuffer(ores.tobytes(), np.uint8),
+                            gres=np.frombuffer(res.tobytes(), np.uint8),
+                            cfg=np.array([d.min_elapse, d.max_elapse, d.nnk, d.max_fine_opt, d.n_q_levels] + [d.q_levels[i] for i in range(3)], np.float64),
+                            lb=np.array([lb.i_ovlp_sum, lb.i_ovlp_max_one, lb.i_in_ang_rng, lb.i_indiv_sim, lb.i_orie_sim, lb.correlation, lb.area_perc,
+                                         lb.neg_est_dist], np.float64))
     db.close()
     ctx.close()
     return bad
