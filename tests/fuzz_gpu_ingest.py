@@ -1,0 +1,56 @@
+"""Randomised ingest parity campaign ON THE GPU (not collected by pytest; run by hand on the GPU box):
+    python tests/fuzz_gpu_ingest.py <seed0> <n_iter>
+The scan generators of tests/fuzz_emu.py (terrain, uniform clouds, blobs, cell borders, walls, heights exactly at the level
+thresholds, duplicates and far outliers), 24 scans of different sizes per cc_ingest_batch call, every descriptor against the
+oracle: integers, contour rows and BCIs bit for bit, keys to the last bits of the f64 exp."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE]
+import cc_amd  # noqa: E402
+import oracle_py as oracle  # noqa: E402
+from fuzz_emu import gen  # noqa: E402
+from parity import compare_desc  # noqa: E402
+
+
+def main():
+    import torch
+    seed0, n_it = int(sys.argv[1]), int(sys.argv[2])
+    cc = cc_amd.load()
+    L = oracle.L
+    ctx = cc.Context(0, None, max_batch=32)
+    n_bad = n_flag = n_scan = 0
+    for it in range(n_it):
+        rng = np.random.default_rng(seed0 + it)
+        scans = []
+        while len(scans) < 24:
+            kind, s = gen(rng)
+            if len(s) > 10:
+                scans.append((kind, s))
+        offs = np.concatenate([[0], np.cumsum([len(s) for _, s in scans])]).astype(np.int64)
+        x = torch.from_numpy(np.concatenate([s for _, s in scans], 0)).cuda()
+        desc = cc.desc_to_numpy(ctx.ingest(x, offs))   # a scan that exceeds a capacity comes back flagged, the call succeeds
+        for k, (kind, s) in enumerate(scans):
+            od = oracle.Scan(s).desc()[0]
+            n_scan += 1
+            if int(od["n_cont"].max()) > L.MAXC or desc[k]["flags"]:
+                n_flag += 1
+                if int(od["n_cont"].max()) > L.MAXC and not (desc[k]["flags"] & 2):
+                    print("seed %d scan %d (%s): capacity case NOT flagged" % (seed0 + it, k, kind))
+                    n_bad += 1
+                continue
+            bad = compare_desc(od, desc[k], float_exact=False)
+            if bad:
+                print("seed %d scan %d (%s, %d points): %s" % (seed0 + it, k, kind, len(s), bad[:3]))
+                n_bad += 1
+        if it % 10 == 9:
+            print("... %d batches, %d scans, %d flagged, %d bad" % (it + 1, n_scan, n_flag, n_bad), flush=True)
+    print("done: %d bad of %d scans (%d capacity cases)" % (n_bad, n_scan, n_flag))
+    return 1 if n_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
