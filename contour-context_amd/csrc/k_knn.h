@@ -984,6 +984,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
   }
   if (mine) CC_KNN_TFETCH()
   CC_KNN_TICK(0)
+  int n_pass_ = 0;  // passes so far (workgroup-uniform)
   for (int par = 0;; par ^= 1) {
     if (PH) pc_[6]++;
     if (has_left) {  // the rest of the last step's pairs first (the pass in between has emptied the queue)
@@ -1105,7 +1106,9 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     }
     const int tot = cum[CC_KNN_TW];
     const bool walking = going != 0;
-    if (tot >= CC_KNN_TPASS || (!walking && tot > 0)) {
+    // the first pass comes early (64 pairs): until it has run every search filters with dist_ub, the widest radius it will ever have
+    if (tot >= (n_pass_ == 0 ? 64 : CC_KNN_TPASS) || (!walking && tot > 0)) {
+      n_pass_++;
       for (int e0 = 0; e0 < tot; e0 += CC_KNN_TPASS) {
         const int e = e0 + tid;
         if (tid < CC_KNN_TPASS && e < tot) {
