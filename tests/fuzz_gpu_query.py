@@ -106,6 +106,30 @@ def one(cc, seed):
     print("seed %d kind %d %s %s n %d nnk %d qlv %s hits %d flagged %d knn-mode %s: %s" % (
         seed, kind, "full" if full else "16x450", "online" if online else "batch", n, d.nnk, qlv, int((ores["n_res"] > 0).sum()), int((dn["flags"] != 0).sum() + (res["flags"] != 0).sum()),
         os.environ["CC_KNN_MODE"], "ok" if not bad else "%d MISMATCHES" % bad), flush=True)
+    if seed % 5 == 2:
+        # tiled against walk K3 on a DB made of R copies of the drive (thousands of scans, every key R times over: exact
+        # distance ties in crowds, groups of sixteen searches, long windows): hit lists must be identical, entry for entry
+        R = int(rng.choice([16, 40, 90]))
+        big = desc.repeat(R, 1).contiguous()
+        nb = big.shape[0]
+        tsb = np.arange(nb, dtype=np.float64) / 10.0
+        sb = rng.choice(1 << 22, nb, replace=False).astype(np.int32)
+        ep = np.full(n, nb, np.int32)
+        ep[::3] = nb // 2
+        out = []
+        for mode in ("0", "2"):
+            os.environ["CC_KNN_MODE"] = mode
+            dbb = cc.Database(ctx, cfg=d, capacity=nb)
+            dbb.add_scans(big, tsb, sb)
+            out.append(dbb.query(desc, ep, lb=lb, ub=ub, want_knn=True, allow_flagged=True))
+            dbb.close()
+        (r1, k1, c1), (r2, k2, c2) = out
+        m = np.arange(k1.shape[-1])[None, None, None, :] < c1[..., None]
+        same = np.array_equal(c1, c2) and all(np.array_equal(k1[f][m], k2[f][m]) for f in ("gidx", "level", "seq", "dist_sq"))
+        same = same and all(np.array_equal(r1[f], r2[f]) for f in INT_FIELDS)
+        if not same:
+            print("  MISMATCH seed %d: tiled and walk K3 differ on the %d-scan DB of %d copies" % (seed, nb, R))
+            bad += 1
     if bad and os.environ.get("CC_FUZZ_DUMP"):  # what a CPU-harness replay of the query side needs (tests/fuzz_emu_query.py --replay)
         os.makedirs(os.environ["CC_FUZZ_DUMP"], exist_ok=True)
         np.savez_compressed(os.path.join(os.environ["CC_FUZZ_DUMP"], "seed%d.npz" % seed), odesc=np.frombuffer(odesc.tobytes(), np.uint8),
