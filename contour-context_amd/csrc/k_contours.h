@@ -1032,8 +1032,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
         ob->dist_bin[1] = bw[1];
         ob->dist_bin[2] = bw[2];
         ob->dist_bin[3] = bw[3];
-        ob->piv_seq = (int8_t)seq;
-        ob->level = (int8_t)ll;
+        // layer_key_bcis_ has piv_firsts_ entries per level (contour_mng.h:835-838): the record's slots beyond that stay all-zero
+        ob->piv_seq = seq < cfg.piv_firsts ? (int8_t)seq : (int8_t)0;
+        ob->level = seq < cfg.piv_firsts ? (int8_t)ll : (int8_t)0;
         ob->n_pts = (uint8_t)n;
         ob->n_segs = (uint8_t)ns;
       }

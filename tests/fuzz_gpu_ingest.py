@@ -1,8 +1,8 @@
 """Randomised ingest parity campaign ON THE GPU (not collected by pytest; run by hand on the GPU box):
     python tests/fuzz_gpu_ingest.py <seed0> <n_iter>
 The scan generators of tests/fuzz_emu.py (terrain, uniform clouds, blobs, cell borders, walls, heights exactly at the level
-thresholds, duplicates and far outliers), 24 scans of different sizes per cc_ingest_batch call, every descriptor against the
-oracle: integers, contour rows and BCIs bit for bit, keys to the last bits of the f64 exp."""
+thresholds, duplicates and far outliers), 24 scans of different sizes per cc_ingest_batch call, a ContourManagerConfig drawn per
+batch (shipped / MulRan levels, grids, resolutions, contour / key / RoI settings), every descriptor against the oracle: integers, contour rows and BCIs bit for bit, keys to the last bits of the f64 exp."""
 import os
 import sys
 
@@ -21,10 +21,29 @@ def main():
     seed0, n_it = int(sys.argv[1]), int(sys.argv[2])
     cc = cc_amd.load()
     L = oracle.L
-    ctx = cc.Context(0, None, max_batch=32)
     n_bad = n_flag = n_scan = 0
     for it in range(n_it):
         rng = np.random.default_rng(seed0 + it)
+        # a ContourManagerConfig per batch: the shipped one, the MulRan level set, other grids and resolutions (the
+        # multiply-by-reciprocal and the IEEE-division instances of the rasteriser), other contour / key / RoI settings
+        mcfg = L.default_manager_cfg(mulran=bool(rng.random() < 0.25))
+        v = int(rng.integers(6))
+        if v == 1:
+            mcfg.reso_row = mcfg.reso_col = 2.0
+            mcfg.n_row = mcfg.n_col = 74
+        elif v == 2:
+            mcfg.reso_row, mcfg.reso_col = 1.5, 0.75
+            mcfg.n_row, mcfg.n_col = 100, 120
+        elif v == 3:
+            mcfg.n_row, mcfg.n_col = 120, 150
+            mcfg.min_cont_cell_cnt, mcfg.min_cont_key_cnt = 5, 12
+        elif v == 4:
+            mcfg.piv_firsts, mcfg.dist_firsts, mcfg.roi_radius = 4, 8, 8.0
+            mcfg.blind_sq = 4.0
+        elif v == 5:
+            mcfg.lidar_height = 1.73
+            mcfg.min_cont_cell_cnt = 4
+        ctx = cc.Context(0, mcfg, max_batch=32)
         scans = []
         while len(scans) < 24:
             kind, s = gen(rng)
@@ -34,7 +53,7 @@ def main():
         x = torch.from_numpy(np.concatenate([s for _, s in scans], 0)).cuda()
         desc = cc.desc_to_numpy(ctx.ingest(x, offs))   # a scan that exceeds a capacity comes back flagged, the call succeeds
         for k, (kind, s) in enumerate(scans):
-            od = oracle.Scan(s).desc()[0]
+            od = oracle.Scan(s, cfg=mcfg).desc()[0]
             n_scan += 1
             if int(od["n_cont"].max()) > L.MAXC or desc[k]["flags"]:
                 n_flag += 1
@@ -46,6 +65,7 @@ def main():
             if bad:
                 print("seed %d scan %d (%s, %d points): %s" % (seed0 + it, k, kind, len(s), bad[:3]))
                 n_bad += 1
+        ctx.close()
         if it % 10 == 9:
             print("... %d batches, %d scans, %d flagged, %d bad" % (it + 1, n_scan, n_flag, n_bad), flush=True)
     print("done: %d bad of %d scans (%d capacity cases)" % (n_bad, n_scan, n_flag))

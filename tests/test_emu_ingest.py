@@ -148,3 +148,14 @@ def test_large_components_go_through_the_eight_lane_walk(oracle):
     scan = np.concatenate(pts)[rng.permutation(sum(len(p) for p in pts))]
     d = _check(oracle, [scan])
     assert d["cont"]["cell_cnt"][0, 0].max() > 1000 and (d["cont"]["cell_cnt"][0, :4].max(axis=1) > 128).all() and (d["flags"] == 0).all()
+
+
+def test_fewer_anchors_and_neighbours_than_the_record_holds(oracle):
+    """piv_firsts_ = 4, dist_firsts_ = 8, roi_radius_ = 8 (the record has room for 6 / 10): the slots the reference does not have
+    stay all-zero -- keys, BCI headers, points -- exactly like the oracle's record (found by tests/fuzz_gpu_ingest.py: the BCI
+    headers of the unused anchors carried their (level, seq))."""
+    cfg = oracle.L.default_manager_cfg()
+    cfg.piv_firsts, cfg.dist_firsts, cfg.roi_radius, cfg.blind_sq = 4, 8, 8.0, 4.0
+    d = _check(oracle, [terrain_scan(4, n=20000, scale=1.2)], cfg=cfg)
+    assert (d["bcis"]["n_pts"][0][:, :4] > 0).any() and (d["bcis"]["n_pts"][0][:, 4:] == 0).all()
+    assert (d["bcis"]["piv_seq"][0][:, 4:] == 0).all() and (d["bcis"]["level"][0][:, 4:] == 0).all()
