@@ -27,6 +27,13 @@ const int NBUCKET = 6;                 // LayerDB::max_num_backets_, contour_db.
 
 struct Bucket {
   float buc_beg, buc_end;
+  // What the bucket's kd-tree INDEXES, as an interval of key dimension 0.  The reference (re)builds a bucket's index only
+  // when popBufferMax moves something out of the buffer (contour_db.h:121-143, rebuildTree :109-117); a re-balance that
+  // appends the neighbour's slice to data_tree_ without such a pop leaves those keys outside the index -- findNeighbors
+  // never reaches them -- until the bucket's next rebuild, and a bucket that has never popped has no tree at all
+  // (TreeBucket::knnSearch returns at once, contour_db.cpp:387).  The slices are contiguous in dimension 0, so the indexed
+  // part of a bucket stays an interval: [idx_lo, idx_hi), empty until the first rebuild, the whole range after every rebuild.
+  float idx_lo, idx_hi;
   std::vector<int> tree;                       // data_tree_/gkidx_tree_ (ids)
   std::vector<std::pair<double, int>> buffer;  // (ts, id), ascending ts
   size_t getTreeSize() const { return tree.size(); }
@@ -49,9 +56,11 @@ struct LayerBook {
     ranges[NBUCKET] = MAX_BUCKET_VAL;
     b[0].buc_beg = -MAX_BUCKET_VAL;
     b[0].buc_end = MAX_BUCKET_VAL;
+    b[0].idx_lo = b[0].idx_hi = -MAX_BUCKET_VAL;  // no tree yet
     for (int i = 1; i < NBUCKET; i++) {
       ranges[i] = MAX_BUCKET_VAL;
       b[i].buc_beg = b[i].buc_end = MAX_BUCKET_VAL;
+      b[i].idx_lo = b[i].idx_hi = MAX_BUCKET_VAL;
     }
   }
 
@@ -84,7 +93,16 @@ struct LayerBook {
         newly_active.push_back(t.buffer[i].second);
       }
       t.buffer.erase(t.buffer.begin(), t.buffer.begin() + gap);
+      t.idx_lo = t.buc_beg;  // rebuildTree(): everything in data_tree_ is indexed from now on
+      t.idx_hi = t.buc_end;
     }
+  }
+  // every bucket's index covers its whole range (or the range is empty): the steady state, in which the searches need no
+  // per-key test
+  bool fullyIndexed() const {
+    for (int i = 0; i < NBUCKET; i++)
+      if (ranges[i] < ranges[i + 1] && !(b[i].idx_lo <= ranges[i] && b[i].idx_hi >= ranges[i + 1]) && !b[i].tree.empty()) return false;
+    return true;
   }
 
   float k0(int id) const { return key0[id]; }
@@ -203,6 +221,13 @@ struct LayerBook {
     }
     tr1.buc_end = tr2.buc_beg = split_val;
     ranges[idx_t1 + 1] = split_val;
+    // the giving bucket's index loses the slice (what the reference's stale index does with it until the bucket's next
+    // rebuild is undefined behaviour: it holds positions of a vector that has been compacted); the receiving bucket's index
+    // does not gain it before ITS next rebuild
+    if (from1)
+      tr1.idx_hi = std::min(tr1.idx_hi, split_val);
+    else
+      tr2.idx_lo = std::max(tr2.idx_lo, split_val);
     auto by_ts = [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first < y.first; };
     std::sort(tr1.buffer.begin(), tr1.buffer.end(), by_ts);
     std::sort(tr2.buffer.begin(), tr2.buffer.end(), by_ts);

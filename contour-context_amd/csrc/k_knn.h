@@ -45,7 +45,24 @@ struct cc_query_meta {  // per query scan, host-built
   int epoch;
   int n_keys[CC_NQLEV];            // keys appended to the layer before this epoch
   float ranges[CC_NQLEV][7];       // LayerDB::bucket_ranges_ at this epoch
+  // What the buckets' kd-trees INDEX at this epoch (cc_hostdb.h, Bucket::idx_lo / idx_hi): a key in a tree is found by the
+  // reference only if its bucket's index has been rebuilt since the key arrived there.  idx_full[l] != 0: every bucket of
+  // the layer indexes its whole range (the steady state, no per-key test); else a key of bucket b is visible iff
+  // idx[l][2 b] <= key[0] < idx[l][2 b + 1].
+  int idx_full[CC_NQLEV];
+  float idx[CC_NQLEV][12];
 };
+
+// the slow path of the visibility test (a layer with a bucket whose index does not cover its range at the query's epoch)
+__device__ __forceinline__ bool cc_knn_key_indexed(const cc_query_meta *qm, int ll, float k0) {
+  bool ok = false;
+#pragma unroll
+  for (int b = 0; b < 6; b++) {
+    const bool in_b = qm->ranges[ll][b] <= k0 && k0 < qm->ranges[ll][b + 1];
+    ok = ok || (in_b && qm->idx[ll][2 * b] <= k0 && k0 < qm->idx[ll][2 * b + 1]);
+  }
+  return ok;
+}
 
 
 // Ascending bitonic sort of 64 * R keys held R per lane: position p lives in v[p / 64] of lane p % 64.
@@ -345,6 +362,7 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
   const unsigned cap = (unsigned)P.cap_k;
   const int epoch = qm->epoch;
   const int nnk = P.nnk;
+  const bool idx_full = qm->idx_full[ll] != 0;  // wave-uniform
 
   // ---- index ranges of the visible buckets (src/cont2/contour_db.cpp:322-369: mid = the bucket of the anchor's first
   // dimension, visited are {0..mid} and {mid + i : i > mid, mid + i < 6}) and the anchor's own position.
@@ -453,6 +471,7 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
         // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
         // distance still compete, on the key id
         pass[dir] = inside[dir] && act[dir] <= epoch && (tightened ? (r <= ub) : (r < ub));
+        if (!idx_full && pass[dir]) pass[dir] = cc_knn_key_indexed(qm, ll, c[dir][0]);  // rare: see cc_query_meta
       }
       kcur[dir] = kid[dir];
       // the step's outermost key decides whether the direction goes on: (key[0] - q[0])^2 is a lower bound of the
@@ -766,6 +785,7 @@ struct cc_knn_tlds {
   unsigned wl[CC_KNN_TW][CC_KNN_TWL];  // (search << 28) | sorted index
   float qk[CC_KNN_TQ][CC_KEY_DIM];     // the searches' keys, for the threads that work off other searches' pairs
   int qb[CC_KNN_TQ][6];                // L0, E1, S2, E2 (visible index ranges), the epoch, the search's own position
+  int qq[CC_KNN_TQ];                   // the search's query, or -1 when the layer's buckets index their whole ranges at its epoch (no per-key test)
   cc_knn_tstate st[CC_KNN_TQ];
   // per round parity (a wave may be one round ahead of another between two barriers):
   int wn[2][CC_KNN_TW];                // pairs pending in each wave's queue
@@ -941,6 +961,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
       L.st[j].cnt = 0;
       L.st[j].tight = 0;
       L.qb[j][4] = qm->epoch;
+      L.qq[j] = qm->idx_full[ll] ? -1 : q;
 #pragma unroll
       for (int d = 0; d < CC_KEY_DIM; d++) L.qk[j][d] = k[d];
     }
@@ -1143,7 +1164,8 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           const float ub = L.st[js].ub;
           // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
           // distance still compete, on the key id
-          if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub))) {
+          const int qq_ = L.qq[js];
+          if (act <= L.qb[js][4] && (L.st[js].tight ? (r_ <= ub) : (r_ < ub)) && (qq_ < 0 || cc_knn_key_indexed(qmeta + qq_, ll, c[0]))) {
             const int slot = atomicAdd(&L.st[js].cnt, 1);
             L.buf[js][slot] = ((unsigned long long)__float_as_uint(r_) << 32) | (unsigned)kid;
           }

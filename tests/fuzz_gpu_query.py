@@ -50,7 +50,19 @@ def one(cc, seed):
     # are unique, which the evaluator CHECKs: distinct values here (a duplicate merges two scans' candidates in the oracle)
     seeds = rng.choice(1 << 20, n, replace=False).astype(np.int32)
     os.environ["CC_KNN_MODE"] = "2" if seed % 2 else "0"
-    ctx = cc.Context(0, None, max_batch=128)
+    # every seventh drive: another ContourManagerConfig (MulRan levels, fewer anchors / neighbours, a coarser grid)
+    mcfg = None
+    if seed % 7 == 3:
+        mcfg = L.default_manager_cfg(mulran=bool(rng.integers(2)))
+        v = int(rng.integers(3))
+        if v == 0:
+            mcfg.piv_firsts, mcfg.dist_firsts, mcfg.roi_radius = 4, 8, 8.0
+        elif v == 1:
+            mcfg.reso_row = mcfg.reso_col = 2.0
+            mcfg.n_row = mcfg.n_col = 74
+        else:
+            mcfg.min_cont_cell_cnt, mcfg.min_cont_key_cnt = 4, 12
+    ctx = cc.Context(0, mcfg, max_batch=128)
     desc = ctx.ingest(x.reshape(-1, 4), offs)
     db = cc.Database(ctx, cfg=d, capacity=n)
     online = seed % 4 == 1
@@ -85,7 +97,7 @@ def one(cc, seed):
         res = np.concatenate(parts)
     torch.cuda.synchronize()
     dn = cc.desc_to_numpy(desc)
-    ores, _, odesc = oracle.run_sequence(x.cpu().numpy().reshape(-1, 4), offs, ts, seeds, dcfg=d, lb=lb, ub=ub, want_desc=True)
+    ores, _, odesc = oracle.run_sequence(x.cpu().numpy().reshape(-1, 4), offs, ts, seeds, mcfg=mcfg, dcfg=d, lb=lb, ub=ub, want_desc=True)
     bad = 0
     for i in range(n):
         if dn["flags"][i] or res["flags"][i]:

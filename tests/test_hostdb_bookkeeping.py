@@ -1,6 +1,7 @@
 """K0: the host-side LayerDB bookkeeping of the product (bucket membership timeline, re-balancing, bucket ranges)
 against the oracle's restatement of TreeBucket/LayerDB, on thousands of hand-made keys that force every bucket to
 be used.  Runs the product's C-ABI through the CPU build (tests/emu)."""
+import os
 import numpy as np
 import pytest
 
@@ -160,3 +161,37 @@ def test_knn_tile_full_group_every_pair_passes(oracle, monkeypatch):
                 m = ocnt[ll, seq]
                 a, b = oknn[ll, seq, :m], knn[kq, ll, seq, :m]
                 assert np.array_equal(a["dist_sq"], b["dist_sq"]) and np.array_equal(a["gidx"], b["gidx"])
+
+
+def test_keys_a_bucket_has_not_indexed_yet_are_not_found(oracle, monkeypatch):
+    """The reference rebuilds a bucket's kd-tree only when popBufferMax moves something out of that bucket's buffer
+    (contour_db.h:109-143): a re-balance that hands a bucket its neighbour's slice without such a pop leaves the slice outside
+    the index -- and a bucket that has never popped has no tree at all (contour_db.cpp:387) -- until the bucket's next
+    rebuild.  The host bookkeeping carries the indexed interval of every bucket per epoch (cc_hostdb.h), the searches test
+    keys against it.  Fixture: the retrieval keys of a 78-scan drive of the randomised GPU campaign (tests/fuzz_gpu_query.py
+    seed 12046, short DB delays) in which layer 0's third bucket holds 53 keys and no tree at the epochs of the last scans: the
+    reference finds 0 neighbours for a key that has 30 within its radius.  Hit counts of every search of every scan, walk and
+    tiled, against the oracle's replay (whose trees are the reference's own nanoflann, oracle/_ref) recorded in the fixture."""
+    L = oracle.L
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_unindexed_bucket_fixture.npz"))
+    n = len(z["ts"])
+    desc = np.zeros(n, L.scan_desc_dt)
+    desc["keys"] = z["keys"]
+    d = L.default_db_cfg()
+    cfg = z["cfg"]
+    d.min_elapse, d.max_elapse, d.nnk, d.max_fine_opt, d.n_q_levels = cfg[0], cfg[1], int(cfg[2]), int(cfg[3]), int(cfg[4])
+    for i in range(3):
+        d.q_levels[i] = int(cfg[5 + i])
+    ts, seeds = z["ts"], z["seeds"]
+    ocnt = z["knn_cnt"]      # the oracle's counts on the drive's full descriptors (tests/golden/make_knn_unindexed_fixture.py)
+    assert ocnt[65, 0, 0] == 0 and ocnt[64, 0].sum() > 50        # the case the fixture is about
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CC_KNN_MODE", mode)
+        api = emu_api.EmuApi(L)
+        ctx = api.create(max_batch=8)
+        db = api.db_create(ctx, d, cap=n)
+        api.db_add(db, desc, ts, seeds)
+        for c0 in range(0, n, 26):
+            q = np.arange(c0, min(c0 + 26, n), dtype=np.int32)
+            _, knn, cnt = api.db_query(db, desc[q], q, want_knn=True)
+            assert np.array_equal(cnt, ocnt[q]), (mode, c0, np.argwhere(cnt != ocnt[q])[:5])
