@@ -319,7 +319,11 @@ __device__ __forceinline__ float cc_knn_reduce(unsigned long long *buf, int cnt,
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(v[0] >> 32), nnk - 1));
 }
 
-// grid = nq * CC_NQLEV * CC_NPIV, block = 64 (one wave per anchor key)
+// grid = nq * CC_NQLEV * CC_NPIV, block = 64 (one wave per anchor key).  VIS: the chunk has a query at an epoch at which some
+// bucket's kd-tree does not index its whole range (cc_query_meta::idx_full): that instance tests every candidate key against
+// its bucket's indexed interval; the common instance carries none of it (the test in the shared loop cost the walk 8 %:
+// the kernel sits at its scalar-register limit).
+template <bool VIS>
 __global__ void __launch_bounds__(64)
 cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query_meta *__restrict__ qmeta,
          cc_knn_hit_t *__restrict__ hits, int *__restrict__ hit_cnt) {
@@ -362,7 +366,7 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
   const unsigned cap = (unsigned)P.cap_k;
   const int epoch = qm->epoch;
   const int nnk = P.nnk;
-  const bool idx_full = qm->idx_full[ll] != 0;  // wave-uniform
+  const bool idx_full = VIS ? qm->idx_full[ll] != 0 : true;  // wave-uniform
 
   // ---- index ranges of the visible buckets (src/cont2/contour_db.cpp:322-369: mid = the bucket of the anchor's first
   // dimension, visited are {0..mid} and {mid + i : i > mid, mid + i < 6}) and the anchor's own position.
@@ -471,7 +475,7 @@ cc_k_knn(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_query
         // before nnk candidates are known a key must be strictly inside dist_ub; afterwards keys AT the nnk-th best
         // distance still compete, on the key id
         pass[dir] = inside[dir] && act[dir] <= epoch && (tightened ? (r <= ub) : (r < ub));
-        if (!idx_full && pass[dir]) pass[dir] = cc_knn_key_indexed(qm, ll, c[dir][0]);  // rare: see cc_query_meta
+        if (VIS && !idx_full && pass[dir]) pass[dir] = cc_knn_key_indexed(qm, ll, c[dir][0]);  // rare: see cc_query_meta
       }
       kcur[dir] = kid[dir];
       // the step's outermost key decides whether the direction goes on: (key[0] - q[0])^2 is a lower bound of the
