@@ -534,26 +534,32 @@ def online_replay(cc, ctx, batches, B, P, n, sub, dev):
            "10 Hz stamps, shipped 15 s / 25 s delays (test/batch_bin_test.cpp:131-237, contour_db.h:814-843)"}
     res = {}
     for mode in ("warmup", "with_update", "without_update"):
-        db = cc.Database(ctx, capacity=n + 16)
-        db.set_lanes(ONLINE_LANES)
-        if mode == "without_update":
-            for k, c in enumerate(chunks):
-                d = ctx.ingest(c, offs)
-                db.add_scans(d, ts[k * sub:(k + 1) * sub], np.arange(k * sub, (k + 1) * sub, dtype=np.int32))
-        torch.cuda.synchronize()
-        gc.collect()
-        gc.disable()
-        t0 = time.perf_counter()
-        r = _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add=(mode != "without_update"))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        gc.enable()
-        res[mode] = r
+        rates = []
+        for rep in range(1 if mode == "warmup" else 3):  # a pass lasts ~14 ms: the median of three (each on a fresh DB) is what is quoted
+            db = cc.Database(ctx, capacity=n + 16)
+            db.set_lanes(ONLINE_LANES)
+            if mode == "without_update":
+                for k, c in enumerate(chunks):
+                    d = ctx.ingest(c, offs)
+                    db.add_scans(d, ts[k * sub:(k + 1) * sub], np.arange(k * sub, (k + 1) * sub, dtype=np.int32))
+            torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()
+            t0 = time.perf_counter()
+            r = _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add=(mode != "without_update"))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            gc.enable()
+            res[mode] = r
+            rates.append((n / dt, dt, {k_: round(v, 4) for k_, v in _replay_pass.host_ms.items()}))
+            db.close()
         if mode != "warmup":
-            out["scans_per_s_" + mode] = n / dt
-            out["ms_per_sub_batch_" + mode] = dt / len(chunks) * 1e3
-            out["host_ms_per_sub_batch_" + mode] = {k_: round(v, 4) for k_, v in _replay_pass.host_ms.items()}
-        db.close()
+            rates.sort(key=lambda t_: t_[0])
+            med = rates[len(rates) // 2]
+            out["scans_per_s_" + mode] = med[0]
+            out["scans_per_s_" + mode + "_min_max"] = [rates[0][0], rates[-1][0]]
+            out["ms_per_sub_batch_" + mode] = med[1] / len(chunks) * 1e3
+            out["host_ms_per_sub_batch_" + mode] = med[2]
     out["loop_closures"] = int((res["with_update"]["n_res"] > 0).sum())
     out["identical_results"] = bool(res["with_update"].tobytes() == res["without_update"].tobytes())
     return out
