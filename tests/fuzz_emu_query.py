@@ -23,8 +23,10 @@ def one(seed):
     L = oracle.L
     rng = np.random.default_rng(seed)
     d = L.default_db_cfg()
-    d.min_elapse = float(rng.uniform(0.8, 2.0))
-    d.max_elapse = d.min_elapse + float(rng.uniform(0.5, 1.5))
+    long_drive = bool(os.environ.get("CC_FUZZ_LONG"))   # 300-500 scans with the shipped 15 s / 25 s delays: many re-balances
+    if not long_drive:
+        d.min_elapse = float(rng.uniform(0.8, 2.0))
+        d.max_elapse = d.min_elapse + float(rng.uniform(0.5, 1.5))
     d.nnk = int(rng.choice([10, 30, 50, 64]))
     d.max_fine_opt = int(rng.choice([2, 5, 10]))
     qlv = [(1, 2, 3), (2, 3), (2, 3, 4), (1, 2, 3)][int(rng.integers(4))]
@@ -36,9 +38,9 @@ def one(seed):
         lb.i_ovlp_sum, lb.i_ovlp_max_one, lb.i_in_ang_rng, lb.i_indiv_sim, lb.i_orie_sim = [int(v) for v in rng.integers(2, 5, 5)]
         lb.correlation = float(rng.uniform(0.1, 0.5))
     kind = int(rng.integers(3))
-    world = cc.synth.World(loop_len=float(rng.uniform(24, 36)), dense=(kind == 1), seed=int(rng.integers(1 << 20))) if kind < 2 else \
+    world = cc.synth.World(loop_len=float(rng.uniform(160, 220) if long_drive else rng.uniform(24, 36)), dense=(kind == 1), seed=int(rng.integers(1 << 20))) if kind < 2 else \
         cc.synth.World(kitti=True, seed=int(rng.integers(1 << 20)), block=float(rng.uniform(36, 50)), tile=300.0)
-    n = int(rng.integers(56, 84))
+    n = int(rng.integers(300, 500)) if long_drive else int(rng.integers(56, 84))
     x, poses, ts = cc.synth.make_sequence(n, world=world, beams=16, azim=450, step=(1.0 if kind < 2 else 3.0))
     P = x.shape[1]
     xs = x.numpy().reshape(-1, 4)

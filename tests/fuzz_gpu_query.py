@@ -24,8 +24,10 @@ def one(cc, seed):
     L = oracle.L
     rng = np.random.default_rng(seed)
     d = L.default_db_cfg()
-    d.min_elapse = float(rng.uniform(0.8, 2.0))
-    d.max_elapse = d.min_elapse + float(rng.uniform(0.5, 1.5))
+    long_drive = bool(os.environ.get("CC_FUZZ_LONG"))   # 300-500 scans with the shipped 15 s / 25 s delays: many re-balances
+    if not long_drive:
+        d.min_elapse = float(rng.uniform(0.8, 2.0))
+        d.max_elapse = d.min_elapse + float(rng.uniform(0.5, 1.5))
     d.nnk = int(rng.choice([10, 30, 50, 64]))
     d.max_fine_opt = int(rng.choice([2, 5, 10]))
     qlv = [(1, 2, 3), (2, 3), (2, 3, 4), (1, 2, 3)][int(rng.integers(4))]
@@ -37,9 +39,9 @@ def one(cc, seed):
         lb.i_ovlp_sum, lb.i_ovlp_max_one, lb.i_in_ang_rng, lb.i_indiv_sim, lb.i_orie_sim = [int(v) for v in rng.integers(2, 5, 5)]
         lb.correlation = float(rng.uniform(0.1, 0.5))
     kind = int(rng.integers(3))
-    world = cc.synth.World(loop_len=float(rng.uniform(24, 36)), dense=(kind == 1), seed=int(rng.integers(1 << 20))) if kind < 2 else \
+    world = cc.synth.World(loop_len=float(rng.uniform(160, 220) if long_drive else rng.uniform(24, 36)), dense=(kind == 1), seed=int(rng.integers(1 << 20))) if kind < 2 else \
         cc.synth.World(kitti=True, seed=int(rng.integers(1 << 20)), block=float(rng.uniform(36, 50)), tile=300.0)
-    n = int(rng.integers(56, 84))
+    n = int(rng.integers(300, 500)) if long_drive else int(rng.integers(56, 84))
     full = seed % 3 == 0
     x, poses, ts = cc.synth.make_sequence(n, world=world, device="cuda", step=(1.0 if kind < 2 else 3.0),
                                           **({} if full else dict(beams=16, azim=450)))
@@ -62,7 +64,7 @@ def one(cc, seed):
             mcfg.n_row = mcfg.n_col = 74
         else:
             mcfg.min_cont_cell_cnt, mcfg.min_cont_key_cnt = 4, 12
-    ctx = cc.Context(0, mcfg, max_batch=128)
+    ctx = cc.Context(0, mcfg, max_batch=512)
     desc = ctx.ingest(x.reshape(-1, 4), offs)
     db = cc.Database(ctx, cfg=d, capacity=n)
     online = seed % 4 == 1
@@ -72,7 +74,7 @@ def one(cc, seed):
     else:
         # the online loop: sub-batch after sub-batch is added and queried at its own epochs with nothing collected in
         # between (cc_db_add_scans[_prepare] / cc_db_query_submit, 1-4 lanes): appends run next to query chunks in flight
-        sub = int(rng.choice([1, 5, 16, 37]))
+        sub = int(rng.choice([1, 5, 16, 37])) if not long_drive else int(rng.choice([16, 37, 128]))
         db.set_lanes(int(rng.choice([1, 2, 4])))
         prep = bool(rng.integers(2))
         parts = []
