@@ -436,4 +436,38 @@ class ContLCDEvaluator {
   double getTPMeanRot() const { return tp_rot_rmse.getMean(); }
   double getTPRMSETrans() const { return tp_trans_rmse.getRMSE(); }
   double getTPRMSERot() const { return tp_rot_rmse.getRMSE(); }
+
+  // evaluator.h:436, src/eval/evaluator.cpp:7-64: the check thresholds from a `name lower upper` text file
+  // (config/score_thres_*.cfg): the five integer gates and correlation / area_perc / neg_est_dist; `#` starts a comment,
+  // unknown names are skipped, a name is echoed as it is read
+  static void loadCheckThres(const std::string &fpath, CandidateScoreEnsemble &thres_lb, CandidateScoreEnsemble &thres_ub) {
+    std::ifstream in(fpath);
+    if (!in.good()) {
+      std::cerr << "Error opening thres config file: " << fpath << std::endl;
+      return;
+    }
+    std::string line, name;
+    while (std::getline(in, line)) {
+      std::istringstream iss(line);
+      if (!(iss >> name)) continue;
+      std::cout << name << std::endl;
+      if (name[0] == '#') continue;
+      if (name == "i_ovlp_sum")
+        iss >> thres_lb.sim_constell.i_ovlp_sum >> thres_ub.sim_constell.i_ovlp_sum;
+      else if (name == "i_ovlp_max_one")
+        iss >> thres_lb.sim_constell.i_ovlp_max_one >> thres_ub.sim_constell.i_ovlp_max_one;
+      else if (name == "i_in_ang_rng")
+        iss >> thres_lb.sim_constell.i_in_ang_rng >> thres_ub.sim_constell.i_in_ang_rng;
+      else if (name == "i_indiv_sim")
+        iss >> thres_lb.sim_pair.i_indiv_sim >> thres_ub.sim_pair.i_indiv_sim;
+      else if (name == "i_orie_sim")
+        iss >> thres_lb.sim_pair.i_orie_sim >> thres_ub.sim_pair.i_orie_sim;
+      else if (name == "correlation")
+        iss >> thres_lb.sim_post.correlation >> thres_ub.sim_post.correlation;
+      else if (name == "area_perc")
+        iss >> thres_lb.sim_post.area_perc >> thres_ub.sim_post.area_perc;
+      else if (name == "neg_est_dist")
+        iss >> thres_lb.sim_post.neg_est_dist >> thres_ub.sim_post.neg_est_dist;
+    }
+  }
 };

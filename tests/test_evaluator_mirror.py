@@ -129,3 +129,23 @@ def test_python_evaluator_reproduces_shipped_outcome(cc, tmp_path):
     for g, r in zip(got, rows):
         assert g[0] == r[0] and g[1] == r[1] and g[6] == r[6] and g[7] == r[7]
         assert abs(float(g[2]) - float(r[2])) <= 1e-6 * max(1.0, abs(float(r[2])))
+
+
+def test_load_check_thres_reads_the_reference_threshold_files(cc, tmp_path):
+    """ContLCDEvaluator::loadCheckThres (evaluator.h:436, src/eval/evaluator.cpp:7-64): `name lower upper` per line, `#`
+    comments, blank lines and unknown names skipped -- the format of the reference's config/score_thres_*.cfg."""
+    import emu_api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "contour-context_amd")
+    emu_so = emu_api.build()
+    exe = str(tmp_path / "thr")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tests", "load_check_thres_check.cpp"), "-I", os.path.join(pkg, "hostcpp"),
+                           "-I", os.path.join(root, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so),
+                           "-pthread", "-o", exe])
+    cfg = tmp_path / "thres.cfg"
+    cfg.write_text("i_ovlp_sum          4       6\ni_ovlp_max_one      3       7\ni_in_ang_rng        4       6\n\ni_indiv_sim         5       6\n"
+                   "i_orie_sim          4       8\n# f_area_perc         5       10\nunknown_name 1 2\ncorrelation         0.40    0.75\n"
+                   "area_perc           0.03    0.15\nneg_est_dist        -5.01    -5.0\n")
+    out = subprocess.check_output([exe, str(cfg)], text=True)
+    assert "RES 4 3 4 5 4 0.4000 0.0300 -5.0100 | 6 7 6 6 8 0.7500 0.1500 -5.0000" in out
+    assert out.splitlines()[0] == "i_ovlp_sum" and "#" in out          # names are echoed as they are read, comments too
