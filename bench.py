@@ -85,6 +85,10 @@ def main():
                          "strong = the --batch scans of a step are split over the ranks (total work fixed)")
     ap.add_argument("--beams", type=int, default=64, help="rays of the synthetic sensor: beams x azim (the metric is quoted on 64 x 1875 = 120 000 points)")
     ap.add_argument("--azim", type=int, default=1875)
+    ap.add_argument("--ingest-cus", default=os.environ.get("CC_BENCH_INGEST_CUS", ""),
+                    help="CU partition of the overlapped step (DESIGN.md section 3): 'a/b' = the ingest stream is created with "
+                         "hipExtStreamCreateWithCUMask on a of every b CUs of each XCD, 'xa/b' = on a of every b XCDs; the query "
+                         "lanes keep the whole chip, so the other CUs' LDS is never taken by K1 / K2.  Empty: no mask")
     ap.add_argument("--tune-sweep", default="",
                     help="tuning aid (library built with -DCC_TUNE): 'VAR=v1,v2;VAR2=...': after the timed run, rebuild the DB "
                          "handle under each setting and print the isolated per-kernel ms of two steps to stderr")
@@ -222,7 +226,7 @@ def main():
     # Two HIP streams: while the query chain of batch s runs on the main stream, the ingest kernels of batch s+1 run on
     # a second one (double-buffered descriptors).  Every batch is ingested AND queried inside the timed region.
     qdesc2 = [qdesc, torch.empty_like(qdesc)]
-    s_ing = None if harness else torch.cuda.Stream(device=dev)
+    s_ing = None if harness else (masked_stream(torch, dev, args.ingest_cus) if args.ingest_cus else torch.cuda.Stream(device=dev))
     s_main = None if harness else torch.cuda.current_stream(dev)
 
     def ingest_async(x, slot):
@@ -316,8 +320,11 @@ def main():
         for spec in [""] + args.ab_env.split(";"):
             kv = [a.split("=") for a in spec.split(",") if a]
             for k_, v_ in kv:
-                if k_ not in ("LANES", "PROF"):
+                if k_ not in ("LANES", "PROF", "INGEST_CUS"):
                     os.environ[k_] = v_
+            if "INGEST_CUS" in dict(kv):  # pseudo-variable: the ingest stream's CU mask ('-' = none)
+                v_ = dict(kv)["INGEST_CUS"]
+                s_ing = torch.cuda.Stream(device=dev) if v_ == "-" else masked_stream(torch, dev, v_)
             db2 = cc.Database(ctx, capacity=n_db + 16)
             lanes_ = int(dict(kv).get("LANES", args.lanes))  # pseudo-variable: cc_db_set_lanes
             if lanes_:
@@ -472,6 +479,36 @@ def main():
 # and collects the previous results (measured: 2 lanes 225-246 k, 3 lanes 257 k, 4 lanes + 512-scan sub-batches 275 k
 # scans/s on the dense world).  The steady-state headline keeps the library default of two lanes (1 024-scan batches).
 ONLINE_LANES = 4
+
+
+_MASKED = []  # (handle, wrapper): the raw streams live as long as the process
+
+
+def masked_stream(torch, dev, spec):
+    """A HIP stream whose kernels are dispatched to a subset of the CUs (hipExtStreamCreateWithCUMask), wrapped for torch.
+    spec 'a/b': a of every b CUs of each XCD; 'xa/b': a of every b XCDs.  Bit i of the mask is CU i // n_xcd of XCD
+    i % n_xcd (the driver deals the bits out to the XCDs in turn)."""
+    import ctypes as C
+    by_xcd = spec.startswith("x")
+    a, b = [int(v) for v in spec.lstrip("x").split("/")]
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_xcd = 8
+    words = (C.c_uint32 * ((n_cu + 31) // 32))()
+    on = 0
+    for i in range(n_cu):
+        unit = (i % n_xcd) if by_xcd else (i // n_xcd)
+        if unit % b < a:
+            words[i // 32] |= 1 << (i % 32)
+            on += 1
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    w = torch.cuda.ExternalStream(st.value, device=dev)
+    _MASKED.append((st, w))
+    print("ingest stream on %d of %d CUs (%s)" % (on, n_cu, spec), file=sys.stderr)
+    return w
 
 
 def _replay_pass(cc, ctx, db, chunks, offs, ts, sub, dev, add):

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/cont2_amd.h"
@@ -74,9 +76,20 @@ struct cc_ctx {
   std::mutex slot_mu;                 // slot_free: cc_scan_ingest may run on a helper thread next to cc_scan_offload / cc_scan_release
   // per-scan loop: two pinned staging buffers (the caller may fill the second one -- e.g. read the next scan's file from
   // another thread -- while the first one's scan is in flight), one device point buffer (the stream orders its reuse)
-  float *h_pts[2] = {nullptr, nullptr}, *d_pts = nullptr;
-  hipEvent_t pts_ev[2] = {nullptr, nullptr};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
-  bool pts_busy[2] = {false, false};
+  // Slots 0 and 1 are the caller's to name (cc_stage_points_slot), slot 2 is cc_stage_points' own -- a thread that stages
+  // without naming a slot (ContourManager::makeBEV) never gets a buffer a read-ahead helper writes.
+  static const int NPTS = 3;
+  float *h_pts[NPTS] = {nullptr, nullptr, nullptr}, *d_pts = nullptr;
+  hipEvent_t pts_ev[NPTS] = {nullptr, nullptr, nullptr};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
+  bool pts_busy[NPTS] = {false, false, false};
+  // Ingest state (the staging slots, d_pts, the offsets ring, the K1/K2 scratch, ev_last) is shared by every call of the
+  // context: ing_mu is held inside cc_ingest_batch / cc_stage_points* / cc_scan_ingest.  A slot handed out by
+  // cc_stage_points* belongs to the calling thread until that thread's cc_scan_ingest has queued its copy (or the thread
+  // stages the slot again); another thread asking for it WAITS (pts_cv) instead of being handed memory that is being filled.
+  std::recursive_mutex ing_mu;
+  std::condition_variable_any pts_cv;
+  bool pts_handed[NPTS] = {false, false, false};
+  std::thread::id pts_owner[NPTS];
   int64_t pts_cap = 0;  // points
   std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
   float *d_loop_bev = nullptr;
@@ -187,7 +200,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
   }
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
-  if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * 16 * max_batch_scans));
+  if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
   {
@@ -225,12 +238,12 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
   HIPCHK(hipSetDevice(c->device));
   if (prof_flush(c) != CC_OK) return set_err(CC_EHIP, "cc_profile_read: event sync failed");
   if (c->d_phase_clk) {  // tuning aid: mean phase durations of the last launch, in microseconds (100 MHz wall clock)
-    std::vector<long long> h(16 * (size_t)c->max_batch);
+    std::vector<long long> h(CC_K2_NCLK * (size_t)c->max_batch);
     HIPCHK(hipMemcpy(h.data(), c->d_phase_clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
     const int n = c->max_batch < 256 ? c->max_batch : 256;
-    double ph[9] = {0};
+    double ph[9] = {0}, sub[8] = {0}, lv[6] = {0};
     for (int i = 0; i < n; i++) {
-      const long long *p = &h[(size_t)i * 16];
+      const long long *p = &h[(size_t)i * CC_K2_NCLK];
       ph[0] += p[1] * 0.01;
       ph[1] += p[2] * 0.01;
       ph[2] += p[3] * 0.01;
@@ -239,9 +252,20 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
       ph[5] += (p[7] - p[6]) * 0.01;
       ph[6] += (p[8] - p[7]) * 0.01;
       ph[7] += (p[8] - p[0]) * 0.01;
+      sub[0] += (p[9] - p[0]) * 0.01;    // fill + active list
+      sub[1] += (p[11] - p[10]) * 0.01;  // list starts + member lists
+      sub[2] += (p[12] - p[11]) * 0.01;  // lane walk
+      sub[3] += (p[4] - p[12]) * 0.01;   // eight-lane walk
+      sub[4] += p[14] * 0.01;            // keys: RoI lists
+      sub[5] += p[15] * 0.01;            // keys: division sums
+      for (int j = 0; j < 6; j++) lv[j] += p[16 + j] * 0.01;
     }
     fprintf(stderr, "[cc_k_contours phases, mean us over %d scans] ccl %.1f  enum+bbox %.1f  walk %.1f  order+sort %.1f  emit %.1f  keys %.1f  bci %.1f  | total %.1f\n",
             n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
+    fprintf(stderr, "[cc_k_contours sub-phases] fill+list %.1f | walk: member lists %.1f  lane walk %.1f  eight-lane walk %.1f | keys: RoI lists %.1f  division sums %.1f\n",
+            sub[0] / n, sub[1] / n, sub[2] / n, sub[3] / n, sub[4] / n, sub[5] / n);
+    fprintf(stderr, "[cc_k_contours level loop, summed over the levels] unions %.1f  flatten+count %.1f  kept roots %.1f  rank %.1f  bbox/area %.1f  records %.1f\n",
+            lv[0] / n, lv[1] / n, lv[2] / n, lv[3] / n, lv[4] / n, lv[5] / n);
   }
   ms_out[0] = c->ms_acc[0];
   ms_out[1] = c->ms_acc[1];
@@ -277,7 +301,7 @@ int cc_destroy(cc_ctx *c) {
     hipStreamSynchronize(c->s_loop);
     hipStreamDestroy(c->s_loop);
   }
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < cc_ctx::NPTS; i++) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
     if (c->pts_ev[i]) hipEventDestroy(c->pts_ev[i]);
   }
@@ -296,6 +320,7 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
                     const cc_ingest_debug_t *dbg, void *stream_) {
   if (!c || !d_xyzi || !h_offsets || !d_out || n_scans < 0) return set_err(CC_EINVAL, "cc_ingest_batch: bad argument");
   hipStream_t stream = (hipStream_t)stream_;
+  std::lock_guard<std::recursive_mutex> ing_lk(c->ing_mu);  // offsets ring, K1/K2 scratch, ev_last: one call at a time
   HIPCHK(hipSetDevice(c->device));
   for (int i = 0; i < n_scans; i++) {
     const int64_t n = h_offsets[i + 1] - h_offsets[i];
@@ -433,53 +458,103 @@ struct cc_scan {
   bool bev_pending = false;
 };
 
-static int loop_reserve_points(cc_ctx *c, int64_t n_points) {
+static int loop_reserve_points(cc_ctx *c, int64_t n_points) {  // ing_mu held
   if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
   if (!c->s_ing) HIPCHK(hipStreamCreateWithFlags(&c->s_ing, hipStreamNonBlocking));
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < cc_ctx::NPTS; i++)
     if (!c->pts_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[i], hipEventDisableTiming));
   if (n_points <= c->pts_cap) return CC_OK;
+  // growing re-allocates every slot: none may be in another thread's hands (being filled) at that moment
+  const std::thread::id me = std::this_thread::get_id();
+  for (int i = 0; i < cc_ctx::NPTS; i++)
+    if (c->pts_handed[i] && c->pts_owner[i] != me)
+      return set_err(CC_EINVAL, "cc_stage_points: the staging buffers must grow while another thread fills one of them (stage the largest "
+                                "scan first, or give every thread its own context)");
   HIPCHK(hipStreamSynchronize(c->s_ing));
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < cc_ctx::NPTS; i++) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
     c->h_pts[i] = nullptr;
     c->pts_busy[i] = false;
+    c->pts_handed[i] = false;
   }
   hipFree(c->d_pts);
   c->d_pts = nullptr;
   c->pts_cap = 0;
   const int64_t cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
-  for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&c->h_pts[i], sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
+  for (int i = 0; i < cc_ctx::NPTS; i++) HIPCHK(hipHostMalloc((void **)&c->h_pts[i], sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
   HIPCHK(hipMalloc(&c->d_pts, sizeof(float) * 4 * (size_t)cap));
   c->pts_cap = cap;
   return CC_OK;
 }
 
-float *cc_stage_points_slot(cc_ctx *c, int64_t n_points, int slot) {
-  if (!c || n_points < 1 || slot < 0 || slot > 1) return nullptr;
+// ing_mu held by `lk`.  Hands slot `slot` to the calling thread: waits while another thread holds it, then for the slot's
+// last H2D copy (that copy, not the stream).
+static float *stage_slot_locked(cc_ctx *c, int64_t n_points, int slot, std::unique_lock<std::recursive_mutex> &lk) {
+  const std::thread::id me = std::this_thread::get_id();
+  c->pts_cv.wait(lk, [&] { return !c->pts_handed[slot] || c->pts_owner[slot] == me; });
   if (hipSetDevice(c->device) != hipSuccess) return nullptr;
   if (loop_reserve_points(c, n_points) != CC_OK) return nullptr;
-  // the slot's last H2D copy may still read the buffer: wait for that copy, not for the stream
   if (c->pts_busy[slot]) {
     if (hipEventSynchronize(c->pts_ev[slot]) != hipSuccess) return nullptr;
     c->pts_busy[slot] = false;
   }
+  c->pts_handed[slot] = true;
+  c->pts_owner[slot] = me;
   return c->h_pts[slot];
 }
-float *cc_stage_points(cc_ctx *c, int64_t n_points) { return cc_stage_points_slot(c, n_points, 0); }
+
+float *cc_stage_points_slot(cc_ctx *c, int64_t n_points, int slot) {
+  if (!c || n_points < 1 || slot < 0 || slot > 1) return nullptr;
+  std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
+  return stage_slot_locked(c, n_points, slot, lk);
+}
+float *cc_stage_points(cc_ctx *c, int64_t n_points) {
+  if (!c || n_points < 1) return nullptr;
+  std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
+  return stage_slot_locked(c, n_points, 2, lk);
+}
+
+int cc_stage_points_cancel(cc_ctx *c, const float *staged) {
+  if (!c || !staged) return set_err(CC_EINVAL, "cc_stage_points_cancel: bad argument");
+  std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
+  for (int i = 0; i < cc_ctx::NPTS; i++)
+    if (c->h_pts[i] == staged) {
+      if (!c->pts_handed[i] || c->pts_owner[i] != std::this_thread::get_id())
+        return set_err(CC_EINVAL, "cc_stage_points_cancel: the buffer is not in this thread's hands");
+      c->pts_handed[i] = false;
+      c->pts_cv.notify_all();
+      return CC_OK;
+    }
+  return set_err(CC_EINVAL, "cc_stage_points_cancel: not a staging buffer of this context");
+}
 
 int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out) {
   if (!c || !h_xyzi || !out || n_points < 1) return set_err(CC_EINVAL, "cc_scan_ingest: bad argument");
+  std::unique_lock<std::recursive_mutex> lk(c->ing_mu);  // d_pts, the slots, the scratch behind cc_ingest_batch
   HIPCHK(hipSetDevice(c->device));
-  int slot = (c->h_pts[1] && h_xyzi == c->h_pts[1]) ? 1 : 0;
-  if (!c->h_pts[0] || (h_xyzi != c->h_pts[0] && h_xyzi != c->h_pts[1])) {
-    float *dst = cc_stage_points_slot(c, n_points, 0);  // waits for slot 0's previous copy, grows the buffers if need be
+  int slot = -1;
+  for (int i = 0; i < cc_ctx::NPTS; i++)
+    if (c->h_pts[i] && h_xyzi == c->h_pts[i]) slot = i;
+  if (slot < 0) {
+    float *dst = stage_slot_locked(c, n_points, 2, lk);  // waits for the slot's holder and its previous copy, grows the buffers if need be
     if (!dst) return set_err(CC_EHIP, "cc_scan_ingest: staging buffer");
     memcpy(dst, h_xyzi, sizeof(float) * 4 * (size_t)n_points);
-    slot = 0;
+    slot = 2;
+  } else if (!c->pts_handed[slot] || c->pts_owner[slot] != std::this_thread::get_id()) {
+    return set_err(CC_EINVAL, "cc_scan_ingest: the staging buffer was not handed to this thread by cc_stage_points* (or was ingested already)");
   } else if (n_points > c->pts_cap) {
     return set_err(CC_EINVAL, "cc_scan_ingest: more points than were staged");
   }
+  // whatever happens below, the buffer is no longer the caller's: the next thread waiting for the slot may have it once this
+  // call has queued (or given up on) the copy
+  struct hand_back {
+    cc_ctx *c;
+    int slot;
+    ~hand_back() {
+      c->pts_handed[slot] = false;
+      c->pts_cv.notify_all();
+    }
+  } hb{c, slot};
   if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
   // Everything of the ingest goes to its own stream: a caller may ingest scan i + 1 (from a helper thread, as the evaluator
   // mirror does) while scan i is queried and added on the loop stream; whoever reads the descriptor waits for `ready`.

@@ -43,7 +43,10 @@ struct cc_k2_scratch {  // per scan of a launch
   uint16_t act[CC_MAX_CELLS];                               // active cells (above the lowest level), raster order
   uint16_t compidx[CC_NLEV][CC_MAX_CELLS];                  // per level: component index of list entry i, 0x7FFF = none
 };
-#define CC_K2_OWN 4       // list entries a thread keeps in registers (beyond: read from the scratch block)
+#define CC_K2_NCLK 32    // phase-clock slots per scan (tuning aid)
+#define CC_K2_OWN 8       // list entries a thread keeps in registers (beyond: read from the scratch block; a street scene has
+                          // 3-4 k active cells: with four per thread half of them were re-read from the scratch block -- an L2 round
+                          // trip -- in every pass of every level)
 #define CC_K2_CACHE 3072  // active cells whose height / position are staged in LDS for the walk
 #define CC_K2_BIG 128     // components with more cells than this are walked by eight lanes, one running sum each
 
@@ -111,6 +114,44 @@ __device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned 
   }
 }
 
+
+// ---- exp(z) for z <= 0, as the retrieval keys need it (gaussPDF, tools/algos.h:54-56: the f64 value is divided by
+// sqrt(2 pi) and rounded to f32 at once).  2^(j/64) from a 64-entry table (LDS), degree-5 polynomial on |r| <= ln2/128:
+// 15 f64 instructions instead of the library routine's ~30 (whose range checks and last-bit polish are wasted on a result
+// that is rounded to 24 bits), error < 1.2 ulp -- the same class as the library's; the result differs from glibc's in the
+// last f64 bit now and then, which reaches the f32 value once in ~1e8 evaluations (keys carry a tolerance).
+__device__ static const unsigned long long cc_exp2_tab64[64] = {
+  0x3ff0000000000000ull, 0x3ff02c9a3e778061ull, 0x3ff059b0d3158574ull, 0x3ff0874518759bc8ull,
+  0x3ff0b5586cf9890full, 0x3ff0e3ec32d3d1a2ull, 0x3ff11301d0125b51ull, 0x3ff1429aaea92de0ull,
+  0x3ff172b83c7d517bull, 0x3ff1a35beb6fcb75ull, 0x3ff1d4873168b9aaull, 0x3ff2063b88628cd6ull,
+  0x3ff2387a6e756238ull, 0x3ff26b4565e27cddull, 0x3ff29e9df51fdee1ull, 0x3ff2d285a6e4030bull,
+  0x3ff306fe0a31b715ull, 0x3ff33c08b26416ffull, 0x3ff371a7373aa9cbull, 0x3ff3a7db34e59ff7ull,
+  0x3ff3dea64c123422ull, 0x3ff4160a21f72e2aull, 0x3ff44e086061892dull, 0x3ff486a2b5c13cd0ull,
+  0x3ff4bfdad5362a27ull, 0x3ff4f9b2769d2ca7ull, 0x3ff5342b569d4f82ull, 0x3ff56f4736b527daull,
+  0x3ff5ab07dd485429ull, 0x3ff5e76f15ad2148ull, 0x3ff6247eb03a5585ull, 0x3ff6623882552225ull,
+  0x3ff6a09e667f3bcdull, 0x3ff6dfb23c651a2full, 0x3ff71f75e8ec5f74ull, 0x3ff75feb564267c9ull,
+  0x3ff7a11473eb0187ull, 0x3ff7e2f336cf4e62ull, 0x3ff82589994cce13ull, 0x3ff868d99b4492edull,
+  0x3ff8ace5422aa0dbull, 0x3ff8f1ae99157736ull, 0x3ff93737b0cdc5e5ull, 0x3ff97d829fde4e50ull,
+  0x3ff9c49182a3f090ull, 0x3ffa0c667b5de565ull, 0x3ffa5503b23e255dull, 0x3ffa9e6b5579fdbfull,
+  0x3ffae89f995ad3adull, 0x3ffb33a2b84f15fbull, 0x3ffb7f76f2fb5e47ull, 0x3ffbcc1e904bc1d2ull,
+  0x3ffc199bdd85529cull, 0x3ffc67f12e57d14bull, 0x3ffcb720dcef9069ull, 0x3ffd072d4a07897cull,
+  0x3ffd5818dcfba487ull, 0x3ffda9e603db3285ull, 0x3ffdfc97337b9b5full, 0x3ffe502ee78b3ff6ull,
+  0x3ffea4afa2a490daull, 0x3ffefa1bee615a27ull, 0x3fff50765b6e4540ull, 0x3fffa7c1819e90d8ull};
+__device__ __forceinline__ double cc_exp_nonpos(double z, const double *tab /* LDS copy of cc_exp2_tab64 */) {
+  if (z < -740.0) return 0.0;                                    // exp underflows (never taken for an RoI of a few metres)
+  const double kf = rint(z * 92.33248261689366);                 // 64 / ln 2
+  const int k = (int)kf;
+  double r = fma(-kf, 0x1.62e42fe000000p-7, z);                  // ln2/64, upper 29 bits: kf * hi is exact
+  r = fma(-kf, 0x1.f473de6af278fp-36, r);
+  const double r2 = r * r;
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r2, r);                                             // e^r - 1
+  const double t = tab[k & 63];
+  return ldexp(fma(t, p, t), k >> 6);
+}
+
 __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
 
 // Rare configuration (min_cont_cell_cnt_ > 3), kept out of line so that its registers do not count against the kernel:
@@ -174,10 +215,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
               cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk) {
   HIP_DYNAMIC_SHARED(char, smem)
-  // optional phase timestamps (tuning aid): phase_clk[scan*16 + i], written by thread 0
+  // optional phase timestamps (tuning aid): phase_clk[scan*CC_K2_NCLK + i], written by thread 0
 #define CC_K2_STAMP(i)                                                                     \
   do {                                                                                     \
-    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); \
+    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + (i)] = (long long)wall_clock64(); \
   } while (0)
   CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
@@ -280,8 +321,18 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }                                                                            \
   }
 
+  CC_K2_STAMP(9);
   int prev_n = 0;
   long long acc_ccl = 0, acc_enum = 0, acc_walk = 0, tmark = phase_clk ? (long long)wall_clock64() : 0;
+  long long sub_acc[6] = {0, 0, 0, 0, 0, 0}, tsub = tmark;  // per pass of the level loop, summed over the levels
+#define CC_K2_SUBLAP(j)                                    \
+  do {                                                     \
+    if (phase_clk) {                                       \
+      const long long now_ = (long long)wall_clock64();    \
+      sub_acc[j] += now_ - tsub;                           \
+      tsub = now_;                                         \
+    }                                                      \
+  } while (0)
 #define CC_K2_LAP(acc)                                     \
   do {                                                     \
     if (phase_clk) {                                       \
@@ -328,6 +379,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       }
     })
     __syncthreads();
+    CC_K2_SUBLAP(0);
     // (b) every cell is pointed at its root (a concurrent find that passes through the cell meets either its old parent or
     //     the root: both lead to the root), and the root's 2-bit saturating size counter is bumped: which roots own
     //     >= min_cont_cell_cnt_ (3) cells
@@ -347,6 +399,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       }
     })
     __syncthreads();
+    CC_K2_SUBLAP(1);
     CC_K2_LAP(acc_ccl);
     // (c) kept roots, then sorted by cell index = raster order of their first cells
     CC_K2_FOR_ACTIVE({
@@ -357,6 +410,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       }
     })
     __syncthreads();
+    CC_K2_SUBLAP(2);
     int n_kept = sh[1];
     if (n_kept > CC_NC) {
       n_kept = CC_NC;
@@ -375,6 +429,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       w_cB[k] = 255;
     }
     __syncthreads();
+    CC_K2_SUBLAP(3);
     // (d) per component: area, column range, last cell of the raster order, first member column of the second row
     //     (the root IS the first cell: first row and its first member column need no search), and for the walk the
     //     component index of every member cell (list position -> index, in the scratch block)
@@ -423,6 +478,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
         __syncthreads();
       }
     }
+    CC_K2_SUBLAP(4);
     CC_K2_LAP(acc_enum);
     // (e) component records; parents of the level above (processed in the previous iteration): index of the root that
     //     owns the child's root cell
@@ -455,7 +511,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     if (tid == 0) sh[8 + l] = n_kept;
     prev_n = n_kept;
     __syncthreads();
+    CC_K2_SUBLAP(5);
   }
+  if (phase_clk && tid == 0)
+    for (int j = 0; j < 6; j++) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + j] = sub_acc[j];
   // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331): ONE LANE
   //      per component.  The reference adds a component's cells one after the other (f32 cell_vol3_, f64 sums): that chain
   //      is serial, but the ~100-600 components of a scan are independent, so each gets a lane and a wave works on 64 of
@@ -475,6 +534,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     uint16_t *mcnt = moff + CC_NLEV * CC_NC;                       // [6][CC_NC] members filed so far
     uint16_t *big = (uint16_t *)(R + 45056);                       // [<= n_tot] components left to the eight-lane pass (the levels' working arrays are dead)
     const int n_cache = n_act < CC_K2_CACHE ? n_act : CC_K2_CACHE;
+    const bool all_cached = n_act <= CC_K2_CACHE;  // block-uniform: every active cell's height and position sit in LDS
     if (tid == 0) sh[3] = 0;
     for (int i = tid; i < n_cache; i += nt) {
       const int c = (int)scr->act[i];
@@ -488,6 +548,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       n_tot += sh[8 + l];
     }
     lev_base[CC_NLEV] = n_tot;
+    CC_K2_STAMP(10);
     for (int l = wave_id; l < CC_NLEV; l += n_waves) {  // list starts: exclusive prefix sum of the areas, each rounded up to a multiple of 8
       const int n = sh[8 + l];
       int run = 0;
@@ -544,6 +605,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }
     __threadfence_block();
     __syncthreads();
+    CC_K2_STAMP(11);
     for (int w = tid; w < n_tot; w += nt) {
       int l = 0;
       for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
@@ -563,26 +625,31 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int poi_i = -1;
       uint4 nx = make_uint4(0u, 0u, 0u, 0u);
       if (area > 0) nx = ml[0];
-      for (int m0 = 0; m0 < area; m0 += 8) {
-        const uint4 cur = nx;
-        if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
-        const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+      if (all_cached) {
+        // Straight-line code per eight cells: the eight heights / positions are fetched before any of them is added (eight
+        // LDS reads in flight instead of read -> nine additions -> next read: 170 cycles per cell, measured), and the tail of
+        // the last stretch is masked to +0.0 instead of branched around -- every sum starts at +0.0 and never becomes -0.0
+        // (a sum of round-to-nearest additions is -0.0 only if every term was), so x + 0.0 == x bit for bit.
+        for (int m0 = 0; m0 < area; m0 += 8) {
+          const uint4 cur = nx;
+          if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+          const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+          const int nv = area - m0;  // >= 8: all eight are members
+          unsigned mk[8];
+          float hv[8];
+          float2 rv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          if (m0 + u < area) {
-            const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
-            float h;
-            float2 rc;
-            if (i < n_cache) {
-              h = cbev[i];
-              rc = cpix[i];
-            } else {
-              const int c = (int)scr->act[i];
-              h = bev[c];
-              rc = pix[c];
-            }
-            const double vr = (double)rc.x, vc = (double)rc.y;
-            rec.cnt += 1;
+          for (int u = 0; u < 8; u++) {
+            mk[u] = (unsigned)-(int)(u < nv);  // all ones for a member, 0 for the list's padding (not initialised)
+            const unsigned iu = ((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & mk[u];
+            hv[u] = cbev[iu];
+            rv[u] = cpix[iu];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const float h = __uint_as_float(__float_as_uint(hv[u]) & mk[u]);
+            const double vr = (double)__uint_as_float(__float_as_uint(rv[u].x) & mk[u]);
+            const double vc = (double)__uint_as_float(__float_as_uint(rv[u].y) & mk[u]);
             rec.ps_x += vr;
             rec.ps_y += vc;
             rec.t_xx += vr * vr;
@@ -591,7 +658,41 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
             rec.vol3 += h;
             rec.tq_x += (double)h * vr;
             rec.tq_y += (double)h * vc;
-            poi_i = i;
+          }
+        }
+        rec.cnt = area;
+        if (area > 0) poi_i = (int)((const uint16_t *)ml)[area - 1];  // the last member in raster order
+      } else {
+        for (int m0 = 0; m0 < area; m0 += 8) {
+          const uint4 cur = nx;
+          if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+          const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            if (m0 + u < area) {
+              const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
+              float h;
+              float2 rc;
+              if (i < n_cache) {
+                h = cbev[i];
+                rc = cpix[i];
+              } else {
+                const int c = (int)scr->act[i];
+                h = bev[c];
+                rc = pix[c];
+              }
+              const double vr = (double)rc.x, vc = (double)rc.y;
+              rec.cnt += 1;
+              rec.ps_x += vr;
+              rec.ps_y += vc;
+              rec.t_xx += vr * vr;
+              rec.t_xy += vr * vc;
+              rec.t_yy += vc * vc;
+              rec.vol3 += h;
+              rec.tq_x += (double)h * vr;
+              rec.tq_y += (double)h * vc;
+              poi_i = i;
+            }
           }
         }
       }
@@ -601,6 +702,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       scr->cont[l][k] = cvw;
     }
     __syncthreads();
+    CC_K2_STAMP(12);
     // The large components (a street scene's ground-connected blob holds a few thousand cells): one lane adding nine running
     // values per cell is ~75 cycles per cell whatever the other 63 lanes do, and the phase lasted as long as the largest
     // component.  Every running sum is a sequential chain of its own, so EIGHT LANES share a component, one sum each
@@ -609,6 +711,10 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     {
       const int n_big = sh[3];
       const int role = tid & 7;
+      // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: nothing of its own; the f32 height sum is kept by every lane).
+      // sum += fa * fb with fa in {h, row, col}, fb in {1, row, col}; the factors are f32 and widened afterwards (exact)
+      const unsigned fa_h = role >= 5 ? ~0u : 0u, fa_y = (role == 1 || role == 4) ? ~0u : 0u, fa_x = ~(fa_h | fa_y);
+      const unsigned fb_1 = role < 2 ? ~0u : 0u, fb_x = (role == 2 || role == 5) ? ~0u : 0u, fb_y = ~(fb_1 | fb_x);
       for (int g0 = 0; g0 < n_big; g0 += nt >> 3) {  // block-uniform trip count
         const int g = g0 + (tid >> 3);
         const bool on = g < n_big;
@@ -624,32 +730,62 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           const int area = (int)mcnt[l * CC_NC + k];
           const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
           uint4 nx = ml[0];
-          for (int m0 = 0; m0 < area; m0 += 8) {
-            const uint4 cur = nx;
-            if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
-            const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+          if (all_cached) {
+            // as the lane walk: straight-line, masked tail.  The lane's two factors are picked with bit masks fixed per role (a
+            // `role == ...` select in the loop body became a nest of divergent branches with a full wait at every join)
+            for (int m0 = 0; m0 < area; m0 += 8) {
+              const uint4 cur = nx;
+              if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+              const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+              const int nv = area - m0;
+              unsigned mk[8];
+              float hv[8];
+              float2 rv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              if (m0 + u < area) {
-                const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
-                float h;
-                float2 rc;
-                if (i < n_cache) {
-                  h = cbev[i];
-                  rc = cpix[i];
-                } else {
-                  const int c = (int)scr->act[i];
-                  h = bev[c];
-                  rc = pix[c];
+              for (int u = 0; u < 8; u++) {
+                mk[u] = (unsigned)-(int)(u < nv);
+                const unsigned iu = ((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & mk[u];
+                hv[u] = cbev[iu];
+                rv[u] = cpix[iu];
+              }
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                const unsigned hb = __float_as_uint(hv[u]) & mk[u], xb = __float_as_uint(rv[u].x) & mk[u], yb = __float_as_uint(rv[u].y) & mk[u];
+                const float fa = __uint_as_float((hb & fa_h) | (xb & fa_x) | (yb & fa_y));
+                const float fb = __uint_as_float((0x3F800000u & fb_1) | (xb & fb_x) | (yb & fb_y));
+                acc += (double)fa * (double)fb;  // a padding slot adds (+0.0) * fb = +0.0
+                vol3 += __uint_as_float(hb);
+              }
+            }
+            cnt = area;
+            poi_i = (int)((const uint16_t *)ml)[area - 1];
+          } else {
+            for (int m0 = 0; m0 < area; m0 += 8) {
+              const uint4 cur = nx;
+              if (m0 + 8 < area) nx = ml[(m0 >> 3) + 1];
+              const unsigned wds[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                if (m0 + u < area) {
+                  const int i = (int)((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu);
+                  float h;
+                  float2 rc;
+                  if (i < n_cache) {
+                    h = cbev[i];
+                    rc = cpix[i];
+                  } else {
+                    const int c = (int)scr->act[i];
+                    h = bev[c];
+                    rc = pix[c];
+                  }
+                  const unsigned hb = __float_as_uint(h), xb = __float_as_uint(rc.x), yb = __float_as_uint(rc.y);
+                  const float fa = __uint_as_float((hb & fa_h) | (xb & fa_x) | (yb & fa_y));
+                  const float fb = __uint_as_float((0x3F800000u & fb_1) | (xb & fb_x) | (yb & fb_y));
+                  acc += (double)fa * (double)fb;
+                  vol3 += h;
+                  cnt += 1;
+                  poi_i = i;
                 }
-                const double vr = (double)rc.x, vc = (double)rc.y, hd = (double)h;
-                // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: the f32 height sum, which every lane keeps)
-                const double fa = role >= 5 ? hd : ((role == 1 || role == 4) ? vc : vr);
-                const double fb = role < 2 ? 1.0 : ((role == 2 || role == 5) ? vr : vc);
-                acc += fa * fb;
-                vol3 += h;
-                cnt += 1;
-                poi_i = i;
               }
             }
           }
@@ -677,9 +813,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   }
   CC_K2_LAP(acc_walk);
   if (phase_clk && tid == 0) {
-    phase_clk[(size_t)blockIdx.x * 16 + 1] = acc_ccl;
-    phase_clk[(size_t)blockIdx.x * 16 + 2] = acc_enum;
-    phase_clk[(size_t)blockIdx.x * 16 + 3] = acc_walk;
+    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 1] = acc_ccl;
+    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 2] = acc_enum;
+    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 3] = acc_walk;
   }
   CC_K2_STAMP(4);
 
@@ -825,6 +961,17 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     accum[tid] = acc;
     cntp[tid] = 0;
   }
+  // the BCI phase's per-wave scratch (R2 + 5504 ...) is idle until then: the exp table and the list of valid anchors
+  double *exp_tab = (double *)(R2 + 5504);                    // 512 B
+  unsigned char *vlist = (unsigned char *)(R2 + 5504 + 512);  // [36] anchors with a key, ascending
+  if (tid >= 64 && tid < 128) exp_tab[tid - 64] = __longlong_as_double((long long)cc_exp2_tab64[tid - 64]);
+  __syncthreads();
+  int NV = 0;
+  for (int a = 0; a < CC_NLEV * CC_NPIV; a++) {  // uniform; 36 broadcast reads
+    const int ok = valid[a];
+    if (ok && tid == 0) vlist[NV] = (unsigned char)a;
+    NV += ok;
+  }
   __syncthreads();
   const int roi_pad = (int)ceilf(cfg.roi_radius + 1.f);
   const float div_len = cfg.roi_radius / (float)(7 * 5);
@@ -840,10 +987,14 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     float *ldist = (float *)R;
     unsigned char *lhi = (unsigned char *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 4);
     int *lcnt = (int *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 5);
-    for (int g0 = 0; g0 < NA; g0 += CC_KEYS_GRP) {
-      for (int a = g0 + wave_id; a < g0 + CC_KEYS_GRP && a < NA; a += n_waves) {
+    long long acc_klist = 0, acc_kexp = 0;
+    tmark = phase_clk ? (long long)wall_clock64() : 0;
+    // groups of CC_KEYS_GRP VALID anchors (a street scene has ~18 of the 36: two groups, not three)
+    for (int g0 = 0; g0 < NV; g0 += CC_KEYS_GRP) {
+      for (int av = g0 + wave_id; av < g0 + CC_KEYS_GRP && av < NV; av += n_waves) {
+        const int a = (int)vlist[av];
         int n = 0;
-        if (valid[a]) {
+        {
           const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
           const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
           const int r_cen = (int)vcx, c_cen = (int)vcy;
@@ -885,38 +1036,45 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
               const unsigned long long m = __ballot(q);
               const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
               if (q && pos < CAP) {
-                ldist[(a - g0) * CAP + pos] = dist;
-                lhi[(a - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+                ldist[(av - g0) * CAP + pos] = dist;
+                lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
               }
               n += __popcll(m);
             }
           }
           if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
         }
-        if (lane == 0) lcnt[a - g0] = n;
+        if (lane == 0) lcnt[av - g0] = n;
       }
       __syncthreads();
+      CC_K2_LAP(acc_klist);
       for (int t = tid; t < CC_KEYS_GRP * 35; t += nt) {
-        const int al = t / 35, d = t - al * 35, a = g0 + al;
-        if (a >= NA) continue;
+        const int al = t / 35, d = t - al * 35;
+        if (g0 + al >= NV) continue;
+        const int a = (int)vlist[g0 + al];
         float acc = 0.f;
         const int n = lcnt[al] < CAP ? lcnt[al] : CAP;
-        if (valid[a]) {
-          // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56)
+        {
+          // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56): exp(-u^2/2) / sqrt(2 pi), here
+          // exp(...) * (1 / sqrt(2 pi)) -- one f64 rounding away from the quotient, gone in the conversion to f32
           const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
-          const double norm = sqrt(2 * 3.14159265358979323846 * 1.0 * 1.0);
           for (int i = 0; i < n; i++) {
             const float dist = ldist[al * CAP + i];
             const int higher = lhi[al * CAP + i];
             const float u = (xg - dist) / 1.0f;
-            const float pdf = (float)(exp(-0.5 * (double)u * (double)u) / norm);
+            const float pdf = (float)(cc_exp_nonpos(-0.5 * (double)u * (double)u, exp_tab) * 0.3989422804014327);
             acc += (float)higher * pdf;
           }
         }
         divs[a * 35 + d] = acc;
-        if (d == 0) cntp[a] = valid[a] ? lcnt[al] : 0;
+        if (d == 0) cntp[a] = lcnt[al];
       }
       __syncthreads();
+      CC_K2_LAP(acc_kexp);
+    }
+    if (phase_clk && tid == 0) {
+      phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 14] = acc_klist;
+      phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 15] = acc_kexp;
     }
   }
   for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -151,6 +152,8 @@ inline int device_id() {
 }
 inline cc_ctx *context(const cc_manager_cfg_t &m) {
   static std::map<std::string, cc_ctx *> pool;
+  static std::mutex pool_mu;  // drivers with several worker threads build ContourManagers of one configuration concurrently
+  std::lock_guard<std::mutex> lk(pool_mu);
   std::string key((const char *)&m, sizeof(m));
   auto it = pool.find(key);
   if (it != pool.end()) return it->second;

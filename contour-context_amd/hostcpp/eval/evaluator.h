@@ -81,12 +81,13 @@ class ContLCDEvaluator {
   // finished waits in `ready`, in address order.
   struct Prefetch {
     static constexpr int AHEAD = 2;  // = the context's staging buffers (cc_stage_points_slot: scan `addr` goes through slot addr & 1)
+    enum class Status { OK, MISSING_FILE, TOO_FEW_POINTS, STAGING_FAILED, INGEST_FAILED };
     struct Item {
       int addr = -1;
       size_t n = 0;
-      bool opened = false;
-      cc_scan *scan = nullptr;  // ingested ahead of time (nullptr: file missing, fewer than 11 points, or the ingest failed: `err`)
-      std::string err;
+      Status status = Status::OK;
+      cc_scan *scan = nullptr;  // ingested ahead of time (non-null iff status == OK)
+      std::string err;          // the library's message for STAGING_FAILED / INGEST_FAILED
     };
     std::thread th;
     std::mutex mu;
@@ -238,15 +239,23 @@ class ContLCDEvaluator {
         pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
         lk.unlock();
         pf_.cv.notify_all();
-        if (!it.opened) {
-          printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
-          exit(-1);
+        switch (it.status) {  // what the reference does at the same points (evaluator.h:285-302, contour_mng.h:507)
+          case Prefetch::Status::MISSING_FILE:
+            printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
+            exit(-1);
+          case Prefetch::Status::TOO_FEW_POINTS:
+            fprintf(stderr, "%s: %zu points\n", info.fpath.c_str(), it.n);
+            CC_CHECK(it.n > 10);
+            abort();
+          case Prefetch::Status::STAGING_FAILED:
+          case Prefetch::Status::INGEST_FAILED:
+            fprintf(stderr, "cont2_amd: %s of %s: %s\n", it.status == Prefetch::Status::STAGING_FAILED ? "staging buffer" : "ingest",
+                    info.fpath.c_str(), it.err.c_str());
+            abort();
+          case Prefetch::Status::OK:
+            break;
         }
-        CC_CHECK(it.n > 10);
-        if (!it.scan) {
-          fprintf(stderr, "cont2_amd: %s\n", it.err.c_str());
-          abort();
-        }
+        CC_CHECK(it.scan);
         cm->adoptIngested(it.scan, with_images, str_id);
         adopted = true;
       } else {  // first scan, a jump, another configuration: the helper is parked and what it fetched is dropped
@@ -258,7 +267,7 @@ class ContLCDEvaluator {
       }
     }
     if (!adopted) {
-      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, 0);
+      float *dst = cc_stage_points(ctx, (int64_t)cap);  // the driver thread's own slot, never one the helper fills
       CC_CHECK(dst);
       FILE *f = fopen(info.fpath.c_str(), "rb");
       if (!f) {
@@ -325,19 +334,23 @@ class ContLCDEvaluator {
       const auto t1 = std::chrono::steady_clock::now();
       auto t2 = t1, t3 = t1;
       if (!dst) {
-        it.opened = true;
-        it.n = 11;
+        it.status = Prefetch::Status::STAGING_FAILED;
         it.err = cc_last_error();  // the message is per thread
       } else {
         FILE *f = fopen(laser_info_[it.addr].fpath.c_str(), "rb");
-        it.opened = f != nullptr;
         it.n = f ? fread(dst, 4 * sizeof(float), cap, f) : 0;
         if (f) fclose(f);
         t2 = std::chrono::steady_clock::now();
-        if (it.n > 10 && cc_scan_ingest(ctx, dst, (int64_t)it.n, with_images ? 1 : 0, &it.scan) != CC_OK) {
+        if (!f)
+          it.status = Prefetch::Status::MISSING_FILE;
+        else if (it.n <= 10)
+          it.status = Prefetch::Status::TOO_FEW_POINTS;
+        else if (cc_scan_ingest(ctx, dst, (int64_t)it.n, with_images ? 1 : 0, &it.scan) != CC_OK) {
           it.scan = nullptr;
+          it.status = Prefetch::Status::INGEST_FAILED;
           it.err = cc_last_error();
         }
+        if (it.status != Prefetch::Status::OK && it.status != Prefetch::Status::INGEST_FAILED) cc_stage_points_cancel(ctx, dst);
         t3 = std::chrono::steady_clock::now();
       }
       lk.lock();

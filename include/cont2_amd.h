@@ -220,7 +220,7 @@ typedef struct {
 } cc_query_result_t;
 #define CC_QF_CHECK_CAP 1 /* a constellation check had more than 256 potential neighbour pairs (contour_mng.h:311-336)
                              or a rotation window of more than 63 pairs (:344-366): pairs were dropped              */
-#define CC_QF_GMM_CAP 2   /* a scan of a correlation problem has more than 128 ellipses on a level (correlation.h:55-78) */
+#define CC_QF_GMM_CAP 2   /* a scan of a correlation problem needs more ellipses of a level than the record holds (CC_MAXC; correlation.h:55-78) */
 #define CC_QF_DESC_CAP 4  /* the correlation needed a contour beyond the CC_MAXC stored per level                     */
 #define CC_QF_QUERY_INEXACT 8 /* the query scan's own descriptor is flagged CC_DESC_INEXACT_* (it exceeded a capacity of the
                                  contour kernel at ingest)                                                             */
@@ -274,15 +274,21 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  * for) is fetched when a getter needs it.  TWO streams: cc_scan_ingest queues on the context's ingest stream and records
  * the scan's `ready` event behind its last kernel; cc_scan_desc / cc_scan_offload / cc_db_query_scan / cc_db_add_scan work on
  * the loop stream, which waits for `ready` first.  So scan i + 1 (and i + 2) can be ingested while scan i is queried and
- * added -- also from ANOTHER host thread: ONE thread at a time may be inside cc_stage_points* / cc_scan_ingest, next to
- * one thread in the other cc_scan_* / cc_db_* calls (the slot pool is locked, cc_last_error is per thread).  The class
+ * added -- also from OTHER host threads: cc_ingest_batch / cc_stage_points* / cc_scan_ingest of one context serialise on
+ * the context's ingest lock (the staging slots, the device point buffer and the K1/K2 scratch are shared), next to one
+ * thread in the other cc_scan_* / cc_db_* calls (the slot pool is locked, cc_last_error is per thread).  The class
  * mirror's evaluator does exactly that (hostcpp/eval/evaluator.h: a helper thread reads the next files and ingests them).
- *   cc_stage_points  : pinned buffer for n_points x (x,y,z,i) f32, valid until the next cc_scan_ingest (write the points
- *                      there to save a host copy), NULL on failure.  cc_stage_points_slot: the same for slot 0 or 1 -- two
- *                      buffers, so that the next scan's file can be read into one while the other's scan is on its way to
- *                      the device; a slot is handed out again once ITS last copy has passed (readKITTIPointCloudBin of scan
- *                      i+1 next to queryRangedKNN of scan i, tools/pointcloud_util.h:9-47, evaluator.h:285-302).  Asking
- *                      for more points than the buffers hold re-allocates BOTH slots (after the ingest stream has drained)
+ *   cc_stage_points  : pinned buffer for n_points x (x,y,z,i) f32 (write the points there to save a host copy), NULL on
+ *                      failure.  The buffer belongs to the CALLING THREAD until that thread passes it to cc_scan_ingest
+ *                      (or gives it up: cc_stage_points_cancel, or stages the same slot again); another thread that asks for
+ *                      the same slot meanwhile waits.  cc_stage_points uses a slot of its own; cc_stage_points_slot names
+ *                      slot 0 or 1 -- two more buffers, so that the next scan's file can be read into one while the other's
+ *                      scan is on its way to the device (a read-ahead thread alternates them, the driver thread's
+ *                      cc_stage_points never collides with it); a slot is handed out again once ITS last copy has passed
+ *                      (readKITTIPointCloudBin of scan i+1 next to queryRangedKNN of scan i, tools/pointcloud_util.h:9-47,
+ *                      evaluator.h:285-302).  Asking for more points than the buffers hold re-allocates ALL slots (after
+ *                      the ingest stream has drained; CC_EINVAL while another thread holds one)
+ *   cc_stage_points_cancel : give a staged buffer back without ingesting it (short file, read error)
  *   cc_scan_ingest   : makeBEV + makeContoursRecurs for the points at h_xyzi (may be a staging pointer); want_bev != 0
  *                      keeps the max-height image for cc_scan_bev.  Returns at once (work is queued on the ingest stream).
  *   cc_scan_desc     : host copy of the descriptor (first call: one D2H copy + sync); CC_ECAPACITY if the scan exceeded a
@@ -294,6 +300,7 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
 typedef struct cc_scan cc_scan;
 float *cc_stage_points(cc_ctx *ctx, int64_t n_points);
 float *cc_stage_points_slot(cc_ctx *ctx, int64_t n_points, int slot);
+int cc_stage_points_cancel(cc_ctx *ctx, const float *staged);
 int cc_scan_ingest(cc_ctx *ctx, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out);
 int cc_scan_desc(cc_scan *scan, const cc_scan_desc_t **h_desc);
 int cc_scan_bev(cc_scan *scan, const float **h_bev);
@@ -421,7 +428,7 @@ int cc_db_debug_passes(cc_db *db, cc_pass_dbg_t *h_out, int cap, int *n_out);
 
 /* ---- the compact per-scan records (multi-GPU exchange) ----
  * cc_pack_scans turns full descriptors into the two records the database keeps per scan: the hot record
- * (cc_hot_desc_t, 18 KB) and the correlation inputs (opaque, 16 KB; cc_packed_sizes gives both sizes).  A rank packs
+ * (cc_hot_desc_t, 18 KB) and the correlation inputs (opaque, 41 KB; cc_packed_sizes gives both sizes).  A rank packs
  * the scans it ingested, the ranks all-gather the two arrays over RCCL (59 KB per scan instead of the 169 KB
  * descriptor), and every rank appends the gathered scans to its replica with cc_db_add_packed -- the same effect as
  * cc_db_add_scans on the full descriptors (which is pack + add_packed).  d_hot_out / d_feat_out: device arrays of n

@@ -289,6 +289,16 @@ static inline float __uint_as_float(unsigned x) {
   std::memcpy(&f, &x, 4);
   return f;
 }
+static inline double __longlong_as_double(long long x) {
+  double f;
+  std::memcpy(&f, &x, 8);
+  return f;
+}
+static inline long long __double_as_longlong(double f) {
+  long long x;
+  std::memcpy(&x, &f, 8);
+  return x;
+}
 
 // ---- host runtime API stand-ins: "device memory" is host memory ----
 typedef int hipError_t;

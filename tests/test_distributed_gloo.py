@@ -11,6 +11,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mgpu_checks import check_multi_gpu_line  # noqa: E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
@@ -133,6 +136,20 @@ def _bench_on_harness(world, extra):
     return json.loads(lines[0])
 
 
+def _harness_packed_sizes():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import cc_amd
+    import emu_api
+    return emu_api.EmuApi(cc_amd.load().L).packed_sizes()
+
+
+def _shard_len():
+    sys.path.insert(0, ROOT)
+    import cc_amd
+    return cc_amd.load().sharding.shard_len
+
+
 def test_bench_runs_end_to_end_on_the_cpu_harness_weak_shared():
     """`python bench.py --gpus 4 --share-descriptors` with CC_BENCH_HARNESS=emu / gloo: self-launch under torch.distributed.run,
     scan-sharded DB build (13 scans over 4 ranks: padded shards), the all-gather, replicated add, the timed step with the
@@ -142,9 +159,8 @@ def test_bench_runs_end_to_end_on_the_cpu_harness_weak_shared():
     assert d["config"]["batch"] == 2 and d["config"]["global_batch"] == 8
     m = d["multi_gpu"]
     assert m["ranks_seen"] == 4 and m["backend"] == "gloo" and len(m["per_rank_scans_per_s"]) == 4
-    assert m["db_exchange"]["bytes_gathered_per_rank"] == 4 * 4 * m["db_exchange"]["bytes_per_scan"]   # 4 ranks x shard_len(13, 4) = 4 records
-    assert m["per_step_exchange"]["bytes_gathered_per_rank"] == 4 * 2 * m["db_exchange"]["bytes_per_scan"] and m["per_step_exchange"]["ms"] > 0
-    assert m["data_path_collectives_in_timed_step"] == 1
+    # the SAME assertions tests/test_gpu_multigpu.py makes on hardware (record sizes from the library underneath)
+    check_multi_gpu_line(d, 4, 13, 2, _harness_packed_sizes(), True, "gloo", _shard_len())
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]                     # whole-job scans / max-over-ranks time
     assert "harness" in d and d["roofline"]["frac"] is None
 
@@ -153,8 +169,7 @@ def test_bench_runs_end_to_end_on_the_cpu_harness_strong():
     """--scaling strong: the step's --batch scans are split over the ranks (2 x 2 here), no collective in the timed step."""
     d = _bench_on_harness(2, ["--batch", "4", "--scaling", "strong"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch"] == 2 and d["config"]["global_batch"] == 4
-    assert d["multi_gpu"]["ranks_seen"] == 2 and d["multi_gpu"]["per_step_exchange"] is None
-    assert d["multi_gpu"]["data_path_collectives_in_timed_step"] == 0
+    check_multi_gpu_line(d, 2, 13, 2, _harness_packed_sizes(), False, "gloo", _shard_len())
     assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
