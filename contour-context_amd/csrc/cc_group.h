@@ -24,6 +24,26 @@ __device__ __forceinline__ void cc_wave_sync() {
 #endif
 }
 
+
+// Volatile reads of LDS words that other lanes are changing (the union-find forest of K2).  A plain `volatile T *` made from a
+// generic pointer keeps the GENERIC address space -- the address-space inference leaves volatile accesses alone -- and is
+// compiled to flat_load + s_waitcnt vmcnt(0) per access (round 4's labelling ran on those); spelled with the LDS address
+// space the same read is a ds_read that is waited for where its value is used.
+#ifndef CC_EMU
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) {
+  return *(const volatile __attribute__((address_space(3))) uint16_t *)p;
+}
+__device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) {
+  return *(const volatile __attribute__((address_space(3))) unsigned *)p;
+}
+#pragma clang diagnostic pop
+#else
+__device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) { return *(const volatile uint16_t *)p; }
+__device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) { return *(const volatile unsigned *)p; }
+#endif
+
 #ifndef CC_EMU
 // LDS hand-off between the lanes of one group: a wave's lanes run in lockstep and its LDS operations are executed in
 // issue order, so only the compiler has to be kept from moving LDS accesses across the hand-off (a wavefront-scope fence

@@ -29,6 +29,7 @@
 
 #define CC_NC CC_MAXC          // kept components per level handled exactly
 #define CC_LAB_NONE 0xFFFFu
+#define CC_LAB_PENDING 0x7FFEu  // a kept root of the list's tail between the kept test and its numbering (never a cell index: n_cell <= 22500)
 
 struct cc_comp_t {  // per kept component, spilled to global scratch between levels
   uint16_t root, area, parent, rank;
@@ -44,7 +45,7 @@ struct cc_k2_scratch {  // per scan of a launch
   uint16_t compidx[CC_NLEV][CC_MAX_CELLS];                  // per level: component index of list entry i, 0x7FFF = none
 };
 #define CC_K2_NCLK 32    // phase-clock slots per scan (tuning aid)
-#define CC_K2_OWN 8       // list entries a thread keeps in registers (beyond: read from the scratch block; a street scene has
+#define CC_K2_OWN 6       // list entries a thread keeps in registers (beyond: read from the scratch block; a street scene has
                           // 3-4 k active cells: with four per thread half of them were re-read from the scratch block -- an L2 round
                           // trip -- in every pass of every level)
 #define CC_K2_CACHE 3072  // active cells whose height / position are staged in LDS for the walk
@@ -79,9 +80,8 @@ __device__ __forceinline__ unsigned cc_lab_comp(const uint16_t *LAB, int c) {
 // smaller index so the root of a component is its smallest cell: the label min-propagation would converge to).
 // Links are 32-bit CAS on the word holding the u16; no plain stores happen while unions run.
 __device__ __forceinline__ unsigned cc_uf_find(const uint16_t *LAB, unsigned x) {
-  const volatile uint16_t *V = LAB;
   unsigned p;
-  while ((p = V[x]) != x) x = p;
+  while ((p = cc_lds_vread16(LAB + x)) != x) x = p;
   return x;
 }
 __device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned b) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void cc_uf_union(uint16_t *LAB, unsigned a, unsigned 
     // a > b: hang root a under b, provided a is still a root
     unsigned *w = (unsigned *)LAB + (a >> 1);
     const int shf = (a & 1) * 16;
-    unsigned old = *(volatile unsigned *)w;
+    unsigned old = cc_lds_vread32(w);
     unsigned cur;
     while (true) {
       cur = (old >> shf) & 0xFFFFu;
@@ -152,6 +152,7 @@ __device__ __forceinline__ double cc_exp_nonpos(double z, const double *tab /* L
   return ldexp(fma(t, p, t), k >> 6);
 }
 
+__device__ __forceinline__ unsigned cc_umin(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return (cnt2[r >> 4] >> ((r & 15) * 2)) & 3; }
 
 // Rare configuration (min_cont_cell_cnt_ > 3), kept out of line so that its registers do not count against the kernel:
@@ -253,8 +254,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   {
     const float4 *bev4 = (const float4 *)bev;
     const int n_quad = n_cell >> 2;
-#pragma unroll 4
-    for (int v = tid; v < n_quad; v += nt) {
+#pragma unroll 6
+    for (int v = tid; v < n_quad; v += nt) {  // 11 loads per thread for the 150 x 150 grid: two batches in flight
       const float4 h4 = bev4[v];
       const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
       unsigned lv4 = 0;
@@ -324,14 +325,18 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   CC_K2_STAMP(9);
   int prev_n = 0;
   long long acc_ccl = 0, acc_enum = 0, acc_walk = 0, tmark = phase_clk ? (long long)wall_clock64() : 0;
-  long long sub_acc[6] = {0, 0, 0, 0, 0, 0}, tsub = tmark;  // per pass of the level loop, summed over the levels
-#define CC_K2_SUBLAP(j)                                    \
-  do {                                                     \
-    if (phase_clk) {                                       \
-      const long long now_ = (long long)wall_clock64();    \
-      sub_acc[j] += now_ - tsub;                           \
-      tsub = now_;                                         \
-    }                                                      \
+  // per pass of the level loop, summed over the levels: accumulated in the clock block itself (thread 0), so that the
+  // production launch (phase_clk == nullptr) carries no accumulator registers for it
+  long long tsub = tmark;
+  if (phase_clk && tid == 0)
+    for (int j = 0; j < 6; j++) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + j] = 0;
+#define CC_K2_SUBLAP(j)                                                                   \
+  do {                                                                                    \
+    if (phase_clk) {                                                                      \
+      const long long now_ = (long long)wall_clock64();                                   \
+      if (tid == 0) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + (j)] += now_ - tsub; \
+      tsub = now_;                                                                        \
+    }                                                                                     \
   } while (0)
 #define CC_K2_LAP(acc)                                     \
   do {                                                     \
@@ -342,92 +347,246 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     }                                                      \
   } while (0)
   unsigned *w_minc = W + CC_NC, *w_maxc = W + 2 * CC_NC, *w_area = W + 3 * CC_NC, *w_cB = W + 4 * CC_NC;
-  const int n_w = (n_cell + 15) >> 4;
+  // "has a second cell" / "has a third cell" bit per root (the kept test of a level), over the working arrays
+  unsigned *bitA = W, *bitB = W + ((n_cell + 31) >> 5);
+  const int n_bw = 2 * ((n_cell + 31) >> 5);
+  unsigned char *scnt = (unsigned char *)cand;   // kept roots per 64-entry stretch of the active list (<= 352 stretches)
+  uint16_t *sbase = (uint16_t *)(sh + 64);       // their exclusive prefix sum
+  const bool has_tail = n_act > CC_K2_OWN * nt;  // block-uniform: more active cells than the threads keep in registers
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  // Per owned cell, once: its level count and, for each of its four backward neighbours (W, NW, N, NE), the number of level
+  // sets the two cells share -- the pair is linked at exactly one level, the highest one that holds both (two cells that
+  // were together in the level above already share a root).  3 bits each: 12 bits per cell, two cells per register.
+  unsigned lvo = 0, ew[CC_K2_OWN / 2];
+  unsigned keptm = 0;  // owned cells that sat in a numbered component of the level above: their component has its three cells
+#pragma unroll
+  for (int u = 0; u < CC_K2_OWN / 2; u++) ew[u] = 0;
+#pragma unroll
+  for (int u = 0; u < CC_K2_OWN; u++) {
+    if (mc[u] >= 0) {
+      const int c = mc[u];
+      const unsigned lvc = LV[c];
+      const int r = c / n_col, cc = c - r * n_col;
+      unsigned f = 0;
+      if (cc > 0) f |= cc_umin(lvc, (unsigned)LV[c - 1]);
+      if (r > 0) {
+        if (cc > 0) f |= cc_umin(lvc, (unsigned)LV[c - n_col - 1]) << 3;
+        f |= cc_umin(lvc, (unsigned)LV[c - n_col]) << 6;
+        if (cc < n_col - 1) f |= cc_umin(lvc, (unsigned)LV[c - n_col + 1]) << 9;
+      }
+      lvo |= lvc << (3 * u);
+      ew[u >> 1] |= f << ((u & 1) * 12);
+    }
+  }
   for (int l = CC_NLEV - 1; l >= 0; --l) {
     // (a) 8-connected labelling of the level set LV > l.  LAB still holds the forest of level l+1 (a subset of this level's
     //     cells, lv_grads ascending): those components stay merged; cells new at this level (LV == l + 1) are still their
-    //     own roots.  One union per adjacent pair (W, NW, N, NE of every cell) that involves a new cell -- two old
-    //     neighbours already share a root.
+    //     own roots.  One union per adjacent pair whose shared level count is l + 1.  A thread's pairs of this level are a
+    //     bit mask over (owned cell, direction); the loop runs once per PAIR -- round 4 walked all 32 (cell, direction)
+    //     slots and a wave entered the union code of a slot as soon as one of its lanes had a pair there: 75 of a street
+    //     scene's 385 us.  The result does not depend on the order of the unions (a root is its component's smallest cell).
 #pragma unroll
     for (int u = 0; u < CC_K2_OWN; u++) CC_OPAQUE_I(mc[u]);  // keeps the neighbour offsets of the owned cells from being hoisted (and then spilled)
-    for (int i = tid; i < n_w; i += nt) CNT2[i] = 0;
-    if (tid == 0) sh[1] = 0;
-    CC_K2_FOR_ACTIVE({
-      (void)i;
-      const int lvc = LV[c];
-      if (lvc > l) {
-        const bool newc = lvc == l + 1;
-        const int r = c / n_col, cc = c - r * n_col;
-        if (cc > 0) {
-          const int lvn = LV[c - 1];
-          if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - 1);
-        }
-        if (r > 0) {
+    for (int i = tid; i < n_bw; i += nt) bitA[i] = 0;
+    {
+      const unsigned t = (unsigned)l + 1u;
+      unsigned em = 0;
+#pragma unroll
+      for (int u = 0; u < CC_K2_OWN; u++) {
+        const unsigned f = ew[u >> 1] >> ((u & 1) * 12);
+#pragma unroll
+        for (int d = 0; d < 4; d++) em |= (((f >> (3 * d)) & 7u) == t ? 1u : 0u) << (u * 4 + d);
+      }
+      while (em) {
+        const int b = __ffs((int)em) - 1;
+        em &= em - 1u;
+        const int u = b >> 2, d = b & 3;
+        int c = mc[0];
+#pragma unroll
+        for (int k = 1; k < CC_K2_OWN; k++) c = u == k ? mc[k] : c;
+        const unsigned nbc = (unsigned)(c - (d == 0 ? 1 : n_col + 2 - d));
+        // two cells with the same parent are in one tree already (most pairs of a cell lead to the component its first pair
+        // joined): two independent reads instead of two finds one after the other
+        if (cc_lds_vread16(LAB + c) != cc_lds_vread16(LAB + nbc)) cc_uf_union(LAB, (unsigned)c, nbc);
+      }
+    }
+    if (has_tail)
+      for (int i = tid + CC_K2_OWN * nt; i < n_act; i += nt) {
+        const int c = (int)scr->act[i];
+        const int lvc = LV[c];
+        if (lvc > l) {
+          const bool newc = lvc == l + 1;
+          const int r = c / n_col, cc = c - r * n_col;
           if (cc > 0) {
-            const int lvn = LV[c - n_col - 1];
-            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col - 1);
+            const int lvn = LV[c - 1];
+            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - 1);
           }
-          {
-            const int lvn = LV[c - n_col];
-            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col);
-          }
-          if (cc < n_col - 1) {
-            const int lvn = LV[c - n_col + 1];
-            if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col + 1);
+          if (r > 0) {
+            if (cc > 0) {
+              const int lvn = LV[c - n_col - 1];
+              if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col - 1);
+            }
+            {
+              const int lvn = LV[c - n_col];
+              if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col);
+            }
+            if (cc < n_col - 1) {
+              const int lvn = LV[c - n_col + 1];
+              if (lvn > l && (newc || lvn == l + 1)) cc_uf_union(LAB, c, c - n_col + 1);
+            }
           }
         }
       }
-    })
     __syncthreads();
     CC_K2_SUBLAP(0);
     // (b) every cell is pointed at its root (a concurrent find that passes through the cell meets either its old parent or
-    //     the root: both lead to the root), and the root's 2-bit saturating size counter is bumped: which roots own
-    //     >= min_cont_cell_cnt_ (3) cells
+    //     the root: both lead to the root); the owned cells' finds advance hop by hop TOGETHER (eight LDS reads in flight,
+    //     not eight chains one after the other).  Which roots own >= min_cont_cell_cnt_ (3) cells: a member that is not the
+    //     root sets the root's bit in A, and in B if A was set already -- A: a second cell, B: a third one.
     const int need = cfg.min_cont_cell_cnt < 3 ? cfg.min_cont_cell_cnt : 3;
-    CC_K2_FOR_ACTIVE({
-      (void)i;
-      if (LV[c] > l) {
-        const unsigned rt = cc_uf_find(LAB, c);
-        if (rt != (unsigned)c) LAB[c] = (uint16_t)rt;
-        const int w = rt >> 4, s2 = (rt & 15) * 2;
-        unsigned old = CNT2[w];
-        while ((int)((old >> s2) & 3u) < 3) {
-          unsigned got = atomicCAS(&CNT2[w], old, old + (1u << s2));
-          if (got == old) break;
-          old = got;
+    unsigned inm = 0, rootm = 0;  // owned cells in the level set / that are roots
+    {
+      unsigned x[CC_K2_OWN];
+#pragma unroll
+      for (int u = 0; u < CC_K2_OWN; u++) {
+        inm |= (((lvo >> (3 * u)) & 7u) > (unsigned)l ? 1u : 0u) << u;
+        x[u] = (unsigned)mc[u];
+      }
+      bool more = inm != 0;
+      while (more) {
+        more = false;
+#pragma unroll
+        for (int u = 0; u < CC_K2_OWN; u++) {
+          const unsigned pq = (inm >> u) & 1u ? cc_lds_vread16(LAB + x[u]) : x[u];
+          more |= pq != x[u];
+          x[u] = pq;
         }
       }
-    })
+#pragma unroll
+      for (int u = 0; u < CC_K2_OWN; u++) {
+        if ((inm >> u) & 1u) {
+          const unsigned rt = x[u];
+          if (rt != (unsigned)mc[u]) {
+            LAB[mc[u]] = (uint16_t)rt;
+            if (!((keptm >> u) & 1u)) {  // else: the component's old root reports it below
+              const unsigned bit = 1u << (rt & 31u);
+              if (atomicOr(&bitA[rt >> 5], bit) & bit) atomicOr(&bitB[rt >> 5], bit);
+            }
+          } else {
+            rootm |= 1u << u;
+          }
+        }
+      }
+    }
+    // a component numbered at the level above (>= 3 cells there) is part of one component here: its old root marks the new
+    // one, its other cells (keptm) skip the bit protocol -- a large component's members no longer queue on one LDS word
+    for (int k = tid; k < prev_n; k += nt) {
+      const unsigned rt = cc_uf_find(LAB, prev_root[k]);
+      const unsigned bit = 1u << (rt & 31u);
+      atomicOr(&bitA[rt >> 5], bit);
+      atomicOr(&bitB[rt >> 5], bit);
+    }
+    if (has_tail)
+      for (int i = tid + CC_K2_OWN * nt; i < n_act; i += nt) {
+        const int c = (int)scr->act[i];
+        if (LV[c] > l) {
+          const unsigned rt = cc_uf_find(LAB, c);
+          if (rt != (unsigned)c) {
+            LAB[c] = (uint16_t)rt;
+            const unsigned bit = 1u << (rt & 31u);
+            if (atomicOr(&bitA[rt >> 5], bit) & bit) atomicOr(&bitB[rt >> 5], bit);
+          }
+        }
+      }
     __syncthreads();
     CC_K2_SUBLAP(1);
     CC_K2_LAP(acc_ccl);
-    // (c) kept roots, then sorted by cell index = raster order of their first cells
-    CC_K2_FOR_ACTIVE({
-      (void)i;
-      if (LV[c] > l && LAB[c] == (unsigned)c && cc_cnt2_get(CNT2, c) >= need) {
-        int k = atomicAdd(&sh[1], 1);
-        if (k < CC_NC) cand[k] = (uint16_t)c;
+    // (c) kept roots, numbered by cell index = raster order of their first cells.  The active list IS in raster order: a
+    //     kept root's number is the count of kept roots before it in the list -- ballots per 64-entry stretch (thread t's
+    //     u-th cell is entry u * nt + t: a wave's u-th cells are one stretch) and a prefix sum over the stretches.  (Round 4:
+    //     an atomic counter, then every root ranked against every other: 24 us of a street scene's scan.)
+#define CC_K2_ROOT_KEPT(c_) (need <= 1 || (((need == 2 ? bitA : bitB)[(c_) >> 5] >> ((c_) & 31)) & 1u))
+    unsigned kpm = 0;
+#pragma unroll
+    for (int u = 0; u < CC_K2_OWN; u++) {
+      const bool kp = ((rootm >> u) & 1u) && CC_K2_ROOT_KEPT(mc[u]);
+      kpm |= (kp ? 1u : 0u) << u;
+      const unsigned long long m = __ballot(kp);
+      if (lane == 0) scnt[u * n_waves + wave_id] = (unsigned char)__popcll(m);
+    }
+    if (has_tail)
+      for (int ib = CC_K2_OWN * nt; ib < n_act; ib += nt) {  // block-uniform trip count
+        const int i = ib + tid;
+        bool kp = false;
+        if (i < n_act) {
+          const int c = (int)scr->act[i];
+          kp = LV[c] > l && LAB[c] == (unsigned)c && CC_K2_ROOT_KEPT(c);
+          if (kp) LAB[c] = (uint16_t)CC_LAB_PENDING;  // remembered for the numbering pass (the bit maps are gone by then); only this thread looks at LAB[c] in between
+        }
+        const unsigned long long m = __ballot(kp);
+        if (lane == 0) scnt[(ib >> 6) + wave_id] = (unsigned char)__popcll(m);
       }
-    })
     __syncthreads();
     CC_K2_SUBLAP(2);
-    int n_kept = sh[1];
-    if (n_kept > CC_NC) {
-      n_kept = CC_NC;
-      if (tid == 0) sh[2] |= 2;  // capacity exceeded: this scan's descriptor is not exact
+    // every wave makes the whole prefix array (identical values from all of them) and then reads its own entries
+    int n_kept = 0;
+    {
+      const int n_str = (((n_act + nt - 1) / nt) * nt) >> 6;  // stretches written above
+      for (int q = 0; q < n_str; q += 64) {
+        const int v = q + lane < n_str ? (int)scnt[q + lane] : 0;
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int w_ = __shfl_up(incl, o);
+          if (lane >= o) incl += w_;
+        }
+        if (q + lane < n_str) sbase[q + lane] = (uint16_t)(n_kept + incl - v);
+        n_kept += __shfl(incl, 63);
+      }
     }
-    for (int k = tid; k < n_kept; k += nt) {
-      const unsigned me = cand[k];
-      int rk = 0;
-      for (int j = 0; j < n_kept; j++) rk += (cand[j] < me) ? 1 : 0;
-      roots[rk] = (uint16_t)me;
-      LAB[me] = (uint16_t)(0x8000u | (unsigned)rk);  // nothing reads LAB in this loop
-      // working arrays of the kept components (W aliases CNT2: the kept test above is done)
-      w_minc[k] = 0xFFFFu;
-      w_maxc[k] = 0;
-      w_area[k] = 0;
-      w_cB[k] = 255;
+    cc_wave_sync();
+    if (n_kept > CC_NC && tid == 0) sh[2] |= 2;  // capacity exceeded: this scan's descriptor is not exact (the CC_NC first roots are kept)
+#pragma unroll
+    for (int u = 0; u < CC_K2_OWN; u++) {
+      const bool kp = (kpm >> u) & 1u;
+      const unsigned long long m = __ballot(kp);
+      if (kp) {
+        const int rk = (int)sbase[u * n_waves + wave_id] + __popcll(m & lane_lt);
+        if (rk < CC_NC) {
+          roots[rk] = (uint16_t)mc[u];
+          LAB[mc[u]] = (uint16_t)(0x8000u | (unsigned)rk);
+          // working arrays of the kept components (they lie over the bit maps: every kept test is behind the barrier above)
+          w_minc[rk] = 0xFFFFu;
+          w_maxc[rk] = 0;
+          w_area[rk] = 0;
+          w_cB[rk] = 255;
+        }
+      }
     }
+    if (has_tail)
+      for (int ib = CC_K2_OWN * nt; ib < n_act; ib += nt) {
+        const int i = ib + tid;
+        bool kp = false;
+        int c = 0;
+        if (i < n_act) {
+          c = (int)scr->act[i];
+          kp = LAB[c] == (unsigned)CC_LAB_PENDING;
+        }
+        const unsigned long long m = __ballot(kp);
+        if (kp) {
+          const int rk = (int)sbase[(ib >> 6) + wave_id] + __popcll(m & lane_lt);
+          if (rk < CC_NC) {
+            roots[rk] = (uint16_t)c;
+            LAB[c] = (uint16_t)(0x8000u | (unsigned)rk);
+            w_minc[rk] = 0xFFFFu;
+            w_maxc[rk] = 0;
+            w_area[rk] = 0;
+            w_cB[rk] = 255;
+          } else {
+            LAB[c] = (uint16_t)c;  // beyond the capacity: an unmarked root again
+          }
+        }
+      }
+    if (n_kept > CC_NC) n_kept = CC_NC;
     __syncthreads();
     CC_K2_SUBLAP(3);
     // (d) per component: area, column range, last cell of the raster order, first member column of the second row
@@ -436,6 +595,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     {
       uint16_t *cidx = scr->compidx[l];
       int16_t *ld = labels_dbg ? labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell : nullptr;
+      unsigned keptm_next = 0;
       CC_K2_FOR_ACTIVE({
         unsigned j = CC_COMP_NONE;
         if (LV[c] > l) {
@@ -456,7 +616,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           }
         }
         cidx[i] = (uint16_t)j;
+        if (i < CC_K2_OWN * nt) keptm_next |= (j != CC_COMP_NONE ? 1u : 0u) << (i / nt);  // i = tid + u * nt: bit u (folds to a constant shift in the unrolled part)
       })
+      keptm = cfg.min_cont_cell_cnt > 3 ? 0u : keptm_next;  // (components dropped below are not in prev_root: no shortcut then)
     }
     __syncthreads();
     // min_cont_cell_cnt_ > 3: the saturating counters only prove ">= 3 cells"; with the exact areas known, drop the
@@ -513,8 +675,6 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     __syncthreads();
     CC_K2_SUBLAP(5);
   }
-  if (phase_clk && tid == 0)
-    for (int j = 0; j < 6; j++) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + j] = sub_acc[j];
   // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331): ONE LANE
   //      per component.  The reference adds a component's cells one after the other (f32 cell_vol3_, f64 sums): that chain
   //      is serial, but the ~100-600 components of a scan are independent, so each gets a lane and a wave works on 64 of
@@ -861,13 +1021,18 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       skey[l * CC_NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
     }
     __syncthreads();
-    for (int k = tid; k < n; k += nt) {
-      const unsigned me = skey[l * CC_NC + k];
+    for (int k0 = 0; k0 < n; k0 += nt >> 2) {  // four threads per component, every fourth key each (block-uniform trip count)
+      const int k = k0 + (tid >> 2), q = tid & 3;
+      const unsigned me = k < n ? skey[l * CC_NC + k] : 0u;
       int rk = 0;
-      for (int j = 0; j < n; j++) rk += (skey[l * CC_NC + j] < me) ? 1 : 0;
-      T[l * CC_NC + k].rank = (uint16_t)rk;
-      // pre-sort sequence: element at insertion position rk is component k
-      arr[l * CC_NC + rk] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+      for (int j = q; j < n; j += 4) rk += (skey[l * CC_NC + j] < me) ? 1 : 0;
+      rk += __shfl_xor(rk, 1);
+      rk += __shfl_xor(rk, 2);
+      if (k < n && q == 0) {
+        T[l * CC_NC + k].rank = (uint16_t)rk;
+        // pre-sort sequence: element at insertion position rk is component k
+        arr[l * CC_NC + rk] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+      }
     }
     __syncthreads();
   }

@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("CC_K2_PHASES", "1")
+if not os.environ.get("CC_PROBE_NOPHASES"):   # the phase clocks cost time themselves (a clock read is a memory operation): true kernel times come without them
+    os.environ.setdefault("CC_K2_PHASES", "1")
 import torch  # noqa: E402
 import cc_amd  # noqa: E402
 
