@@ -122,6 +122,9 @@ def main():
         return
     import cc_amd
     cc = cc_amd.load()
+    if os.environ.get("CC_BENCH_LIB"):  # tuning aid: time another build of the library (an ablation, an older kernel set)
+        cc.LIB_PATH = os.path.abspath(os.environ["CC_BENCH_LIB"])
+        print("bench.py: library %s" % cc.LIB_PATH, file=sys.stderr)
     L = cc.L
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

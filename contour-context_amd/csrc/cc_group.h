@@ -39,9 +39,11 @@ __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) {
   return *(const volatile __attribute__((address_space(3))) unsigned *)p;
 }
 #pragma clang diagnostic pop
+__device__ __forceinline__ double cc_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }  // v_rsq_f64
 #else
 __device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) { return *(const volatile uint16_t *)p; }
 __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) { return *(const volatile unsigned *)p; }
+__device__ __forceinline__ double cc_rsq_seed(double x) { return 1.0 / sqrt(x); }
 #endif
 
 #ifndef CC_EMU

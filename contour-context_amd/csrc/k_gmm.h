@@ -14,6 +14,7 @@
 #include "cc_dev.h"
 #include "cc_group.h"
 #include "cc_sort.h"
+#include "cc_fmath.h"
 #include "k_merge.h"
 
 #define CC_GMM_ECAP_L CC_MAXC  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat): as many as the descriptor
@@ -203,12 +204,21 @@ cc_k_gmm_prep(const cc_scan_desc_t *__restrict__ desc, int n, cc_gmm_feat *__res
 // problems at once, G lanes each (G = 16 for the common instance, 64 for the large-cap instance); every cross-lane
 // operation below is G-wide, so problems in the same wave may diverge freely.
 
-// One selected (src, tgt) ellipse pair as the evaluations read it: the f32 values of the two cc_ell records.
+// One selected (src, tgt) ellipse pair as the evaluations read it: what does NOT depend on the pose, combined once
+// when the pair is filed (round 4 kept the sixteen f32 values and every evaluation -- ~40 per refined problem -- widened and
+// combined them again).  With C_s = m I + [d b; b -d] + a J (m = (c00+c11)/2, d = (c00-c11)/2, b = (c01+c10)/2, a = (c10-c01)/2)
+// the matrix N = 2 (R C_s R^T + C_t) of a term is
+//   N00 = a00 + 2p, N11 = a11 - 2p, N01 = a01 + 2q, N10 = a10 + 2q      p = d cos2t - b sin2t, q = d sin2t + b cos2t
+// and only N01 + N10 = as + 4q and N01 N10 = (2q)^2 + 2q as + ap are needed.
 struct cc_gpair {
-  float s00, s01, s10, s11, t00, t01, t10, t11;
-  float smx, smy, tmx, tmy, sw, tw, pad0, pad1;
-};  // 64 B
-static_assert(sizeof(cc_gpair) == 64, "four 16-byte loads per pair");
+  double sd, sb;    // d, b of the src covariance
+  double a00, a11;  // 2 (m + t00), 2 (m + t11)
+  double as, ap;    // a01 + a10 and a01 * a10 with a01 = 2 (t01 - a), a10 = 2 (t10 + a)
+  double w;         // w_s * w_t
+  double pad_;
+  float smx, smy, tmx, tmy;
+};  // 80 B: five 16-byte units (sd sb | a00 a11 | as ap | w - | means)
+static_assert(sizeof(cc_gpair) == 80, "five 16-byte loads per pair");
 
 // sum over the lanes of a problem, result in every lane
 template <int G>
@@ -256,29 +266,36 @@ __device__ __forceinline__ void cc_gsum4(double &a, double &b, double &c, double
 struct cc_gterm {
   double v, gx, gy, gt;
 };
-__device__ __forceinline__ cc_gterm cc_gmm_term(const cc_gpair &P, double px, double py, double c, double s, double c2, double s2) {
-  const double sm = 0.5 * ((double)P.s00 + (double)P.s11), sd = 0.5 * ((double)P.s00 - (double)P.s11);
-  const double sb = 0.5 * ((double)P.s01 + (double)P.s10), sa = 0.5 * ((double)P.s10 - (double)P.s01);
-  const double p = sd * c2 - sb * s2, q = sd * s2 + sb * c2;
-  const double n00 = 2.0 * (sm + p + (double)P.t00), n11 = 2.0 * (sm - p + (double)P.t11);
-  const double n01 = 2.0 * (q - sa + (double)P.t01), n10 = 2.0 * (q + sa + (double)P.t10);
-  const double nx = n01 + n10;
-  const double det = n00 * n11 - n01 * n10;
-  const double ddet = 4.0 * (q * (n00 - n11) - p * nx);
-  const double g0 = -s * (double)P.smx - c * (double)P.smy, g1 = c * (double)P.smx - s * (double)P.smy;  // d mu / d theta
-  const double m0 = g1 + px - (double)P.tmx, m1 = -g0 + py - (double)P.tmy;
-  const double E = m0 * m0 * n11 - m0 * m1 * nx + m1 * m1 * n00;
-  const double dE = 2.0 * m0 * g0 * n11 + m0 * m0 * (4.0 * q) - (g0 * m1 + m0 * g1) * nx - m0 * m1 * (8.0 * p) + 2.0 * m1 * g1 * n00 -
-                    m1 * m1 * (4.0 * q);
-  const double idet = 1.0 / det;
-  const double Q = -0.5 * E * idet;
-  const double v = -((double)P.tw * (double)P.sw) / sqrt(det) * exp(Q);
-  cc_gterm r;
-  r.v = v;
-  r.gx = v * (-0.5 * idet * (2.0 * m0 * n11 - m1 * nx));
-  r.gy = v * (-0.5 * idet * (2.0 * m1 * n00 - m0 * nx));
-  r.gt = v * (-0.5 * dE * idet - Q * ddet * idet - 0.5 * ddet * idet);
-  return r;
+// Round 5: ~95 f64 instructions per term instead of ~190.  The pose-independent half comes combined (cc_gpair), the
+// products are fused (the translation unit is built with -ffp-contract=off, so every fma below is written out), 1 / det
+// and 1 / sqrt(det) are one reciprocal square root and its square, the exponential is the table routine of cc_fmath.h.
+// Each of these moves a term by a few ulp -- the correlation by ~1e-15 -- inside the 1e-4 the contract gives the scores
+// (BASELINE.json) and far below what changes a gate, a candidate order or an outcome (tests + tests/fuzz_gpu_query.py).
+__device__ __forceinline__ cc_gterm cc_gmm_term(const cc_gpair &P, double px, double py, double c, double s, double c2, double s2,
+                                                const double *exp_tab) {
+  const double p = fma(P.sd, c2, -(P.sb * s2)), q = fma(P.sd, s2, P.sb * c2);
+  const double p2 = p + p, q2 = q + q;
+  const double n00 = P.a00 + p2, n11 = P.a11 - p2;
+  const double nx = fma(4.0, q, P.as);
+  const double det = fma(n00, n11, -fma(q2, q2 + P.as, P.ap));
+  const double ddet = 4.0 * fma(q, n00 - n11, -(p * nx));
+  const double smx = (double)P.smx, smy = (double)P.smy;
+  const double g0 = -fma(s, smx, c * smy), g1 = fma(c, smx, -(s * smy));  // d mu / d theta
+  const double m0 = g1 + (px - (double)P.tmx), m1 = (py - (double)P.tmy) - g0;
+  const double m00 = m0 * m0, m11 = m1 * m1, m01 = m0 * m1;
+  const double E = fma(m00, n11, fma(m11, n00, -(m01 * nx)));
+  const double dE = fma(2.0, fma(m0 * g0, n11, m1 * g1 * n00), fma(4.0 * q, m00 - m11, -fma(fma(g0, m1, m0 * g1), nx, 8.0 * p * m01)));
+  const double r = cc_rsqrt(det);
+  const double idet = r * r;
+  const double hi = -0.5 * idet;
+  const double Q = hi * E;
+  const double v = -(P.w * r) * cc_exp_nonpos(Q, exp_tab);
+  cc_gterm o;
+  o.v = v;
+  o.gx = v * (hi * fma(2.0 * m0, n11, -(m1 * nx)));
+  o.gy = v * (hi * fma(2.0 * m1, n00, -(m0 * nx)));
+  o.gt = v * (idet * fma(-0.5, dE, -(ddet * (Q + 0.5))));
+  return o;
 }
 
 // the pair pre-selection test of GMMPair's ctor (correlation.h:85-96) on dx, dy = transformed src mean - tgt mean:
@@ -295,22 +312,22 @@ __device__ __forceinline__ bool cc_gmm_pair_near(double dx, double dy, float sma
   return sqrt(x) < y;
 }
 __device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_ell &et) {
+  const double s00 = (double)es.c00, s01 = (double)es.c01, s10 = (double)es.c10, s11 = (double)es.c11;
+  const double sm = 0.5 * (s00 + s11), sa = 0.5 * (s10 - s01);
+  const double a01 = 2.0 * ((double)et.c01 - sa), a10 = 2.0 * ((double)et.c10 + sa);
   cc_gpair P;
-  P.s00 = es.c00;
-  P.s01 = es.c01;
-  P.s10 = es.c10;
-  P.s11 = es.c11;
-  P.t00 = et.c00;
-  P.t01 = et.c01;
-  P.t10 = et.c10;
-  P.t11 = et.c11;
+  P.sd = 0.5 * (s00 - s11);
+  P.sb = 0.5 * (s01 + s10);
+  P.a00 = 2.0 * (sm + (double)et.c00);
+  P.a11 = 2.0 * (sm + (double)et.c11);
+  P.as = a01 + a10;
+  P.ap = a01 * a10;
+  P.w = (double)es.w * (double)et.w;
   P.smx = es.mx;
   P.smy = es.my;
   P.tmx = et.mx;
   P.tmy = et.my;
-  P.sw = es.w;
-  P.tw = et.w;
-  P.pad0 = P.pad1 = 0.f;
+  P.pad_ = 0.0;
   return P;
 }
 
@@ -470,7 +487,8 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
 // that holds thousands, and the kernel lasted as long as the largest grid).
 template <int G>
 __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
-                                                const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl) {
+                                                const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl,
+                                                const double *exp_tab) {
   const cc_gmm_problem pb = probs[pidx];
   const cc_gmm_feat *fsrc = db_feat + pb.gidx;
   const cc_gmm_feat *ftgt = qfeat + pb.q;
@@ -483,7 +501,7 @@ __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict
       const int code = (int)L.code[e];
       const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
       const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
-      acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2).v;
+      acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2, exp_tab).v;
     }
     cc_gsync<G>();
   });
@@ -509,58 +527,70 @@ __global__ void __launch_bounds__(64)
 cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
               const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
   __shared__ cc_gmm_scan_lds lds[64 / CC_G];
+  __shared__ double exp_tab[64];
+  exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
+  cc_wave_sync();
   const int n_prob = *n_prob_p;
   if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
-    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x);
+    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab);
     return;
   }
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
   for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
-    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl);
+    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab);
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes
 template <int G>
 __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, int np, int sl, const double p[3], double *cost,
-                                            double grad[3]) {
+                                            double grad[3], const double *exp_tab) {
   double c, s;
   sincos(p[2], &s, &c);
   const double c2 = c * c - s * s, s2 = 2.0 * s * c;
   double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
-  // the next pair's record is requested before this pair's ~190 f64 instructions are issued: with one wave per SIMD (few,
+  // the next pair's record is requested before this pair's ~95 f64 instructions are issued: with one wave per SIMD (few,
   // long problems) nothing else hides the L2 round trip
-  float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
+  double2 w0 = make_double2(0.0, 0.0), w1 = w0, w2 = w0, w3 = w0;
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (sl < np) {
-    const float4 *g4 = (const float4 *)(pairs + sl);
-    w0 = g4[0], w1 = g4[1], w2 = g4[2], w3 = g4[3];
+    const double2 *g2 = (const double2 *)(pairs + sl);
+    w0 = g2[0], w1 = g2[1], w2 = g2[2], w3 = g2[3];
+    w4 = *(const float4 *)(g2 + 4);
   }
   for (int i = sl; i < np; i += G) {
-    float4 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+    double2 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+    float4 n4 = w4;
     if (i + G < np) {
-      const float4 *g4 = (const float4 *)(pairs + i + G);
-      n0 = g4[0], n1 = g4[1], n2 = g4[2], n3 = g4[3];
+      const double2 *g2 = (const double2 *)(pairs + i + G);
+      n0 = g2[0], n1 = g2[1], n2 = g2[2], n3 = g2[3];
+      n4 = *(const float4 *)(g2 + 4);
     }
     cc_gpair P;
-    P.s00 = w0.x;
-    P.s01 = w0.y;
-    P.s10 = w0.z;
-    P.s11 = w0.w;
-    P.t00 = w1.x;
-    P.t01 = w1.y;
-    P.t10 = w1.z;
-    P.t11 = w1.w;
-    P.smx = w2.x;
-    P.smy = w2.y;
-    P.tmx = w2.z;
-    P.tmy = w2.w;
-    P.sw = w3.x;
-    P.tw = w3.y;
-    const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2);
+    P.sd = w0.x;
+    P.sb = w0.y;
+    P.a00 = w1.x;
+    P.a11 = w1.y;
+    P.as = w2.x;
+    P.ap = w2.y;
+    P.w = w3.x;
+    P.smx = w4.x;
+    P.smy = w4.y;
+    P.tmx = w4.z;
+    P.tmy = w4.w;
+    const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2, exp_tab);
+#ifdef CC_TUNE_GMM_TWICE  // tuning aid: the pair arithmetic twice (what it costs = this build's K5 minus the product's)
+    {
+      cc_gpair P2 = P;
+      P2.w = P.w * 1.0000001;
+      const cc_gterm t2 = cc_gmm_term(P2, p[0], p[1], c, s, c2, s2, exp_tab);
+      a += 1e-300 * (t2.v + t2.gx + t2.gy + t2.gt);
+    }
+#endif
     a += t.v;
     ax += t.gx;
     ay += t.gy;
     at += t.gt;
-    w0 = n0, w1 = n1, w2 = n2, w3 = n3;
+    w0 = n0, w1 = n1, w2 = n2, w3 = n3, w4 = n4;
   }
   cc_gsum4<G>(a, ax, ay, at);
   *cost = a;
@@ -571,6 +601,7 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
 
 struct cc_gmm_ctx {  // what a line-search evaluation needs
   const cc_gpair *pairs;
+  const double *exp_tab;  // cc_exp2_tab64 in LDS
   int np, sl;
 };
 // ---- Ceres 2.x line search pieces (see oracle/orc_gmm.h for the provenance notes) ----
@@ -841,7 +872,7 @@ __device__ __forceinline__ void cc_ls_eval(const cc_gmm_ctx &S, const double pos
   o->x = x;
   double vx[3];
   for (int i = 0; i < 3; i++) vx[i] = pos[i] + x * dir[i];
-  cc_gmm_eval<G>(S.pairs, S.np, S.sl, vx, &o->value, o->vg);
+  cc_gmm_eval<G>(S.pairs, S.np, S.sl, vx, &o->value, o->vg, S.exp_tab);
   o->value_ok = isfinite(o->value);
   o->grad_ok = o->value_ok && isfinite(o->vg[0]) && isfinite(o->vg[1]) && isfinite(o->vg[2]);
   o->gradient = dir[0] * o->vg[0] + dir[1] * o->vg[1] + dir[2] * o->vg[2];
@@ -958,6 +989,9 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
   __shared__ double hist_all[NP][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
   __shared__ cc_gmm_scan_lds scan_lds[NP];
   __shared__ int s_off;
+  __shared__ double exp_tab[64];
+  if (threadIdx.x < 64) exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
+  if (G == 256) __syncthreads(); else cc_wave_sync();
   const int sub = threadIdx.x / G, sl = threadIdx.x % G;
   double *hist = hist_all[sub];
   cc_gmm_scan_lds &L = scan_lds[sub];
@@ -1004,11 +1038,12 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     cc_gsync<G>();
     cc_gmm_ctx S;
     S.pairs = pool + off;
+    S.exp_tab = exp_tab;
     S.np = np;
     S.sl = sl;
     double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
     double cost, g[3];
-    cc_gmm_eval<G>(S.pairs, S.np, S.sl, x, &cost, g);
+    cc_gmm_eval<G>(S.pairs, S.np, S.sl, x, &cost, g, S.exp_tab);
     const double denom = sqrt(fsrc->ac * ftgt->ac);
     {
     // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations

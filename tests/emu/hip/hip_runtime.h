@@ -60,6 +60,7 @@ static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) {
 struct double2 {
   double x, y;
 };
+static inline double2 make_double2(double a, double b) { return {a, b}; }
 static inline float2 make_float2(float a, float b) { return {a, b}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 static inline int2 make_int2(int a, int b) { return {a, b}; }
