@@ -85,6 +85,11 @@ def main():
                          "strong = the --batch scans of a step are split over the ranks (total work fixed)")
     ap.add_argument("--beams", type=int, default=64, help="rays of the synthetic sensor: beams x azim (the metric is quoted on 64 x 1875 = 120 000 points)")
     ap.add_argument("--azim", type=int, default=1875)
+    ap.add_argument("--comm-owner", choices=("torch", "c"), default=os.environ.get("CC_BENCH_COMM_OWNER", "torch"),
+                    help="who issues the path's collective (the all-gather of the packed records): torch.distributed (nccl = RCCL; the "
+                         "default, covered by the gloo twin on CPU) or the library's own cc_comm_allgather_packed (ncclAllGather "
+                         "through the C-ABI, what a C++ host uses: hostcpp/examples/batch_replay_mgpu.cpp); the barrier and the "
+                         "max-over-ranks timing stay with torch.distributed either way.  'c' also runs at N = 1 (a world of one)")
     ap.add_argument("--ingest-cus", default=os.environ.get("CC_BENCH_INGEST_CUS", ""),
                     help="CU partition of the overlapped step (DESIGN.md section 3): 'a/b' = the ingest stream is created with "
                          "hipExtStreamCreateWithCUMask on a of every b CUs of each XCD, 'xa/b' = on a of every b XCDs; the query "
@@ -193,9 +198,15 @@ def main():
     if world > 1:
         dist.barrier()
     t_x = time.perf_counter()
-    rec_db, exchange_bytes = SH.gather_records(rec_local, n_db, world, dist)   # RCCL over xGMI: 59 KB per scan (the descriptor is 169 KB)
+    c_comm = None
+    if args.comm_owner == "c" and not harness:
+        c_comm, c_rank, c_world = cc.comm_from_env()
+        assert (c_rank, c_world) == (rank, world), (c_rank, c_world, rank, world)
+        rec_db, exchange_bytes = SH.gather_records_c(cc, c_comm, rec_local, n_db, world)   # ncclAllGather issued by the library
+    else:
+        rec_db, exchange_bytes = SH.gather_records(rec_local, n_db, world, dist)   # RCCL over xGMI: 59 KB per scan (the descriptor is 169 KB)
     sync()
-    exchange_ms = (time.perf_counter() - t_x) * 1e3 if world > 1 else 0.0
+    exchange_ms = (time.perf_counter() - t_x) * 1e3 if (world > 1 or c_comm is not None) else 0.0
     db = _HarnessDb(ctx, n_db + 16) if harness else cc.Database(ctx, capacity=n_db + 16)
     if args.no_overlap:
         db.set_lanes(1)
@@ -260,7 +271,13 @@ def main():
                 hq, fq = ctx.pack(q)
                 rec_q[:, :HB] = hq
                 rec_q[:, HB:] = fq
-                if harness:
+                if c_comm is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    cc.comm_allgather(c_comm, rec_q.data_ptr(), gathered.data_ptr(), int(rec_q.numel()), torch.cuda.current_stream(dev).cuda_stream)
+                    e1.record()
+                    share_ev.append((e0, e1))
+                elif harness:
                     t_s = time.perf_counter()
                     dist.all_gather_into_tensor(gathered, rec_q)
                     share_ev.append((time.perf_counter() - t_s) * 1e3)
@@ -429,6 +446,7 @@ def main():
             HBq, FBq = cc.packed_sizes() if not harness else ctx.api.packed_sizes()
             out["multi_gpu"] = {
                 "ranks_seen": dist.get_world_size(), "backend": backend, "scaling": args.scaling,
+                "collective_issued_by": "cc_comm_allgather_packed (the library: ncclAllGather)" if c_comm is not None else "torch.distributed.all_gather_into_tensor",
                 "per_rank_scans_per_s": per_rank,
                 "db_exchange": {"collective": "all_gather_into_tensor of the packed per-scan records (hot record + correlation inputs)",
                                 "bytes_per_scan": HBq + FBq, "bytes_gathered_per_rank": exchange_bytes, "ms": exchange_ms,
@@ -439,6 +457,8 @@ def main():
                                        "achieved_GBs": gathered.numel() * (world - 1) / world / (share_ms * 1e-3) / 1e9 if share_ms else None}
                                       if share else None),
                 "data_path_collectives_in_timed_step": 1 if share else 0}
+        if world == 1 and c_comm is not None:  # --comm-owner c on one GPU: the library's RCCL call with a world of one
+            out["comm_owner_c_world1"] = {"collective": "cc_comm_allgather_packed (ncclAllGather, world = 1)", "bytes": exchange_bytes, "ms": exchange_ms}
         batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
             # the reference's online loop on the scans already resident: from an empty DB, per 512-scan sub-batch

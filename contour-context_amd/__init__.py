@@ -23,7 +23,7 @@ import sharding  # noqa: E402,F401
 
 LIB_PATH = os.path.join(_HERE, "libcont2_amd.so")
 _SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_group.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "cc_fmath.h", "k_rasterize.h", "k_contours.h",
-         "k_knn.h", "k_check.h", "k_merge.h", "k_gmm.h", "cc_hostdb.h", "cc_db_api.inc"]
+         "k_knn.h", "k_check.h", "k_merge.h", "k_gmm.h", "cc_hostdb.h", "cc_db_api.inc", "cc_comm.inc"]
 
 
 def build(force=False, verbose=False):
@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", os.path.join(_HERE, "csrc", "cont2_amd.hip"), "-o", LIB_PATH]
+           "-Wno-unused-value", os.path.join(_HERE, "csrc", "cont2_amd.hip"), "-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -50,7 +50,8 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
            "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host", "cc_db_debug_passes",
            "cc_stage_points", "cc_stage_points_slot", "cc_stage_points_cancel", "cc_scan_ingest", "cc_scan_desc", "cc_scan_bev", "cc_scan_offload", "cc_scan_on_device", "cc_scan_release", "cc_db_query_scan",
-           "cc_db_add_scan"]
+           "cc_db_add_scan",
+           "cc_comm_unique_id", "cc_comm_create", "cc_comm_create_from_env", "cc_comm_rank", "cc_comm_world", "cc_comm_allgather_packed", "cc_comm_destroy"]
 
 
 def lib():
@@ -114,6 +115,24 @@ class IngestDebug(C.Structure):
 
 
 DESC_BYTES = L.scan_desc_dt.itemsize
+
+
+def comm_from_env():
+    """cc_comm_create_from_env: (handle, rank, world) from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT (one node)."""
+    h, r, w = C.c_void_p(), C.c_int(), C.c_int()
+    lib().cc_comm_create_from_env.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(lib().cc_comm_create_from_env(C.byref(h), C.byref(r), C.byref(w)), "cc_comm_create_from_env")
+    return h, r.value, w.value
+
+
+def comm_allgather(comm, d_send, d_recv, bytes_per_rank, stream):
+    lib().cc_comm_allgather_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    _chk(lib().cc_comm_allgather_packed(comm, d_send, d_recv, bytes_per_rank, stream), "cc_comm_allgather_packed")
+
+
+def comm_destroy(comm):
+    lib().cc_comm_destroy.argtypes = [C.c_void_p]
+    lib().cc_comm_destroy(comm)
 
 
 def packed_sizes():

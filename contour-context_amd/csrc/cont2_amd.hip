@@ -57,6 +57,11 @@ struct cc_ctx {
   cc_k1_scan_out *d_k1 = nullptr;
   cc_k1_part k1_part;               // scratch of the split rasterisation (calls of <= CC_K1_SPLIT_MAX_SCANS scans), allocated at first use
   cc_k2_scratch *d_scr = nullptr;
+  // the slow path of K2 (scans with more than CC_MAXC components on a level): queue filled by the fast launch, a few
+  // workgroups with CC_NC_BIG-sized tables in global memory
+  static const int N_BIG_SLOTS = 8;
+  cc_k2_big_queue *d_bigq = nullptr;
+  cc_k2_big_slot *d_bigslots = nullptr;
   long long *d_offsets = nullptr;
   // pinned staging ring for the per-chunk point offsets: a slot is reused only after the copy that read it has finished
   static const int NSLOT = 4;
@@ -195,6 +200,9 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   CREATE_CHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
   CREATE_CHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
   CREATE_CHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
+  CREATE_CHK(hipMalloc(&c->d_bigq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)max_batch_scans));
+  CREATE_CHK(hipMemset(c->d_bigq, 0, sizeof(cc_k2_big_queue)));  // the slow launch leaves it empty again
+  CREATE_CHK(hipMalloc(&c->d_bigslots, sizeof(cc_k2_big_slot) * cc_ctx::N_BIG_SLOTS));
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
     CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * (max_batch_scans + 1), hipHostMallocDefault));
     CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
@@ -218,6 +226,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     c->k1_nosplit = (e2 && atoi(e2) == 1) ? 1 : 0;
   }
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
 #undef CREATE_CHK
   *out = c;
   return CC_OK;
@@ -287,6 +296,8 @@ int cc_destroy(cc_ctx *c) {
   hipFree(c->k1_part.red);
   hipFree(c->d_scr);
   hipFree(c->d_offsets);
+  hipFree(c->d_bigq);
+  hipFree(c->d_bigslots);
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
     if (c->h_off[i]) hipHostFree(c->h_off[i]);
     if (c->off_ev[i]) hipEventDestroy(c->off_ev[i]);
@@ -376,7 +387,10 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
-                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab, c->d_phase_clk);
+                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab, c->d_phase_clk, c->d_bigq);
+    // the scans the launch above could not number (more than CC_MAXC components on a level): exact, slow, usually none
+    hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < cc_ctx::N_BIG_SLOTS ? nb : cc_ctx::N_BIG_SLOTS), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
+                       (const float *)c->d_bev, (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_bigslots, c->d_bigq, d_out + b0, lab);
     if (pe) HIPCHK(hipEventRecord(pe[2], stream));
     HIPCHK(hipGetLastError());
     if (dbg && dbg->d_bev)
@@ -704,5 +718,6 @@ int cc_scan_release(cc_scan *sc) {
 }
 
 #include "cc_db_api.inc"
+#include "cc_comm.inc"
 
 }  // extern "C"

@@ -37,13 +37,37 @@ struct cc_comp_t {  // per kept component, spilled to global scratch between lev
   uint8_t r0, r1, c0, c1, cA, cB, pad[2];
 };  // 16 B
 
-struct cc_k2_scratch {  // per scan of a launch
-  cc_comp_t comp[CC_NLEV][CC_NC];
-  cc_contour_t cont[CC_NLEV][CC_NC];
-  alignas(16) uint16_t memb[CC_NLEV][((CC_MAX_CELLS + 7) & ~7) + 8 * CC_NC];  // per level: the components' member lists (positions in `act`, raster
+template <int NC>
+struct cc_k2_scratch_t {  // per scan of a launch
+  cc_comp_t comp[CC_NLEV][NC];
+  cc_contour_t cont[CC_NLEV][NC];
+  alignas(16) uint16_t memb[CC_NLEV][((CC_MAX_CELLS + 7) & ~7) + 8 * NC];  // per level: the components' member lists (positions in `act`, raster
                                                               // order), every list starts on a 16-byte boundary
   uint16_t act[CC_MAX_CELLS];                               // active cells (above the lowest level), raster order
   uint16_t compidx[CC_NLEV][CC_MAX_CELLS];                  // per level: component index of list entry i, 0x7FFF = none
+};
+typedef cc_k2_scratch_t<CC_NC> cc_k2_scratch;
+// The exact slow path for scans with more than CC_NC components on a level (the reference has no such limit,
+// contour_mng.h:92-110): the same kernel body with room for CC_NC_BIG components per level, its per-component tables in a
+// global block instead of LDS.  CC_NC_BIG < 4096 (the sort replay's range); a 150 x 150 image cannot hold that many
+// 8-separated components of three cells (each needs one of the 5 625 aligned 2 x 2 blocks to itself, and its neighbours'
+// blocks cannot all be used).
+#define CC_NC_BIG 3840
+struct cc_k2_big_tables {  // what the fast instance keeps in LDS, sized for CC_NC_BIG
+  unsigned W[7 * CC_NC_BIG];
+  uint16_t roots[CC_NC_BIG], cand[CC_NC_BIG], prev_root[CC_NC_BIG];
+  uint16_t moff[CC_NLEV * CC_NC_BIG], mcnt[CC_NLEV * CC_NC_BIG];
+  uint16_t big[CC_NLEV * CC_NC_BIG];
+  alignas(16) cc_comp_t T[CC_NLEV * CC_NC_BIG];
+  unsigned skey[CC_NLEV * CC_NC_BIG], arr[CC_NLEV * CC_NC_BIG];
+};
+struct cc_k2_big_slot {  // one workgroup of the slow path
+  cc_k2_scratch_t<CC_NC_BIG> scr;
+  cc_k2_big_tables tab;
+};
+struct cc_k2_big_queue {  // filled by the fast launch, drained by the slow one (whose last workgroup leaves it empty again)
+  int n_flagged, next, exited, pad_;
+  int scan[1];  // [max_batch] follows
 };
 #define CC_K2_NCLK 32    // phase-clock slots per scan (tuning aid)
 #define CC_K2_OWN 6       // list entries a thread keeps in registers (beyond: read from the scratch block; a street scene has
@@ -124,7 +148,7 @@ __device__ __forceinline__ int cc_cnt2_get(const unsigned *cnt2, int r) { return
 // become unmarked again.  Entries only move to lower indices, so chunks of blockDim components go front to back.
 // wsum: 8 ints of LDS.  Returns the new count (uniform).
 __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *W, uint16_t *roots, uint16_t *LAB, int *wsum,
-                                            uint16_t *remap /*[old index] = new index or 0x7FFF*/) {
+                                            uint16_t *remap /*[old index] = new index or 0x7FFF*/, int nc /* row stride of W */) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave_id = tid >> 6, n_waves = nt >> 6;
   int n_new = 0;
   for (int k0 = 0; k0 < n_kept; k0 += nt) {
@@ -133,12 +157,12 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
     bool keep = false;
     if (k < n_kept) {
       v0 = W[k];
-      v1 = W[CC_NC + k];
-      v2 = W[2 * CC_NC + k];
-      v3 = W[3 * CC_NC + k];
-      v4 = W[4 * CC_NC + k];
-      v5 = W[5 * CC_NC + k];
-      v6 = W[6 * CC_NC + k];
+      v1 = W[nc + k];
+      v2 = W[2 * nc + k];
+      v3 = W[3 * nc + k];
+      v4 = W[4 * nc + k];
+      v5 = W[5 * nc + k];
+      v6 = W[6 * nc + k];
       rt = roots[k];
       keep = (int)v3 >= min_cnt;  // W[3] = area
     }
@@ -154,12 +178,12 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
     if (k < n_kept) {
       if (keep) {
         W[off] = v0;
-        W[CC_NC + off] = v1;
-        W[2 * CC_NC + off] = v2;
-        W[3 * CC_NC + off] = v3;
-        W[4 * CC_NC + off] = v4;
-        W[5 * CC_NC + off] = v5;
-        W[6 * CC_NC + off] = v6;
+        W[nc + off] = v1;
+        W[2 * nc + off] = v2;
+        W[3 * nc + off] = v3;
+        W[4 * nc + off] = v4;
+        W[5 * nc + off] = v5;
+        W[6 * nc + off] = v6;
         roots[off] = (uint16_t)rt;
         LAB[rt] = (uint16_t)(0x8000u | (unsigned)off);
         remap[k] = (uint16_t)off;
@@ -174,37 +198,38 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
   return n_new;
 }
 
-// 4 waves per SIMD = two 512-thread workgroups (scans) per CU: at most 128 VGPRs
-__global__ void __launch_bounds__(CC_K2_BLOCK, 4)
-cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
-              const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
-              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk) {
-  HIP_DYNAMIC_SHARED(char, smem)
+// The kernel body.  NC = components per level it handles exactly; BIG = the per-component tables live in `bigtab` (global)
+// instead of LDS.  `scan` indexes the launch's inputs and outputs, `scr` is the scratch block to use.
+template <int NC, bool BIG>
+__device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+                                           const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch_t<NC> *__restrict__ scr,
+                                           cc_k2_big_tables *__restrict__ bigtab, cc_k2_big_queue *__restrict__ queue, int scan,
+                                           cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
+                                           char *smem) {
   // optional phase timestamps (tuning aid): phase_clk[scan*CC_K2_NCLK + i], written by thread 0
 #define CC_K2_STAMP(i)                                                                     \
   do {                                                                                     \
-    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + (i)] = (long long)wall_clock64(); \
+    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)scan * CC_K2_NCLK + (i)] = (long long)wall_clock64(); \
   } while (0)
   CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int scan = blockIdx.x;
 
   unsigned char *LV = (unsigned char *)smem;                       // #levels the cell's height exceeds: bev > lv_grads[l] <=> LV > l
   char *R = smem + CC_K2_LV_BYTES(n_cell);
   // ---- region R, phase "levels" ----
+  // (the LDS offsets below are the fast instance's layout, NC components per level; the big instance keeps the same
+  // offsets for what does not grow with the component count and takes the rest from `bigtab`)
   uint16_t *LAB = (uint16_t *)R;                                   // n_cell u16 (45000)
-  unsigned *W = (unsigned *)(R + 45056);                           // 7 * CC_NC u32 working arrays / CNT2 alias (8960)
-  uint16_t *roots = (uint16_t *)(R + 45056 + 8960);                // CC_NC u16
-  uint16_t *cand = roots + CC_NC;                                  // CC_NC u16
-  uint16_t *prev_root = cand + CC_NC;                              // CC_NC u16
+  unsigned *W = BIG ? bigtab->W : (unsigned *)(R + 45056);         // 7 * NC u32 working arrays (8960 B of LDS, over the bit maps)
+  uint16_t *roots = BIG ? bigtab->roots : (uint16_t *)(R + 45056 + 8960);                // NC u16
+  uint16_t *cand = BIG ? bigtab->cand : roots + NC;                                      // NC u16
+  uint16_t *prev_root = BIG ? bigtab->prev_root : cand + NC;                             // NC u16
   int *sh = (int *)(R + 45056 + 8960 + 3 * CC_NC * 2 + 64);        // small scalars
-  // sh[0]=changed flag  sh[1]=n_cand  sh[2]=flags  sh[8+l]=n_kept[l]  sh[16+l]=layer_cell_cnt[l]
-  unsigned *CNT2 = W;  // 2-bit saturating counters, (n_cell+15)/16 words (5628 B <= 8960)
+  // sh[2]=flags  sh[3]=#large components  sh[8+l]=n_kept[l]  sh[24+w]=per-wave counts
 
   const float *bev = bev_in + (size_t)scan * n_cell;
   const float2 *pix = pix_in + (size_t)scan * n_cell;
-  cc_k2_scratch *scr = scratch_all + scan;
   cc_scan_desc_t *desc = desc_out + scan;
 
   // ---- level index of every cell; the ACTIVE cells (above the lowest level) as a raster-ordered list ----
@@ -293,12 +318,12 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   // production launch (phase_clk == nullptr) carries no accumulator registers for it
   long long tsub = tmark;
   if (phase_clk && tid == 0)
-    for (int j = 0; j < 6; j++) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + j] = 0;
+    for (int j = 0; j < 6; j++) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + j] = 0;
 #define CC_K2_SUBLAP(j)                                                                   \
   do {                                                                                    \
     if (phase_clk) {                                                                      \
       const long long now_ = (long long)wall_clock64();                                   \
-      if (tid == 0) phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 16 + (j)] += now_ - tsub; \
+      if (tid == 0) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + (j)] += now_ - tsub; \
       tsub = now_;                                                                        \
     }                                                                                     \
   } while (0)
@@ -310,11 +335,11 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       tmark = now_;                                        \
     }                                                      \
   } while (0)
-  unsigned *w_minc = W + CC_NC, *w_maxc = W + 2 * CC_NC, *w_area = W + 3 * CC_NC, *w_cB = W + 4 * CC_NC;
+  unsigned *w_minc = W + NC, *w_maxc = W + 2 * NC, *w_area = W + 3 * NC, *w_cB = W + 4 * NC;
   // "has a second cell" / "has a third cell" bit per root (the kept test of a level), over the working arrays
-  unsigned *bitA = W, *bitB = W + ((n_cell + 31) >> 5);
+  unsigned *bitA = (unsigned *)(R + 45056), *bitB = bitA + ((n_cell + 31) >> 5);
   const int n_bw = 2 * ((n_cell + 31) >> 5);
-  unsigned char *scnt = (unsigned char *)cand;   // kept roots per 64-entry stretch of the active list (<= 352 stretches)
+  unsigned char *scnt = (unsigned char *)(R + 45056 + 8960 + CC_NC * 2);  // kept roots per 64-entry stretch of the active list (<= 352 stretches; the fast instance's `cand`)
   uint16_t *sbase = (uint16_t *)(sh + 64);       // their exclusive prefix sum
   const bool has_tail = n_act > CC_K2_OWN * nt;  // block-uniform: more active cells than the threads keep in registers
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -508,14 +533,14 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       }
     }
     cc_wave_sync();
-    if (n_kept > CC_NC && tid == 0) sh[2] |= 2;  // capacity exceeded: this scan's descriptor is not exact (the CC_NC first roots are kept)
+    if (n_kept > NC && tid == 0) sh[2] |= 2;  // capacity exceeded: this scan's descriptor is not exact (the NC first roots are kept)
 #pragma unroll
     for (int u = 0; u < CC_K2_OWN; u++) {
       const bool kp = (kpm >> u) & 1u;
       const unsigned long long m = __ballot(kp);
       if (kp) {
         const int rk = (int)sbase[u * n_waves + wave_id] + __popcll(m & lane_lt);
-        if (rk < CC_NC) {
+        if (rk < NC) {
           roots[rk] = (uint16_t)mc[u];
           LAB[mc[u]] = (uint16_t)(0x8000u | (unsigned)rk);
           // working arrays of the kept components (they lie over the bit maps: every kept test is behind the barrier above)
@@ -538,7 +563,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
         const unsigned long long m = __ballot(kp);
         if (kp) {
           const int rk = (int)sbase[(ib >> 6) + wave_id] + __popcll(m & lane_lt);
-          if (rk < CC_NC) {
+          if (rk < NC) {
             roots[rk] = (uint16_t)c;
             LAB[c] = (uint16_t)(0x8000u | (unsigned)rk);
             w_minc[rk] = 0xFFFFu;
@@ -550,7 +575,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           }
         }
       }
-    if (n_kept > CC_NC) n_kept = CC_NC;
+    if (n_kept > NC) n_kept = NC;
     __syncthreads();
     CC_K2_SUBLAP(3);
     // (d) per component: area, column range, last cell of the raster order, first member column of the second row
@@ -589,7 +614,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     // components below the bar (stats(n,4) < cfg_.min_cont_cell_cnt_, contour_mng.cpp:303) and renumber the rest
     if (cfg.min_cont_cell_cnt > 3) {
       const int n_before = n_kept;
-      n_kept = cc_k2_drop_small(cfg.min_cont_cell_cnt, n_kept, W, roots, LAB, sh + 24, cand);
+      n_kept = cc_k2_drop_small(cfg.min_cont_cell_cnt, n_kept, W, roots, LAB, sh + 24, cand, NC);
       if (n_kept != n_before) {  // uniform: the walk's index image follows the renumbering (cand[old] = new or 0x7FFF)
         uint16_t *cidx = scr->compidx[l];
         int16_t *ld = labels_dbg ? labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell : nullptr;
@@ -639,6 +664,15 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     __syncthreads();
     CC_K2_SUBLAP(5);
   }
+  // More components on a level than this instance numbers: the scan goes to the slow path (cc_k_contours_big), which
+  // redoes it with room for CC_NC_BIG per level; nothing of this workgroup's output is kept (block-uniform exit).
+  if (!BIG && queue != nullptr && (sh[2] & 2)) {
+    if (tid == 0) {
+      queue->scan[atomicAdd(&queue->n_flagged, 1)] = scan;
+      desc_out[scan].flags = CC_DESC_INEXACT_COMPONENTS;  // stands until the slow path has rewritten the descriptor
+    }
+    return;
+  }
   // ---- (f) raster-order running statistics of every kept component of every level (contour_mng.cpp:317-331): ONE LANE
   //      per component.  The reference adds a component's cells one after the other (f32 cell_vol3_, f64 sums): that chain
   //      is serial, but the ~100-600 components of a scan are independent, so each gets a lane and a wave works on 64 of
@@ -654,9 +688,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   {
     float *cbev = (float *)R;                                      // [CC_K2_CACHE]
     float2 *cpix = (float2 *)(R + CC_K2_CACHE * 4);                // [CC_K2_CACHE]
-    uint16_t *moff = (uint16_t *)(R + CC_K2_CACHE * 12);           // [6][CC_NC] start of a component's list in memb[l], in units of 8
-    uint16_t *mcnt = moff + CC_NLEV * CC_NC;                       // [6][CC_NC] members filed so far
-    uint16_t *big = (uint16_t *)(R + 45056);                       // [<= n_tot] components left to the eight-lane pass (the levels' working arrays are dead)
+    uint16_t *moff = BIG ? bigtab->moff : (uint16_t *)(R + CC_K2_CACHE * 12);  // [6][NC] start of a component's list in memb[l], in units of 8
+    uint16_t *mcnt = BIG ? bigtab->mcnt : moff + CC_NLEV * NC;                 // [6][NC] members filed so far
+    uint16_t *big = BIG ? bigtab->big : (uint16_t *)(R + 45056);               // [<= n_tot] components left to the eight-lane pass (the levels' working arrays are dead)
     const int n_cache = n_act < CC_K2_CACHE ? n_act : CC_K2_CACHE;
     const bool all_cached = n_act <= CC_K2_CACHE;  // block-uniform: every active cell's height and position sit in LDS
     if (tid == 0) sh[3] = 0;
@@ -665,7 +699,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       cbev[i] = bev[c];
       cpix[i] = pix[c];
     }
-    for (int i = tid; i < CC_NLEV * CC_NC; i += nt) mcnt[i] = 0;
+    for (int i = tid; i < CC_NLEV * NC; i += nt) mcnt[i] = 0;
     int n_tot = 0, lev_base[CC_NLEV + 1];
     for (int l = 0; l < CC_NLEV; l++) {
       lev_base[l] = n_tot;
@@ -684,7 +718,7 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           const int v = __shfl_up(incl, o);
           if (lane >= o) incl += v;
         }
-        if (k < n) moff[l * CC_NC + k] = (uint16_t)(run + incl - a8);
+        if (k < n) moff[l * NC + k] = (uint16_t)(run + incl - a8);
         run += __shfl(incl, 63);
       }
     }
@@ -692,8 +726,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     for (int l = wave_id; l < CC_NLEV; l += n_waves) {  // member lists, a wave per level
       const uint16_t *cidx = scr->compidx[l];
       uint16_t *memb = scr->memb[l];
-      uint16_t *cnt_l = mcnt + l * CC_NC;
-      const uint16_t *off_l = moff + l * CC_NC;
+      uint16_t *cnt_l = mcnt + l * NC;
+      const uint16_t *off_l = moff + l * NC;
       const unsigned long long lt = (1ull << lane) - 1ull;
       unsigned jn = lane < n_act ? (unsigned)cidx[lane] : CC_COMP_NONE;
       for (int b0 = 0; b0 < n_act; b0 += 64) {
@@ -736,12 +770,12 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int kbase = 0;
       for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
       const int k = w - kbase;
-      const int area = (int)mcnt[l * CC_NC + k];  // == comp[l][k].area
+      const int area = (int)mcnt[l * NC + k];  // == comp[l][k].area
       if (area > CC_K2_BIG) {  // left to the eight-lane pass below
         big[atomicAdd(&sh[3], 1)] = (uint16_t)w;
         continue;
       }
-      const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
+      const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * NC + k] * 8);
       cc_running_stat rec;
       rec.cnt = 0;
       rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
@@ -851,8 +885,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
           int kbase = 0;
           for (int e = 0; e < CC_NLEV; e++) kbase = (e == l) ? lev_base[e] : kbase;
           k = w - kbase;
-          const int area = (int)mcnt[l * CC_NC + k];
-          const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * CC_NC + k] * 8);
+          const int area = (int)mcnt[l * NC + k];
+          const uint4 *ml = (const uint4 *)(scr->memb[l] + (int)moff[l * NC + k] * 8);
           uint4 nx = ml[0];
           if (all_cached) {
             // as the lane walk: straight-line, masked tail.  The lane's two factors are picked with bit masks fixed per role (a
@@ -937,9 +971,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   }
   CC_K2_LAP(acc_walk);
   if (phase_clk && tid == 0) {
-    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 1] = acc_ccl;
-    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 2] = acc_enum;
-    phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 3] = acc_walk;
+    phase_clk[(size_t)scan * CC_K2_NCLK + 1] = acc_ccl;
+    phase_clk[(size_t)scan * CC_K2_NCLK + 2] = acc_enum;
+    phase_clk[(size_t)scan * CC_K2_NCLK + 3] = acc_walk;
   }
   CC_K2_STAMP(4);
 
@@ -952,25 +986,25 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
 #define CC_NLEV_AT(i) ((i) == 0 ? n_lev[0] : (i) == 1 ? n_lev[1] : (i) == 2 ? n_lev[2] : (i) == 3 ? n_lev[3] : (i) == 4 ? n_lev[4] : n_lev[5])
   const int flags0 = sh[2];
   __syncthreads();
-  cc_comp_t *T = (cc_comp_t *)R;                                            // [6][NC] 30720 B
-  unsigned *skey = (unsigned *)(R + 30720);                                 // [6][NC] u32 7680 B
-  unsigned *arr = (unsigned *)(R + 30720 + 7680);                           // [6][NC] u32 7680 B
+  cc_comp_t *T = BIG ? bigtab->T : (cc_comp_t *)R;                          // [6][NC] 30720 B
+  unsigned *skey = BIG ? bigtab->skey : (unsigned *)(R + 30720);            // [6][NC] u32 7680 B
+  unsigned *arr = BIG ? bigtab->arr : (unsigned *)(R + 30720 + 7680);       // [6][NC] u32 7680 B
   cc_anchor_lds *top = (cc_anchor_lds *)(R + 30720 + 2 * 7680);             // [6][10] 1200 B
   int *sh2 = (int *)(R + 30720 + 2 * 7680 + 1280);                          // scalars (64 ints)
   char *R2 = R + 30720 + 2 * 7680 + 1280 + 256;                             // free for keys / BCI (~17.8 KB) -- see below
   for (int l = 0; l < CC_NLEV; l++)
-    for (int k = tid; k < n_lev[l]; k += nt) T[l * CC_NC + k] = scr->comp[l][k];
+    for (int k = tid; k < n_lev[l]; k += nt) T[l * NC + k] = scr->comp[l][k];
   __syncthreads();
   // insertion rank, bottom-up
   for (int l = 0; l < CC_NLEV; l++) {
     const int n = n_lev[l];
     for (int k = tid; k < n; k += nt) {
-      const cc_comp_t cp = T[l * CC_NC + k];
+      const cc_comp_t cp = T[l * NC + k];
       int py0 = 0, px0 = 0, prank = 0;
       if (l > 0) {
         unsigned p = cp.parent;
         if (p < (unsigned)n_lev[l - 1]) {
-          const cc_comp_t pp = T[(l - 1) * CC_NC + p];
+          const cc_comp_t pp = T[(l - 1) * NC + p];
           py0 = pp.r0;
           px0 = pp.c0;
           prank = pp.rank;
@@ -982,20 +1016,20 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       int cm = cp.cA;
       if (ra == rmin && cp.cB < cm) cm = cp.cB;
       const int bcol = (cm - px0) >> 1;
-      skey[l * CC_NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
+      skey[l * NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
     }
     __syncthreads();
     for (int k0 = 0; k0 < n; k0 += nt >> 2) {  // four threads per component, every fourth key each (block-uniform trip count)
       const int k = k0 + (tid >> 2), q = tid & 3;
-      const unsigned me = k < n ? skey[l * CC_NC + k] : 0u;
+      const unsigned me = k < n ? skey[l * NC + k] : 0u;
       int rk = 0;
-      for (int j = q; j < n; j += 4) rk += (skey[l * CC_NC + j] < me) ? 1 : 0;
+      for (int j = q; j < n; j += 4) rk += (skey[l * NC + j] < me) ? 1 : 0;
       rk += __shfl_xor(rk, 1);
       rk += __shfl_xor(rk, 2);
       if (k < n && q == 0) {
-        T[l * CC_NC + k].rank = (uint16_t)rk;
+        T[l * NC + k].rank = (uint16_t)rk;
         // pre-sort sequence: element at insertion position rk is component k
-        arr[l * CC_NC + rk] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+        arr[l * NC + rk] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
       }
     }
     __syncthreads();
@@ -1004,15 +1038,15 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   // lane per level, ~40 of a KITTI-shaped scan's 440 us): parallel partitions + stable rank, cc_sort.h.  The rank keys of
   // the insertion order (skey) are dead by now: their rows hold the partitions' stopper lists, then the ranked copy.
   for (int l = wave_id; l < CC_NLEV; l += n_waves) {
-    unsigned *a = arr + l * CC_NC;
+    unsigned *a = arr + l * NC;
     const int n = CC_NLEV_AT(l);
-    unsigned short *lpos = (unsigned short *)(skey + l * CC_NC), *rasc = lpos + CC_NC;
+    unsigned short *lpos = (unsigned short *)(skey + l * NC), *rasc = lpos + NC;
     ccsort::std_sort_wave(
         a, n, [](unsigned x) { return 0xFFFFu - (x >> 16); },
         [&]() {
-          for (int k = lane; k < n; k += 64) a[T[l * CC_NC + k].rank] = ((unsigned)T[l * CC_NC + k].area << 16) | (unsigned)k;
+          for (int k = lane; k < n; k += 64) a[T[l * NC + k].rank] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
         },
-        lane, lpos, rasc, skey + l * CC_NC, (unsigned *)R2 + l * CC_SORT_STACK);
+        lane, lpos, rasc, skey + l * NC, (unsigned *)R2 + l * CC_SORT_STACK);
     int tot = 0;
     for (int i = lane; i < n; i += 64) tot += (int)(a[i] >> 16);
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
@@ -1028,11 +1062,11 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     unsigned *dst = (unsigned *)&desc->cont[l][0];
     for (int w = tid; w < n_words; w += nt) {
       const int seq = w / 19, off = w - seq * 19;
-      const int k = (int)(arr[l * CC_NC + seq] & 0xFFFFu);
+      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
       dst[w] = src[k * 19 + off];
     }
     for (int seq = tid; seq < CC_NDIST && seq < n; seq += nt) {
-      const int k = (int)(arr[l * CC_NC + seq] & 0xFFFFu);
+      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
       const cc_contour_t *cv = &scr->cont[l][k];
       cc_anchor_lds a;
       a.pm[0] = cv->pos_mean[0];
@@ -1053,18 +1087,20 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     desc->max_bin_val = k1.max_bin_val;
     desc->min_bin_val = k1.min_bin_val;
     desc->n_pix = k1.n_pix;
-    desc->flags = flags0;
+    int fl = flags0;
+    for (int l = 0; l < CC_NLEV; l++) fl |= n_lev[l] > CC_MAXC ? CC_DESC_TRUNCATED : 0;  // exact, the CC_MAXC largest are stored
+    desc->flags = fl;
   }
   if (labels_dbg) {
     // component index -> seq (position after the size sort); skey is free now
     for (int l = 0; l < CC_NLEV; l++)
-      for (int seq = tid; seq < n_lev[l]; seq += nt) skey[l * CC_NC + (arr[l * CC_NC + seq] & 0xFFFFu)] = (unsigned)seq;
+      for (int seq = tid; seq < n_lev[l]; seq += nt) skey[l * NC + (arr[l * NC + seq] & 0xFFFFu)] = (unsigned)seq;
     __syncthreads();
     for (int l = 0; l < CC_NLEV; l++) {
       int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
       for (int c = tid; c < n_cell; c += nt) {
         int16_t v = ld[c];
-        if (v >= 0) ld[c] = (int16_t)skey[l * CC_NC + v];
+        if (v >= 0) ld[c] = (int16_t)skey[l * NC + v];
       }
     }
   }
@@ -1202,8 +1238,8 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
       CC_K2_LAP(acc_kexp);
     }
     if (phase_clk && tid == 0) {
-      phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 14] = acc_klist;
-      phase_clk[(size_t)blockIdx.x * CC_K2_NCLK + 15] = acc_kexp;
+      phase_clk[(size_t)scan * CC_K2_NCLK + 14] = acc_klist;
+      phase_clk[(size_t)scan * CC_K2_NCLK + 15] = acc_kexp;
     }
   }
   for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {
@@ -1349,4 +1385,44 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
     dst[2] = __float_as_uint(th);
   }
   CC_K2_STAMP(8);
+}
+#undef CC_K2_STAMP
+
+// 4 waves per SIMD = two 512-thread workgroups (scans) per CU: at most 128 VGPRs
+__global__ void __launch_bounds__(CC_K2_BLOCK, 4)
+cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+              const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
+              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
+              cc_k2_big_queue *__restrict__ queue) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  cc_k2_body<CC_NC, false>(cfg, bev_in, pix_in, k1_out, scratch_all + blockIdx.x, nullptr, queue, (int)blockIdx.x, desc_out, labels_dbg, phase_clk,
+                           smem);
+}
+
+// The slow path: a few workgroups take the scans the fast launch has queued, one after the other, each with its own block
+// of global scratch.  Launched behind every fast launch (the host cannot know whether anything was queued without waiting
+// for it); with an empty queue it ends at once.
+__global__ void __launch_bounds__(CC_K2_BLOCK, 2)
+cc_k_contours_big(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+                  const cc_k1_scan_out *__restrict__ k1_out, cc_k2_big_slot *__restrict__ slots, cc_k2_big_queue *__restrict__ queue,
+                  cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  __shared__ int s_next;
+  for (;;) {
+    __syncthreads();  // the previous scan's LDS is no longer read
+    if (threadIdx.x == 0) s_next = atomicAdd(&queue->next, 1);
+    __syncthreads();
+    const int k = s_next;
+    if (k >= queue->n_flagged) {
+      // the last workgroup to leave resets the queue for the next call (no memset launch per ingest call)
+      if (threadIdx.x == 0 && atomicAdd(&queue->exited, 1) == (int)gridDim.x - 1) {
+        queue->n_flagged = 0;
+        queue->next = 0;
+        queue->exited = 0;
+      }
+      return;
+    }
+    cc_k2_body<CC_NC_BIG, true>(cfg, bev_in, pix_in, k1_out, &slots[blockIdx.x].scr, &slots[blockIdx.x].tab, nullptr, queue->scan[k], desc_out,
+                                labels_dbg, nullptr, smem);
+  }
 }

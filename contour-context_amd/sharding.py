@@ -49,3 +49,18 @@ def gather_records(rec_local, n, world, dist, out=None):
     dist.all_gather_into_tensor(out, rec_local.contiguous())
     order = torch.from_numpy(scan_order(n, world)).to(out.device)
     return out.index_select(0, order), int(out.numel())
+
+
+def gather_records_c(cc, comm, rec_local, n, world, stream=None):
+    """gather_records with the collective owned by the C library (cc_comm_allgather_packed = ncclAllGather over RCCL, called
+    through ctypes; `comm` = a cc_comm handle, e.g. from cc.comm_from_env()): what a C++ host does
+    (hostcpp/examples/batch_replay_mgpu.cpp).  The collective runs at world == 1 as well (RCCL with a world of one)."""
+    import torch
+    s = shard_len(n, world)
+    assert rec_local.shape[0] == s and rec_local.dtype == torch.uint8 and rec_local.is_cuda
+    rec_local = rec_local.contiguous()
+    out = torch.empty((world * s, rec_local.shape[1]), dtype=torch.uint8, device=rec_local.device)
+    st = torch.cuda.current_stream(rec_local.device).cuda_stream if stream is None else stream
+    cc.comm_allgather(comm, rec_local.data_ptr(), out.data_ptr(), int(rec_local.numel()), st)
+    order = torch.from_numpy(scan_order(n, world)).to(out.device)
+    return out.index_select(0, order), int(out.numel())

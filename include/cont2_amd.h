@@ -140,15 +140,18 @@ typedef struct {
  * (contour_mng.h:426-436): sorted contour tables, per-level totals, 36 keys, 36 BCIs.
  * cont_perc_[l][j] is not stored: it is cell_cnt * 1.0f / layer_cell_cnt[l]
  * (contour_mng.h:607) and is recomputed bit-identically where needed. */
-/* Descriptor flags.  The reference has no capacities; this build stores at most CC_MAXC contours per level (only the
- * first piv_firsts_/dist_firsts_ and the largest ~95 % of the area are ever read downstream).
- *   CC_DESC_TRUNCATED          : a level has more than CC_MAXC contours, the CC_MAXC largest are stored (exact otherwise;
- *                                set by the CPU restatement only -- the device reports the next bit instead)
- *   CC_DESC_INEXACT_COMPONENTS : the device met more than CC_MAXC components (>= min_cont_cell_cnt_ cells) on a level:
- *                                the descriptor is NOT exact and must not be used
- *   CC_DESC_INEXACT_KEYS       : a retrieval-key RoI held more cells than the kernel's list: the keys are NOT exact
- * cc_ingest_host returns CC_ECAPACITY for the last two; callers of cc_ingest_batch (device output) check `flags`
- * themselves.  KITTI/MulRan-like scans have tens to ~100 contours per level. */
+/* Descriptor flags.  The reference has no capacities; this build STORES at most CC_MAXC contours per level (only the
+ * first piv_firsts_/dist_firsts_ and the largest ~95 % of the area are ever read downstream) and handles any number:
+ * a scan with more than CC_MAXC components on a level is redone by an exact slow path (cc_k_contours_big: up to 3 840
+ * per level, more than a 150 x 150 image can hold) behind the same call.
+ *   CC_DESC_TRUNCATED          : a level has more than CC_MAXC contours, the CC_MAXC largest are stored in std::sort's
+ *                                order; everything in the descriptor is exact (the oracle sets the same bit)
+ *   CC_DESC_INEXACT_COMPONENTS : not produced any more (rounds 1-4: more than CC_MAXC components on a level); it stands
+ *                                in a descriptor only between the fast launch and the slow one of the same call
+ *   CC_DESC_INEXACT_KEYS       : a retrieval-key RoI held more cells than the kernel's list (roi_radius_ > 10 on a
+ *                                densely built image): the keys are NOT exact
+ * cc_ingest_host returns CC_ECAPACITY for CC_DESC_INEXACT_*; callers of cc_ingest_batch (device output) check `flags`
+ * themselves.  KITTI/MulRan-like scans have tens to ~150 contours per level. */
 #define CC_DESC_TRUNCATED 1
 #define CC_DESC_INEXACT_COMPONENTS 2
 #define CC_DESC_INEXACT_KEYS 4
@@ -458,6 +461,29 @@ int cc_db_set_lanes(cc_db *db, int n);
 /* Host-side introspection of the K0 bookkeeping for parity tests:
  * tree sizes per (layer, bucket) and bucket ranges at the current epoch. */
 int cc_db_bucket_state(const cc_db *db, int32_t *tree_sizes /*[3][6]*/, float *ranges /*[3][7]*/);
+
+/* ---- the multi-GPU exchange, owned by the library ----
+ * One process per GPU.  The path has ONE collective: the all-gather of the compact per-scan records (cc_pack_scans ->
+ * cc_db_add_packed on every rank; 59 KB per scan) over RCCL / xGMI -- ncclAllGather, no all-reduce anywhere.  The reference
+ * has no counterpart (it is a single-process CPU library); these calls are what a C++ multi-GPU driver binds
+ * (hostcpp/examples/batch_replay_mgpu.cpp) and what bench.py --comm-owner c reaches through ctypes.  RCCL is loaded with
+ * dlopen at the first call: a single-GPU process never touches it.
+ *   cc_comm_unique_id        : rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others by any means
+ *   cc_comm_create           : ncclCommInitRank on `device` (collective over the world)
+ *   cc_comm_create_from_env  : the two above for a launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT
+ *                              (torch.distributed.run, batch_replay_mgpu's forker) on ONE node: the id travels through a
+ *                              file under /dev/shm named after MASTER_PORT
+ *   cc_comm_allgather_packed : d_send = this rank's bytes_per_rank bytes, d_recv = world x bytes_per_rank, rank-major;
+ *                              queued on `stream` (hipStream_t)
+ * UNMEASURED on hardware with more than one rank: the build boxes have one GPU (world = 1 runs there: tests/test_gpu_comm.py). */
+typedef struct cc_comm cc_comm;
+int cc_comm_unique_id(void *id128);
+int cc_comm_create(int device, int rank, int world, const void *id128, cc_comm **out);
+int cc_comm_create_from_env(cc_comm **out, int *rank_out, int *world_out);
+int cc_comm_rank(const cc_comm *comm);
+int cc_comm_world(const cc_comm *comm);
+int cc_comm_allgather_packed(cc_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int cc_comm_destroy(cc_comm *comm);
 
 /* ------------------------------------------------------------ pose helpers (host) ------- */
 /* ConstellCorrelation::getEstSensTF (correlation.h:287-296): BEV-frame T_delta -> sensor

@@ -21,7 +21,7 @@ def main():
     seed0, n_it = int(sys.argv[1]), int(sys.argv[2])
     cc = cc_amd.load()
     L = oracle.L
-    n_bad = n_flag = n_scan = 0
+    n_bad = n_flag = n_scan = n_big = 0
     for it in range(n_it):
         rng = np.random.default_rng(seed0 + it)
         # a ContourManagerConfig per batch: the shipped one, the MulRan level set, other grids and resolutions (the
@@ -55,20 +55,22 @@ def main():
         for k, (kind, s) in enumerate(scans):
             od = oracle.Scan(s, cfg=mcfg).desc()[0]
             n_scan += 1
-            if int(od["n_cont"].max()) > L.MAXC or desc[k]["flags"]:
+            if desc[k]["flags"] & 6:   # CC_DESC_INEXACT_*: since round 5 only an over-full key RoI (roi_radius_ > 10) can do that
                 n_flag += 1
-                if int(od["n_cont"].max()) > L.MAXC and not (desc[k]["flags"] & 2):
-                    print("seed %d scan %d (%s): capacity case NOT flagged" % (seed0 + it, k, kind))
+                if desc[k]["flags"] & 2:
+                    print("seed %d scan %d (%s): CC_DESC_INEXACT_COMPONENTS (n_cont max %d): the slow path must have made it exact"
+                          % (seed0 + it, k, kind, int(od["n_cont"].max())))
                     n_bad += 1
                 continue
+            n_big += int(od["n_cont"].max()) > L.MAXC   # went through cc_k_contours_big; compared like every other scan
             bad = compare_desc(od, desc[k], float_exact=False)
             if bad:
                 print("seed %d scan %d (%s, %d points): %s" % (seed0 + it, k, kind, len(s), bad[:3]))
                 n_bad += 1
         ctx.close()
         if it % 10 == 9:
-            print("... %d batches, %d scans, %d flagged, %d bad" % (it + 1, n_scan, n_flag, n_bad), flush=True)
-    print("done: %d bad of %d scans (%d capacity cases)" % (n_bad, n_scan, n_flag))
+            print("... %d batches, %d scans, %d through the slow path, %d flagged, %d bad" % (it + 1, n_scan, n_big, n_flag, n_bad), flush=True)
+    print("done: %d bad of %d scans (%d with more than CC_MAXC components on a level, compared; %d flagged inexact)" % (n_bad, n_scan, n_big, n_flag))
     return 1 if n_bad else 0
 
 

@@ -80,21 +80,20 @@ def test_mulran_level_set(oracle):
     assert (d["n_cont"][:, 5] > 0).all() and (d["flags"] == 0).all() and d["n_cont"].max() > 200
 
 
-def test_component_capacity_is_reported(oracle):
-    """More than CC_MAXC components on a level: the device marks the descriptor as not exact and cc_ingest_host refuses
-    it (the reference has no such capacity; real scans stay far below it)."""
+def test_component_capacity_is_gone(oracle):
+    """More than CC_MAXC components on a level (round 1-4: CC_DESC_INEXACT_COMPONENTS, cc_ingest_host refused the scan): the
+    slow path makes the descriptor exact, the host-buffer entry point accepts it."""
     L = oracle.L
     s = terrain_scan(13, n=7000, scale=4.0)
-    assert oracle.Scan(s).desc()[0]["n_cont"].max() > L.MAXC
+    od = oracle.Scan(s).desc()[0]
+    assert od["n_cont"].max() > L.MAXC and od["flags"] == 1
     api = emu_api.EmuApi(L)
     ctx = api.create(max_batch=1)
     offs = np.array([0, len(s)], np.int64)
-    try:
-        api.ingest_host(ctx, s, offs)
-    except RuntimeError as e:
-        assert "(-4)" in str(e) and "not exact" in str(e)
-    else:
-        raise AssertionError("expected CC_ECAPACITY")
+    d = api.ingest_host(ctx, s, offs)
+    assert not compare_desc(od, d[0], float_exact=True)
+    assert d["flags"][0] == 1   # CC_DESC_TRUNCATED: the table holds the CC_MAXC largest contours of such a level
+    _check(oracle, [s])         # labels and images, too
 
 
 def test_min_cont_cell_cnt_above_three(oracle):
@@ -159,3 +158,40 @@ def test_fewer_anchors_and_neighbours_than_the_record_holds(oracle):
     d = _check(oracle, [terrain_scan(4, n=20000, scale=1.2)], cfg=cfg)
     assert (d["bcis"]["n_pts"][0][:, :4] > 0).any() and (d["bcis"]["n_pts"][0][:, 4:] == 0).all()
     assert (d["bcis"]["piv_seq"][0][:, 4:] == 0).all() and (d["bcis"]["level"][0][:, 4:] == 0).all()
+
+
+def _blob_scene(seed, n_blobs=520, pitch=6):
+    """Hundreds of separate little objects (3-14 cells, random shapes and heights, a few points per cell): more than CC_MAXC =
+    320 components on several levels, sizes full of ties -- what the slow path of K2 (cc_k_contours_big) is for."""
+    rng = np.random.default_rng(seed)
+    per_row = 150 // pitch - 1
+    pts = []
+    for b in range(n_blobs):
+        r0, c0 = 3 + pitch * (b // per_row), 3 + pitch * (b % per_row)
+        if r0 + 4 >= 150:
+            break
+        cells = {(0, 0)}
+        while len(cells) < rng.integers(3, 15):
+            r, c = list(cells)[rng.integers(len(cells))]
+            dr, dc = rng.integers(-1, 2, 2)
+            if 0 <= r + dr < pitch - 2 and 0 <= c + dc < pitch - 2:
+                cells.add((int(r + dr), int(c + dc)))
+        top = rng.uniform(-0.3, 2.4)   # + lidar_height 2.0: between the lowest and above the highest level
+        for (r, c) in cells:
+            x, y = (r0 + r) - 75 + 0.5, (c0 + c) - 75 + 0.5
+            if x * x + y * y < 16:
+                continue
+            for _ in range(2):
+                pts.append((x + rng.uniform(-0.4, 0.4), y + rng.uniform(-0.4, 0.4), top - rng.uniform(0, 0.6) * (r + c > 1), 0.0))
+    return np.asarray(pts, np.float32)
+
+
+def test_more_components_than_cc_maxc_take_the_exact_slow_path(oracle):
+    """The reference has no limit on cont_views_[l].size() (contour_mng.h:92-110).  A level with more than CC_MAXC = 320
+    components is redone by cc_k_contours_big: labels, the 320 largest contours in std::sort's order, keys and BCIs equal
+    the oracle's, flags == CC_DESC_TRUNCATED (a table that does not hold every contour), never CC_DESC_INEXACT_*."""
+    scenes = [_blob_scene(1), terrain_scan(2, n=20000, scale=1.2), _blob_scene(2, n_blobs=560, pitch=5)]
+    d = _check(oracle, scenes)
+    assert d["n_cont"][0].max() > 320 and d["n_cont"][2].max() > 320, d["n_cont"]
+    assert d["flags"][0] == 1 and d["flags"][1] == 0 and d["flags"][2] == 1, d["flags"]
+    assert (d["n_stored"][0] <= 320).all()
