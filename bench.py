@@ -1024,6 +1024,8 @@ def dropin_loop(batch0, P, n):
         for line in r.stderr.splitlines():
             if line.startswith("[evaluator helper"):     # CC_EVAL_TIMERS=1: what the prefetch thread spent per scan
                 out["helper_thread"] = line
+            if line.startswith("[ContourDB read-ahead") or line.startswith("[cc_db appends"):  # CC_EVAL_TIMERS=1 / CC_ADD_TIMERS=1
+                out.setdefault("db_read_ahead", []).append(line)
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <deque>
+#include <memory>
 
 #include "../tools/bm_util.h"
 #include "contour_mng.h"
@@ -45,6 +46,123 @@ class ContourDB {
   mutable cc_db *db_ = nullptr;  // created lazily by the first call that sees a ContourManager (queryRangedKNN is const)
   int capacity_;
   std::vector<std::shared_ptr<const ContourManager>> all_bevs_;
+  std::vector<double> all_ts_;   // addScan's time stamp and pushAndBalance's seed of every added scan: what a rebuild needs
+  std::vector<int> all_seed_;
+
+  // ---- read-ahead of the database (mirror-only; the reference's loop is strictly sequential) ----
+  // The driver's loop is  query(i) -> add(i) -> query(i+1) -> ...  and every call waits for a chain of ~20 small kernels.
+  // When the scan source has published the scans that come next (cc_host::lookahead(): the evaluator mirror's read-ahead)
+  // the database works ahead on the device: it appends scan k and queues scan k+1's query at epoch k+1 -- exactly the
+  // state the sequential loop queries it in -- for up to SPEC_DEPTH scans, several chains in flight.  The driver's later
+  // calls are then VALIDATED against that work instead of launching it: queryRangedKNN(k) hands out the queued answer if it
+  // is the same scan with the same thresholds, addScan / pushAndBalance(k) is a no-op if it is the same scan, time stamp
+  // and seed.  Any other call sequence stays correct: a different query is answered at the official epoch (an epoch hides
+  // the scans appended after it), a different add REBUILDS the device database from the scans the driver really added.
+  struct Spec {
+    cc_scan *scan = nullptr;
+    double ts = 0;
+    int seed = 0;
+    cc_score_t lb, ub;
+    std::unique_ptr<cc_query_result_t> res;  // queued at epoch = position of the scan; filled by cc_db_query_wait
+    bool collected = false;
+  };
+  mutable std::deque<Spec> spec_;   // scans appended ahead of the driver, oldest first (spec_[j] sits at DB index n_official + j)
+  mutable bool have_thres_ = false;
+  mutable cc_score_t last_lb_, last_ub_;
+  mutable long n_spec_hit_ = 0, n_spec_miss_ = 0, n_rebuild_ = 0;
+  mutable double t_ra_[3] = {0, 0, 0};  // host seconds in the three calls of a read-ahead step (CC_EVAL_TIMERS prints them)
+  mutable long n_ra_ = 0;
+  mutable bool need_rebuild_ = false;  // the device database holds scans the driver has not added (and will not): rebuilt at the next call
+  int hub_token_ = -1;
+  static int specDepth() {
+    static const int d = [] {
+      // Scans worked ahead (CC_DB_READ_AHEAD=n).  OFF by default: measured on MI355X the loop does not get faster -- the answers
+      // are there when the driver asks (queryRangedKNN 0.22 -> 0.03 ms), but every step now needs the NEWEST published scan,
+      // whose single-scan ingest (~0.25 ms of K1 + K2 on the one ingest stream) becomes the wait: 2 500 -> 1 950 scans/s
+      // (profiles/r5/dropin_read_ahead.txt).  It pays once single-scan ingests overlap (several ingest streams + scratch slots).
+      const char *e = getenv("CC_DB_READ_AHEAD");
+      return e ? std::max(0, atoi(e)) : 0;
+    }();
+    return d;
+  }
+  static bool same(const cc_score_t &a, const cc_score_t &b) { return memcmp(&a, &b, sizeof(cc_score_t)) == 0; }
+  static void die_cc() {
+    fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
+    abort();
+  }
+  void collectSpec() const {  // every queued answer is on the host afterwards
+    bool pending = false;
+    for (auto &sp : spec_) pending = pending || !sp.collected;
+    if (!pending) return;
+    if (cc_db_query_wait(db_) != CC_OK) die_cc();
+    for (auto &sp : spec_) sp.collected = true;
+  }
+  // the device database back to the scans the driver has added (all_bevs_): after the driver left the predicted sequence
+  void rebuild() const {
+    n_rebuild_++;
+    need_rebuild_ = false;
+    if (db_) {
+      cc_db_query_wait(db_);
+      cc_db_destroy(db_);
+      db_ = nullptr;
+    }
+    spec_.clear();
+    if (all_bevs_.empty()) return;
+    ensure(*all_bevs_[0]);
+    for (size_t i = 0; i < all_bevs_.size(); i++) {
+      cc_scan *h = all_bevs_[i]->scanHandle();
+      const int rc = h && cc_scan_on_device(h) ? cc_db_add_scan(db_, h, all_ts_[i], all_seed_[i]) : cc_db_add_scan_host(db_, &all_bevs_[i]->desc(), all_ts_[i], all_seed_[i]);
+      if (rc != CC_OK) die_cc();
+    }
+  }
+  void dropReadAhead() {  // the scan source is about to release the scans spec_ refers to: nothing of them may stay in flight
+    if (spec_.empty()) return;
+    if (db_ && cc_db_query_wait(db_) != CC_OK) die_cc();
+    spec_.clear();
+    need_rebuild_ = true;  // their records are still in the device database: rebuilt when (if) the database is used again
+  }
+  // append + queue for the scans the source has published, behind what is there already
+  void readAhead() const {
+    if (specDepth() <= 0 || !have_thres_ || !db_) return;
+    const auto up = cc_host::lookahead().snapshot();
+    // the published scans that are not in spec_ yet must continue it: spec_ = a prefix of (scan in the driver's hands?, upcoming...)
+    size_t pos = 0;
+    if (!spec_.empty()) {  // what follows spec_.back() among the published scans is new
+      bool found = false;
+      for (size_t j = 0; j < up.size(); j++)
+        if (up[j].scan == spec_.back().scan) {
+          pos = j + 1;
+          found = true;
+        }
+      if (!found) return;
+    }
+    int seed_next = (all_seed_.empty() ? 0 : all_seed_.back() + 1) + (int)spec_.size();  // the driver counts its scans (batch_bin_test.cpp:237)
+    for (; pos < up.size() && (int)spec_.size() < specDepth(); pos++) {
+      const int epoch = cc_db_size(db_);
+      if (epoch + 1 >= capacity_) return;
+      Spec sp;
+      sp.scan = up[pos].scan;
+      sp.ts = up[pos].ts;
+      sp.seed = seed_next++;
+      sp.lb = last_lb_;
+      sp.ub = last_ub_;
+      sp.res.reset(new cc_query_result_t());
+      if (!cc_scan_on_device(sp.scan)) return;
+      // the append's first half (compact records, keys on their way to the host) goes first: by the time the ~20 launches of
+      // the query chain are queued, the commit below finds the keys on the host instead of waiting behind that chain
+      TicToc t0;
+      if (cc_db_add_scan_prepare(db_, sp.scan) != CC_OK) die_cc();
+      t_ra_[0] += t0.toc();
+      TicToc t1;
+      if (cc_db_query_scan_submit(db_, sp.scan, epoch, &sp.lb, &sp.ub, sp.res.get()) != CC_OK) die_cc();
+      t_ra_[1] += t1.toc();
+      TicToc t2;
+      if (cc_db_add_scan(db_, sp.scan, sp.ts, sp.seed) != CC_OK) die_cc();
+      t_ra_[2] += t2.toc();
+      n_ra_++;
+      spec_.push_back(std::move(sp));
+    }
+  }
 
   static cc_score_t to_c(const CandidateScoreEnsemble &e) {
     cc_score_t s;
@@ -81,13 +199,27 @@ class ContourDB {
     // per-stage DEVICE times of every query under the reference's stage names (six events per query: they cost a few
     // per cent, so only on request); the wall time of the call is recorded either way
     if (getenv("CC_STP_DEVICE_TIMERS")) cc_db_profile_enable(db_, 1);
+    if (specDepth() > 0) cc_db_set_lanes(db_, 4);  // one chain per queued query
   }
 
  public:
   explicit ContourDB(const ContourDBConfig &config, int capacity_scans = 65536) : cfg_(config), capacity_(capacity_scans) {
     CC_CHECK(!cfg_.q_levels_.empty());
+    if (specDepth() > 0) hub_token_ = cc_host::lookahead().subscribe([this] { dropReadAhead(); });
   }
-  ~ContourDB() { cc_db_destroy(db_); }
+  ContourDB(const ContourDB &) = delete;
+  ContourDB &operator=(const ContourDB &) = delete;
+  ~ContourDB() {
+    if (hub_token_ >= 0) cc_host::lookahead().unsubscribe(hub_token_);
+    if (getenv("CC_EVAL_TIMERS"))
+    {
+      if (n_ra_ > 0)
+        fprintf(stderr, "[ContourDB read-ahead, mean host us per step over %ld steps] prepare %.1f  query submit %.1f  append commit %.1f\n", n_ra_,
+                1e6 * t_ra_[0] / n_ra_, 1e6 * t_ra_[1] / n_ra_, 1e6 * t_ra_[2] / n_ra_);
+      fprintf(stderr, "[ContourDB read-ahead] answers handed out from queued queries %ld, launched on the spot %ld, rebuilds %ld\n", n_spec_hit_, n_spec_miss_, n_rebuild_);
+    }
+    cc_db_destroy(db_);
+  }
 
   // contour_db.h:698-703
   void queryRangedKNN(const std::shared_ptr<const ContourManager> &q_ptr, const CandidateScoreEnsemble &thres_lb,
@@ -100,13 +232,34 @@ class ContourDB {
     const cc_score_t lb = to_c(thres_lb), ub = to_c(thres_ub);
     cc_query_result_t r;
     TicToc wall;
-    // the scan is normally still on the device (made by makeBEV just before); one that was offloaded goes by its host copy
-    const int rc = q_ptr->scanHandle() && cc_scan_on_device(q_ptr->scanHandle())
-                       ? cc_db_query_scan(db_, q_ptr->scanHandle(), &lb, &ub, &r)
-                       : cc_db_query_host(db_, &q_ptr->desc(), &lb, &ub, &r);
-    if (rc != CC_OK) {  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.; also CC_ECAPACITY (the reference has no capacities)
-      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
-      abort();
+    if (need_rebuild_) rebuild();
+    last_lb_ = lb;
+    last_ub_ = ub;
+    have_thres_ = true;
+    cc_scan *qh = q_ptr->scanHandle();
+    if (!spec_.empty() && qh && spec_.front().scan == qh && same(spec_.front().lb, lb) && same(spec_.front().ub, ub)) {
+      // the answer was queued when the scan was published (at the epoch the database is officially in now); only ITS chain is
+      // waited for, the queries queued behind it stay in flight
+      if (!spec_.front().collected) {
+        if (cc_db_query_collect(db_, spec_.front().res.get(), 1) != CC_OK) die_cc();
+        spec_.front().collected = true;
+      }
+      r = *spec_.front().res;
+      n_spec_hit_++;
+    } else {
+      n_spec_miss_++;
+      const int32_t epoch = (int32_t)all_bevs_.size();  // the scans appended ahead of the driver are hidden by the epoch
+      int rc;
+      if (qh && cc_scan_on_device(qh)) {
+        rc = cc_db_query_scan_submit(db_, qh, epoch, &lb, &ub, &r);
+        const int r2 = cc_db_query_wait(db_);
+        for (auto &sp : spec_) sp.collected = true;
+        if (rc == CC_OK) rc = r2;
+      } else {  // a scan that was offloaded goes by its host copy
+        collectSpec();
+        rc = cc_db_query_batch_host(db_, &q_ptr->desc(), 1, &epoch, &lb, &ub, &r);
+      }
+      if (rc != CC_OK) die_cc();  // CHECK(sim_lb.strictSmaller(sim_ub)) etc.; also CC_ECAPACITY (the reference has no capacities)
     }
     stp.addSample("queryRangedKNN (wall)", wall.toc());
     {  // the reference's stage names (contour_db.h:755,772,787), with the device times of this query's kernels:
@@ -138,12 +291,21 @@ class ContourDB {
     // the C-ABI couples addScan + pushAndBalance (they are always called back to back, batch_bin_test.cpp:234-237)
     CC_CHECK(pending_);
     (void)curr_timestamp;
+    if (need_rebuild_) rebuild();
     cc_scan *h = pending_->scanHandle();
-    const int rc = h && cc_scan_on_device(h) ? cc_db_add_scan(db_, h, pending_ts_, seed) : cc_db_add_scan_host(db_, &pending_->desc(), pending_ts_, seed);
-    if (rc != CC_OK) {
-      fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
-      abort();
+    if (!spec_.empty() && h && spec_.front().scan == h && spec_.front().ts == pending_ts_ && spec_.front().seed == seed) {
+      // appended ahead of time, with exactly these arguments.  (Its own query has been handed out, or is no longer wanted:
+      // its answer buffer must outlive the chain that writes it.)
+      if (!spec_.front().collected && cc_db_query_collect(db_, spec_.front().res.get(), 1) != CC_OK) die_cc();
+      spec_.pop_front();
+    } else {
+      if (!spec_.empty()) rebuild();  // the driver left the predicted sequence: back to the scans it really added
+      ensure(*pending_);
+      const int rc = h && cc_scan_on_device(h) ? cc_db_add_scan(db_, h, pending_ts_, seed) : cc_db_add_scan_host(db_, &pending_->desc(), pending_ts_, seed);
+      if (rc != CC_OK) die_cc();
     }
+    all_ts_.push_back(pending_ts_);
+    all_seed_.push_back(seed);
     // The DB keeps its own compact records of the scan.  The full descriptor (169 KB) stays in its device slot for now: its
     // host copy is fetched when a getter first asks for it, and moving every scan to the host right here cost the loop a
     // 169 KB copy + a stream synchronisation per scan.  Only the most recent residentScans() descriptors stay (1.4 GB at
@@ -159,6 +321,7 @@ class ContourDB {
     }
     all_bevs_.push_back(pending_);
     pending_.reset();
+    readAhead();
   }
   // how many added scans keep their full descriptor on the device (env CC_SCANS_ON_DEVICE; 0: none, as before round 4)
   static size_t residentScans() {

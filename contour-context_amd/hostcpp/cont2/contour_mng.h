@@ -7,6 +7,8 @@
 #include <array>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <memory>
@@ -164,6 +166,47 @@ inline cc_ctx *context(const cc_manager_cfg_t &m) {
   }
   pool[key] = c;
   return c;
+}
+// What a driver's scan source knows about the scans AFTER the one the driver holds: their device handles (ingested ahead of
+// time) and time stamps, in the order the driver will ask for them.  The evaluator mirror publishes its read-ahead here;
+// ContourDB reads it to append those scans and queue their queries early (contour_db.h: "read-ahead of the database").
+// A source that changes its mind (a jump in the scan list) calls invalidate(): every database that has worked ahead drops
+// that work first (the scans it refers to are about to be released).
+struct ScanLookahead {
+  struct Entry {
+    cc_scan *scan;
+    double ts;
+  };
+  std::mutex mu;
+  std::deque<Entry> upcoming;                        // under mu
+  std::map<int, std::function<void()>> on_invalidate;  // registered by the databases (driver thread only)
+  int next_token = 0;
+  int subscribe(std::function<void()> f) {
+    on_invalidate[next_token] = std::move(f);
+    return next_token++;
+  }
+  void unsubscribe(int token) { on_invalidate.erase(token); }
+  void push(cc_scan *scan, double ts) {
+    std::lock_guard<std::mutex> lk(mu);
+    upcoming.push_back({scan, ts});
+  }
+  void popFront(cc_scan *scan) {  // the driver has taken the scan
+    std::lock_guard<std::mutex> lk(mu);
+    if (!upcoming.empty() && upcoming.front().scan == scan) upcoming.pop_front();
+  }
+  std::vector<Entry> snapshot() {
+    std::lock_guard<std::mutex> lk(mu);
+    return std::vector<Entry>(upcoming.begin(), upcoming.end());
+  }
+  void invalidate() {  // driver thread
+    for (auto &f : on_invalidate) f.second();
+    std::lock_guard<std::mutex> lk(mu);
+    upcoming.clear();
+  }
+};
+inline ScanLookahead &lookahead() {
+  static ScanLookahead h;
+  return h;
 }
 }  // namespace cc_host
 

@@ -80,7 +80,7 @@ class ContLCDEvaluator {
   // One helper thread for the evaluator's lifetime runs up to AHEAD scans ahead of the scan the driver holds; what it has
   // finished waits in `ready`, in address order.
   struct Prefetch {
-    static constexpr int AHEAD = 2;  // = the context's staging buffers (cc_stage_points_slot: scan `addr` goes through slot addr & 1)
+    static constexpr int AHEAD = 4;  // scans in flight ahead of the driver (staging buffers: scan `addr` goes through slot addr & 1, reused when its copy has passed)
     enum class Status { OK, MISSING_FILE, TOO_FEW_POINTS, STAGING_FAILED, INGEST_FAILED };
     struct Item {
       int addr = -1;
@@ -202,6 +202,9 @@ class ContLCDEvaluator {
     return true;
   }
 
+  // Mirror-only (tests): the next loadNewScan() loads address `addr` -- a driver that does not walk its list in order
+  void jumpTo(int addr) { p_lidar_curr = addr - 1; }
+
   const LaserScanInfo &getCurrScanInfo() const {
     CC_CHECK(p_lidar_curr >= 0 && p_lidar_curr < (int)laser_info_.size());
     return laser_info_[p_lidar_curr];
@@ -236,6 +239,7 @@ class ContLCDEvaluator {
         pf_.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
         Prefetch::Item it = std::move(pf_.ready.front());
         pf_.ready.pop_front();
+        if (it.scan) cc_host::lookahead().popFront(it.scan);  // the driver's from here on
         pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
         lk.unlock();
         pf_.cv.notify_all();
@@ -261,6 +265,7 @@ class ContLCDEvaluator {
       } else {  // first scan, a jump, another configuration: the helper is parked and what it fetched is dropped
         pf_.next = -1;
         pf_.cv.wait(lk, [this] { return !pf_.busy; });
+        cc_host::lookahead().invalidate();  // databases that worked ahead on these scans drop that work before the scans go
         for (auto &it : pf_.ready)
           if (it.scan) cc_scan_release(it.scan);
         pf_.ready.clear();
@@ -307,6 +312,7 @@ class ContLCDEvaluator {
       pf_.cv.notify_all();
       pf_.th.join();
     }
+    cc_host::lookahead().invalidate();
     for (auto &it : pf_.ready)
       if (it.scan) cc_scan_release(it.scan);
     if (getenv("CC_EVAL_TIMERS") && pf_.n_done > 0)
@@ -360,6 +366,7 @@ class ContLCDEvaluator {
       pf.n_done++;
       pf.busy = false;
       if (pf.next == it.addr) {  // still wanted (the driver did not jump meanwhile)
+        if (it.scan) cc_host::lookahead().push(it.scan, laser_info_[it.addr].ts);
         pf.ready.push_back(std::move(it));
         pf.next++;
       } else if (it.scan) {

@@ -386,6 +386,18 @@ int cc_db_query_host(cc_db *db, const cc_scan_desc_t *h_qdesc, const cc_score_t 
  * cc_db_query_scan answers against the current DB state; cc_db_add_scan = addScan + pushAndBalance. */
 int cc_db_query_scan(cc_db *db, cc_scan *scan, const cc_score_t *thres_lb, const cc_score_t *thres_ub, cc_query_result_t *h_res);
 int cc_db_add_scan(cc_db *db, cc_scan *scan, double ts, int32_t seed);
+/* cc_db_query_scan without the wait, at an explicit epoch (0 .. cc_db_size): *h_res is filled by the next cc_db_query_wait.
+ * A per-scan driver that knows its next scans (the evaluator mirror does: test/batch_bin_test.cpp:131-237 walks a list) appends
+ * them and queues scan k's query at epoch k while the driver is still busy with scan i < k; the answers are the ones the
+ * strictly sequential loop gets (a query at epoch k sees the database as it was after k scans). */
+int cc_db_query_scan_submit(cc_db *db, cc_scan *scan, int32_t epoch, const cc_score_t *thres_lb, const cc_score_t *thres_ub,
+                            cc_query_result_t *h_res);
+/* cc_db_query_wait for the chunks that write into [h_res, h_res + n) only: the caller's own answer, while later submissions
+ * stay in flight. */
+int cc_db_query_collect(cc_db *db, const cc_query_result_t *h_res, int n);
+/* cc_db_add_scans_prepare (the asynchronous first half of an append) for a scan handle; cc_db_add_scan on the same scan
+ * later only commits. */
+int cc_db_add_scan_prepare(cc_db *db, cc_scan *scan);
 
 /* The two batched calls with host descriptor buffers (one H2D copy each): for drivers that keep descriptors on the host,
  * e.g. an offline replay of a whole sequence (all scans added, then scan i queried against epoch i). */

@@ -53,9 +53,15 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
     cfg = cfg.replace("/path/to/outcome-kitti08.txt", str(tmp_path / "outcome.txt"))
     cfg = cfg.replace("max_elapse_: 25.0", "max_elapse_: 10.0").replace("min_elapse_: 15.0", "min_elapse_: 6.0")
     (proj / "config" / "batch_bin_test_config.yaml").write_text(cfg)
-    env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_STP_DEVICE_TIMERS="1")  # device stage timers: on request
+    env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_STP_DEVICE_TIMERS="1", CC_EVAL_TIMERS="1", CC_DB_READ_AHEAD="3")  # device stage timers and the database's read-ahead: on request
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
+    # with CC_DB_READ_AHEAD the database mirror works ahead of this unchanged driver: most answers were queued before the driver
+    # asked, none of it had to be undone (hostcpp/cont2/contour_db.h "read-ahead of the database")
+    ra = [l for l in out.stderr.splitlines() if l.startswith("[ContourDB read-ahead]")]
+    assert ra, out.stderr[-1500:]
+    hit, miss, rebuilds = [int(v) for v in __import__("re").findall(r"(\d+)", ra[-1])][-3:]
+    assert hit + miss == n and hit >= n // 2 and rebuilds == 0, ra[-1]
     rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "outcome.txt")]
     assert len(rows) == n
     dcfg = cc.L.default_db_cfg()
@@ -96,3 +102,38 @@ def test_evaluator_read_ahead_paths_give_the_same_descriptors(cc, tmp_path):
             g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
     out = subprocess.run([exe, str(pos), str(lst)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and ("OK %d" % n) in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_database_read_ahead_survives_any_driver(cc, tmp_path, mode):
+    """tests/db_read_ahead_check.cpp: the reference's loop, repeated queries with other thresholds, scans that are never added, a
+    jump in the scan list -- with the mirror's read-ahead on (default) and off (CC_DB_READ_AHEAD=0) every answer is the same."""
+    emu_so = emu_api.build()
+    exe = str(tmp_path / "db_read_ahead_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "db_read_ahead_check.cpp"), "-I", os.path.join(PKG, "hostcpp"),
+                           "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so),
+                           "-pthread", "-o", exe])
+    n = 48
+    x, poses, ts = cc.synth.make_sequence(n, world=cc.synth.World(loop_len=40.0), beams=16, azim=450)
+    ts = ts * 4.0
+    xs = x.numpy()
+    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
+    with open(lst, "w") as f, open(pos, "w") as g:
+        for i in range(n):
+            p = tmp_path / ("%06d.bin" % i)
+            xs[i].astype(np.float32).tofile(p)
+            f.write("%.6f %d %s\n" % (ts[i], i, p))
+            g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
+    outs = []
+    for ra in ("3", "0"):
+        env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_DB_READ_AHEAD=ra, CC_EVAL_TIMERS="1")
+        r = subprocess.run([exe, str(pos), str(lst), str(mode)], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+        outs.append(([l for l in r.stdout.splitlines() if l[:1] in "qtd" and not l.startswith("===")], r.stderr))
+    assert outs[0][0] == outs[1][0] and outs[0][0][-1].startswith("done")
+    assert any(l.split()[1] != "-1" for l in outs[0][0] if l.startswith("q")), "the sequence should close loops"
+    ra = [l for l in outs[0][1].splitlines() if l.startswith("[ContourDB read-ahead]")]
+    hit, miss, rebuilds = [int(v) for v in __import__("re").findall(r"(\d+)", ra[-1])][-3:]
+    assert hit > 0, ra[-1]
+    if mode in (2, 3):
+        assert rebuilds > 0, ra[-1]   # the driver left the predicted sequence: the device database was rebuilt
