@@ -97,6 +97,7 @@ struct cc_ctx {
   std::thread::id pts_owner[NPTS];
   int64_t pts_cap = 0;  // points
   std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
+  std::vector<int> slot_block_n;  // slots per block
   float *d_loop_bev = nullptr;
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
@@ -580,7 +581,11 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
   {
     std::lock_guard<std::mutex> lk(c->slot_mu);
     if (c->slot_free.empty()) {
-      const int nblk = 64;
+      // the pool grows geometrically (64, 64, 128, 256, ... up to 1 024 slots = 169 MB per block): a hipMalloc synchronises the
+      // device, and a driver that keeps thousands of scans resident should not pay that every 64 scans of its loop
+      size_t have = 0;
+      for (size_t b = 0; b < c->slot_blocks.size(); b++) have += c->slot_block_n[b];
+      const int nblk = (int)(have < 64 ? 64 : (have > 1024 ? 1024 : have));
       cc_scan_desc_t *blk = nullptr;
       const hipError_t e_ = hipMalloc(&blk, sizeof(cc_scan_desc_t) * nblk);
       if (e_ != hipSuccess) {
@@ -588,6 +593,7 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
         return set_err(CC_EHIP, "cc_scan_ingest: descriptor slots", e_);
       }
       c->slot_blocks.push_back(blk);
+      c->slot_block_n.push_back(nblk);
       for (int i = nblk - 1; i >= 0; i--) c->slot_free.push_back(blk + i);
     }
     sc->d_desc = c->slot_free.back();
