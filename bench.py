@@ -428,12 +428,12 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "synthetic Velodyne-64 scans (%dx%d=%d pts), %s world, %d-scan DB, %d query scans/step/GPU, "
-                                   "%s (loop closures found: %d of %d on rank 0); a step = ingest + query of "
+                                   "%s (loop closures found: %d of %d on rank 0); inputs resident in HBM before the timed region; a step = ingest + query of "
                                    "the batch, the DB update (addScan/pushAndBalance) is outside the timed step"
                                    % (args.beams, args.azim, P, args.workload, n_db, B, "the drive goes on through the town: about a tenth of the query scans revisit a DB place"
                                       if args.workload == "kitti" else "queries revisit DB places", n_found, K * B),
                        "world": args.workload, "workload_stats": wl_stats, "dtype_note": DTYPE_NOTE,
-                       "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10, <= 320 contours/level (flagged otherwise)",
+                       "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10; the 320 largest contours of a level are stored, a scan with more components on a level goes through the exact slow path (cc_k_contours_big)",
                        "db_scans": n_db, "batch": B, "global_batch": B * world, "points_per_scan": P,
                        "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
             "roofline": roof,
@@ -1083,6 +1083,7 @@ def pmc_traffic(kernel, batch, db_scans, workload):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))  # round tags sort by name
     parts = {"cc_k_check": ["cc_k_check_a", "cc_k_check_b1", "cc_k_compact_cstl", "cc_k_check_b2", "cc_k_check_c"],
              "cc_k_gmm": ["cc_k_gmm_init", "cc_k_select", "cc_k_gmm_refine"]}.get(kernel, [kernel])
+    optional = {"cc_k_contours": ["cc_k_contours_big"]}.get(kernel, [])  # (the slow path's launch: in the summaries since round 5)
     d = ks = None
     for f in reversed(files):   # the newest summary taken on this configuration
         try:
@@ -1098,6 +1099,7 @@ def pmc_traffic(kernel, batch, db_scans, workload):
         return None, None
     per_step = 1 if kernel in ("cc_k_rasterize", "cc_k_contours") else ((batch + 1023) // 1024 if batch >= 1024 else 2)
     src = os.path.relpath(files[-1], ROOT) + (" (taken at %s)" % d["git_head"] if d.get("git_head") else "")
+    parts = parts + [p for p in optional if p in ks and "hbm_bytes_per_launch" in ks[p]]
     return sum(ks[p]["hbm_bytes_per_launch"] for p in parts) * per_step, src
 
 
@@ -1177,7 +1179,11 @@ def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q, all_cores=True):
            "seconds_per_scan": {"make bev": t_ing / n_q, "KNN search": tq["KNN search"] / n_q, "Constell": tq["Constell"] / n_q,
                                 "L2 opt": tq["L2 opt"] / n_q, "Update database (outside `value`, like the GPU step)": t_upd / n_q},
            "online_loop_scans_per_s": n_q / (dt + t_upd),
-           "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
+           "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
+           "ratios_this_supports": "GPU value / cpu_baseline.value is a ratio to ONE host core (the reference is single-threaded per "
+                                   "scan); GPU value / all_cores_measured.value is the ratio to N independent single-threaded copies "
+                                   "(N = the cores this container may use, not a socket: the 'single-socket' figure of north_star is "
+                                   "not measurable here)"}
     if not all_cores:
         return out
     # ---- measured all-cores figure: N independent single-threaded copies on disjoint scans
