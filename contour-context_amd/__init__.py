@@ -59,7 +59,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libcont2_amd.so is not built (run __graft_entry__.build()); there is no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(os.environ.get("CC_AMD_LIB") or LIB_PATH)  # CC_AMD_LIB: tuning aid (another build of the same library)
         _lib.cc_last_error.restype = C.c_char_p
         _lib.cc_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib.cc_destroy.argtypes = [C.c_void_p]
