@@ -52,39 +52,57 @@ struct cc_ctx {
   cc_manager_cfg_t mcfg;
   cc_dev_cfg dcfg;
   int max_batch = 0;
-  float *d_bev = nullptr;
-  float2 *d_pix = nullptr;
-  cc_k1_scan_out *d_k1 = nullptr;
-  cc_k1_part k1_part;               // scratch of the split rasterisation (calls of <= CC_K1_SPLIT_MAX_SCANS scans), allocated at first use
-  cc_k2_scratch *d_scr = nullptr;
-  // the slow path of K2 (scans with more than CC_MAXC components on a level): queue filled by the fast launch, a few
-  // workgroups with CC_NC_BIG-sized tables in global memory
+  // What ONE ingest launch chain works in.  Calls on the same set are ordered (ev_last: the next call waits, on the device,
+  // for the previous one's last kernel when it comes in on another stream); different sets may be in flight together.  The
+  // context has the set of the batched calls (`main`, max_batch scans) and, for the per-scan loop, CC_NCHAN one-scan sets
+  // (`chan[i]`, made at first use): consecutive scans of the loop are ingested on alternating channels, so the ~0.25 ms one
+  // scan's K1 + K2 take overlap with the next scan's instead of queueing behind them.
+  struct Scratch {
+    int cap = 0;  // scans
+    float *d_bev = nullptr;
+    float2 *d_pix = nullptr;
+    cc_k1_scan_out *d_k1 = nullptr;
+    cc_k1_part k1_part;  // scratch of the split rasterisation (calls of <= CC_K1_SPLIT_MAX_SCANS scans), allocated at first use
+    cc_k2_scratch *d_scr = nullptr;
+    long long *d_offsets = nullptr;
+    // the slow path of K2 (scans with more than CC_MAXC components on a level): queue filled by the fast launch, a few
+    // workgroups with CC_NC_BIG-sized tables in global memory
+    int n_bigslots = 0;
+    cc_k2_big_queue *d_bigq = nullptr;
+    cc_k2_big_slot *d_bigslots = nullptr;
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+  };
   static const int N_BIG_SLOTS = 8;
-  cc_k2_big_queue *d_bigq = nullptr;
-  cc_k2_big_slot *d_bigslots = nullptr;
-  long long *d_offsets = nullptr;
+  Scratch main;
   // pinned staging ring for the per-chunk point offsets: a slot is reused only after the copy that read it has finished
   static const int NSLOT = 4;
   long long *h_off[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t off_ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
   bool off_busy[NSLOT] = {false, false, false, false};
   int off_next = 0;
-  // the ingest scratch (d_bev, d_pix, d_k1, d_scr, d_offsets) is shared by all calls: the previous call's last kernel
-  // is waited for (on the device) when the next call comes in on a different stream
-  hipEvent_t ev_last = nullptr;
-  hipStream_t last_stream = nullptr;
-  bool has_last = false;
   long long *d_phase_clk = nullptr;  // tuning aid: per-scan phase timestamps of cc_k_contours (CC_K2_PHASES=1)
   // the per-scan loop (cc_scan_*): own stream, pinned + device point staging, a pool of device descriptor slots
   hipStream_t s_loop = nullptr;       // per-scan loop: descriptor fetches, cc_db_query_scan / cc_db_add_scan
-  hipStream_t s_ing = nullptr;        // per-scan loop: cc_scan_ingest (copy of the points, K1, K2); a scan's `ready` event is recorded here
+  // per-scan loop: cc_scan_ingest (copy of the points, K1, K2) goes to the next of CC_NCHAN channels -- own stream, device point
+  // buffer, one-scan scratch set; a scan's `ready` event is recorded on its channel's stream
+  static const int NCHAN = 2;
+  struct Channel {
+    hipStream_t s = nullptr;
+    float *d_pts = nullptr;
+    float *d_bev_copy = nullptr;  // the max-height image of a scan that asked for it (want_bev), until its copy to the host has passed
+    Scratch scr;
+  };
+  Channel chan[NCHAN];
+  int chan_next = 0;
   std::mutex slot_mu;                 // slot_free: cc_scan_ingest may run on a helper thread next to cc_scan_offload / cc_scan_release
   // per-scan loop: two pinned staging buffers (the caller may fill the second one -- e.g. read the next scan's file from
   // another thread -- while the first one's scan is in flight), one device point buffer (the stream orders its reuse)
   // Slots 0 and 1 are the caller's to name (cc_stage_points_slot), slot 2 is cc_stage_points' own -- a thread that stages
   // without naming a slot (ContourManager::makeBEV) never gets a buffer a read-ahead helper writes.
   static const int NPTS = 3;
-  float *h_pts[NPTS] = {nullptr, nullptr, nullptr}, *d_pts = nullptr;
+  float *h_pts[NPTS] = {nullptr, nullptr, nullptr};
   hipEvent_t pts_ev[NPTS] = {nullptr, nullptr, nullptr};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
   bool pts_busy[NPTS] = {false, false, false};
   // Ingest state (the staging slots, d_pts, the offsets ring, the K1/K2 scratch, ev_last) is shared by every call of the
@@ -98,7 +116,6 @@ struct cc_ctx {
   int64_t pts_cap = 0;  // points
   std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
   std::vector<int> slot_block_n;  // slots per block
-  float *d_loop_bev = nullptr;
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
   int k1_nosplit = 0;  // CC_K1_NOSPLIT=1: one workgroup per scan also for calls of a few scans (A/B aid)
@@ -122,6 +139,37 @@ static int prof_flush(cc_ctx *c) {
   }
   c->ev_used = 0;
   return CC_OK;
+}
+
+
+static int scratch_alloc(cc_ctx *c, cc_ctx::Scratch &S, int cap, int n_bigslots) {
+  const size_t nc = (size_t)c->dcfg.n_cell;
+  S.cap = cap;
+  HIPCHK(hipMalloc(&S.d_bev, sizeof(float) * nc * cap));
+  HIPCHK(hipMalloc(&S.d_pix, sizeof(float2) * nc * cap));
+  HIPCHK(hipMalloc(&S.d_k1, sizeof(cc_k1_scan_out) * cap));
+  HIPCHK(hipMalloc(&S.d_scr, sizeof(cc_k2_scratch) * cap));
+  HIPCHK(hipMalloc(&S.d_offsets, sizeof(long long) * (cap + 1)));
+  HIPCHK(hipMalloc(&S.d_bigq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)cap));
+  HIPCHK(hipMemset(S.d_bigq, 0, sizeof(cc_k2_big_queue)));  // the slow launch leaves it empty again
+  S.n_bigslots = n_bigslots < cap ? n_bigslots : cap;
+  HIPCHK(hipMalloc(&S.d_bigslots, sizeof(cc_k2_big_slot) * S.n_bigslots));
+  HIPCHK(hipEventCreateWithFlags(&S.ev_last, hipEventDisableTiming));
+  return CC_OK;
+}
+static void scratch_free(cc_ctx::Scratch &S) {
+  hipFree(S.d_bev);
+  hipFree(S.d_pix);
+  hipFree(S.d_k1);
+  hipFree(S.k1_part.key);
+  hipFree(S.k1_part.idx);
+  hipFree(S.k1_part.red);
+  hipFree(S.d_scr);
+  hipFree(S.d_offsets);
+  hipFree(S.d_bigq);
+  hipFree(S.d_bigslots);
+  if (S.ev_last) hipEventDestroy(S.ev_last);
+  S = cc_ctx::Scratch();
 }
 
 extern "C" {
@@ -196,19 +244,14 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   c->dcfg = dc;
   c->max_batch = max_batch_scans;
   const size_t nc = (size_t)dc.n_cell;
-  CREATE_CHK(hipMalloc(&c->d_bev, sizeof(float) * nc * max_batch_scans));
-  CREATE_CHK(hipMalloc(&c->d_pix, sizeof(float2) * nc * max_batch_scans));
-  CREATE_CHK(hipMalloc(&c->d_k1, sizeof(cc_k1_scan_out) * max_batch_scans));
-  CREATE_CHK(hipMalloc(&c->d_scr, sizeof(cc_k2_scratch) * max_batch_scans));
-  CREATE_CHK(hipMalloc(&c->d_offsets, sizeof(long long) * (max_batch_scans + 1)));
-  CREATE_CHK(hipMalloc(&c->d_bigq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)max_batch_scans));
-  CREATE_CHK(hipMemset(c->d_bigq, 0, sizeof(cc_k2_big_queue)));  // the slow launch leaves it empty again
-  CREATE_CHK(hipMalloc(&c->d_bigslots, sizeof(cc_k2_big_slot) * cc_ctx::N_BIG_SLOTS));
+  if (scratch_alloc(c, c->main, max_batch_scans, cc_ctx::N_BIG_SLOTS) != CC_OK) {
+    cc_destroy(c);
+    return CC_EHIP;  // (the message is set)
+  }
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
     CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * (max_batch_scans + 1), hipHostMallocDefault));
     CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
   }
-  CREATE_CHK(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
   if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * max_batch_scans));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
@@ -289,26 +332,21 @@ int cc_destroy(cc_ctx *c) {
   if (!c) return CC_OK;
   hipSetDevice(c->device);
   for (auto &e : c->ev) hipEventDestroy(e);
-  hipFree(c->d_bev);
-  hipFree(c->d_pix);
-  hipFree(c->d_k1);
-  hipFree(c->k1_part.key);
-  hipFree(c->k1_part.idx);
-  hipFree(c->k1_part.red);
-  hipFree(c->d_scr);
-  hipFree(c->d_offsets);
-  hipFree(c->d_bigq);
-  hipFree(c->d_bigslots);
+  for (auto &ch : c->chan) {
+    if (ch.s) {
+      hipStreamSynchronize(ch.s);
+      hipStreamDestroy(ch.s);
+    }
+    hipFree(ch.d_pts);
+    hipFree(ch.d_bev_copy);
+    scratch_free(ch.scr);
+  }
+  scratch_free(c->main);
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
     if (c->h_off[i]) hipHostFree(c->h_off[i]);
     if (c->off_ev[i]) hipEventDestroy(c->off_ev[i]);
   }
-  if (c->ev_last) hipEventDestroy(c->ev_last);
   hipFree(c->d_phase_clk);
-  if (c->s_ing) {
-    hipStreamSynchronize(c->s_ing);
-    hipStreamDestroy(c->s_ing);
-  }
   if (c->s_loop) {
     hipStreamSynchronize(c->s_loop);
     hipStreamDestroy(c->s_loop);
@@ -317,8 +355,6 @@ int cc_destroy(cc_ctx *c) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
     if (c->pts_ev[i]) hipEventDestroy(c->pts_ev[i]);
   }
-  hipFree(c->d_pts);
-  hipFree(c->d_loop_bev);
   for (auto *b : c->slot_blocks) hipFree(b);
   delete c;
   return CC_OK;
@@ -328,11 +364,9 @@ __global__ void cc_k_fill_f32(float *p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *d_out,
-                    const cc_ingest_debug_t *dbg, void *stream_) {
-  if (!c || !d_xyzi || !h_offsets || !d_out || n_scans < 0) return set_err(CC_EINVAL, "cc_ingest_batch: bad argument");
-  hipStream_t stream = (hipStream_t)stream_;
-  std::lock_guard<std::recursive_mutex> ing_lk(c->ing_mu);  // offsets ring, K1/K2 scratch, ev_last: one call at a time
+// cc_ingest_batch on the scratch set S (c->ing_mu held by the caller)
+static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *d_out,
+                     const cc_ingest_debug_t *dbg, hipStream_t stream) {
   HIPCHK(hipSetDevice(c->device));
   for (int i = 0; i < n_scans; i++) {
     const int64_t n = h_offsets[i + 1] - h_offsets[i];
@@ -340,21 +374,21 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     if (n >= (1 << CC_K1_IDX_BITS)) return set_err(CC_EINVAL, "cc_ingest_batch: scan with >= 2^21 points");
   }
   const size_t nc = (size_t)c->dcfg.n_cell;
-  if (c->has_last && c->last_stream != stream) HIPCHK(hipStreamWaitEvent(stream, c->ev_last, 0));
-  for (int b0 = 0; b0 < n_scans; b0 += c->max_batch) {
-    const int nb = (n_scans - b0 < c->max_batch) ? n_scans - b0 : c->max_batch;
+  if (S.has_last && S.last_stream != stream) HIPCHK(hipStreamWaitEvent(stream, S.ev_last, 0));
+  for (int b0 = 0; b0 < n_scans; b0 += S.cap) {
+    const int nb = (n_scans - b0 < S.cap) ? n_scans - b0 : S.cap;
     // offsets relative to the chunk's first point, staged in pinned memory: the call only queues work
     const int slot = c->off_next;
     c->off_next = (slot + 1) % cc_ctx::NSLOT;
     if (c->off_busy[slot]) HIPCHK(hipEventSynchronize(c->off_ev[slot]));
     long long *off = c->h_off[slot];
     for (int i = 0; i <= nb; i++) off[i] = (long long)(h_offsets[b0 + i] - h_offsets[b0]);
-    HIPCHK(hipMemcpyAsync(c->d_offsets, off, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(S.d_offsets, off, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, stream));
     HIPCHK(hipEventRecord(c->off_ev[slot], stream));
     c->off_busy[slot] = true;
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
     if (dbg && dbg->d_pix_rc)
-      hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)c->d_pix, -1.f, nc * 2 * nb);
+      hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)S.d_pix, -1.f, nc * 2 * nb);
     hipEvent_t *pe = nullptr;
     if (c->prof) {
       if (c->ev_used + 3 > c->ev.size() && prof_flush(c) != CC_OK) return set_err(CC_EHIP, "profiling event sync failed");
@@ -365,46 +399,54 @@ int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, in
     if (nb <= CC_K1_SPLIT_MAX_SCANS && !c->k1_nosplit) {
       // a handful of scans (the per-scan loop brings one): CC_K1_SPLIT workgroups per scan sweep a range of its points each,
       // a second small kernel combines the ranges (first range wins ties: file order)
-      if (!c->k1_part.key) {
+      if (!S.k1_part.key) {
         const size_t np = (size_t)CC_K1_SPLIT_MAX_SCANS * CC_K1_SPLIT;
-        HIPCHK(hipMalloc(&c->k1_part.key, sizeof(unsigned) * np * nc));
-        HIPCHK(hipMalloc(&c->k1_part.idx, sizeof(int) * np * nc));
-        HIPCHK(hipMalloc(&c->k1_part.red, sizeof(unsigned) * np * 2));
+        HIPCHK(hipMalloc(&S.k1_part.key, sizeof(unsigned) * np * nc));
+        HIPCHK(hipMalloc(&S.k1_part.idx, sizeof(int) * np * nc));
+        HIPCHK(hipMalloc(&S.k1_part.red, sizeof(unsigned) * np * 2));
       }
       if (c->dcfg.reso_pow2 && !c->k1_div)
         hipLaunchKernelGGL((cc_k_rasterize<4, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)c->d_offsets, c->d_bev, c->d_pix, c->d_k1, c->k1_part);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part);
       else
         hipLaunchKernelGGL((cc_k_rasterize<4, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)c->d_offsets, c->d_bev, c->d_pix, c->d_k1, c->k1_part);
-      hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)c->d_offsets, c->k1_part, c->d_bev,
-                         c->d_pix, c->d_k1);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part);
+      hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)S.d_offsets, S.k1_part, S.d_bev,
+                         S.d_pix, S.d_k1);
     } else if (c->dcfg.reso_pow2 && !c->k1_div)
-      hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
-                         c->d_bev, c->d_pix, c->d_k1, cc_k1_part());
+      hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part());
     else
-      hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)c->d_offsets,
-                         c->d_bev, c->d_pix, c->d_k1, cc_k1_part());
+      hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part());
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
-    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)c->d_bev,
-                       (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_scr, d_out + b0, lab, c->d_phase_clk, c->d_bigq);
+    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
+                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_bigq);
     // the scans the launch above could not number (more than CC_MAXC components on a level): exact, slow, usually none
-    hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < cc_ctx::N_BIG_SLOTS ? nb : cc_ctx::N_BIG_SLOTS), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
-                       (const float *)c->d_bev, (const float2 *)c->d_pix, (const cc_k1_scan_out *)c->d_k1, c->d_bigslots, c->d_bigq, d_out + b0, lab);
+    hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < S.n_bigslots ? nb : S.n_bigslots), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
+                       (const float *)S.d_bev, (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_bigslots, S.d_bigq, d_out + b0, lab);
     if (pe) HIPCHK(hipEventRecord(pe[2], stream));
     HIPCHK(hipGetLastError());
     if (dbg && dbg->d_bev)
-      HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, c->d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipMemcpyAsync(dbg->d_bev + (size_t)b0 * nc, S.d_bev, sizeof(float) * nc * nb, hipMemcpyDeviceToDevice, stream));
     if (dbg && dbg->d_pix_rc)
-      HIPCHK(hipMemcpyAsync(dbg->d_pix_rc + (size_t)b0 * nc * 2, c->d_pix, sizeof(float2) * nc * nb, hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipMemcpyAsync(dbg->d_pix_rc + (size_t)b0 * nc * 2, S.d_pix, sizeof(float2) * nc * nb, hipMemcpyDeviceToDevice, stream));
   }
   if (n_scans > 0) {
-    HIPCHK(hipEventRecord(c->ev_last, stream));
-    c->last_stream = stream;
-    c->has_last = true;
+    HIPCHK(hipEventRecord(S.ev_last, stream));
+    S.last_stream = stream;
+    S.has_last = true;
   }
   return CC_OK;
+}
+
+
+int cc_ingest_batch(cc_ctx *c, const float *d_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *d_out,
+                    const cc_ingest_debug_t *dbg, void *stream_) {
+  if (!c || !d_xyzi || !h_offsets || !d_out || n_scans < 0) return set_err(CC_EINVAL, "cc_ingest_batch: bad argument");
+  std::lock_guard<std::recursive_mutex> ing_lk(c->ing_mu);  // offsets ring, K1/K2 scratch, ev_last: one call at a time
+  return ingest_on(c, c->main, d_xyzi, h_offsets, n_scans, d_out, dbg, (hipStream_t)stream_);
 }
 
 int cc_ingest_host(cc_ctx *c, const float *h_xyzi, const int64_t *h_offsets, int n_scans, cc_scan_desc_t *h_out) {
@@ -475,7 +517,13 @@ struct cc_scan {
 
 static int loop_reserve_points(cc_ctx *c, int64_t n_points) {  // ing_mu held
   if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
-  if (!c->s_ing) HIPCHK(hipStreamCreateWithFlags(&c->s_ing, hipStreamNonBlocking));
+  for (auto &ch : c->chan) {
+    if (!ch.s) HIPCHK(hipStreamCreateWithFlags(&ch.s, hipStreamNonBlocking));
+    if (ch.scr.cap == 0) {
+      const int rc = scratch_alloc(c, ch.scr, 1, 1);
+      if (rc != CC_OK) return rc;
+    }
+  }
   for (int i = 0; i < cc_ctx::NPTS; i++)
     if (!c->pts_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[i], hipEventDisableTiming));
   if (n_points <= c->pts_cap) return CC_OK;
@@ -485,19 +533,21 @@ static int loop_reserve_points(cc_ctx *c, int64_t n_points) {  // ing_mu held
     if (c->pts_handed[i] && c->pts_owner[i] != me)
       return set_err(CC_EINVAL, "cc_stage_points: the staging buffers must grow while another thread fills one of them (stage the largest "
                                 "scan first, or give every thread its own context)");
-  HIPCHK(hipStreamSynchronize(c->s_ing));
+  for (auto &ch : c->chan) HIPCHK(hipStreamSynchronize(ch.s));
   for (int i = 0; i < cc_ctx::NPTS; i++) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
     c->h_pts[i] = nullptr;
     c->pts_busy[i] = false;
     c->pts_handed[i] = false;
   }
-  hipFree(c->d_pts);
-  c->d_pts = nullptr;
+  for (auto &ch : c->chan) {
+    hipFree(ch.d_pts);
+    ch.d_pts = nullptr;
+  }
   c->pts_cap = 0;
   const int64_t cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
   for (int i = 0; i < cc_ctx::NPTS; i++) HIPCHK(hipHostMalloc((void **)&c->h_pts[i], sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
-  HIPCHK(hipMalloc(&c->d_pts, sizeof(float) * 4 * (size_t)cap));
+  for (auto &ch : c->chan) HIPCHK(hipMalloc(&ch.d_pts, sizeof(float) * 4 * (size_t)cap));
   c->pts_cap = cap;
   return CC_OK;
 }
@@ -570,11 +620,14 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
       c->pts_cv.notify_all();
     }
   } hb{c, slot};
-  if (want_bev && !c->d_loop_bev) HIPCHK(hipMalloc(&c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell));
-  // Everything of the ingest goes to its own stream: a caller may ingest scan i + 1 (from a helper thread, as the evaluator
-  // mirror does) while scan i is queried and added on the loop stream; whoever reads the descriptor waits for `ready`.
-  HIPCHK(hipMemcpyAsync(c->d_pts, c->h_pts[slot], sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, c->s_ing));
-  HIPCHK(hipEventRecord(c->pts_ev[slot], c->s_ing));
+  // The scan goes to the next channel: its own stream, device point buffer and one-scan scratch set, so that it can run next to
+  // the scan before it (a caller may ingest scans i + 1, i + 2 -- from a helper thread, as the evaluator mirror does -- while scan i
+  // is queried and added on the loop stream); whoever reads the descriptor waits for `ready`.
+  cc_ctx::Channel &ch = c->chan[c->chan_next];
+  c->chan_next = (c->chan_next + 1) % cc_ctx::NCHAN;
+  if (want_bev && !ch.d_bev_copy) HIPCHK(hipMalloc(&ch.d_bev_copy, sizeof(float) * (size_t)c->dcfg.n_cell));
+  HIPCHK(hipMemcpyAsync(ch.d_pts, c->h_pts[slot], sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, ch.s));
+  HIPCHK(hipEventRecord(c->pts_ev[slot], ch.s));
   c->pts_busy[slot] = true;
   cc_scan *sc = new cc_scan();  // from here on every failure path gives the handle (and, once taken, the descriptor slot) back
   sc->ctx = c;
@@ -610,10 +663,10 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
   };
   const int64_t off[2] = {0, n_points};
   cc_ingest_debug_t dbg;
-  dbg.d_bev = want_bev ? c->d_loop_bev : nullptr;
+  dbg.d_bev = want_bev ? ch.d_bev_copy : nullptr;
   dbg.d_pix_rc = nullptr;
   dbg.d_labels = nullptr;
-  const int rc = cc_ingest_batch(c, c->d_pts, off, 1, sc->d_desc, want_bev ? &dbg : nullptr, c->s_ing);
+  const int rc = ingest_on(c, ch.scr, ch.d_pts, off, 1, sc->d_desc, want_bev ? &dbg : nullptr, ch.s);
   if (rc != CC_OK) {
     give_back();
     return rc;
@@ -624,7 +677,7 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
       give_back();
       return set_err(CC_ENOMEM, "cc_scan_ingest: out of host memory");
     }
-    const hipError_t e_ = hipMemcpyAsync(sc->h_bev, c->d_loop_bev, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, c->s_ing);
+    const hipError_t e_ = hipMemcpyAsync(sc->h_bev, ch.d_bev_copy, sizeof(float) * (size_t)c->dcfg.n_cell, hipMemcpyDeviceToHost, ch.s);
     if (e_ != hipSuccess) {
       give_back();
       return set_err(CC_EHIP, "cc_scan_ingest: copy of the BEV image", e_);
@@ -632,9 +685,9 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
     sc->bev_pending = true;
   }
   hipError_t e_ = hipEventCreateWithFlags(&sc->ready, hipEventDisableTiming);
-  if (e_ == hipSuccess) e_ = hipEventRecord(sc->ready, c->s_ing);
+  if (e_ == hipSuccess) e_ = hipEventRecord(sc->ready, ch.s);
   if (e_ != hipSuccess) {
-    hipStreamSynchronize(c->s_ing);  // the queued kernels write the slot
+    hipStreamSynchronize(ch.s);  // the queued kernels write the slot
     give_back();
     return set_err(CC_EHIP, "cc_scan_ingest: ready event", e_);
   }

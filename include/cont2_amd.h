@@ -274,8 +274,9 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  * ContourDB::queryRangedKNN (contour_db.h:698) and ContourDB::addScan (:814): the class mirror's ContourManager holds one.
  * Nothing is allocated per scan: the context owns pinned staging buffers for the points, a device point buffer and a pool
  * of descriptor slots; the calls only queue work, the host copy of the descriptor (and of the max-height image, if asked
- * for) is fetched when a getter needs it.  TWO streams: cc_scan_ingest queues on the context's ingest stream and records
- * the scan's `ready` event behind its last kernel; cc_scan_desc / cc_scan_offload / cc_db_query_scan / cc_db_add_scan work on
+ * for) is fetched when a getter needs it.  Streams: cc_scan_ingest queues on the next of the context's two ingest CHANNELS
+ * (own stream, device point buffer and one-scan scratch: consecutive scans' ingests overlap) and records the scan's `ready`
+ * event behind its last kernel; cc_scan_desc / cc_scan_offload / cc_db_query_scan / cc_db_add_scan work on
  * the loop stream, which waits for `ready` first.  So scan i + 1 (and i + 2) can be ingested while scan i is queried and
  * added -- also from OTHER host threads: cc_ingest_batch / cc_stage_points* / cc_scan_ingest of one context serialise on
  * the context's ingest lock (the staging slots, the device point buffer and the K1/K2 scratch are shared), next to one
