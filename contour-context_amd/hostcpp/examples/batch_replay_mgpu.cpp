@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -215,6 +216,8 @@ int main(int argc, char **argv) {
   // our own launcher: one process per GPU, forked BEFORE anything touches HIP
   char port[32];
   snprintf(port, sizeof(port), "%d", 20000 + (int)(getpid() % 20000));
+  char token[64];
+  snprintf(token, sizeof(token), "%d-%ld", (int)getpid(), (long)time(nullptr));
   std::vector<pid_t> kids;
   for (int r = 0; r < gpus; r++) {
     const pid_t p = fork();
@@ -226,6 +229,7 @@ int main(int argc, char **argv) {
       snprintf(b, sizeof(b), "%d", gpus);
       setenv("WORLD_SIZE", b, 1);
       setenv("MASTER_PORT", port, 1);
+      setenv("CC_COMM_TOKEN", token, 1);  // names this job's id file (cc_comm_create_from_env)
       setenv("MASTER_ADDR", "127.0.0.1", 1);
       setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf IPC between the ranks of one node
       return run_rank(argv[1], argv[2]);
