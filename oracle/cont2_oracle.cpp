@@ -503,8 +503,6 @@ int orc_knn_scan(const float *keys, int n, const float *q, int k, float max_dist
     tb.gkidx_tree_.emplace_back((size_t)i, 0, 0);
   }
   tb.tree_built = true;
-  tb.snap_data_ = tb.data_tree_;  // "indexed" without going through the kd-tree backend: this entry point checks the exact scan
-  tb.snap_gkidx_ = tb.gkidx_tree_;
   RetrievalKey qk;
   std::memcpy(qk.array, q, 40);
   std::vector<IndexOfKey> ri;

@@ -83,14 +83,6 @@ struct TreeBucket {
   std::vector<RetrTriplet> buffer_;
   std::vector<IndexOfKey> gkidx_tree_;
   std::shared_ptr<void> kd_;  // backend tree handle
-  // What the bucket's kd-tree INDEXES: nanoflann's index covers the points that were in data_tree_ at buildIndex
-  // (contour_db.h:109-118); LayerDB::rebuild moves slices between two buckets' data_tree_ and rebuilds a tree only when
-  // something leaves the bucket's own buffer (popBufferMax), so a tree can be older than its vector.  Both search paths below
-  // answer from this snapshot (taken at every rebuildTree): a slice a bucket RECEIVED since is not found until its next
-  // rebuild (as in the reference); a slice it GAVE AWAY is still found (the reference reads a vector that has shrunk under
-  // the index there -- undefined; the product treats the slice as gone: DESIGN.md section 6).
-  std::vector<RetrievalKey> snap_data_;
-  std::vector<IndexOfKey> snap_gkidx_;
 
   TreeBucket(const TreeBucketConfig &config, KeyFloatType beg, KeyFloatType end) : cfg_(config), buc_beg_(beg), buc_end_(end) {}
   size_t getTreeSize() const { return data_tree_.size(); }
@@ -102,8 +94,6 @@ struct TreeBucket {
   }
   void rebuildTree() {
     tree_built = true;
-    snap_data_ = data_tree_;
-    snap_gkidx_ = gkidx_tree_;
     KnnBackend &be = knn_backend();
     if (be.create) {
       if (!kd_) kd_ = std::shared_ptr<void>(be.create(), be.destroy);
@@ -136,18 +126,18 @@ struct TreeBucket {
     ret_idx.reserve(num_res);
     std::vector<size_t> idx(num_res, 0);
     if (knn_backend().create && kd_) {
-      if (!snap_data_.empty()) knn_backend().query(kd_.get(), q_key.array, num_res, max_dist_sq, idx.data(), out_dist_sq.data());
+      if (!data_tree_.empty()) knn_backend().query(kd_.get(), q_key.array, num_res, max_dist_sq, idx.data(), out_dist_sq.data());
       else out_dist_sq[num_res - 1] = max_dist_sq;
-      for (int i = 0; i < num_res; i++) ret_idx.emplace_back(snap_gkidx_.empty() ? IndexOfKey(0, 0, 0) : snap_gkidx_[idx[i]]);
+      for (int i = 0; i < num_res; i++) ret_idx.emplace_back(gkidx_tree_.empty() ? IndexOfKey(0, 0, 0) : gkidx_tree_[idx[i]]);
       return;
     }
     // MyKNNResSet::init
     size_t count = 0;
     const size_t capacity = num_res;
     if (capacity) out_dist_sq[capacity - 1] = max_dist_sq;
-    if (!snap_data_.empty()) {
-      for (size_t p = 0; p < snap_data_.size(); p++) {
-        KeyFloatType dist = l2_nanoflann(q_key.array, snap_data_[p].array);
+    if (!data_tree_.empty()) {
+      for (size_t p = 0; p < data_tree_.size(); p++) {
+        KeyFloatType dist = l2_nanoflann(q_key.array, data_tree_[p].array);
         if (dist < out_dist_sq[capacity - 1]) {
           // KNNResultSet::addPoint
           size_t i;
@@ -168,7 +158,7 @@ struct TreeBucket {
         }
       }
     }
-    for (int i = 0; i < num_res; i++) ret_idx.emplace_back(snap_gkidx_.empty() ? IndexOfKey(0, 0, 0) : snap_gkidx_[idx[i]]);
+    for (int i = 0; i < num_res; i++) ret_idx.emplace_back(gkidx_tree_.empty() ? IndexOfKey(0, 0, 0) : gkidx_tree_[idx[i]]);
   }
 };
 
