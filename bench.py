@@ -994,6 +994,15 @@ def dropin_loop(batch0, P, n):
                 xs[i].tofile(p)
                 f.write("%.6f %d %s\n" % (i / 10.0, i, p))
                 g.write("%.6f 1 0 0 %.3f 0 1 0 0 0 0 1 0\n" % (i / 10.0, float(i)))
+        # The files are read once before the driver starts: the first read(2) of a freshly WRITTEN tmpfs page activates it under
+        # the kernel's LRU lock, which serialises parallel readers (measured on the MI355X host: 4 threads 163 us per file on that
+        # first pass, 28 us on any later one; profiles/r5/read_pinned_bench.cpp) -- an artefact of producing the input right
+        # here, not a property of reading scans.  (CC_DROPIN_COLD_FILES=1 skips this.)
+        if not os.environ.get("CC_DROPIN_COLD_FILES"):
+            for i in range(n):
+                with open(os.path.join(tmp, "%06d.bin" % i), "rb", buffering=0) as f:
+                    while f.read(1 << 22):
+                        pass
         cfg = open(os.path.join(ROOT, "contour-context_amd", "hostcpp", "examples", "batch_bin_test_config.yaml")).read()
         cfg = cfg.replace("/path/to/ts-sens_pose-kitti08.txt", os.path.join(tmp, "poses.txt"))
         cfg = cfg.replace("/path/to/ts-lidar_bins-kitti08.txt", os.path.join(tmp, "scans.txt"))
@@ -1006,7 +1015,7 @@ def dropin_loop(batch0, P, n):
         if r.returncode != 0:
             return {"error": "driver exit code %d: %s" % (r.returncode, r.stderr[-300:])}
         out = {"scans": n, "what": "hostcpp/examples/batch_bin_test (the reference driver's loop through the class mirror): per scan "
-               ".bin file -> makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance, DB empty at the start; "
+               ".bin file (tmpfs, in the page cache) -> makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance, DB empty at the start; "
                "seconds per call = wall clock inside the driver", "process_wall_s": wall}
         for line in r.stdout.splitlines():
             p = line.split()
@@ -1019,6 +1028,10 @@ def dropin_loop(batch0, P, n):
             if line.startswith("Loop wall time:"):
                 out["loop_wall_s"] = float(p[3])
                 out["scans_per_s"] = n / float(p[3])
+            if line.startswith("Construction time:"):   # evaluator + ContourDB constructors: lists, device runtime, stream pool
+                out["construction_s"] = float(p[2])
+        if "construction_s" in out and "loop_wall_s" in out:
+            out["scans_per_s_with_construction"] = n / (out["loop_wall_s"] + out["construction_s"])
         if "seconds_per_call" in out:
             out["ms_per_scan_three_calls"] = 1e3 * sum(out["seconds_per_call"].values())
         for line in r.stderr.splitlines():

@@ -50,7 +50,7 @@ EXPORTS = ["cc_last_error", "cc_version", "cc_default_manager_cfg", "cc_default_
            "cc_db_add_scan_host", "cc_db_query_host", "cc_db_set_lanes",
            "cc_db_add_scans_host", "cc_db_query_batch_host", "cc_db_check_hints", "cc_db_check_hints_host", "cc_db_debug_passes",
            "cc_stage_points", "cc_stage_points_slot", "cc_stage_points_cancel", "cc_scan_ingest", "cc_scan_desc", "cc_scan_bev", "cc_scan_offload", "cc_scan_on_device", "cc_scan_release", "cc_db_query_scan",
-           "cc_db_add_scan", "cc_db_query_scan_submit", "cc_db_query_collect", "cc_db_add_scan_prepare",
+           "cc_db_add_scan", "cc_db_query_scan_submit", "cc_db_query_collect", "cc_db_add_scan_prepare", "cc_runtime_init", "cc_scan_ingest_batch", "cc_scan_ready", "cc_db_add_scan_batch", "cc_db_query_scan_batch_submit",
            "cc_comm_unique_id", "cc_comm_create", "cc_comm_create_from_env", "cc_comm_rank", "cc_comm_world", "cc_comm_allgather_packed", "cc_comm_destroy"]
 
 

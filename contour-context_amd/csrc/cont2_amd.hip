@@ -91,6 +91,8 @@ struct cc_ctx {
   struct Channel {
     hipStream_t s = nullptr;
     float *d_pts = nullptr;
+    int64_t d_pts_cap = 0;             // points d_pts holds (one staging buffer's worth; CC_SCAN_BATCH_MAX of them once a batch came by)
+    cc_scan_desc_t *d_desc_tmp = nullptr;  // [CC_SCAN_BATCH_MAX] where a batch's descriptors are written before they go to their slots
     float *d_bev_copy = nullptr;  // the max-height image of a scan that asked for it (want_bev), until its copy to the host has passed
     Scratch scr;
   };
@@ -101,17 +103,20 @@ struct cc_ctx {
   // another thread -- while the first one's scan is in flight), one device point buffer (the stream orders its reuse)
   // Slots 0 and 1 are the caller's to name (cc_stage_points_slot), slot 2 is cc_stage_points' own -- a thread that stages
   // without naming a slot (ContourManager::makeBEV) never gets a buffer a read-ahead helper writes.
-  static const int NPTS = 3;
-  float *h_pts[NPTS] = {nullptr, nullptr, nullptr};
-  hipEvent_t pts_ev[NPTS] = {nullptr, nullptr, nullptr};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
-  bool pts_busy[NPTS] = {false, false, false};
+  // Round 5: 2 * CC_SCAN_BATCH_MAX caller slots (a read-ahead thread fills one batch of files while the batch before it is on
+  // its way: cc_scan_ingest_batch), each allocated when it is first asked for; the last slot is cc_stage_points' own.
+  static const int NPTS = 2 * CC_SCAN_BATCH_MAX + 1;
+  static const int OWN_SLOT = NPTS - 1;
+  float *h_pts[NPTS] = {};
+  hipEvent_t pts_ev[NPTS] = {};  // recorded behind a slot's H2D copy: the slot may be rewritten once it has passed
+  bool pts_busy[NPTS] = {};
   // Ingest state (the staging slots, d_pts, the offsets ring, the K1/K2 scratch, ev_last) is shared by every call of the
   // context: ing_mu is held inside cc_ingest_batch / cc_stage_points* / cc_scan_ingest.  A slot handed out by
   // cc_stage_points* belongs to the calling thread until that thread's cc_scan_ingest has queued its copy (or the thread
   // stages the slot again); another thread asking for it WAITS (pts_cv) instead of being handed memory that is being filled.
   std::recursive_mutex ing_mu;
   std::condition_variable_any pts_cv;
-  bool pts_handed[NPTS] = {false, false, false};
+  bool pts_handed[NPTS] = {};
   std::thread::id pts_owner[NPTS];
   int64_t pts_cap = 0;  // points
   std::vector<cc_scan_desc_t *> slot_free, slot_blocks;
@@ -221,6 +226,56 @@ void cc_default_thresholds(cc_score_t *lb, cc_score_t *ub) {
   ub->neg_est_dist = -5.0f;
 }
 
+// ---- start of the device runtime, and a per-device pool of streams ----
+// Measured on MI355X / ROCm 7.2: the first HIP call of a process takes ~54 ms, loading the code object ~5-20 ms, and
+// hipStreamCreateWithFlags 16 / 8.5 / 8.5 / 8.5 ms for the first four streams of a process and 3.4 ms for every further one
+// (profiles/r5/stream_probe.cpp) -- a per-scan driver's context + database use 4-7 streams.  cc_runtime_init pays all of that
+// in one call a host can make when it starts (the class mirror: the ContourDB / evaluator constructors); contexts and
+// databases take their streams from the pool and give them back when they are destroyed.
+#define CC_RT_MAX_DEV 64
+static std::mutex g_rt_mu;
+static std::vector<hipStream_t> g_stream_pool[CC_RT_MAX_DEV];
+static hipError_t stream_take(int device, hipStream_t *out) {
+  if (device >= 0 && device < CC_RT_MAX_DEV) {
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    if (!g_stream_pool[device].empty()) {
+      *out = g_stream_pool[device].back();
+      g_stream_pool[device].pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void stream_give(int device, hipStream_t s) {
+  hipStreamSynchronize(s);
+  if (device >= 0 && device < CC_RT_MAX_DEV) {
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    if (g_stream_pool[device].size() < 32) {
+      g_stream_pool[device].push_back(s);
+      return;
+    }
+  }
+  hipStreamDestroy(s);
+}
+int cc_runtime_init(int device, int n_streams) {
+  if (device < 0 || n_streams < 0 || n_streams > 32) return set_err(CC_EINVAL, "cc_runtime_init: bad argument (0..32 streams)");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipFree(nullptr));
+  hipFuncAttributes fa;
+  HIPCHK(hipFuncGetAttributes(&fa, (const void *)cc_k_contours));  // loads the code object
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(g_rt_mu);
+      if (device >= CC_RT_MAX_DEV || (int)g_stream_pool[device].size() >= n_streams) break;
+    }
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    g_stream_pool[device].push_back(s);
+  }
+  return CC_OK;
+}
+
 int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_ctx **out) {
   if (!cfg || !out || max_batch_scans < 1) return set_err(CC_EINVAL, "cc_create: bad argument");
   cc_dev_cfg dc;
@@ -249,7 +304,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     return CC_EHIP;  // (the message is set)
   }
   for (int i = 0; i < cc_ctx::NSLOT; i++) {
-    CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * (max_batch_scans + 1), hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * ((max_batch_scans > CC_SCAN_BATCH_MAX ? max_batch_scans : CC_SCAN_BATCH_MAX) + 1), hipHostMallocDefault));
     CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
   }
   if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * max_batch_scans));
@@ -334,10 +389,10 @@ int cc_destroy(cc_ctx *c) {
   for (auto &e : c->ev) hipEventDestroy(e);
   for (auto &ch : c->chan) {
     if (ch.s) {
-      hipStreamSynchronize(ch.s);
-      hipStreamDestroy(ch.s);
+      stream_give(c->device, ch.s);
     }
     hipFree(ch.d_pts);
+    hipFree(ch.d_desc_tmp);
     hipFree(ch.d_bev_copy);
     scratch_free(ch.scr);
   }
@@ -348,8 +403,7 @@ int cc_destroy(cc_ctx *c) {
   }
   hipFree(c->d_phase_clk);
   if (c->s_loop) {
-    hipStreamSynchronize(c->s_loop);
-    hipStreamDestroy(c->s_loop);
+    stream_give(c->device, c->s_loop);
   }
   for (int i = 0; i < cc_ctx::NPTS; i++) {
     if (c->h_pts[i]) hipHostFree(c->h_pts[i]);
@@ -516,16 +570,14 @@ struct cc_scan {
 };
 
 static int loop_reserve_points(cc_ctx *c, int64_t n_points) {  // ing_mu held
-  if (!c->s_loop) HIPCHK(hipStreamCreateWithFlags(&c->s_loop, hipStreamNonBlocking));
+  if (!c->s_loop) HIPCHK(stream_take(c->device, &c->s_loop));
   for (auto &ch : c->chan) {
-    if (!ch.s) HIPCHK(hipStreamCreateWithFlags(&ch.s, hipStreamNonBlocking));
+    if (!ch.s) HIPCHK(stream_take(c->device, &ch.s));
     if (ch.scr.cap == 0) {
       const int rc = scratch_alloc(c, ch.scr, 1, 1);
       if (rc != CC_OK) return rc;
     }
   }
-  for (int i = 0; i < cc_ctx::NPTS; i++)
-    if (!c->pts_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[i], hipEventDisableTiming));
   if (n_points <= c->pts_cap) return CC_OK;
   // growing re-allocates every slot: none may be in another thread's hands (being filled) at that moment
   const std::thread::id me = std::this_thread::get_id();
@@ -543,12 +595,19 @@ static int loop_reserve_points(cc_ctx *c, int64_t n_points) {  // ing_mu held
   for (auto &ch : c->chan) {
     hipFree(ch.d_pts);
     ch.d_pts = nullptr;
+    ch.d_pts_cap = 0;
   }
-  c->pts_cap = 0;
-  const int64_t cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
-  for (int i = 0; i < cc_ctx::NPTS; i++) HIPCHK(hipHostMalloc((void **)&c->h_pts[i], sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
-  for (auto &ch : c->chan) HIPCHK(hipMalloc(&ch.d_pts, sizeof(float) * 4 * (size_t)cap));
-  c->pts_cap = cap;
+  c->pts_cap = n_points < 262144 ? 262144 : n_points;  // 1 M floats = what readKITTIPointCloudBin reads at most
+  for (auto &ch : c->chan) {
+    HIPCHK(hipMalloc(&ch.d_pts, sizeof(float) * 4 * (size_t)c->pts_cap));
+    ch.d_pts_cap = c->pts_cap;
+  }
+  return CC_OK;
+}
+// a slot's pinned buffer (pts_cap points) and copy event exist from its first use on
+static int loop_slot_alloc(cc_ctx *c, int slot) {  // ing_mu held
+  if (!c->pts_ev[slot]) HIPCHK(hipEventCreateWithFlags(&c->pts_ev[slot], hipEventDisableTiming));
+  if (!c->h_pts[slot]) HIPCHK(hipHostMalloc((void **)&c->h_pts[slot], sizeof(float) * 4 * (size_t)c->pts_cap, hipHostMallocDefault));
   return CC_OK;
 }
 
@@ -559,6 +618,7 @@ static float *stage_slot_locked(cc_ctx *c, int64_t n_points, int slot, std::uniq
   c->pts_cv.wait(lk, [&] { return !c->pts_handed[slot] || c->pts_owner[slot] == me; });
   if (hipSetDevice(c->device) != hipSuccess) return nullptr;
   if (loop_reserve_points(c, n_points) != CC_OK) return nullptr;
+  if (loop_slot_alloc(c, slot) != CC_OK) return nullptr;
   if (c->pts_busy[slot]) {
     if (hipEventSynchronize(c->pts_ev[slot]) != hipSuccess) return nullptr;
     c->pts_busy[slot] = false;
@@ -569,14 +629,14 @@ static float *stage_slot_locked(cc_ctx *c, int64_t n_points, int slot, std::uniq
 }
 
 float *cc_stage_points_slot(cc_ctx *c, int64_t n_points, int slot) {
-  if (!c || n_points < 1 || slot < 0 || slot > 1) return nullptr;
+  if (!c || n_points < 1 || slot < 0 || slot >= cc_ctx::OWN_SLOT) return nullptr;
   std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
   return stage_slot_locked(c, n_points, slot, lk);
 }
 float *cc_stage_points(cc_ctx *c, int64_t n_points) {
   if (!c || n_points < 1) return nullptr;
   std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
-  return stage_slot_locked(c, n_points, 2, lk);
+  return stage_slot_locked(c, n_points, cc_ctx::OWN_SLOT, lk);
 }
 
 int cc_stage_points_cancel(cc_ctx *c, const float *staged) {
@@ -601,10 +661,10 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
   for (int i = 0; i < cc_ctx::NPTS; i++)
     if (c->h_pts[i] && h_xyzi == c->h_pts[i]) slot = i;
   if (slot < 0) {
-    float *dst = stage_slot_locked(c, n_points, 2, lk);  // waits for the slot's holder and its previous copy, grows the buffers if need be
+    float *dst = stage_slot_locked(c, n_points, cc_ctx::OWN_SLOT, lk);  // waits for the slot's holder and its previous copy, grows the buffers if need be
     if (!dst) return set_err(CC_EHIP, "cc_scan_ingest: staging buffer");
     memcpy(dst, h_xyzi, sizeof(float) * 4 * (size_t)n_points);
-    slot = 2;
+    slot = cc_ctx::OWN_SLOT;
   } else if (!c->pts_handed[slot] || c->pts_owner[slot] != std::this_thread::get_id()) {
     return set_err(CC_EINVAL, "cc_scan_ingest: the staging buffer was not handed to this thread by cc_stage_points* (or was ingested already)");
   } else if (n_points > c->pts_cap) {
@@ -693,6 +753,154 @@ int cc_scan_ingest(cc_ctx *c, const float *h_xyzi, int64_t n_points, int want_be
   }
   *out = sc;
   return CC_OK;
+}
+
+// cc_scan_ingest for 1..CC_SCAN_BATCH_MAX staged scans at once: ONE K1/K2 launch chain for all of them on the next channel (a
+// single scan's chain takes ~0.2 ms of launch latencies whatever it holds; a loop that reads its files ahead pays that per batch).
+// The batch's descriptors are written side by side and then moved to their own slots of the pool by one small kernel, so every
+// handle is an ordinary cc_scan afterwards.  All-or-nothing: on an error no handle is returned and every buffer is given back.
+struct cc_desc_out_tab {
+  cc_scan_desc_t *p[CC_SCAN_BATCH_MAX];
+};
+#define CC_SCATTER_BLOCKS 16  // workgroups per descriptor
+__global__ void __launch_bounds__(256)
+cc_k_scatter_desc(cc_desc_out_tab tab, int n, const cc_scan_desc_t *__restrict__ src) {
+  const int s = (int)blockIdx.x / CC_SCATTER_BLOCKS, part = (int)blockIdx.x % CC_SCATTER_BLOCKS;
+  if (s >= n) return;
+  const unsigned long long *__restrict__ in = (const unsigned long long *)(src + s);
+  unsigned long long *__restrict__ out = (unsigned long long *)tab.p[s];
+  const int nv = (int)(sizeof(cc_scan_desc_t) / 8);
+  for (int i = part * 256 + (int)threadIdx.x; i < nv; i += CC_SCATTER_BLOCKS * 256) out[i] = in[i];
+}
+
+int cc_scan_ingest_batch(cc_ctx *c, const float *const *h_xyzi, const int64_t *n_points, int n, cc_scan **out) {
+  if (!c || !h_xyzi || !n_points || !out || n < 1 || n > CC_SCAN_BATCH_MAX)
+    return set_err(CC_EINVAL, "cc_scan_ingest_batch: bad argument (1..CC_SCAN_BATCH_MAX scans)");
+  static_assert(sizeof(cc_scan_desc_t) % 8 == 0, "cc_k_scatter_desc copies 8 bytes per lane");
+  std::unique_lock<std::recursive_mutex> lk(c->ing_mu);
+  HIPCHK(hipSetDevice(c->device));
+  const std::thread::id me = std::this_thread::get_id();
+  int slot[CC_SCAN_BATCH_MAX];
+  int64_t off[CC_SCAN_BATCH_MAX + 1];
+  off[0] = 0;
+  for (int i = 0; i < n; i++) {
+    slot[i] = -1;
+    for (int k = 0; k < cc_ctx::NPTS; k++)
+      if (c->h_pts[k] && h_xyzi[i] == c->h_pts[k]) slot[i] = k;
+    if (slot[i] < 0 || !c->pts_handed[slot[i]] || c->pts_owner[slot[i]] != me)
+      return set_err(CC_EINVAL, "cc_scan_ingest_batch: every buffer must be a staging buffer handed to this thread by cc_stage_points*");
+    for (int k = 0; k < i; k++)
+      if (slot[k] == slot[i]) return set_err(CC_EINVAL, "cc_scan_ingest_batch: the same staging buffer twice");
+    if (n_points[i] < 1 || n_points[i] > c->pts_cap) return set_err(CC_EINVAL, "cc_scan_ingest_batch: more points than were staged");
+    if (!(n_points[i] > 10)) return set_err(CC_EINVAL, "cc_scan_ingest_batch: scan with <= 10 points (CHECK_GT(size, 10), contour_mng.h:507)");
+    off[i + 1] = off[i] + n_points[i];
+  }
+  // from here on the buffers are no longer the caller's, whatever happens
+  struct hand_back {
+    cc_ctx *c;
+    const int *slot;
+    int n;
+    ~hand_back() {
+      for (int i = 0; i < n; i++) c->pts_handed[slot[i]] = false;
+      c->pts_cv.notify_all();
+    }
+  } hb{c, slot, n};
+  cc_ctx::Channel &ch = c->chan[c->chan_next];
+  c->chan_next = (c->chan_next + 1) % cc_ctx::NCHAN;
+  // the channel's point buffer, scratch set and descriptor row grow to a batch's size the first time a batch comes by
+  if (ch.d_pts_cap < off[n] || ch.scr.cap < n || !ch.d_desc_tmp) {
+    HIPCHK(hipStreamSynchronize(ch.s));
+    if (ch.d_pts_cap < (int64_t)CC_SCAN_BATCH_MAX * c->pts_cap) {
+      hipFree(ch.d_pts);
+      ch.d_pts = nullptr;
+      ch.d_pts_cap = 0;
+      HIPCHK(hipMalloc(&ch.d_pts, sizeof(float) * 4 * (size_t)c->pts_cap * CC_SCAN_BATCH_MAX));
+      ch.d_pts_cap = (int64_t)CC_SCAN_BATCH_MAX * c->pts_cap;
+    }
+    if (ch.scr.cap < CC_SCAN_BATCH_MAX) {
+      scratch_free(ch.scr);
+      const int rc = scratch_alloc(c, ch.scr, CC_SCAN_BATCH_MAX, CC_SCAN_BATCH_MAX);
+      if (rc != CC_OK) return rc;
+    }
+    if (!ch.d_desc_tmp) HIPCHK(hipMalloc(&ch.d_desc_tmp, sizeof(cc_scan_desc_t) * CC_SCAN_BATCH_MAX));
+  }
+  for (int i = 0; i < n; i++) {
+    HIPCHK(hipMemcpyAsync(ch.d_pts + 4 * (size_t)off[i], c->h_pts[slot[i]], sizeof(float) * 4 * (size_t)n_points[i], hipMemcpyHostToDevice, ch.s));
+    HIPCHK(hipEventRecord(c->pts_ev[slot[i]], ch.s));
+    c->pts_busy[slot[i]] = true;
+  }
+  cc_scan *sc[CC_SCAN_BATCH_MAX] = {};
+  cc_desc_out_tab tab;
+  for (int i = 0; i < CC_SCAN_BATCH_MAX; i++) tab.p[i] = nullptr;
+  int n_have = 0;
+  auto give_back = [&](void) {
+    {
+      std::lock_guard<std::mutex> slk(c->slot_mu);
+      for (int i = 0; i < n_have; i++)
+        if (sc[i] && sc[i]->d_desc) c->slot_free.push_back(sc[i]->d_desc);
+    }
+    for (int i = 0; i < n_have; i++) {
+      if (!sc[i]) continue;
+      if (sc[i]->ready) hipEventDestroy(sc[i]->ready);
+      delete sc[i];
+    }
+  };
+  {
+    std::lock_guard<std::mutex> slk(c->slot_mu);
+    for (int i = 0; i < n; i++) {
+      if (c->slot_free.empty()) {
+        size_t have = 0;
+        for (size_t b = 0; b < c->slot_blocks.size(); b++) have += c->slot_block_n[b];
+        const int nblk = (int)(have < 64 ? 64 : (have > 1024 ? 1024 : have));
+        cc_scan_desc_t *blk = nullptr;
+        const hipError_t e_ = hipMalloc(&blk, sizeof(cc_scan_desc_t) * nblk);
+        if (e_ != hipSuccess) {
+          for (int k = 0; k < n_have; k++) {
+            c->slot_free.push_back(sc[k]->d_desc);
+            delete sc[k];
+          }
+          return set_err(CC_EHIP, "cc_scan_ingest_batch: descriptor slots", e_);
+        }
+        c->slot_blocks.push_back(blk);
+        c->slot_block_n.push_back(nblk);
+        for (int k = nblk - 1; k >= 0; k--) c->slot_free.push_back(blk + k);
+      }
+      sc[i] = new cc_scan();
+      sc[i]->ctx = c;
+      sc[i]->d_desc = c->slot_free.back();
+      c->slot_free.pop_back();
+      tab.p[i] = sc[i]->d_desc;
+      n_have = i + 1;
+    }
+  }
+  const int rc = ingest_on(c, ch.scr, ch.d_pts, off, n, ch.d_desc_tmp, nullptr, ch.s);
+  if (rc != CC_OK) {
+    give_back();
+    return rc;
+  }
+  hipLaunchKernelGGL(cc_k_scatter_desc, dim3(n * CC_SCATTER_BLOCKS), dim3(256), 0, ch.s, tab, n, (const cc_scan_desc_t *)ch.d_desc_tmp);
+  hipError_t e_ = hipGetLastError();
+  for (int i = 0; i < n && e_ == hipSuccess; i++) {
+    e_ = hipEventCreateWithFlags(&sc[i]->ready, hipEventDisableTiming);
+    if (e_ == hipSuccess) e_ = hipEventRecord(sc[i]->ready, ch.s);
+  }
+  if (e_ != hipSuccess) {
+    hipStreamSynchronize(ch.s);  // the queued kernels write the slots
+    give_back();
+    return set_err(CC_EHIP, "cc_scan_ingest_batch: launch / ready events", e_);
+  }
+  for (int i = 0; i < n; i++) out[i] = sc[i];
+  return CC_OK;
+}
+
+// 1: the scan's ingest has finished on the device (its descriptor can be read without waiting), 0: still in flight
+int cc_scan_ready(const cc_scan *sc) {
+  if (!sc) return 0;
+  if (!sc->ready) return 1;
+  hipSetDevice(sc->ctx->device);
+  const hipError_t e_ = hipEventQuery(sc->ready);
+  if (e_ != hipSuccess) (void)hipGetLastError();
+  return e_ == hipSuccess ? 1 : 0;
 }
 
 // the loop stream (or the host) behind the scan's ingest

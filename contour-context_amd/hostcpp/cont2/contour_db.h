@@ -63,27 +63,39 @@ class ContourDB {
     double ts = 0;
     int seed = 0;
     cc_score_t lb, ub;
-    std::unique_ptr<cc_query_result_t> res;  // queued at epoch = position of the scan; filled by cc_db_query_wait
+    std::shared_ptr<std::vector<cc_query_result_t>> block;  // the answers of the batch the scan was queued with (epoch = position of the scan)
+    int idx = 0;                                             // ... this scan's among them; filled by cc_db_query_collect / _wait
     bool collected = false;
+    cc_query_result_t *result() const { return block->data() + idx; }
   };
+  static constexpr int SPEC_LOW = 2;  // fewer answers than this queued ahead of the driver: a step goes out with whatever has been published
   mutable std::deque<Spec> spec_;   // scans appended ahead of the driver, oldest first (spec_[j] sits at DB index n_official + j)
   mutable bool have_thres_ = false;
   mutable cc_score_t last_lb_, last_ub_;
   mutable long n_spec_hit_ = 0, n_spec_miss_ = 0, n_rebuild_ = 0;
-  mutable double t_ra_[3] = {0, 0, 0};  // host seconds in the three calls of a read-ahead step (CC_EVAL_TIMERS prints them)
-  mutable long n_ra_ = 0;
+  mutable double t_ra_[2] = {0, 0};  // host seconds in the two calls of a read-ahead step (CC_EVAL_TIMERS prints them)
+  mutable long n_ra_ = 0, n_ra_scans_ = 0;
   mutable bool need_rebuild_ = false;  // the device database holds scans the driver has not added (and will not): rebuilt at the next call
   int hub_token_ = -1;
   static int specDepth() {
     static const int d = [] {
-      // Scans worked ahead (CC_DB_READ_AHEAD=n).  OFF by default: measured on MI355X the loop does not get faster -- the answers
-      // are there when the driver asks (queryRangedKNN 0.22 -> 0.03 ms), but every step now needs the NEWEST published scan,
-      // whose single-scan ingest (~0.25 ms of K1 + K2 on the one ingest stream) becomes the wait: 2 500 -> 1 950 scans/s
-      // (profiles/r5/dropin_read_ahead.txt).  It pays once single-scan ingests overlap (several ingest streams + scratch slots).
+      // Scans worked ahead (CC_DB_READ_AHEAD=n, 0: off).  Round 5, first version (one scan per step, one chain of launches per
+      // scan): the answers were there when the driver asked and the loop got SLOWER (2 500 -> 1 950 scans/s: every step needed
+      // the newest published scan, whose single-scan ingest became the wait).  Batched (a step appends and queries
+      // specBatch() scans with ONE chain each; the evaluator ingests its files eight at a time, cc_scan_ingest_batch):
+      // 3 080 -> 8 200-8 900 scans/s on MI355X (profiles/r5/dropin_batched_read_ahead.txt).  On by default: 16 scans deep.
       const char *e = getenv("CC_DB_READ_AHEAD");
-      return e ? std::max(0, atoi(e)) : 0;
+      return e ? std::max(0, atoi(e)) : 16;
     }();
     return d;
+  }
+  static int specBatch() {  // scans per read-ahead step (CC_DB_READ_AHEAD_BATCH; default: half the depth, at most 8)
+    static const int b = [] {
+      const char *e = getenv("CC_DB_READ_AHEAD_BATCH");
+      const int v = e ? atoi(e) : std::min(8, specDepth() / 2);
+      return std::max(1, std::min({v, CC_SCAN_BATCH_MAX, std::max(1, specDepth())}));
+    }();
+    return b;
   }
   static bool same(const cc_score_t &a, const cc_score_t &b) { return memcmp(&a, &b, sizeof(cc_score_t)) == 0; }
   static void die_cc() {
@@ -121,7 +133,10 @@ class ContourDB {
     spec_.clear();
     need_rebuild_ = true;  // their records are still in the device database: rebuilt when (if) the database is used again
   }
-  // append + queue for the scans the source has published, behind what is there already
+  // append + queue for the scans the source has published, behind what is there already: up to specBatch() scans per step
+  // (ONE append and ONE chain of query launches for all of them: the loop is bound by the number of launches, host and
+  // device side, not by their work).  A step waits until a whole batch has been published unless the queued work is
+  // about to run out.
   void readAhead() const {
     if (specDepth() <= 0 || !have_thres_ || !db_) return;
     const auto up = cc_host::lookahead().snapshot();
@@ -137,31 +152,58 @@ class ContourDB {
       if (!found) return;
     }
     int seed_next = (all_seed_.empty() ? 0 : all_seed_.back() + 1) + (int)spec_.size();  // the driver counts its scans (batch_bin_test.cpp:237)
-    for (; pos < up.size() && (int)spec_.size() < specDepth(); pos++) {
-      const int epoch = cc_db_size(db_);
-      if (epoch + 1 >= capacity_) return;
-      Spec sp;
-      sp.scan = up[pos].scan;
-      sp.ts = up[pos].ts;
-      sp.seed = seed_next++;
-      sp.lb = last_lb_;
-      sp.ub = last_ub_;
-      sp.res.reset(new cc_query_result_t());
-      if (!cc_scan_on_device(sp.scan)) return;
-      // the append's first half (compact records, keys on their way to the host) goes first: by the time the ~20 launches of
-      // the query chain are queued, the commit below finds the keys on the host instead of waiting behind that chain
+    for (;;) {
+      const int room = specDepth() - (int)spec_.size();
+      int n = (int)std::min<size_t>(up.size() - pos, (size_t)std::max(0, std::min(room, specBatch())));
+      const int epoch0 = cc_db_size(db_);
+      n = std::min(n, capacity_ - 1 - epoch0);
+      for (int j = 0; j < n; j++)
+        if (!cc_scan_on_device(up[pos + j].scan)) n = j;
+      if (n <= 0) return;
+      if ((int)spec_.size() > SPEC_LOW) {  // the queue is not about to run dry: a whole batch, and only scans that have ARRIVED
+        if (n < specBatch()) return;       // (a published scan may still be on its way through K1 / K2: the append would wait for it)
+        for (int j = n - 1; j >= 0; j--)
+          if (!cc_scan_ready(up[pos + j].scan)) return;
+      }
+      cc_scan *scans[CC_SCAN_BATCH_MAX];
+      double ts[CC_SCAN_BATCH_MAX];
+      int32_t seed[CC_SCAN_BATCH_MAX], epoch[CC_SCAN_BATCH_MAX];
+      auto block = std::make_shared<std::vector<cc_query_result_t>>((size_t)n);
+      for (int j = 0; j < n; j++) {
+        scans[j] = up[pos + j].scan;
+        ts[j] = up[pos + j].ts;
+        seed[j] = seed_next++;
+        epoch[j] = epoch0 + j;  // scan j's query sees the database as it is after the scans before it (an epoch hides the later ones)
+      }
       TicToc t0;
-      if (cc_db_add_scan_prepare(db_, sp.scan) != CC_OK) die_cc();
+      if (cc_db_add_scan_batch(db_, scans, n, ts, seed) != CC_OK) die_cc();
       t_ra_[0] += t0.toc();
       TicToc t1;
-      if (cc_db_query_scan_submit(db_, sp.scan, epoch, &sp.lb, &sp.ub, sp.res.get()) != CC_OK) die_cc();
+      if (cc_db_query_scan_batch_submit(db_, scans, n, epoch, &last_lb_, &last_ub_, block->data()) != CC_OK) die_cc();
       t_ra_[1] += t1.toc();
-      TicToc t2;
-      if (cc_db_add_scan(db_, sp.scan, sp.ts, sp.seed) != CC_OK) die_cc();
-      t_ra_[2] += t2.toc();
       n_ra_++;
-      spec_.push_back(std::move(sp));
+      n_ra_scans_ += n;
+      for (int j = 0; j < n; j++) {
+        Spec sp;
+        sp.scan = scans[j];
+        sp.ts = ts[j];
+        sp.seed = seed[j];
+        sp.lb = last_lb_;
+        sp.ub = last_ub_;
+        sp.block = block;
+        sp.idx = j;
+        spec_.push_back(std::move(sp));
+      }
+      pos += (size_t)n;
     }
+  }
+  // the answer of spec_[i] on the host (its whole batch's chain is waited for; batches queued behind it stay in flight)
+  void collectOne(size_t i) const {
+    Spec &sp = spec_[i];
+    if (sp.collected) return;
+    if (cc_db_query_collect(db_, sp.result(), 1) != CC_OK) die_cc();
+    for (auto &o : spec_)
+      if (o.block == sp.block) o.collected = true;
   }
 
   static cc_score_t to_c(const CandidateScoreEnsemble &e) {
@@ -205,6 +247,7 @@ class ContourDB {
  public:
   explicit ContourDB(const ContourDBConfig &config, int capacity_scans = 65536) : cfg_(config), capacity_(capacity_scans) {
     CC_CHECK(!cfg_.q_levels_.empty());
+    cc_host::runtime_warm();
     if (specDepth() > 0) hub_token_ = cc_host::lookahead().subscribe([this] { dropReadAhead(); });
   }
   ContourDB(const ContourDB &) = delete;
@@ -214,8 +257,8 @@ class ContourDB {
     if (getenv("CC_EVAL_TIMERS"))
     {
       if (n_ra_ > 0)
-        fprintf(stderr, "[ContourDB read-ahead, mean host us per step over %ld steps] prepare %.1f  query submit %.1f  append commit %.1f\n", n_ra_,
-                1e6 * t_ra_[0] / n_ra_, 1e6 * t_ra_[1] / n_ra_, 1e6 * t_ra_[2] / n_ra_);
+        fprintf(stderr, "[ContourDB read-ahead, mean host us per step over %ld steps of %.1f scans] append %.1f  query submit %.1f\n", n_ra_,
+                (double)n_ra_scans_ / n_ra_, 1e6 * t_ra_[0] / n_ra_, 1e6 * t_ra_[1] / n_ra_);
       fprintf(stderr, "[ContourDB read-ahead] answers handed out from queued queries %ld, launched on the spot %ld, rebuilds %ld\n", n_spec_hit_, n_spec_miss_, n_rebuild_);
     }
     cc_db_destroy(db_);
@@ -240,11 +283,8 @@ class ContourDB {
     if (!spec_.empty() && qh && spec_.front().scan == qh && same(spec_.front().lb, lb) && same(spec_.front().ub, ub)) {
       // the answer was queued when the scan was published (at the epoch the database is officially in now); only ITS chain is
       // waited for, the queries queued behind it stay in flight
-      if (!spec_.front().collected) {
-        if (cc_db_query_collect(db_, spec_.front().res.get(), 1) != CC_OK) die_cc();
-        spec_.front().collected = true;
-      }
-      r = *spec_.front().res;
+      collectOne(0);
+      r = *spec_.front().result();
       n_spec_hit_++;
     } else {
       n_spec_miss_++;
@@ -296,7 +336,7 @@ class ContourDB {
     if (!spec_.empty() && h && spec_.front().scan == h && spec_.front().ts == pending_ts_ && spec_.front().seed == seed) {
       // appended ahead of time, with exactly these arguments.  (Its own query has been handed out, or is no longer wanted:
       // its answer buffer must outlive the chain that writes it.)
-      if (!spec_.front().collected && cc_db_query_collect(db_, spec_.front().res.get(), 1) != CC_OK) die_cc();
+      collectOne(0);
       spec_.pop_front();
     } else {
       if (!spec_.empty()) rebuild();  // the driver left the predicted sequence: back to the scans it really added

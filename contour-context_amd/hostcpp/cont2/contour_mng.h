@@ -152,6 +152,15 @@ inline int device_id() {
   const char *e = getenv("CC_DEVICE");
   return e ? atoi(e) : 0;
 }
+// once per process: the device runtime, the code object and the streams a per-scan driver's context and database will use
+// (cc_runtime_init) -- called by the constructors of ContourDB and of the evaluator mirror, i.e. before a driver's loop
+inline void runtime_warm() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (getenv("CC_NO_RUNTIME_INIT")) return;
+    (void)cc_runtime_init(device_id(), 8);  // no device (the evaluator's bookkeeping alone needs none): whoever uses one reports it
+  });
+}
 inline cc_ctx *context(const cc_manager_cfg_t &m) {
   static std::map<std::string, cc_ctx *> pool;
   static std::mutex pool_mu;  // drivers with several worker threads build ContourManagers of one configuration concurrently

@@ -7,6 +7,7 @@
 //   outcome   : `tfpn \t tgt-src \t correlation \t err_x \t err_y \t err_theta \t tgt_path \t src_path` (`x` = no candidate)
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -77,10 +78,101 @@ class ContLCDEvaluator {
   const double sim_thres;             // similarity at or above which a prediction counts as positive
   int p_lidar_curr = -1;
   // The scans ahead of the driver's position on their way: file -> pinned staging buffer -> device (getCurrContourManager).
-  // One helper thread for the evaluator's lifetime runs up to AHEAD scans ahead of the scan the driver holds; what it has
+  // One helper thread for the evaluator's lifetime runs up to ahead() scans ahead of the scan the driver holds; what it has
   // finished waits in `ready`, in address order.
   struct Prefetch {
-    static constexpr int AHEAD = 4;  // scans in flight ahead of the driver (staging buffers: scan `addr` goes through slot addr & 1, reused when its copy has passed)
+    // Scans in flight ahead of the driver (env CC_EVAL_AHEAD, 1..64; default four ingest batches).  The helper works in
+    // BATCHES of up to ingestBatch() scans (env CC_EVAL_INGEST_BATCH, 1..CC_SCAN_BATCH_MAX, default 8): their files are read in
+    // parallel by readers() threads (env CC_EVAL_READERS, default 4; a 1.9 MB KITTI file takes ~0.15 ms to read into pinned
+    // memory, four threads bring a batch of eight over in ~0.4 ms) and go to the device as ONE launch chain (cc_scan_ingest_batch) -- a scan's own chain takes ~0.2 ms of launch
+    // latencies whatever it holds.  Staging buffers: scan `addr` goes through slot addr % (2 * CC_SCAN_BATCH_MAX), reused
+    // when its copy has passed.
+    static int envInt(const char *name, int lo, int hi, int dflt) {
+      const char *e = getenv(name);
+      return e ? std::min(hi, std::max(lo, atoi(e))) : dflt;
+    }
+    static int ingestBatch() {
+      static const int b = envInt("CC_EVAL_INGEST_BATCH", 1, CC_SCAN_BATCH_MAX, 8);
+      return b;
+    }
+    static int ahead() {
+      static const int a = envInt("CC_EVAL_AHEAD", 1, 64, std::max(4, 4 * ingestBatch()));
+      return a;
+    }
+    static int readers() {
+      static const int r = envInt("CC_EVAL_READERS", 1, 8, 4);
+      return r;
+    }
+    struct ReadJob {
+      const std::string *path = nullptr;
+      float *dst = nullptr;
+      size_t cap = 0, n = 0;
+      bool opened = false;
+    };
+    std::vector<std::thread> rd;  // readers() - 1 threads next to the helper, which reads too
+    std::mutex rmu;
+    std::condition_variable rcv;
+    std::deque<ReadJob *> rq;  // under rmu
+    int r_open = 0;            // jobs of the current batch not finished yet (under rmu)
+    bool r_quit = false;
+    std::atomic<long> job_ns{0}, job_n{0};  // tuning aid: time inside the reads themselves
+    void readOne(ReadJob &j) {
+      const auto t0 = std::chrono::steady_clock::now();
+      FILE *f = fopen(j.path->c_str(), "rb");
+      j.opened = f != nullptr;
+      j.n = f ? fread(j.dst, 4 * sizeof(float), j.cap, f) : 0;
+      if (f) fclose(f);
+      job_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      job_n++;
+    }
+    void readerLoop() {
+      for (;;) {
+        std::unique_lock<std::mutex> lk(rmu);
+        rcv.wait(lk, [this] { return r_quit || !rq.empty(); });
+        if (r_quit) return;
+        ReadJob *j = rq.front();
+        rq.pop_front();
+        lk.unlock();
+        readOne(*j);
+        lk.lock();
+        if (--r_open == 0) rcv.notify_all();
+      }
+    }
+    // all jobs read, by the pool and the calling thread
+    void readAll(std::vector<ReadJob> &jobs) {
+      while ((int)rd.size() < readers() - 1) rd.emplace_back([this] { readerLoop(); });
+      {
+        std::lock_guard<std::mutex> lk(rmu);
+        for (auto &j : jobs) rq.push_back(&j);
+        r_open = (int)jobs.size();
+      }
+      rcv.notify_all();
+      for (;;) {
+        std::unique_lock<std::mutex> lk(rmu);
+        if (rq.empty()) {
+          rcv.wait(lk, [this] { return r_open == 0; });
+          return;
+        }
+        ReadJob *j = rq.front();
+        rq.pop_front();
+        lk.unlock();
+        readOne(*j);
+        lk.lock();
+        if (--r_open == 0) {
+          rcv.notify_all();
+          return;
+        }
+      }
+    }
+    void stopReaders() {
+      {
+        std::lock_guard<std::mutex> lk(rmu);
+        r_quit = true;
+      }
+      rcv.notify_all();
+      for (auto &t : rd) t.join();
+      rd.clear();
+    }
     enum class Status { OK, MISSING_FILE, TOO_FEW_POINTS, STAGING_FAILED, INGEST_FAILED };
     struct Item {
       int addr = -1;
@@ -99,7 +191,7 @@ class ContLCDEvaluator {
     bool with_images = false;
     std::deque<Item> ready;
     double t_stage = 0, t_read = 0, t_ingest = 0;  // helper seconds (CC_EVAL_TIMERS=1 prints them when the evaluator goes)
-    long n_done = 0;
+    long n_done = 0, n_batches = 0;
     double t_wait = 0, t_call = 0;  // driver thread: waiting for the helper's item / the whole getCurrContourManager call
     long n_call = 0;
   };
@@ -110,6 +202,7 @@ class ContLCDEvaluator {
 
  public:
   ContLCDEvaluator(const std::string &fpath_pose, const std::string &fpath_laser, const double &bar) : sim_thres(bar) {
+    cc_host::runtime_warm();
     // 1. stamped ground-truth poses, sorted by time
     std::ifstream f_pose(fpath_pose);
     if (!f_pose.good()) {
@@ -240,7 +333,7 @@ class ContLCDEvaluator {
         Prefetch::Item it = std::move(pf_.ready.front());
         pf_.ready.pop_front();
         if (it.scan) cc_host::lookahead().popFront(it.scan);  // the driver's from here on
-        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::ahead());
         lk.unlock();
         pf_.cv.notify_all();
         switch (it.status) {  // what the reference does at the same points (evaluator.h:285-302, contour_mng.h:507)
@@ -292,7 +385,7 @@ class ContLCDEvaluator {
           pf_.ctx = ctx;
           pf_.with_images = with_images;
           pf_.next = p_lidar_curr + 1;
-          pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::AHEAD);
+          pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::ahead());
         }
         if (!pf_.th.joinable()) pf_.th = std::thread([this, cap] { prefetchLoop(cap); });
         pf_.cv.notify_all();
@@ -312,66 +405,118 @@ class ContLCDEvaluator {
       pf_.cv.notify_all();
       pf_.th.join();
     }
+    pf_.stopReaders();
     cc_host::lookahead().invalidate();
     for (auto &it : pf_.ready)
       if (it.scan) cc_scan_release(it.scan);
     if (getenv("CC_EVAL_TIMERS") && pf_.n_done > 0)
-      fprintf(stderr, "[evaluator helper, mean us over %ld scans] staging buffer %.1f  file read %.1f  cc_scan_ingest %.1f | driver thread: wait for the helper %.1f of %.1f per getCurrContourManager (the first call creates the context)\n",
-              pf_.n_done, 1e6 * pf_.t_stage / pf_.n_done, 1e6 * pf_.t_read / pf_.n_done, 1e6 * pf_.t_ingest / pf_.n_done,
-              1e6 * pf_.t_wait / std::max(1L, pf_.n_call), 1e6 * pf_.t_call / std::max(1L, pf_.n_call));
+      fprintf(stderr, "[evaluator helper, mean us PER SCAN over %ld scans in %ld batches] staging buffer %.1f  file read %.1f  cc_scan_ingest %.1f | driver thread: wait for the helper %.1f of %.1f per getCurrContourManager (the first call creates the context); one file's read took %.1f us\n",
+              pf_.n_done, pf_.n_batches, 1e6 * pf_.t_stage / pf_.n_done, 1e6 * pf_.t_read / pf_.n_done, 1e6 * pf_.t_ingest / pf_.n_done,
+              1e6 * pf_.t_wait / std::max(1L, pf_.n_call), 1e6 * pf_.t_call / std::max(1L, pf_.n_call), 1e-3 * pf_.job_ns / std::max(1L, pf_.job_n.load()));
   }
 
  private:
   void prefetchLoop(size_t cap) const {
     Prefetch &pf = pf_;
+    const int n_scans = (int)laser_info_.size();
     for (;;) {
       std::unique_lock<std::mutex> lk(pf.mu);
-      pf.cv.wait(lk, [&pf] { return pf.quit || (pf.next >= 0 && pf.next < pf.limit && (int)pf.ready.size() < Prefetch::AHEAD); });
+      int nb = 0;
+      // a batch goes out when a whole one fits ahead of the driver -- or with whatever fits when little is queued (the driver
+      // is about to wait) or the list ends
+      pf.cv.wait(lk, [&] {
+        if (pf.quit) return true;
+        if (pf.next < 0 || pf.next >= pf.limit) return false;
+        const int want = std::min(pf.limit - pf.next, Prefetch::ahead() - (int)pf.ready.size());
+        const int ib = pf.with_images ? 1 : Prefetch::ingestBatch();  // a scan that keeps its image goes alone (cc_scan_ingest)
+        if (want <= 0) return false;
+        if (want < ib && (int)pf.ready.size() >= 2 && pf.limit < n_scans) return false;
+        nb = std::min(want, ib);
+        return true;
+      });
       if (pf.quit) return;
-      Prefetch::Item it;
-      it.addr = pf.next;
+      const int first = pf.next;
       cc_ctx *ctx = pf.ctx;
       const bool with_images = pf.with_images;
       pf.busy = true;
       lk.unlock();
-      // the slot's previous occupant is scan addr - 2: its copy to the device was queued long ago and is waited for here
+      // a slot's previous occupant is scan addr - 2 * CC_SCAN_BATCH_MAX: its copy to the device was queued long ago and is waited for here
       const auto t0 = std::chrono::steady_clock::now();
-      float *dst = cc_stage_points_slot(ctx, (int64_t)cap, it.addr & 1);
-      const auto t1 = std::chrono::steady_clock::now();
-      auto t2 = t1, t3 = t1;
-      if (!dst) {
-        it.status = Prefetch::Status::STAGING_FAILED;
-        it.err = cc_last_error();  // the message is per thread
-      } else {
-        FILE *f = fopen(laser_info_[it.addr].fpath.c_str(), "rb");
-        it.n = f ? fread(dst, 4 * sizeof(float), cap, f) : 0;
-        if (f) fclose(f);
-        t2 = std::chrono::steady_clock::now();
-        if (!f)
-          it.status = Prefetch::Status::MISSING_FILE;
-        else if (it.n <= 10)
-          it.status = Prefetch::Status::TOO_FEW_POINTS;
-        else if (cc_scan_ingest(ctx, dst, (int64_t)it.n, with_images ? 1 : 0, &it.scan) != CC_OK) {
-          it.scan = nullptr;
-          it.status = Prefetch::Status::INGEST_FAILED;
-          it.err = cc_last_error();
+      std::vector<Prefetch::Item> items((size_t)nb);
+      std::vector<Prefetch::ReadJob> jobs;
+      std::vector<float *> dst((size_t)nb, nullptr);
+      int n_staged = 0;
+      for (int j = 0; j < nb; j++) {
+        items[j].addr = first + j;
+        dst[j] = cc_stage_points_slot(ctx, (int64_t)cap, (first + j) % (2 * CC_SCAN_BATCH_MAX));
+        if (!dst[j]) {
+          items[j].status = Prefetch::Status::STAGING_FAILED;
+          items[j].err = cc_last_error();  // the message is per thread
+          break;
         }
-        if (it.status != Prefetch::Status::OK && it.status != Prefetch::Status::INGEST_FAILED) cc_stage_points_cancel(ctx, dst);
-        t3 = std::chrono::steady_clock::now();
+        n_staged = j + 1;
       }
+      const auto t1 = std::chrono::steady_clock::now();
+      jobs.resize((size_t)n_staged);
+      for (int j = 0; j < n_staged; j++) {
+        jobs[j].path = &laser_info_[first + j].fpath;
+        jobs[j].dst = dst[j];
+        jobs[j].cap = cap;
+      }
+      if (n_staged > 0) pf.readAll(jobs);
+      const auto t2 = std::chrono::steady_clock::now();
+      // the scans up to the first one that cannot be ingested go to the device together; that one is reported when the driver
+      // gets there (the reference stops there: evaluator.h:285-302, contour_mng.h:507); what was staged behind it is given back
+      int n_good = 0;
+      for (int j = 0; j < n_staged; j++) {
+        items[j].n = jobs[j].n;
+        if (!jobs[j].opened)
+          items[j].status = Prefetch::Status::MISSING_FILE;
+        else if (jobs[j].n <= 10)
+          items[j].status = Prefetch::Status::TOO_FEW_POINTS;
+        if (items[j].status != Prefetch::Status::OK) break;
+        n_good = j + 1;
+      }
+      int n_items = n_good;  // items that will be queued
+      if (n_good < nb) n_items = n_good + 1;
+      if (n_good > 0) {
+        cc_scan *sc[CC_SCAN_BATCH_MAX] = {};
+        int rc;
+        if (n_good == 1) {
+          rc = cc_scan_ingest(ctx, dst[0], (int64_t)items[0].n, with_images ? 1 : 0, &sc[0]);
+        } else {
+          int64_t np[CC_SCAN_BATCH_MAX];
+          for (int j = 0; j < n_good; j++) np[j] = (int64_t)items[j].n;
+          rc = cc_scan_ingest_batch(ctx, dst.data(), np, n_good, sc);
+        }
+        if (rc != CC_OK) {  // nothing of the batch was ingested: its first scan carries the error
+          items[0].status = Prefetch::Status::INGEST_FAILED;
+          items[0].err = cc_last_error();
+          n_items = 1;
+          n_good = 0;
+        } else {
+          for (int j = 0; j < n_good; j++) items[j].scan = sc[j];
+        }
+      }
+      for (int j = n_good; j < n_staged; j++) cc_stage_points_cancel(ctx, dst[j]);  // (a no-op for buffers an ingest call has taken)
+      const auto t3 = std::chrono::steady_clock::now();
       lk.lock();
       pf.t_stage += std::chrono::duration<double>(t1 - t0).count();
       pf.t_read += std::chrono::duration<double>(t2 - t1).count();
       pf.t_ingest += std::chrono::duration<double>(t3 - t2).count();
-      pf.n_done++;
+      pf.n_done += n_items;
+      pf.n_batches++;
       pf.busy = false;
-      if (pf.next == it.addr) {  // still wanted (the driver did not jump meanwhile)
-        if (it.scan) cc_host::lookahead().push(it.scan, laser_info_[it.addr].ts);
-        pf.ready.push_back(std::move(it));
-        pf.next++;
-      } else if (it.scan) {
+      if (pf.next == first) {  // still wanted (the driver did not jump meanwhile)
+        for (int j = 0; j < n_items; j++) {
+          if (items[j].scan) cc_host::lookahead().push(items[j].scan, laser_info_[first + j].ts);
+          pf.ready.push_back(std::move(items[j]));
+        }
+        pf.next += n_items;
+      } else {
         lk.unlock();
-        cc_scan_release(it.scan);
+        for (int j = 0; j < n_items; j++)
+          if (items[j].scan) cc_scan_release(items[j].scan);
         lk.lock();
       }
       lk.unlock();

@@ -236,6 +236,13 @@ typedef struct cc_db cc_db;   /* opaque: device-resident scan descriptors + key 
 const char *cc_last_error(void);
 int cc_version(void);
 
+/* Optional: start the device runtime, load the code object and put n_streams (0..32) streams into the per-device pool that
+ * contexts and databases take theirs from.  Measured on MI355X / ROCm 7.2: first HIP call ~54 ms, code object 5-20 ms, a
+ * stream 3.4-16 ms (a per-scan driver's context + database use 4-7).  A host that calls this when it starts (the class
+ * mirror's ContourDB and evaluator constructors do) keeps those one-off costs out of its first scan.  Not calling it
+ * changes nothing but when they are paid. */
+int cc_runtime_init(int device, int n_streams);
+
 /* Replaces ContourManager::ContourManager (contour_mng.h:478-498): validates the config
  * (n_row,n_col even, <= 150x150, 6 increasing levels) and allocates per-device scratch. */
 int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_ctx **out);
@@ -286,7 +293,7 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  *                      failure.  The buffer belongs to the CALLING THREAD until that thread passes it to cc_scan_ingest
  *                      (or gives it up: cc_stage_points_cancel, or stages the same slot again); another thread that asks for
  *                      the same slot meanwhile waits.  cc_stage_points uses a slot of its own; cc_stage_points_slot names
- *                      slot 0 or 1 -- two more buffers, so that the next scan's file can be read into one while the other's
+ *                      slot 0 .. 2 * CC_SCAN_BATCH_MAX - 1 (each allocated when first asked for) -- so that the next scan's file can be read into one while the other's
  *                      scan is on its way to the device (a read-ahead thread alternates them, the driver thread's
  *                      cc_stage_points never collides with it); a slot is handed out again once ITS last copy has passed
  *                      (readKITTIPointCloudBin of scan i+1 next to queryRangedKNN of scan i, tools/pointcloud_util.h:9-47,
@@ -301,11 +308,18 @@ int cc_ingest_host_bev(cc_ctx *ctx, const float *h_xyzi, const int64_t *h_offset
  *                      mirror keeps the descriptors of the last CC_SCANS_ON_DEVICE = 8 192 added scans on the device --
  *                      169 KB each -- and offloads the oldest beyond that: a copy + sync per scan the loop does not need)
  *   cc_scan_release  : free the handle (waits for the scan's ingest and for queued readers of its slot) */
+#define CC_SCAN_BATCH_MAX 16 /* scans per cc_scan_ingest_batch / cc_db_add_scan_batch / cc_db_query_scan_batch_submit */
 typedef struct cc_scan cc_scan;
 float *cc_stage_points(cc_ctx *ctx, int64_t n_points);
 float *cc_stage_points_slot(cc_ctx *ctx, int64_t n_points, int slot);
 int cc_stage_points_cancel(cc_ctx *ctx, const float *staged);
 int cc_scan_ingest(cc_ctx *ctx, const float *h_xyzi, int64_t n_points, int want_bev, cc_scan **out);
+/* cc_scan_ingest (want_bev = 0) for 1..CC_SCAN_BATCH_MAX scans at once: h_xyzi[i] must be staging buffers (cc_stage_points_slot,
+ * distinct slots) in the calling thread's hands; ONE K1 / K2 launch chain for the batch (a chain takes ~0.2 ms of launch
+ * latencies whatever it holds), out[i] are ordinary scan handles.  All or nothing: on an error no handle is returned.
+ * cc_scan_ready: 1 once the scan's ingest has finished on the device, 0 while it is in flight (never blocks). */
+int cc_scan_ingest_batch(cc_ctx *ctx, const float *const *h_xyzi, const int64_t *n_points, int n, cc_scan **out);
+int cc_scan_ready(const cc_scan *scan);
 int cc_scan_desc(cc_scan *scan, const cc_scan_desc_t **h_desc);
 int cc_scan_bev(cc_scan *scan, const float **h_bev);
 int cc_scan_offload(cc_scan *scan);
@@ -399,6 +413,16 @@ int cc_db_query_collect(cc_db *db, const cc_query_result_t *h_res, int n);
 /* cc_db_add_scans_prepare (the asynchronous first half of an append) for a scan handle; cc_db_add_scan on the same scan
  * later only commits. */
 int cc_db_add_scan_prepare(cc_db *db, cc_scan *scan);
+
+/* cc_db_add_scan and cc_db_query_scan_submit for 1..CC_SCAN_BATCH_MAX scan handles at a time: scans[i] is appended with
+ * (h_ts[i], h_seed[i]) in the order given; scans[i] is queried at h_epoch[i] (0 .. cc_db_size), its answer goes to h_res[i]
+ * (cc_db_query_collect / cc_db_query_wait).  The answers are those of the same calls made one by one; what changes is the
+ * number of launches: one chain per batch.  A per-scan driver that knows its next B scans appends them in one call and then
+ * queues each one's query at its own position (scan k at epoch k sees the database as it was after k scans): the class
+ * mirror's read-ahead does (hostcpp/cont2/contour_db.h). */
+int cc_db_add_scan_batch(cc_db *db, cc_scan *const *scans, int n, const double *h_ts, const int32_t *h_seed);
+int cc_db_query_scan_batch_submit(cc_db *db, cc_scan *const *scans, int n, const int32_t *h_epoch, const cc_score_t *thres_lb,
+                                  const cc_score_t *thres_ub, cc_query_result_t *h_res);
 
 /* The two batched calls with host descriptor buffers (one H2D copy each): for drivers that keep descriptors on the host,
  * e.g. an offline replay of a whole sequence (all scans added, then scan i queried against epoch i). */

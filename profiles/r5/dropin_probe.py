@@ -1,5 +1,5 @@
 """Tuning aid: the drop-in per-scan loop (bench.py:dropin_loop = hostcpp/examples/batch_bin_test on 1 024 .bin files) under
-different settings of the mirror's read-ahead.   python profiles/r5/dropin_probe.py "0,1,3" """
+different settings of the mirror's read-ahead.   python profiles/r5/dropin_probe.py "0,1,3" ["4,8,16"]   (read-ahead depths, evaluator look-ahead) """
 import json
 import os
 import sys
@@ -16,8 +16,10 @@ n = 1024
 x, _, _ = cc.synth.make_sequence(n, world=cc.synth.World(), device=torch.device("cuda", 0), start=5000, beams=64, azim=1875)
 P = x.shape[1]
 b0 = x.reshape(-1, 4).contiguous()
-for ra in (sys.argv[1] if len(sys.argv) > 1 else "0,3").split(","):
-    os.environ["CC_DB_READ_AHEAD"] = ra
-    d = bench.dropin_loop(b0, P, n)
-    d.pop("what", None)
-    print("CC_DB_READ_AHEAD=%s %s" % (ra, json.dumps(d)), flush=True)
+for ahead in (sys.argv[2] if len(sys.argv) > 2 else "4").split(","):
+    os.environ["CC_EVAL_AHEAD"] = ahead
+    for ra in (sys.argv[1] if len(sys.argv) > 1 else "0,3").split(","):
+        os.environ["CC_DB_READ_AHEAD"] = ra
+        d = bench.dropin_loop(b0, P, n)
+        d.pop("what", None)
+        print("CC_EVAL_AHEAD=%s CC_DB_READ_AHEAD=%s %s" % (ahead, ra, json.dumps(d)), flush=True)

@@ -323,6 +323,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hi
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0;
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
@@ -351,6 +352,8 @@ static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess
 static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+struct hipFuncAttributes { int numRegs = 0; size_t sharedSizeBytes = 0; };
+static inline hipError_t hipFuncGetAttributes(hipFuncAttributes *, const void *) { return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) emu::launch(kernel, (grid).x, (block).x, (size_t)(smem), __VA_ARGS__)
 
 namespace emu {

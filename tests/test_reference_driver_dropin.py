@@ -125,12 +125,14 @@ def test_database_read_ahead_survives_any_driver(cc, tmp_path, mode):
             f.write("%.6f %d %s\n" % (ts[i], i, p))
             g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
     outs = []
-    for ra in ("3", "0"):
-        env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_DB_READ_AHEAD=ra, CC_EVAL_TIMERS="1")
+    for ra, ahead in (("8", "12"), ("0", "4"), ("3", "4")):   # depth 8: steps of four scans; depth 3: one scan per step
+        env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_DB_READ_AHEAD=ra, CC_EVAL_AHEAD=ahead, CC_EVAL_TIMERS="1")
         r = subprocess.run([exe, str(pos), str(lst), str(mode)], env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
         outs.append(([l for l in r.stdout.splitlines() if l[:1] in "qtd" and not l.startswith("===")], r.stderr))
-    assert outs[0][0] == outs[1][0] and outs[0][0][-1].startswith("done")
+    assert outs[0][0] == outs[1][0] and outs[2][0] == outs[1][0] and outs[0][0][-1].startswith("done")
+    steps = [l for l in outs[0][1].splitlines() if l.startswith("[ContourDB read-ahead, mean")]
+    assert steps and float(__import__("re").search(r"steps of ([0-9.]+) scans", steps[-1]).group(1)) > 1.0, steps   # some steps took several scans (how many depends on how far the helper thread got)
     assert any(l.split()[1] != "-1" for l in outs[0][0] if l.startswith("q")), "the sequence should close loops"
     ra = [l for l in outs[0][1].splitlines() if l.startswith("[ContourDB read-ahead]")]
     hit, miss, rebuilds = [int(v) for v in __import__("re").findall(r"(\d+)", ra[-1])][-3:]
