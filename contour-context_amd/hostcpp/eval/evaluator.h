@@ -6,6 +6,7 @@
 //   scan list : `ts seq path` per line, ordered by ts and seq
 //   outcome   : `tfpn \t tgt-src \t correlation \t err_x \t err_y \t err_theta \t tgt_path \t src_path` (`x` = no candidate)
 #pragma once
+#include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -85,7 +86,7 @@ class ContLCDEvaluator {
     // BATCHES of up to ingestBatch() scans (env CC_EVAL_INGEST_BATCH, 1..CC_SCAN_BATCH_MAX, default 8): their files are read in
     // parallel by readers() threads (env CC_EVAL_READERS, default 4; a 1.9 MB KITTI file takes ~0.15 ms to read into pinned
     // memory, four threads bring a batch of eight over in ~0.4 ms) and go to the device as ONE launch chain (cc_scan_ingest_batch) -- a scan's own chain takes ~0.2 ms of launch
-    // latencies whatever it holds.  Staging buffers: scan `addr` goes through slot addr % (2 * CC_SCAN_BATCH_MAX), reused
+    // latencies whatever it holds.  Staging buffers: scan `addr` goes through slot addr % (2 * ingestBatch()), reused
     // when its copy has passed.
     static int envInt(const char *name, int lo, int hi, int dflt) {
       const char *e = getenv(name);
@@ -102,6 +103,14 @@ class ContLCDEvaluator {
     static int readers() {
       static const int r = envInt("CC_EVAL_READERS", 1, 8, 4);
       return r;
+    }
+    // records a scan file holds, at most what readKITTIPointCloudBin reads (1 000 000 floats); 0 if it cannot be examined.
+    // Staging buffers are pinned memory (~0.2-0.6 ms per MB to allocate on the MI355X host): they are asked for at the
+    // files' size, not at the reader's maximum.
+    static size_t filePoints(const std::string &path, size_t cap) {
+      struct stat st;
+      if (stat(path.c_str(), &st) != 0 || st.st_size <= 0) return 0;
+      return std::min(cap, (size_t)st.st_size / (4 * sizeof(float)));
     }
     struct ReadJob {
       const std::string *path = nullptr;
@@ -365,14 +374,15 @@ class ContLCDEvaluator {
       }
     }
     if (!adopted) {
-      float *dst = cc_stage_points(ctx, (int64_t)cap);  // the driver thread's own slot, never one the helper fills
-      CC_CHECK(dst);
       FILE *f = fopen(info.fpath.c_str(), "rb");
       if (!f) {
         printf("Lidar bin file %s does not exist.\n", info.fpath.c_str());
         exit(-1);
       }
-      const size_t n = fread(dst, 4 * sizeof(float), cap, f);
+      const size_t cap_f = std::max<size_t>(16, Prefetch::filePoints(info.fpath, cap));
+      float *dst = cc_stage_points(ctx, (int64_t)cap_f);  // the driver thread's own slot, never one the helper fills
+      CC_CHECK(dst);
+      const size_t n = fread(dst, 4 * sizeof(float), cap_f, f);
       fclose(f);
       cm->makeBEVFromStaged(dst, n, str_id);
       static const bool read_ahead = [] {  // CC_EVAL_READ_AHEAD=0: every scan is read and ingested by the call that asks for it
@@ -440,15 +450,24 @@ class ContLCDEvaluator {
       const bool with_images = pf.with_images;
       pf.busy = true;
       lk.unlock();
-      // a slot's previous occupant is scan addr - 2 * CC_SCAN_BATCH_MAX: its copy to the device was queued long ago and is waited for here
+      // a slot's previous occupant is scan addr - n_slots: its copy to the device was queued a batch ago and is waited for here
       const auto t0 = std::chrono::steady_clock::now();
       std::vector<Prefetch::Item> items((size_t)nb);
       std::vector<Prefetch::ReadJob> jobs;
       std::vector<float *> dst((size_t)nb, nullptr);
+      std::vector<size_t> caps((size_t)nb, 0);
+      const int n_slots = 2 * (with_images ? 1 : Prefetch::ingestBatch());  // one batch is read while the one before it is copied
       int n_staged = 0;
+      // every buffer of the batch is asked for at the batch's largest file: if the context's buffers have to grow (they are all
+      // re-allocated then), that happens at the first request, before a pointer of this batch is held
+      size_t cap_batch = 16;
+      for (int j = 0; j < nb; j++) {
+        caps[j] = std::max<size_t>(16, Prefetch::filePoints(laser_info_[first + j].fpath, cap));  // (a missing file is found by its reader)
+        cap_batch = std::max(cap_batch, caps[j]);
+      }
       for (int j = 0; j < nb; j++) {
         items[j].addr = first + j;
-        dst[j] = cc_stage_points_slot(ctx, (int64_t)cap, (first + j) % (2 * CC_SCAN_BATCH_MAX));
+        dst[j] = cc_stage_points_slot(ctx, (int64_t)cap_batch, (first + j) % n_slots);
         if (!dst[j]) {
           items[j].status = Prefetch::Status::STAGING_FAILED;
           items[j].err = cc_last_error();  // the message is per thread
@@ -461,7 +480,7 @@ class ContLCDEvaluator {
       for (int j = 0; j < n_staged; j++) {
         jobs[j].path = &laser_info_[first + j].fpath;
         jobs[j].dst = dst[j];
-        jobs[j].cap = cap;
+        jobs[j].cap = caps[j];
       }
       if (n_staged > 0) pf.readAll(jobs);
       const auto t2 = std::chrono::steady_clock::now();
