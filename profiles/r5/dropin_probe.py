@@ -16,8 +16,9 @@ n = 1024
 x, _, _ = cc.synth.make_sequence(n, world=cc.synth.World(), device=torch.device("cuda", 0), start=5000, beams=64, azim=1875)
 P = x.shape[1]
 b0 = x.reshape(-1, 4).contiguous()
-for ahead in (sys.argv[2] if len(sys.argv) > 2 else "4").split(","):
-    os.environ["CC_EVAL_AHEAD"] = ahead
+for ahead in (sys.argv[2] if len(sys.argv) > 2 else "default").split(","):
+    if ahead != "default":
+        os.environ["CC_EVAL_AHEAD"] = ahead
     for ra in (sys.argv[1] if len(sys.argv) > 1 else "0,3").split(","):
         os.environ["CC_DB_READ_AHEAD"] = ra
         d = bench.dropin_loop(b0, P, n)

@@ -15,15 +15,17 @@ import bench  # noqa: E402
 import cc_amd  # noqa: E402
 
 cc = cc_amd.load()
-ra = sys.argv[1] if len(sys.argv) > 1 else "0"
-ahead = sys.argv[2] if len(sys.argv) > 2 else "4"
+ra = sys.argv[1] if len(sys.argv) > 1 else "default"
+ahead = sys.argv[2] if len(sys.argv) > 2 else "default"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 x, _, _ = cc.synth.make_sequence(n, world=cc.synth.World(), device=torch.device("cuda", 0), start=5000, beams=64, azim=1875)
 P = x.shape[1]
 b0 = x.reshape(-1, 4).contiguous()
 out = os.path.join(ROOT, "gpurun_out", "dtrace_%s_%s" % (ra, ahead))
-os.environ["CC_DB_READ_AHEAD"] = ra
-os.environ["CC_EVAL_AHEAD"] = ahead
+if ra != "default":
+    os.environ["CC_DB_READ_AHEAD"] = ra
+if ahead != "default":
+    os.environ["CC_EVAL_AHEAD"] = ahead
 os.environ["CC_DROPIN_PREFIX"] = "rocprofv3 --kernel-trace --output-format csv -d %s --" % out
 d = bench.dropin_loop(b0, P, n)
 d.pop("what", None)
