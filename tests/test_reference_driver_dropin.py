@@ -88,62 +88,3 @@ def test_reference_driver_runs_on_the_cpu_harness(cc, oracle, tmp_path):
     timing = (proj / "log" / "timing_cont2.txt").read_text()
     for name in ("make bev", "KNN search", "Constell", "L2 opt", "Update database", "queryRangedKNN (wall)"):
         assert name in timing, timing
-
-
-def test_evaluator_read_ahead_paths_give_the_same_descriptors(cc, tmp_path):
-    """hostcpp/eval/evaluator.h reads and ingests up to two scans ahead on a helper thread; a scan asked for twice, or with
-    the image switch flipped in between, goes the direct way -- same descriptors either way (tests/evaluator_prefetch_check.cpp)."""
-    emu_so = emu_api.build()
-    exe = str(tmp_path / "prefetch_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "evaluator_prefetch_check.cpp"), "-I", os.path.join(PKG, "hostcpp"),
-                           "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so),
-                           "-pthread", "-o", exe])
-    n = 9
-    x, poses, ts = cc.synth.make_sequence(n, world=cc.synth.World(loop_len=40.0), beams=16, azim=450)
-    xs = x.numpy()
-    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
-    with open(lst, "w") as f, open(pos, "w") as g:
-        for i in range(n):
-            p = tmp_path / ("%06d.bin" % i)
-            xs[i].astype(np.float32).tofile(p)
-            f.write("%.6f %d %s\n" % (ts[i], i, p))
-            g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
-    out = subprocess.run([exe, str(pos), str(lst)], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and ("OK %d" % n) in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
-
-
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_database_read_ahead_survives_any_driver(cc, tmp_path, mode):
-    """tests/db_read_ahead_check.cpp: the reference's loop, repeated queries with other thresholds, scans that are never added, a
-    jump in the scan list -- with the mirror's read-ahead on (default) and off (CC_DB_READ_AHEAD=0) every answer is the same."""
-    emu_so = emu_api.build()
-    exe = str(tmp_path / "db_read_ahead_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "db_read_ahead_check.cpp"), "-I", os.path.join(PKG, "hostcpp"),
-                           "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so),
-                           "-pthread", "-o", exe])
-    n = 48
-    x, poses, ts = cc.synth.make_sequence(n, world=cc.synth.World(loop_len=40.0), beams=16, azim=450)
-    ts = ts * 4.0
-    xs = x.numpy()
-    lst, pos = tmp_path / "scans.txt", tmp_path / "poses.txt"
-    with open(lst, "w") as f, open(pos, "w") as g:
-        for i in range(n):
-            p = tmp_path / ("%06d.bin" % i)
-            xs[i].astype(np.float32).tofile(p)
-            f.write("%.6f %d %s\n" % (ts[i], i, p))
-            g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
-    outs = []
-    for ra, ahead in (("8", "12"), ("0", "4"), ("3", "4")):   # depth 8: steps of four scans; depth 3: one scan per step
-        env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_DB_READ_AHEAD=ra, CC_EVAL_AHEAD=ahead, CC_EVAL_TIMERS="1")
-        r = subprocess.run([exe, str(pos), str(lst), str(mode)], env=env, capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
-        outs.append(([l for l in r.stdout.splitlines() if l[:1] in "qtd" and not l.startswith("===")], r.stderr))
-    assert outs[0][0] == outs[1][0] and outs[2][0] == outs[1][0] and outs[0][0][-1].startswith("done")
-    steps = [l for l in outs[0][1].splitlines() if l.startswith("[ContourDB read-ahead, mean")]
-    assert steps and float(__import__("re").search(r"steps of ([0-9.]+) scans", steps[-1]).group(1)) > 1.0, steps   # some steps took several scans (how many depends on how far the helper thread got)
-    assert any(l.split()[1] != "-1" for l in outs[0][0] if l.startswith("q")), "the sequence should close loops"
-    ra = [l for l in outs[0][1].splitlines() if l.startswith("[ContourDB read-ahead]")]
-    hit, miss, rebuilds = [int(v) for v in __import__("re").findall(r"(\d+)", ra[-1])][-3:]
-    assert hit > 0, ra[-1]
-    if mode in (2, 3):
-        assert rebuilds > 0, ra[-1]   # the driver left the predicted sequence: the device database was rebuilt
