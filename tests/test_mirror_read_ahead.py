@@ -51,12 +51,15 @@ def _read_ahead_any_driver(cc, tmp_path, mode, gpu):
     jump in the scan list -- with the mirror's read-ahead in steps of several scans, one scan per step, and off
     (CC_DB_READ_AHEAD=0) every answer is the same."""
     exe = _build(tmp_path, "db_read_ahead_check.cpp", "db_read_ahead_check", gpu)
-    n = 160 if gpu else 48
+    n = 96 if gpu else 48
     lst, pos = _lists(cc, tmp_path, n, 64 if gpu else 16, 1875 if gpu else 450, 4.0, "cuda" if gpu else None)
     outs = []
     # default: 16 deep, steps of eight (evaluator: 32 ahead, ingest batches of eight) | off | depth 8: steps of four | depth 3: one scan per step
-    for env_ra in ({}, {"CC_DB_READ_AHEAD": "0", "CC_EVAL_AHEAD": "4", "CC_EVAL_INGEST_BATCH": "1"}, {"CC_DB_READ_AHEAD": "8", "CC_EVAL_AHEAD": "12"},
-                   {"CC_DB_READ_AHEAD": "3", "CC_EVAL_AHEAD": "4"}):
+    cfgs = [{}, {"CC_DB_READ_AHEAD": "0", "CC_EVAL_AHEAD": "4", "CC_EVAL_INGEST_BATCH": "1"}, {"CC_DB_READ_AHEAD": "8", "CC_EVAL_AHEAD": "12"},
+            {"CC_DB_READ_AHEAD": "3", "CC_EVAL_AHEAD": "4"}]
+    if gpu:
+        cfgs = cfgs[:3]   # (the one-scan-per-step depth is covered on the CPU harness)
+    for env_ra in cfgs:
         env = dict(os.environ, CC_EVAL_TIMERS="1", **env_ra)
         if not gpu:
             env.update(CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6")
