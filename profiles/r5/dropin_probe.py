@@ -1,5 +1,5 @@
 """Tuning aid: the drop-in per-scan loop (bench.py:dropin_loop = hostcpp/examples/batch_bin_test on 1 024 .bin files) under
-different settings of the mirror's read-ahead.   python profiles/r5/dropin_probe.py "0,1,3" ["4,8,16"]   (read-ahead depths, evaluator look-ahead) """
+different settings of the mirror's read-ahead.   python profiles/r5/dropin_probe.py "0,1,3" ["4,8,16"|default] [laps]   (read-ahead depths, evaluator look-ahead, laps over the 1 024 files) """
 import json
 import os
 import sys
@@ -21,6 +21,6 @@ for ahead in (sys.argv[2] if len(sys.argv) > 2 else "default").split(","):
         os.environ["CC_EVAL_AHEAD"] = ahead
     for ra in (sys.argv[1] if len(sys.argv) > 1 else "0,3").split(","):
         os.environ["CC_DB_READ_AHEAD"] = ra
-        d = bench.dropin_loop(b0, P, n)
+        d = bench.dropin_loop(b0, P, n, laps=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
         d.pop("what", None)
         print("CC_EVAL_AHEAD=%s CC_DB_READ_AHEAD=%s %s" % (ahead, ra, json.dumps(d)), flush=True)
