@@ -1038,6 +1038,14 @@ def dropin_loop(batch0, P, n, laps=1):
                 out["scans_per_s"] = n / float(p[3])
             if line.startswith("Construction time:"):   # evaluator + ContourDB constructors: lists, device runtime, stream pool
                 out["construction_s"] = float(p[2])
+        try:   # what the driver decided, scan by scan (outcome file without its two path columns): equal for every read-ahead setting
+            import hashlib
+            h = hashlib.sha1()
+            for line in open(os.path.join(tmp, "outcome.txt")):
+                h.update("\t".join(line.rstrip("\n").split("\t")[:6]).encode() + b"\n")
+            out["outcome_sha1"] = h.hexdigest()
+        except OSError:
+            pass
         if "construction_s" in out and "loop_wall_s" in out:
             out["scans_per_s_with_construction"] = n / (out["loop_wall_s"] + out["construction_s"])
         if "seconds_per_call" in out:

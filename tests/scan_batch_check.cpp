@@ -62,10 +62,11 @@ int main(int argc, char **argv) {
     memcpy(dst, pts[i].data(), pts[i].size() * 4);
     CHK(cc_scan_ingest(ctx, dst, (int64_t)pts[i].size() / 4, 0, &a[i]));
   }
-  // 2. in batches of 1..5 scans, slots walking through the ring
+  // 2. in batches of 1..16 scans, slots walking through the ring
   int slot = 0;
   for (int i0 = 0, round = 0; i0 < n; round++) {
-    const int nb = std::min(n - i0, 1 + round % 5);
+    static const int sizes[7] = {1, 2, 5, 8, 9, CC_SCAN_BATCH_MAX, 3};  // <= 8 scans: K1 split over eight workgroups per scan; more: one each
+    const int nb = std::min(n - i0, sizes[round % 7]);
     const float *src[CC_SCAN_BATCH_MAX];
     int64_t np[CC_SCAN_BATCH_MAX];
     for (int j = 0; j < nb; j++) {
@@ -112,7 +113,8 @@ int main(int argc, char **argv) {
     CHK(cc_db_add_scan(d1, a[i], dt * i, i));
   }
   for (int i0 = 0, round = 0; i0 < n; round++) {
-    const int nb = std::min(n - i0, 1 + (round * 3) % 7);
+    static const int steps[6] = {1, 4, 7, CC_SCAN_BATCH_MAX, 2, 8};
+    const int nb = std::min(n - i0, steps[round % 6]);
     double ts[CC_SCAN_BATCH_MAX];
     int32_t seed[CC_SCAN_BATCH_MAX], epoch[CC_SCAN_BATCH_MAX];
     for (int j = 0; j < nb; j++) {
