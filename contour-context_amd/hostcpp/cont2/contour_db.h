@@ -75,6 +75,7 @@ class ContourDB {
   mutable long n_spec_hit_ = 0, n_spec_miss_ = 0, n_rebuild_ = 0;
   mutable double t_ra_[2] = {0, 0};  // host seconds in the two calls of a read-ahead step (CC_EVAL_TIMERS prints them)
   mutable long n_ra_ = 0, n_ra_scans_ = 0;
+  mutable int ra_pause_ = 0, ra_backoff_ = 16;  // driver steps the read-ahead still sits out after a rebuild | the next pause (see rebuild())
   mutable bool need_rebuild_ = false;  // the device database holds scans the driver has not added (and will not): rebuilt at the next call
   int hub_token_ = -1;
   static int specDepth() {
@@ -110,9 +111,15 @@ class ContourDB {
     for (auto &sp : spec_) sp.collected = true;
   }
   // the device database back to the scans the driver has added (all_bevs_): after the driver left the predicted sequence
+  // A rebuild costs one append per scan the driver has added so far (batched, sixteen handles per call): a driver that keeps
+  // leaving the predicted sequence (every fifth scan never added, two databases fed alternately) would pay that again and
+  // again.  So every rebuild PAUSES the read-ahead for ra_backoff_ of the driver's steps and doubles that number: a driver that
+  // deviates at a steady rate meets O(log n) rebuilds, one that deviated once is back to full speed sixteen scans later.
   void rebuild() const {
     n_rebuild_++;
     need_rebuild_ = false;
+    ra_pause_ = ra_backoff_;
+    ra_backoff_ = std::min(ra_backoff_ * 2, 1 << 24);
     if (db_) {
       cc_db_query_wait(db_);
       cc_db_destroy(db_);
@@ -121,9 +128,22 @@ class ContourDB {
     spec_.clear();
     if (all_bevs_.empty()) return;
     ensure(*all_bevs_[0]);
-    for (size_t i = 0; i < all_bevs_.size(); i++) {
-      cc_scan *h = all_bevs_[i]->scanHandle();
-      const int rc = h && cc_scan_on_device(h) ? cc_db_add_scan(db_, h, all_ts_[i], all_seed_[i]) : cc_db_add_scan_host(db_, &all_bevs_[i]->desc(), all_ts_[i], all_seed_[i]);
+    for (size_t i = 0; i < all_bevs_.size();) {
+      cc_scan *hs[CC_SCAN_BATCH_MAX];
+      int n = 0;
+      while (i + n < all_bevs_.size() && n < CC_SCAN_BATCH_MAX) {
+        cc_scan *h = all_bevs_[i + n]->scanHandle();
+        if (!h || !cc_scan_on_device(h)) break;
+        hs[n++] = h;
+      }
+      int rc;
+      if (n > 0) {
+        rc = cc_db_add_scan_batch(db_, hs, n, &all_ts_[i], &all_seed_[i]);
+        i += (size_t)n;
+      } else {  // a scan whose descriptor was moved to the host goes by that copy
+        rc = cc_db_add_scan_host(db_, &all_bevs_[i]->desc(), all_ts_[i], all_seed_[i]);
+        i++;
+      }
       if (rc != CC_OK) die_cc();
     }
   }
@@ -139,6 +159,10 @@ class ContourDB {
   // about to run out.
   void readAhead() const {
     if (specDepth() <= 0 || !have_thres_ || !db_) return;
+    if (ra_pause_ > 0) {  // called once per pushAndBalance: the driver's steps
+      ra_pause_--;
+      return;
+    }
     const auto up = cc_host::lookahead().snapshot();
     // the published scans that are not in spec_ yet must continue it: spec_ = a prefix of (scan in the driver's hands?, upcoming...)
     size_t pos = 0;
