@@ -20,7 +20,14 @@
 #define CC_GMM_ECAP_L CC_MAXC  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat): as many as the descriptor
                                // stores contours, so the correlation has no capacity of its own (round 3: 128 -- a street scene
                                // with ~100 contours on a level keeps up to ~150 ellipses, the KITTI-shaped world showed it)
-#define CC_GMM_G16_MAX_PAIRS 96   // refined by the 16-lane instance up to this many pairs, by the 64-lane instance above,
+// Refined by the 16-lane instance (four problems per wave) up to this many pairs, by the 64-lane instance above.  Rounds 3-5a: 96.
+// Round 5: once the term had lost half of its instructions, an ablation showed the pair arithmetic at 5-10 % of the refinement --
+// what a problem costs is the SERIAL part every lane repeats (L-BFGS recursion, Wolfe search: IEEE divisions, square roots), and
+// four problems share it on a 16-lane wave.  Measured per 1 024 headline queries: 96: 0.456 ms, 192: 0.419, 256: 0.354, 384: 0.358,
+// 768: 0.354; KITTI-shaped (long lists): 0.64 up to 384, 1.06 at 512, 1.16 at 768 (a wave lasts as long as its longest member).
+#ifndef CC_GMM_G16_MAX_PAIRS
+#define CC_GMM_G16_MAX_PAIRS 256
+#endif
 #define CC_GMM_G64_MAX_PAIRS 0x7FFFFFFF  // a 256-lane instance (a workgroup per problem, template value 256 below) exists for lists beyond
                                          // this; measured on KITTI-shaped input (~3 000 pairs x ~40 evaluations per problem) it LOSES: the
                                          // refinement is bound by f64 issue, not by one wave's latency, and four waves repeat the serial
