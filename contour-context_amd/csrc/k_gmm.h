@@ -20,18 +20,27 @@
 #define CC_GMM_ECAP_L CC_MAXC  // ellipses per level kept in a scan's correlation inputs (cc_gmm_feat): as many as the descriptor
                                // stores contours, so the correlation has no capacity of its own (round 3: 128 -- a street scene
                                // with ~100 contours on a level keeps up to ~150 ellipses, the KITTI-shaped world showed it)
-// Refined by the 16-lane instance (four problems per wave) up to this many pairs, by the 64-lane instance above.  Rounds 3-5a: 96.
+// Refined by the 16-lane instance (four problems per wave) up to this many pairs, by the 64-lane instance above CC_GMM_MID_MAX_PAIRS.
 // Round 5: once the term had lost half of its instructions, an ablation showed the pair arithmetic at 5-10 % of the refinement --
 // what a problem costs is the SERIAL part every lane repeats (L-BFGS recursion, Wolfe search: IEEE divisions, square roots), and
-// four problems share it on a 16-lane wave.  Measured per 1 024 headline queries: 96: 0.456 ms, 192: 0.419, 256: 0.354, 384: 0.358,
-// 768: 0.354; KITTI-shaped (long lists): 0.64 up to 384, 1.06 at 512, 1.16 at 768 (a wave lasts as long as its longest member).
+// four problems share it on a 16-lane wave.  Measured per 1 024 headline queries with everything up to N pairs on the 16-lane
+// instance: 96: 0.456 ms, 192: 0.419, 256: 0.354, 384: 0.358, 768: 0.354; KITTI-shaped (long lists): 0.64 up to 384, 1.06 at 512, 1.16 at 768 (a wave lasts as long as its longest member).
 #ifndef CC_GMM_G16_MAX_PAIRS
-#define CC_GMM_G16_MAX_PAIRS 256
+#define CC_GMM_G16_MAX_PAIRS 96
 #endif
-#define CC_GMM_G64_MAX_PAIRS 0x7FFFFFFF  // a 256-lane instance (a workgroup per problem, template value 256 below) exists for lists beyond
-                                         // this; measured on KITTI-shaped input (~3 000 pairs x ~40 evaluations per problem) it LOSES: the
-                                         // refinement is bound by f64 issue, not by one wave's latency, and four waves repeat the serial
-                                         // line-search code (cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk).  Not launched.
+// ... and the problems in between (CC_GMM_G16_MAX_PAIRS < pairs <= CC_GMM_MID_MAX_PAIRS) go where the chunk's problem COUNT says:
+// with few problems to refine (an online sub-batch against a young database: fewer than the chip has wave slots) one wave
+// each spreads them over the SIMDs; with many (the headline: ~8 000 per chunk) four to a wave share the serial code.
+// Measured: everything up to 256 pairs on the 16-lane instance made the online replay 3.5 % slower (297 k against 307-310 k scans/s).
+#ifndef CC_GMM_MID_MAX_PAIRS
+#define CC_GMM_MID_MAX_PAIRS 256
+#endif
+#ifndef CC_GMM_PACK_MIN_PROBLEMS
+#define CC_GMM_PACK_MIN_PROBLEMS 3072   // selected problems of a chunk from which the in-between ones are packed four to a wave
+#endif
+// (A 256-lane instance -- a workgroup per problem, template value 256 below -- exists for very long lists; measured on KITTI-shaped
+// input, ~3 000 pairs x ~40 evaluations per problem, it LOSES: four waves repeat the serial line-search code,
+// cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk.  Not launched.)
 
 struct cc_gmm_result {
   double corr_init;
@@ -990,6 +999,7 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 template <int G>
 __global__ void __launch_bounds__(G == 256 ? 256 : 64) __attribute__((amdgpu_waves_per_eu(2)))
 cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
+                const int *__restrict__ n_mid_p, const int *__restrict__ mid_list, const int *__restrict__ n_other_p,
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
                 cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
   constexpr int NP = G >= 64 ? 1 : 64 / G;  // problems per workgroup
@@ -1002,9 +1012,12 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
   const int sub = threadIdx.x / G, sl = threadIdx.x % G;
   double *hist = hist_all[sub];
   cc_gmm_scan_lds &L = scan_lds[sub];
-  const int n_sel = *n_sel_p;
+  // this instance's own list, then the in-between problems if the chunk's problem count sends them here
+  const int n_own = *n_sel_p, n_mid = *n_mid_p;
+  const bool mid_here = ((n_own + n_mid + *n_other_p) >= CC_GMM_PACK_MIN_PROBLEMS) == (G == 16);
+  const int n_sel = n_own + (mid_here ? n_mid : 0);
   for (int k = blockIdx.x * NP + sub; k < n_sel; k += gridDim.x * NP) {
-    const int pidx = sel_list[k];
+    const int pidx = k < n_own ? sel_list[k] : mid_list[k - n_own];
     cc_gmm_result R = results[pidx];
     if ((float)R.corr_init < corr_lb) continue;
     const cc_gmm_problem pb = probs[pidx];
@@ -1250,15 +1263,16 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
   const int n = cc_tidy_order(nc, has, idx, scr, perm_tab, lane);
   if (n <= 0) return;
   const int pre = max_fine_opt < n ? max_fine_opt : n;
-  // three lists by pair count: the 16-lane refinement instance, the 64-lane one, the 256-lane one
+  // three lists by pair count: the 16-lane refinement instance, the 64-lane one, and the problems in between, which go to
+  // one or the other by the chunk's problem count (cc_k_gmm_refine)
   // (one atomic per list and query, not one per problem: same-address atomics are served one after the other)
   const unsigned long long lt = (1ull << lane) - 1ull;
   int n_big = 0, n_wide = 0;
   for (int i0 = 0; i0 < pre; i0 += 64) {
     const int i = i0 + lane;
     const int np = i < pre ? gres[gm[idx[i]]].n_pairs : 0;
-    n_big += __popcll(__ballot(np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_G64_MAX_PAIRS));
-    n_wide += __popcll(__ballot(np > CC_GMM_G64_MAX_PAIRS));
+    n_big += __popcll(__ballot(np > CC_GMM_MID_MAX_PAIRS));
+    n_wide += __popcll(__ballot(np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_MID_MAX_PAIRS));
   }
   const int n_small = pre - n_big - n_wide;
   if (lane == 0) {
@@ -1272,7 +1286,8 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
     const int i = i0 + lane;
     const int g = i < pre ? gm[idx[i]] : 0;
     const int np = i < pre ? gres[g].n_pairs : 0;
-    const bool wide = i < pre && np > CC_GMM_G64_MAX_PAIRS, big = i < pre && !wide && np > CC_GMM_G16_MAX_PAIRS, small = i < pre && !wide && !big;
+    const bool wide = i < pre && np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_MID_MAX_PAIRS /* the in-between list */, big = i < pre && np > CC_GMM_MID_MAX_PAIRS,
+               small = i < pre && !wide && !big;
     const unsigned long long mw = __ballot(wide), mbig = __ballot(big), msm = __ballot(small);
     if (wide) sel_list[2 * (size_t)sel_stride + o_wide + __popcll(mw & lt)] = g;
     if (big) sel_list[(size_t)sel_stride + o_big + __popcll(mbig & lt)] = g;
