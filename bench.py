@@ -977,7 +977,7 @@ def measure_config(cc, ctx, dev, wld, n_db, B, K, W, P, first_query=None, rec=No
     return out, rec
 
 
-def dropin_loop(batch0, P, n, laps=1):
+def dropin_loop(batch0, P, n, laps=1, reps=3):
     """The reference's per-scan driver loop through the C++ class mirror (hostcpp/examples/batch_bin_test.cpp: the
     reference's test/batch_bin_test.cpp without ROS, same ContourManager / ContourDB calls): n KITTI-format .bin files are
     read one by one, makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance per scan, DB empty at the
@@ -1015,46 +1015,60 @@ def dropin_loop(batch0, P, n, laps=1):
         cfg = cfg.replace("/path/to/ts-lidar_bins-kitti08.txt", os.path.join(tmp, "scans.txt"))
         cfg = cfg.replace("/path/to/outcome-kitti08.txt", os.path.join(tmp, "outcome.txt"))
         open(os.path.join(tmp, "cfg.yaml"), "w").write(cfg)
-        t0 = time.perf_counter()
-        prefix = os.environ.get("CC_DROPIN_PREFIX", "").split()   # tuning aid: e.g. a rocprofv3 command line in front of the driver
-        r = subprocess.run(prefix + [exe, os.path.join(tmp, "cfg.yaml")], capture_output=True, text=True, timeout=600)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            return {"error": "driver exit code %d: %s" % (r.returncode, r.stderr[-300:])}
-        n_files, n = n, n * laps
-        out = {"scans": n, "files": n_files, "what": "hostcpp/examples/batch_bin_test (the reference driver's loop through the class mirror): per scan "
-               ".bin file (tmpfs, in the page cache) -> makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance, DB empty at the start; "
-               "seconds per call = wall clock inside the driver", "process_wall_s": wall}
-        for line in r.stdout.splitlines():
-            p = line.split()
-            for name in ("make bev", "queryRangedKNN (wall)", "Update database"):
-                if name in line and len(p) >= 6:
-                    try:
-                        out.setdefault("seconds_per_call", {})[name] = float(p[-5])
-                    except ValueError:
-                        pass
-            if line.startswith("Loop wall time:"):
-                out["loop_wall_s"] = float(p[3])
-                out["scans_per_s"] = n / float(p[3])
-            if line.startswith("Construction time:"):   # evaluator + ContourDB constructors: lists, device runtime, stream pool
-                out["construction_s"] = float(p[2])
-        try:   # what the driver decided, scan by scan (outcome file without its two path columns): equal for every read-ahead setting
-            import hashlib
-            h = hashlib.sha1()
-            for line in open(os.path.join(tmp, "outcome.txt")):
-                h.update("\t".join(line.rstrip("\n").split("\t")[:6]).encode() + b"\n")
-            out["outcome_sha1"] = h.hexdigest()
-        except OSError:
-            pass
-        if "construction_s" in out and "loop_wall_s" in out:
-            out["scans_per_s_with_construction"] = n / (out["loop_wall_s"] + out["construction_s"])
-        if "seconds_per_call" in out:
-            out["ms_per_scan_three_calls"] = 1e3 * sum(out["seconds_per_call"].values())
-        for line in r.stderr.splitlines():
-            if line.startswith("[evaluator helper"):     # CC_EVAL_TIMERS=1: what the prefetch thread spent per scan
-                out["helper_thread"] = line
-            if line.startswith("[ContourDB read-ahead") or line.startswith("[cc_db appends"):  # CC_EVAL_TIMERS=1 / CC_ADD_TIMERS=1
-                out.setdefault("db_read_ahead", []).append(line)
+        def one_run():
+            t0 = time.perf_counter()
+            prefix = os.environ.get("CC_DROPIN_PREFIX", "").split()   # tuning aid: e.g. a rocprofv3 command line in front of the driver
+            r = subprocess.run(prefix + [exe, os.path.join(tmp, "cfg.yaml")], capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "driver exit code %d: %s" % (r.returncode, r.stderr[-300:])}
+            n_files, n_scans = n, n * laps
+            out = {"scans": n_scans, "files": n_files, "what": "hostcpp/examples/batch_bin_test (the reference driver's loop through the class mirror): per scan "
+                   ".bin file (tmpfs, in the page cache) -> makeBEV + makeContoursRecurs -> queryRangedKNN -> addScan + pushAndBalance, DB empty at the start; "
+                   "seconds per call = wall clock inside the driver; the run with the median loop rate of `scans_per_s_runs`", "process_wall_s": wall}
+            for line in r.stdout.splitlines():
+                p = line.split()
+                for name in ("make bev", "queryRangedKNN (wall)", "Update database"):
+                    if name in line and len(p) >= 6:
+                        try:
+                            out.setdefault("seconds_per_call", {})[name] = float(p[-5])
+                        except ValueError:
+                            pass
+                if line.startswith("Loop wall time:"):
+                    out["loop_wall_s"] = float(p[3])
+                    out["scans_per_s"] = n_scans / float(p[3])
+                if line.startswith("Construction time:"):   # evaluator + ContourDB constructors: lists, device runtime, stream pool
+                    out["construction_s"] = float(p[2])
+            try:   # what the driver decided, scan by scan (outcome file without its two path columns): equal for every read-ahead setting
+                import hashlib
+                h = hashlib.sha1()
+                for line in open(os.path.join(tmp, "outcome.txt")):
+                    h.update("\t".join(line.rstrip("\n").split("\t")[:6]).encode() + b"\n")
+                out["outcome_sha1"] = h.hexdigest()
+            except OSError:
+                pass
+            if "construction_s" in out and "loop_wall_s" in out:
+                out["scans_per_s_with_construction"] = n_scans / (out["loop_wall_s"] + out["construction_s"])
+            if "seconds_per_call" in out:
+                out["ms_per_scan_three_calls"] = 1e3 * sum(out["seconds_per_call"].values())
+            for line in r.stderr.splitlines():
+                if line.startswith("[evaluator helper"):     # CC_EVAL_TIMERS=1: what the prefetch thread spent per scan
+                    out["helper_thread"] = line
+                if line.startswith("[ContourDB read-ahead") or line.startswith("[cc_db appends"):  # CC_EVAL_TIMERS=1 / CC_ADD_TIMERS=1
+                    out.setdefault("db_read_ahead", []).append(line)
+            return out
+
+        # the driver is run `reps` times on the same files (a process that starts a device runtime, creates streams and pins memory is
+        # at the mercy of whatever else the host is doing for a few hundred ms: one run in eight of this loop came out at half the rate
+        # of the others); the run with the median loop rate is reported, every run's rate is listed
+        runs = [one_run() for _ in range(max(1, reps))]
+        bad = [r_ for r_ in runs if "error" in r_]
+        if bad:
+            return bad[0]
+        runs.sort(key=lambda r_: r_.get("scans_per_s", 0.0))
+        out = runs[len(runs) // 2]
+        out["scans_per_s_runs"] = [round(r_.get("scans_per_s", 0.0), 1) for r_ in runs]
+        out["outcome_identical_across_runs"] = len({r_.get("outcome_sha1") for r_ in runs}) == 1
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -27,7 +27,7 @@ if ra != "default":
 if ahead != "default":
     os.environ["CC_EVAL_AHEAD"] = ahead
 os.environ["CC_DROPIN_PREFIX"] = "rocprofv3 --kernel-trace --output-format csv -d %s --" % out
-d = bench.dropin_loop(b0, P, n)
+d = bench.dropin_loop(b0, P, n, reps=1)
 d.pop("what", None)
 print(json.dumps(d))
 rows = []
