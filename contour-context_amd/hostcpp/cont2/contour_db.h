@@ -76,6 +76,7 @@ class ContourDB {
   mutable double t_ra_[2] = {0, 0};  // host seconds in the two calls of a read-ahead step (CC_EVAL_TIMERS prints them)
   mutable long n_ra_ = 0, n_ra_scans_ = 0;
   mutable int ra_pause_ = 0, ra_backoff_ = 16;  // driver steps the read-ahead still sits out after a rebuild | the next pause (see rebuild())
+  mutable const void *source_ = nullptr;  // the scan source of the driver's last scan (ContourManager::scanSource): the one sequence this database predicts
   mutable bool need_rebuild_ = false;  // the device database holds scans the driver has not added (and will not): rebuilt at the next call
   int hub_token_ = -1;
   static int specDepth() {
@@ -163,7 +164,8 @@ class ContourDB {
       ra_pause_--;
       return;
     }
-    const auto up = cc_host::lookahead().snapshot();
+    if (!source_) return;  // the last scan came from a source that publishes nothing
+    const auto up = cc_host::lookahead().snapshot(source_);
     // the published scans that are not in spec_ yet must continue it: spec_ = a prefix of (scan in the driver's hands?, upcoming...)
     size_t pos = 0;
     if (!spec_.empty()) {  // what follows spec_.back() among the published scans is new
@@ -272,7 +274,9 @@ class ContourDB {
   explicit ContourDB(const ContourDBConfig &config, int capacity_scans = 65536) : cfg_(config), capacity_(capacity_scans) {
     CC_CHECK(!cfg_.q_levels_.empty());
     cc_host::runtime_warm();
-    if (specDepth() > 0) hub_token_ = cc_host::lookahead().subscribe([this] { dropReadAhead(); });
+    if (specDepth() > 0) hub_token_ = cc_host::lookahead().subscribe([this](const void *src) {
+      if (src == source_) dropReadAhead();  // (another source's scans are not among the ones this database has worked ahead on)
+    });
   }
   ContourDB(const ContourDB &) = delete;
   ContourDB &operator=(const ContourDB &) = delete;
@@ -384,6 +388,7 @@ class ContourDB {
       on_device_.pop_front();
     }
     all_bevs_.push_back(pending_);
+    source_ = pending_->scanSource();
     pending_.reset();
     readAhead();
   }

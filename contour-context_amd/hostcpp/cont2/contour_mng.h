@@ -185,32 +185,40 @@ struct ScanLookahead {
   struct Entry {
     cc_scan *scan;
     double ts;
+    const void *source;  // who published it (an evaluator): a database follows ONE source, the one its last scan came from
   };
   std::mutex mu;
-  std::deque<Entry> upcoming;                        // under mu
-  std::map<int, std::function<void()>> on_invalidate;  // registered by the databases (driver thread only)
+  std::deque<Entry> upcoming;                        // under mu; the entries of one source are in that source's order
+  std::map<int, std::function<void(const void *)>> on_invalidate;  // registered by the databases (driver thread only); argument: the source
   int next_token = 0;
-  int subscribe(std::function<void()> f) {
+  int subscribe(std::function<void(const void *)> f) {
     on_invalidate[next_token] = std::move(f);
     return next_token++;
   }
   void unsubscribe(int token) { on_invalidate.erase(token); }
-  void push(cc_scan *scan, double ts) {
+  void push(cc_scan *scan, double ts, const void *source) {
     std::lock_guard<std::mutex> lk(mu);
-    upcoming.push_back({scan, ts});
+    upcoming.push_back({scan, ts, source});
   }
-  void popFront(cc_scan *scan) {  // the driver has taken the scan
+  void popFront(cc_scan *scan) {  // the driver has taken the scan (the oldest one of its source)
     std::lock_guard<std::mutex> lk(mu);
-    if (!upcoming.empty() && upcoming.front().scan == scan) upcoming.pop_front();
+    for (auto it = upcoming.begin(); it != upcoming.end(); ++it)
+      if (it->scan == scan) {
+        upcoming.erase(it);
+        return;
+      }
   }
-  std::vector<Entry> snapshot() {
+  std::vector<Entry> snapshot(const void *source) {
     std::lock_guard<std::mutex> lk(mu);
-    return std::vector<Entry>(upcoming.begin(), upcoming.end());
+    std::vector<Entry> v;
+    for (const Entry &e : upcoming)
+      if (e.source == source) v.push_back(e);
+    return v;
   }
-  void invalidate() {  // driver thread
-    for (auto &f : on_invalidate) f.second();
+  void invalidate(const void *source) {  // driver thread: `source` is about to release what it has published
+    for (auto &f : on_invalidate) f.second(source);
     std::lock_guard<std::mutex> lk(mu);
-    upcoming.clear();
+    for (auto it = upcoming.begin(); it != upcoming.end();) it = it->source == source ? upcoming.erase(it) : it + 1;
   }
 };
 inline ScanLookahead &lookahead() {
@@ -231,8 +239,11 @@ class ContourManager {
   // ContourDB::queryRangedKNN / addScan, its host copy (what the getters below read) is fetched on first use.
   cc_scan *scan_ = nullptr;
   bool want_images_ = false;
+  const void *source_ = nullptr;  // mirror-only: the scan source that handed the scan out (ContourDB's read-ahead follows it)
 
  public:
+  const void *scanSource() const { return source_; }
+  void setScanSource(const void *src) { source_ = src; }
   explicit ContourManager(const ContourManagerConfig &config, int int_id) : cfg_(config), int_id_(int_id) {
     CC_CHECK(cfg_.n_col_ % 2 == 0);
     CC_CHECK(cfg_.n_row_ % 2 == 0);

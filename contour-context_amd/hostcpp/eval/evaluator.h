@@ -367,7 +367,7 @@ class ContLCDEvaluator {
       } else {  // first scan, a jump, another configuration: the helper is parked and what it fetched is dropped
         pf_.next = -1;
         pf_.cv.wait(lk, [this] { return !pf_.busy; });
-        cc_host::lookahead().invalidate();  // databases that worked ahead on these scans drop that work before the scans go
+        cc_host::lookahead().invalidate(this);  // databases that worked ahead on these scans drop that work before the scans go
         for (auto &it : pf_.ready)
           if (it.scan) cc_scan_release(it.scan);
         pf_.ready.clear();
@@ -401,6 +401,7 @@ class ContLCDEvaluator {
         pf_.cv.notify_all();
       }
     }
+    cm->setScanSource(this);
     cm->makeContoursRecurs();
     pf_.t_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     pf_.n_call++;
@@ -416,7 +417,7 @@ class ContLCDEvaluator {
       pf_.th.join();
     }
     pf_.stopReaders();
-    cc_host::lookahead().invalidate();
+    cc_host::lookahead().invalidate(this);
     for (auto &it : pf_.ready)
       if (it.scan) cc_scan_release(it.scan);
     if (getenv("CC_EVAL_TIMERS") && pf_.n_done > 0)
@@ -528,7 +529,7 @@ class ContLCDEvaluator {
       pf.busy = false;
       if (pf.next == first) {  // still wanted (the driver did not jump meanwhile)
         for (int j = 0; j < n_items; j++) {
-          if (items[j].scan) cc_host::lookahead().push(items[j].scan, laser_info_[first + j].ts);
+          if (items[j].scan) cc_host::lookahead().push(items[j].scan, laser_info_[first + j].ts, this);
           pf.ready.push_back(std::move(items[j]));
         }
         pf.next += n_items;

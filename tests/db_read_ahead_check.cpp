@@ -7,6 +7,8 @@
 //   mode 1: every scan queried twice, the second time with tighter thresholds
 //   mode 2: every fifth scan is queried but never added
 //   mode 3: the list is walked 0..n/2, then again from n/4 (a jump: the scans in between are read a second time and added again)
+//   mode 4: TWO evaluators over the same list feed TWO databases in turn (scan i of A, scan i of B, scan i + 1 of A ...): each
+//           database must follow its own source's sequence (lines "q" from A's database, "p" from B's)
 #include <cstdio>
 #include <cstdlib>
 
@@ -51,6 +53,25 @@ int main(int argc, char **argv) {
     db.queryRangedKNN(cm, l, u, cands, corr, tfs);
     printf("%s%d %d %.6f\n", label, cm->getIntID(), cands.empty() ? -1 : cands[0]->getIntID(), cands.empty() ? 0.0 : corr[0]);
   };
+  if (mode == 4) {
+    ContourDB db2(dcfg);
+    ContLCDEvaluator ev2(argv[1], argv[2], 0.5);
+    int s2 = 0;
+    while (ev.loadNewScan() && ev2.loadNewScan()) {
+      auto cm = ev.getCurrContourManager(cfg);
+      ask("q", cm, lb, ub);
+      db.addScan(cm, ev.getCurrScanInfo().ts);
+      db.pushAndBalance(seq++, ev.getCurrScanInfo().ts);
+      auto cm2 = ev2.getCurrContourManager(cfg);
+      db2.queryRangedKNN(cm2, lb, ub, cands, corr, tfs);
+      printf("p%d %d %.6f\n", cm2->getIntID(), cands.empty() ? -1 : cands[0]->getIntID(), cands.empty() ? 0.0 : corr[0]);
+      db2.addScan(cm2, ev2.getCurrScanInfo().ts);
+      db2.pushAndBalance(s2++, ev2.getCurrScanInfo().ts);
+      n_total++;
+    }
+    printf("done %d\n", n_total);
+    return 0;
+  }
   while (ev.loadNewScan()) {
     const auto info = ev.getCurrScanInfo();
     auto cm = ev.getCurrContourManager(cfg);
