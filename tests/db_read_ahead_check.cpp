@@ -7,6 +7,8 @@
 //   mode 1: every scan queried twice, the second time with tighter thresholds
 //   mode 2: every fifth scan is queried but never added
 //   mode 3: the list is walked 0..n/2, then again from n/4 (a jump: the scans in between are read a second time and added again)
+//   mode >= 100: a RANDOM driver seeded by the mode: per scan a second query with other thresholds (15 %), the scan not added (10 %), added with
+//           another seed than the one the driver's count predicts (5 %) or a later time stamp (5 %), a jump back in the list (4 %, at most six); odd modes: all of it at 0.3 of these rates
 //   mode 4: TWO evaluators over the same list feed TWO databases in turn (scan i of A, scan i of B, scan i + 1 of A ...): each
 //           database must follow its own source's sequence (lines "q" from A's database, "p" from B's)
 #include <cstdio>
@@ -68,6 +70,42 @@ int main(int argc, char **argv) {
       db2.addScan(cm2, ev2.getCurrScanInfo().ts);
       db2.pushAndBalance(s2++, ev2.getCurrScanInfo().ts);
       n_total++;
+    }
+    printf("done %d\n", n_total);
+    return 0;
+  }
+  if (mode >= 100) {
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)mode + 12345;
+    auto rnd = [&]() {  // uniform in [0, 1)
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      return (double)((st >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53);
+    };
+    const double k = (mode & 1) ? 0.3 : 1.0;  // odd modes: a driver that deviates rarely (long stretches answered from the queued work)
+    double last_ts = -1e9, t_off = 0.0;
+    int jumps = 0, addr = 0;
+    while (ev.loadNewScan()) {
+      const auto info = ev.getCurrScanInfo();
+      auto cm = ev.getCurrContourManager(cfg);
+      ask("q", cm, lb, ub);
+      if (rnd() < 0.15 * k) ask("t", cm, lb2, ub2);
+      if (rnd() >= 0.10 * k) {
+        if (rnd() < 0.05 * k) t_off += 0.5;
+        double ts = info.ts + t_off;
+        if (ts <= last_ts) ts = last_ts + 0.01;  // time stamps keep increasing, whatever the walk does
+        last_ts = ts;
+        const int sd = rnd() < 0.05 * k ? seq + 1000 : seq;
+        seq++;
+        db.addScan(cm, ts);
+        db.pushAndBalance(sd, ts);
+      }
+      n_total++;
+      addr++;
+      if (addr > 8 && jumps < 6 && rnd() < 0.04 * k) {
+        jumps++;
+        addr = addr - 1 - (int)(rnd() * 6.0);
+        t_off += 1000.0;
+        ev.jumpTo(addr);
+      }
     }
     printf("done %d\n", n_total);
     return 0;
