@@ -1,5 +1,5 @@
 """Randomised campaign of the class mirror's read-ahead on the CPU harness (run by hand):
-    python tests/fuzz_emu_read_ahead.py <seed0> <n_iter>
+    python tests/fuzz_emu_read_ahead.py <seed0> <n_iter> [gpu]     ("gpu": through libcont2_amd.so on the device, full-size scans)
 tests/db_read_ahead_check.cpp with a RANDOM driver (mode = 100 + seed: second queries with other thresholds, scans that are
 not added, adds with an unexpected seed or time stamp, jumps back in the scan list) on a random drive: the answers with the
 read-ahead in steps of several scans, one scan per step, and off must be the same lines."""
@@ -21,22 +21,30 @@ import emu_api  # noqa: E402
 def main():
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n_iter = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
     cc = cc_amd.load()
-    emu_so = emu_api.build()
     tmp = tempfile.mkdtemp(prefix="cc_fuzz_ra_")
     exe = os.path.join(tmp, "db_read_ahead_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(HERE, "db_read_ahead_check.cpp"), "-I", os.path.join(PKG, "hostcpp"), "-I",
-                           os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so), "-pthread",
-                           "-o", exe])
+    if gpu:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(HERE, "db_read_ahead_check.cpp"), "-I", os.path.join(PKG, "hostcpp"),
+                               "-I", os.path.join(ROOT, "include"), "-L", PKG, "-lcont2_amd", "-Wl,-rpath," + PKG, "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    else:
+        emu_so = emu_api.build()
+        subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(HERE, "db_read_ahead_check.cpp"), "-I", os.path.join(PKG, "hostcpp"), "-I",
+                               os.path.join(ROOT, "include"), "-L", os.path.dirname(emu_so), "-lcc_emu", "-Wl,-rpath," + os.path.dirname(emu_so), "-pthread",
+                               "-o", exe])
     bad = 0
     for it in range(n_iter):
         seed = seed0 + it
         rng = np.random.default_rng(seed)
-        n = int(rng.integers(36, 60))
+        n = int(rng.integers(120, 200)) if gpu else int(rng.integers(36, 60))
         w = cc.synth.World(loop_len=float(rng.uniform(24, 44)), dense=bool(rng.integers(2)), seed=int(rng.integers(1 << 20)))
-        x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
+        if gpu:
+            x, poses, ts = cc.synth.make_sequence(n, world=w, beams=64, azim=1875, device="cuda")
+        else:
+            x, poses, ts = cc.synth.make_sequence(n, world=w, beams=16, azim=450)
         ts = ts * float(rng.choice([1.0, 4.0]))
-        xs = x.numpy()
+        xs = x.cpu().numpy()
         lst, pos = os.path.join(tmp, "scans.txt"), os.path.join(tmp, "poses.txt")
         with open(lst, "w") as f, open(pos, "w") as g:
             for i in range(n):
@@ -46,7 +54,9 @@ def main():
                 g.write("%.6f 1 0 0 %.9f 0 1 0 %.9f 0 0 1 0\n" % (ts[i], poses[i, 0], poses[i, 1]))
         outs = []
         for env_ra in ({}, {"CC_DB_READ_AHEAD": "0", "CC_EVAL_AHEAD": "4", "CC_EVAL_INGEST_BATCH": "1"}, {"CC_DB_READ_AHEAD": "3", "CC_EVAL_AHEAD": "6", "CC_EVAL_INGEST_BATCH": "3"}):
-            env = dict(os.environ, CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6", CC_EVAL_TIMERS="1", **env_ra)
+            env = dict(os.environ, CC_EVAL_TIMERS="1", **env_ra)
+            if not gpu:
+                env.update(CC_B1_GRID="6", CC_B2_GRID="6", CC_GMM_GRID="6")
             r = subprocess.run([exe, pos, lst, str(100 + seed)], env=env, capture_output=True, text=True, timeout=3000)
             if r.returncode != 0:
                 outs.append(["crash %d: %s" % (r.returncode, r.stderr[-400:])])
