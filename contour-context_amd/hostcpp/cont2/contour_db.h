@@ -85,20 +85,24 @@ class ContourDB {
       // scan): the answers were there when the driver asked and the loop got SLOWER (2 500 -> 1 950 scans/s: every step needed
       // the newest published scan, whose single-scan ingest became the wait).  Batched (a step appends and queries
       // specBatch() scans with ONE chain each; the evaluator ingests its files eight at a time, cc_scan_ingest_batch):
-      // 3 080 -> 8 200-8 900 scans/s on MI355X (profiles/r5/dropin_batched_read_ahead.txt).  On by default: 16 scans deep.
+      // 3 080 -> 8 200-8 900 scans/s on MI355X (profiles/r5/dropin_batched_read_ahead.txt).  On by default: 32 scans deep.
       const char *e = getenv("CC_DB_READ_AHEAD");
-      return e ? std::max(0, atoi(e)) : 16;
+      return e ? std::max(0, atoi(e)) : 32;
     }();
     return d;
   }
-  static int specBatch() {  // scans per read-ahead step (CC_DB_READ_AHEAD_BATCH; default: half the depth, at most 8)
+  // scans per read-ahead step: as many of the published scans as have ARRIVED, at most specBatch() (CC_DB_READ_AHEAD_BATCH, default
+  // CC_SCAN_BATCH_MAX) and -- unless the queue is about to run dry -- at least specMin() (half of that, at most 8): the step follows
+  // the source's own batches (the evaluator publishes eight or sixteen scans at a time)
+  static int specBatch() {
     static const int b = [] {
       const char *e = getenv("CC_DB_READ_AHEAD_BATCH");
-      const int v = e ? atoi(e) : std::min(8, specDepth() / 2);
+      const int v = e ? atoi(e) : CC_SCAN_BATCH_MAX;
       return std::max(1, std::min({v, CC_SCAN_BATCH_MAX, std::max(1, specDepth())}));
     }();
     return b;
   }
+  static int specMin() { return std::max(1, std::min(8, specBatch() / 2 + specBatch() % 2)); }
   static bool same(const cc_score_t &a, const cc_score_t &b) { return memcmp(&a, &b, sizeof(cc_score_t)) == 0; }
   static void die_cc() {
     fprintf(stderr, "cont2_amd: %s\n", cc_last_error());
@@ -186,10 +190,12 @@ class ContourDB {
       for (int j = 0; j < n; j++)
         if (!cc_scan_on_device(up[pos + j].scan)) n = j;
       if (n <= 0) return;
-      if ((int)spec_.size() > SPEC_LOW) {  // the queue is not about to run dry: a whole batch, and only scans that have ARRIVED
-        if (n < specBatch()) return;       // (a published scan may still be on its way through K1 / K2: the append would wait for it)
-        for (int j = n - 1; j >= 0; j--)
-          if (!cc_scan_ready(up[pos + j].scan)) return;
+      if ((int)spec_.size() > SPEC_LOW) {  // the queue is not about to run dry: only scans that have ARRIVED, and enough of them
+        if (n < specMin()) return;         // (a published scan may still be on its way through K1 / K2: the append would wait for it)
+        int n_ready = 0;
+        while (n_ready < n && cc_scan_ready(up[pos + n_ready].scan)) n_ready++;
+        n = n_ready;
+        if (n < specMin()) return;
       }
       cc_scan *scans[CC_SCAN_BATCH_MAX];
       double ts[CC_SCAN_BATCH_MAX];

@@ -83,7 +83,7 @@ class ContLCDEvaluator {
   // finished waits in `ready`, in address order.
   struct Prefetch {
     // Scans in flight ahead of the driver (env CC_EVAL_AHEAD, 1..64; default four ingest batches).  The helper works in
-    // BATCHES of up to ingestBatch() scans (env CC_EVAL_INGEST_BATCH, 1..CC_SCAN_BATCH_MAX, default 8): their files are read in
+    // BATCHES of up to ingestBatch() scans (env CC_EVAL_INGEST_BATCH, 1..CC_SCAN_BATCH_MAX, default 8, 16 for a long list): their files are read in
     // parallel by readers() threads (env CC_EVAL_READERS, default 4; a 1.9 MB KITTI file takes ~0.15 ms to read into pinned
     // memory, four threads bring a batch of eight over in ~0.4 ms) and go to the device as ONE launch chain (cc_scan_ingest_batch) -- a scan's own chain takes ~0.2 ms of launch
     // latencies whatever it holds.  Staging buffers: scan `addr` goes through slot addr % (2 * ingestBatch()), reused
@@ -92,14 +92,15 @@ class ContLCDEvaluator {
       const char *e = getenv(name);
       return e ? std::min(hi, std::max(lo, atoi(e))) : dflt;
     }
-    static int ingestBatch() {
-      static const int b = envInt("CC_EVAL_INGEST_BATCH", 1, CC_SCAN_BATCH_MAX, 8);
-      return b;
+    // set when the helper starts (the list's length is known then): batches of sixteen for a long list (>= 2 048 scans: 13.6 k
+    // against 11.2 k scans/s on a 4 096-scan drive), of eight for a short one (even on 1 024 scans, and half the pinned memory)
+    int ib_ = 8, ahead_ = 32;
+    void configure(int n_scans) {
+      ib_ = envInt("CC_EVAL_INGEST_BATCH", 1, CC_SCAN_BATCH_MAX, n_scans >= 2048 ? 16 : 8);
+      ahead_ = envInt("CC_EVAL_AHEAD", 1, 64, std::max(4, 4 * ib_));
     }
-    static int ahead() {
-      static const int a = envInt("CC_EVAL_AHEAD", 1, 64, std::max(4, 4 * ingestBatch()));
-      return a;
-    }
+    int ingestBatch() const { return ib_; }
+    int ahead() const { return ahead_; }
     static int readers() {
       static const int r = envInt("CC_EVAL_READERS", 1, 8, 4);
       return r;
@@ -342,7 +343,7 @@ class ContLCDEvaluator {
         Prefetch::Item it = std::move(pf_.ready.front());
         pf_.ready.pop_front();
         if (it.scan) cc_host::lookahead().popFront(it.scan);  // the driver's from here on
-        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::ahead());
+        pf_.limit = std::min(n_scans, p_lidar_curr + 1 + pf_.ahead());
         lk.unlock();
         pf_.cv.notify_all();
         switch (it.status) {  // what the reference does at the same points (evaluator.h:285-302, contour_mng.h:507)
@@ -394,8 +395,9 @@ class ContLCDEvaluator {
           std::lock_guard<std::mutex> lk(pf_.mu);
           pf_.ctx = ctx;
           pf_.with_images = with_images;
+          pf_.configure(n_scans);
           pf_.next = p_lidar_curr + 1;
-          pf_.limit = std::min(n_scans, p_lidar_curr + 1 + Prefetch::ahead());
+          pf_.limit = std::min(n_scans, p_lidar_curr + 1 + pf_.ahead());
         }
         if (!pf_.th.joinable()) pf_.th = std::thread([this, cap] { prefetchLoop(cap); });
         pf_.cv.notify_all();
@@ -438,8 +440,8 @@ class ContLCDEvaluator {
       pf.cv.wait(lk, [&] {
         if (pf.quit) return true;
         if (pf.next < 0 || pf.next >= pf.limit) return false;
-        const int want = std::min(pf.limit - pf.next, Prefetch::ahead() - (int)pf.ready.size());
-        const int ib = pf.with_images ? 1 : Prefetch::ingestBatch();  // a scan that keeps its image goes alone (cc_scan_ingest)
+        const int want = std::min(pf.limit - pf.next, pf.ahead() - (int)pf.ready.size());
+        const int ib = pf.with_images ? 1 : pf.ingestBatch();  // a scan that keeps its image goes alone (cc_scan_ingest)
         if (want <= 0) return false;
         if (want < ib && (int)pf.ready.size() >= 2 && pf.limit < n_scans) return false;
         nb = std::min(want, ib);
@@ -457,7 +459,7 @@ class ContLCDEvaluator {
       std::vector<Prefetch::ReadJob> jobs;
       std::vector<float *> dst((size_t)nb, nullptr);
       std::vector<size_t> caps((size_t)nb, 0);
-      const int n_slots = 2 * (with_images ? 1 : Prefetch::ingestBatch());  // one batch is read while the one before it is copied
+      const int n_slots = 2 * (with_images ? 1 : pf.ingestBatch());  // one batch is read while the one before it is copied
       int n_staged = 0;
       // every buffer of the batch is asked for at the batch's largest file: if the context's buffers have to grow (they are all
       // re-allocated then), that happens at the first request, before a pointer of this batch is held

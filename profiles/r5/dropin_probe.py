@@ -20,7 +20,10 @@ for ahead in (sys.argv[2] if len(sys.argv) > 2 else "default").split(","):
     if ahead != "default":
         os.environ["CC_EVAL_AHEAD"] = ahead
     for ra in (sys.argv[1] if len(sys.argv) > 1 else "0,3").split(","):
-        os.environ["CC_DB_READ_AHEAD"] = ra
+        if ra != "default":
+            os.environ["CC_DB_READ_AHEAD"] = ra
+        else:
+            os.environ.pop("CC_DB_READ_AHEAD", None)
         d = bench.dropin_loop(b0, P, n, laps=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
         d.pop("what", None)
         print("CC_EVAL_AHEAD=%s CC_DB_READ_AHEAD=%s %s" % (ahead, ra, json.dumps(d)), flush=True)
