@@ -22,6 +22,7 @@
 #include "cc_hostcfg.h"
 #include "k_rasterize.h"
 #include "k_contours.h"
+#include "k_contours_list.h"
 #include "k_knn.h"
 #include "k_check.h"
 #include "k_merge.h"
@@ -69,6 +70,7 @@ struct cc_ctx {
     // workgroups with CC_NC_BIG-sized tables in global memory
     int n_bigslots = 0;
     cc_k2_big_queue *d_bigq = nullptr;
+    cc_k2_big_queue *d_midq = nullptr;  // scans the list kernel hands to the original body (cc_k_contours_mid)
     cc_k2_big_slot *d_bigslots = nullptr;
     hipEvent_t ev_last = nullptr;
     hipStream_t last_stream = nullptr;
@@ -157,6 +159,8 @@ static int scratch_alloc(cc_ctx *c, cc_ctx::Scratch &S, int cap, int n_bigslots)
   HIPCHK(hipMalloc(&S.d_offsets, sizeof(long long) * (cap + 1)));
   HIPCHK(hipMalloc(&S.d_bigq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)cap));
   HIPCHK(hipMemset(S.d_bigq, 0, sizeof(cc_k2_big_queue)));  // the slow launch leaves it empty again
+  HIPCHK(hipMalloc(&S.d_midq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)cap));
+  HIPCHK(hipMemset(S.d_midq, 0, sizeof(cc_k2_big_queue)));
   S.n_bigslots = n_bigslots < cap ? n_bigslots : cap;
   HIPCHK(hipMalloc(&S.d_bigslots, sizeof(cc_k2_big_slot) * S.n_bigslots));
   HIPCHK(hipEventCreateWithFlags(&S.ev_last, hipEventDisableTiming));
@@ -172,6 +176,7 @@ static void scratch_free(cc_ctx::Scratch &S) {
   hipFree(S.d_scr);
   hipFree(S.d_offsets);
   hipFree(S.d_bigq);
+  hipFree(S.d_midq);
   hipFree(S.d_bigslots);
   if (S.ev_last) hipEventDestroy(S.ev_last);
   S = cc_ctx::Scratch();
@@ -307,7 +312,8 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     CREATE_CHK(hipHostMalloc((void **)&c->h_off[i], sizeof(long long) * ((max_batch_scans > CC_SCAN_BATCH_MAX ? max_batch_scans : CC_SCAN_BATCH_MAX) + 1), hipHostMallocDefault));
     CREATE_CHK(hipEventCreateWithFlags(&c->off_ev[i], hipEventDisableTiming));
   }
-  if (getenv("CC_K2_PHASES")) CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * max_batch_scans));
+  if (getenv("CC_K2_PHASES"))  // (a channel launch brings up to CC_SCAN_BATCH_MAX scans whatever max_batch_scans is)
+    CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * (size_t)(max_batch_scans > CC_SCAN_BATCH_MAX ? max_batch_scans : CC_SCAN_BATCH_MAX)));
   c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
   c->lds2 = CC_K2_LDS_BYTES(nc);
   {
@@ -324,7 +330,12 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     const char *e2 = getenv("CC_K1_NOSPLIT");
     c->k1_nosplit = (e2 && atoi(e2) == 1) ? 1 : 0;
   }
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
+  if (nc > (size_t)CC_MAX_CELLS) {
+    cc_destroy(c);
+    return set_err(CC_EINVAL, "cc_create: grid larger than 150 x 150 cells");
+  }
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC_K2L_LDS_BYTES));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
   CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_contours_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds2));
 #undef CREATE_CHK
   *out = c;
@@ -475,8 +486,11 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
                          S.d_bev, S.d_pix, S.d_k1, cc_k1_part());
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
-    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK < CC_INGEST_BLOCK ? CC_K2_BLOCK : CC_INGEST_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
-                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_bigq);
+    hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK), (size_t)CC_K2L_LDS_BYTES, stream, c->dcfg, (const float *)S.d_bev,
+                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_midq);
+    // the scans the list kernel handed on (more active cells / components than its LDS tables hold): the original body
+    hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < 512 ? nb : 512), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
+                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab);
     // the scans the launch above could not number (more than CC_MAXC components on a level): exact, slow, usually none
     hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < S.n_bigslots ? nb : S.n_bigslots), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
                        (const float *)S.d_bev, (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_bigslots, S.d_bigq, d_out + b0, lab);

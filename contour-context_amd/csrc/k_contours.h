@@ -198,6 +198,465 @@ __device__ __noinline__ int cc_k2_drop_small(int min_cnt, int n_kept, unsigned *
   return n_new;
 }
 
+// optional phase timestamps (tuning aid): phase_clk[scan*CC_K2_NCLK + i], written by thread 0; the macros below expect
+// `phase_clk`, `scan`, `tid`, `tmark`, `tsub` in scope
+#define CC_K2_STAMP(i)                                                                     \
+  do {                                                                                     \
+    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)scan * CC_K2_NCLK + (i)] = (long long)wall_clock64(); \
+  } while (0)
+#define CC_K2_SUBLAP(j)                                                                   \
+  do {                                                                                    \
+    if (phase_clk) {                                                                      \
+      const long long now_ = (long long)wall_clock64();                                   \
+      if (tid == 0) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + (j)] += now_ - tsub; \
+      tsub = now_;                                                                        \
+    }                                                                                     \
+  } while (0)
+#define CC_K2_LAP(acc)                                     \
+  do {                                                     \
+    if (phase_clk) {                                       \
+      const long long now_ = (long long)wall_clock64();    \
+      acc += now_ - tmark;                                 \
+      tmark = now_;                                        \
+    }                                                      \
+  } while (0)
+
+// How the back half (ordering, emit, keys, BCI) looks up the level count of a cell: the cell-indexed level image of the
+// original front half, or the list front half's occupancy bit map + per-entry level bytes.
+struct cc_k2_levmap {
+  const unsigned char *LV;
+  const unsigned long long *bitmap;  // bit c & 63 of word c >> 6: cell c is active
+  const uint16_t *cbase;             // active cells before chunk c >> 6
+  const unsigned char *lev;          // level count per list entry
+};
+template <bool LISTED>
+__device__ __forceinline__ int cc_k2_lev_at(const cc_k2_levmap &M, int cell) {
+  if (!LISTED) return (int)M.LV[cell];
+  const unsigned long long m = M.bitmap[cell >> 6];
+  const int bit = cell & 63;
+  if (!((m >> bit) & 1ull)) return 0;
+  return (int)M.lev[(int)M.cbase[cell >> 6] + __popcll(m & ((1ull << bit) - 1ull))];
+}
+
+// The back half of K2: insertion order, size sort, emit, retrieval keys, BCIs -- from the per-level component records
+// (scr->comp) and contour rows (scr->cont) a front half has left in the scratch block.  R: 57 344 bytes of LDS to carve.
+template <int NC, bool BIG, bool LISTED>
+__device__ __forceinline__ void cc_k2_back(const cc_dev_cfg &cfg, const float2 *__restrict__ pix, const cc_k1_scan_out *__restrict__ k1_out,
+                                           cc_k2_scratch_t<NC> *__restrict__ scr, cc_k2_big_tables *__restrict__ bigtab, int scan,
+                                           cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
+                                           char *R, const int *n_lev_in, int flags_in, const cc_k2_levmap &lm) {
+  const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  cc_scan_desc_t *desc = desc_out + scan;
+  long long tmark = 0;
+  // =========================== phase "order": region R re-carved ===========================
+  int n_lev[CC_NLEV];
+  for (int l = 0; l < CC_NLEV; l++) n_lev[l] = n_lev_in[l];
+  // lane-dependent level index: a select chain over the six registers (a lane-indexed array would live in scratch memory)
+#define CC_NLEV_AT(i) ((i) == 0 ? n_lev[0] : (i) == 1 ? n_lev[1] : (i) == 2 ? n_lev[2] : (i) == 3 ? n_lev[3] : (i) == 4 ? n_lev[4] : n_lev[5])
+  const int flags0 = flags_in;
+  cc_comp_t *T = BIG ? bigtab->T : (cc_comp_t *)R;                          // [6][NC] 30720 B
+  unsigned *skey = BIG ? bigtab->skey : (unsigned *)(R + 30720);            // [6][NC] u32 7680 B
+  unsigned *arr = BIG ? bigtab->arr : (unsigned *)(R + 30720 + 7680);       // [6][NC] u32 7680 B
+  cc_anchor_lds *top = (cc_anchor_lds *)(R + 30720 + 2 * 7680);             // [6][10] 1200 B
+  int *sh2 = (int *)(R + 30720 + 2 * 7680 + 1280);                          // scalars (64 ints)
+  char *R2 = R + 30720 + 2 * 7680 + 1280 + 256;                             // free for keys / BCI (~17.8 KB) -- see below
+  for (int l = 0; l < CC_NLEV; l++)
+    for (int k = tid; k < n_lev[l]; k += nt) T[l * NC + k] = scr->comp[l][k];
+  __syncthreads();
+  // insertion rank, bottom-up
+  for (int l = 0; l < CC_NLEV; l++) {
+    const int n = n_lev[l];
+    for (int k = tid; k < n; k += nt) {
+      const cc_comp_t cp = T[l * NC + k];
+      int py0 = 0, px0 = 0, prank = 0;
+      if (l > 0) {
+        unsigned p = cp.parent;
+        if (p < (unsigned)n_lev[l - 1]) {
+          const cc_comp_t pp = T[(l - 1) * NC + p];
+          py0 = pp.r0;
+          px0 = pp.c0;
+          prank = pp.rank;
+        }
+      }
+      const int rmin = cp.r0;
+      const int brow = (rmin - py0) >> 1;
+      const int ra = py0 + 2 * brow;
+      int cm = cp.cA;
+      if (ra == rmin && cp.cB < cm) cm = cp.cB;
+      const int bcol = (cm - px0) >> 1;
+      skey[l * NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += nt >> 2) {  // four threads per component, every fourth key each (block-uniform trip count)
+      const int k = k0 + (tid >> 2), q = tid & 3;
+      const unsigned me = k < n ? skey[l * NC + k] : 0u;
+      int rk = 0;
+      for (int j = q; j < n; j += 4) rk += (skey[l * NC + j] < me) ? 1 : 0;
+      rk += __shfl_xor(rk, 1);
+      rk += __shfl_xor(rk, 2);
+      if (k < n && q == 0) {
+        T[l * NC + k].rank = (uint16_t)rk;
+        // pre-sort sequence: element at insertion position rk is component k
+        arr[l * NC + rk] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
+      }
+    }
+    __syncthreads();
+  }
+  // size sort, bigger first (contour_mng.h:596-599): libstdc++'s std::sort replayed by one WAVE per level (round 3: one
+  // lane per level, ~40 of a KITTI-shaped scan's 440 us): parallel partitions + stable rank, cc_sort.h.  The rank keys of
+  // the insertion order (skey) are dead by now: their rows hold the partitions' stopper lists, then the ranked copy.
+  for (int l = wave_id; l < CC_NLEV; l += n_waves) {
+    unsigned *a = arr + l * NC;
+    const int n = CC_NLEV_AT(l);
+    unsigned short *lpos = (unsigned short *)(skey + l * NC), *rasc = lpos + NC;
+    ccsort::std_sort_wave(
+        a, n, [](unsigned x) { return 0xFFFFu - (x >> 16); },
+        [&]() {
+          for (int k = lane; k < n; k += 64) a[T[l * NC + k].rank] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
+        },
+        lane, lpos, rasc, skey + l * NC, (unsigned *)R2 + l * CC_SORT_STACK);
+    int tot = 0;
+    for (int i = lane; i < n; i += 64) tot += (int)(a[i] >> 16);
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) sh2[l] = tot;
+  }
+  __syncthreads();
+  CC_K2_STAMP(5);
+  // emit sorted contour tables + header
+  for (int l = 0; l < CC_NLEV; l++) {
+    const int n = n_lev[l] < CC_MAXC ? n_lev[l] : CC_MAXC;
+    const int n_words = n * (int)(sizeof(cc_contour_t) / 4);
+    const unsigned *src = (const unsigned *)&scr->cont[l][0];
+    unsigned *dst = (unsigned *)&desc->cont[l][0];
+    for (int w = tid; w < n_words; w += nt) {
+      const int seq = w / 19, off = w - seq * 19;
+      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
+      dst[w] = src[k * 19 + off];
+    }
+    for (int seq = tid; seq < CC_NDIST && seq < n; seq += nt) {
+      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
+      const cc_contour_t *cv = &scr->cont[l][k];
+      cc_anchor_lds a;
+      a.pm[0] = cv->pos_mean[0];
+      a.pm[1] = cv->pos_mean[1];
+      a.ev[0] = cv->eig_vals[0];
+      a.ev[1] = cv->eig_vals[1];
+      a.cnt = cv->cell_cnt;
+      top[l * CC_NDIST + seq] = a;
+    }
+  }
+  if (tid < CC_NLEV) {
+    desc->n_cont[tid] = CC_NLEV_AT(tid);
+    desc->n_stored[tid] = CC_NLEV_AT(tid) < CC_MAXC ? CC_NLEV_AT(tid) : CC_MAXC;
+    desc->layer_cell_cnt[tid] = sh2[tid];
+  }
+  if (tid == 0) {
+    const cc_k1_scan_out k1 = k1_out[scan];
+    desc->max_bin_val = k1.max_bin_val;
+    desc->min_bin_val = k1.min_bin_val;
+    desc->n_pix = k1.n_pix;
+    int fl = flags0;
+    for (int l = 0; l < CC_NLEV; l++) fl |= n_lev[l] > CC_MAXC ? CC_DESC_TRUNCATED : 0;  // exact, the CC_MAXC largest are stored
+    desc->flags = fl;
+  }
+  if (labels_dbg) {
+    // component index -> seq (position after the size sort); skey is free now
+    for (int l = 0; l < CC_NLEV; l++)
+      for (int seq = tid; seq < n_lev[l]; seq += nt) skey[l * NC + (arr[l * NC + seq] & 0xFFFFu)] = (unsigned)seq;
+    __syncthreads();
+    for (int l = 0; l < CC_NLEV; l++) {
+      int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
+      for (int c = tid; c < n_cell; c += nt) {
+        int16_t v = ld[c];
+        if (v >= 0) ld[c] = (int16_t)skey[l * NC + v];
+      }
+    }
+  }
+  __syncthreads();
+
+  CC_K2_STAMP(6);
+  // =========================== phase "keys" (contour_mng.h:693-830) ===========================
+  // R2 layout: divs f32 [36][35] (5040) | cntp int[36] | valid int[36] | acc int[36] | bci tmp | bci pts
+  float *divs = (float *)R2;
+  int *cntp = (int *)(R2 + 5056);
+  int *valid = cntp + 36;
+  int *accum = valid + 36;
+  const int NA = CC_NLEV * CC_NPIV;
+  if (tid < NA) {
+    const int ll = tid / CC_NPIV, seq = tid - ll * CC_NPIV;
+    int ok = 0, acc = 0;
+    if (seq < cfg.piv_firsts) {
+      for (int s = 0; s <= seq; s++)
+        if (s < CC_NLEV_AT(ll)) acc += top[ll * CC_NDIST + s].cnt;  // accumulate_cell_cnt (contour_mng.h:705-706)
+      ok = (seq < CC_NLEV_AT(ll) && top[ll * CC_NDIST + seq].cnt >= cfg.min_cont_key_cnt) ? 1 : 0;
+    }
+    valid[tid] = ok;
+    accum[tid] = acc;
+    cntp[tid] = 0;
+  }
+  // the BCI phase's per-wave scratch (R2 + 5504 ...) is idle until then: the exp table and the list of valid anchors
+  double *exp_tab = (double *)(R2 + 5504);                    // 512 B
+  unsigned char *vlist = (unsigned char *)(R2 + 5504 + 512);  // [36] anchors with a key, ascending
+  if (tid >= 64 && tid < 128) exp_tab[tid - 64] = __longlong_as_double((long long)cc_exp2_tab64[tid - 64]);
+  __syncthreads();
+  int NV = 0;
+  for (int a = 0; a < CC_NLEV * CC_NPIV; a++) {  // uniform; 36 broadcast reads
+    const int ok = valid[a];
+    if (ok && tid == 0) vlist[NV] = (unsigned char)a;
+    NV += ok;
+  }
+  __syncthreads();
+  const int roi_pad = (int)ceilf(cfg.roi_radius + 1.f);
+  const float div_len = cfg.roi_radius / (float)(7 * 5);
+  const float bin_len = cfg.roi_radius / (float)7;
+  const double r_lim = (double)cfg.roi_radius - 1e-2;
+  // The 35 divisions of an anchor accumulate over the same cells (RoI cells above level 1 within the radius, in raster
+  // order; contour_mng.h:735-770): the cell list -- distance to the anchor, number of levels above -- is built once per
+  // anchor by a wave (ballot-ordered, so raster order is kept), then one lane per (anchor, division) walks it in LDS with
+  // the reference's f32 accumulation order.  Anchors are handled CC_KEYS_GRP at a time; the lists live where the
+  // ordering tables were.
+  {
+    const int CAP = CC_KEYS_CAP;
+    float *ldist = (float *)R;
+    unsigned char *lhi = (unsigned char *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 4);
+    int *lcnt = (int *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 5);
+    long long acc_klist = 0, acc_kexp = 0;
+    tmark = phase_clk ? (long long)wall_clock64() : 0;
+    // groups of CC_KEYS_GRP VALID anchors (a street scene has ~18 of the 36: two groups, not three)
+    for (int g0 = 0; g0 < NV; g0 += CC_KEYS_GRP) {
+      for (int av = g0 + wave_id; av < g0 + CC_KEYS_GRP && av < NV; av += n_waves) {
+        const int a = (int)vlist[av];
+        int n = 0;
+        {
+          const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+          const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
+          const int r_cen = (int)vcx, c_cen = (int)vcy;
+          const int r_min = r_cen - roi_pad > 0 ? r_cen - roi_pad : 0;
+          const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
+          const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
+          const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
+          const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
+          // nine 64-cell stretches (a 23 x 23 window) at a time: their level bytes and positions are fetched before any
+          // of them is compacted, so the L2 round trips of the positions overlap
+          const int KB = 9;
+          for (int base0 = 0; base0 < tot; base0 += 64 * KB) {
+            int lvv[KB];
+            float2 rcv[KB];
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              const int idx = base0 + 64 * u + lane;
+              lvv[u] = 0;
+              rcv[u] = make_float2(0.f, 0.f);
+              if (idx < tot) {
+                const int ro = idx / W;
+                const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
+                // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
+                // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
+                lvv[u] = cc_k2_lev_at<LISTED>(lm, cell);
+                if (lvv[u] >= 2) rcv[u] = pix[cell];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              if (base0 + 64 * u >= tot) break;  // uniform
+              bool q = false;
+              float dist = 0.f;
+              if (lvv[u] >= 2) {
+                const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
+                dist = sqrtf(dx * dx + dy * dy);
+                q = (double)dist < r_lim;
+              }
+              const unsigned long long m = __ballot(q);
+              const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+              if (q && pos < CAP) {
+                ldist[(av - g0) * CAP + pos] = dist;
+                lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+              }
+              n += __popcll(m);
+            }
+          }
+          if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
+        }
+        if (lane == 0) lcnt[av - g0] = n;
+      }
+      __syncthreads();
+      CC_K2_LAP(acc_klist);
+      for (int t = tid; t < CC_KEYS_GRP * 35; t += nt) {
+        const int al = t / 35, d = t - al * 35;
+        if (g0 + al >= NV) continue;
+        const int a = (int)vlist[g0 + al];
+        float acc = 0.f;
+        const int n = lcnt[al] < CAP ? lcnt[al] : CAP;
+        {
+          // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56): exp(-u^2/2) / sqrt(2 pi), here
+          // exp(...) * (1 / sqrt(2 pi)) -- one f64 rounding away from the quotient, gone in the conversion to f32
+          const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
+          for (int i = 0; i < n; i++) {
+            const float dist = ldist[al * CAP + i];
+            const int higher = lhi[al * CAP + i];
+            const float u = (xg - dist) / 1.0f;
+            const float pdf = (float)(cc_exp_nonpos(-0.5 * (double)u * (double)u, exp_tab) * 0.3989422804014327);
+            acc += (float)higher * pdf;
+          }
+        }
+        divs[a * 35 + d] = acc;
+        if (d == 0) cntp[a] = lcnt[al];
+      }
+      __syncthreads();
+      CC_K2_LAP(acc_kexp);
+    }
+    if (phase_clk && tid == 0) {
+      phase_clk[(size_t)scan * CC_K2_NCLK + 14] = acc_klist;
+      phase_clk[(size_t)scan * CC_K2_NCLK + 15] = acc_kexp;
+    }
+  }
+  for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {
+    const int a = t / CC_KEY_DIM, kd = t - a * CC_KEY_DIM;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    float v = 0.f;
+    if (valid[a]) {
+      const cc_anchor_lds an = top[ll * CC_NDIST + seq];
+      if (kd == 0)
+        v = sqrtf(an.ev[1] * (float)an.cnt);
+      else if (kd == 1)
+        v = sqrtf(an.ev[0] * (float)an.cnt);
+      else if (kd == 2)
+        v = (float)sqrt((double)accum[a]);
+      else {
+        const int b = kd - 3;
+        float ring = 0.f;
+        for (int d = 0; d < 5; d++) ring += divs[a * 35 + b * 5 + d];
+        ring = (float)((double)ring * ((double)bin_len / sqrt((double)cntp[a])));
+        v = ring;
+      }
+    }
+    desc->keys[ll][seq][kd] = v;
+  }
+  __syncthreads();
+
+  CC_K2_STAMP(7);
+  // =========================== phase "BCI" (contour_mng.h:848-883) ===========================
+  struct bci_tmp {
+    int ok;
+    int bit;
+    float r, theta;
+  };
+  bci_tmp *btmp = (bci_tmp *)(R + 17280);                          // [36][40] 23040 B  (T/skey/arr dead; ends < top)
+  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
+    const int a = t / CC_BCI_MAXPTS, q = t - a * CC_BCI_MAXPTS;
+    const int bl = q / CC_NDIST, j = q - bl * CC_NDIST;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    bci_tmp o;
+    o.ok = 0;
+    o.bit = 0;
+    o.r = 0.f;
+    o.theta = 0.f;
+    const int lev = bl + 1;  // DIST_BIN_LAYERS = {1,2,3,4}
+    const int lim = cfg.dist_firsts < CC_NLEV_AT(lev) ? cfg.dist_firsts : CC_NLEV_AT(lev);
+    if (valid[a] && j < lim && !(ll == lev && j == seq)) {
+      const float vx = top[lev * CC_NDIST + j].pm[0] - top[ll * CC_NDIST + seq].pm[0];
+      const float vy = top[lev * CC_NDIST + j].pm[1] - top[ll * CC_NDIST + seq].pm[1];
+      const float dist = sqrtf(vx * vx + vy * vy);
+      const double dd = (double)dist;
+      if (!(dd > (CC_BITS_PER_LAYER - 1) * 1.01 + 5.43 - 1e-3 || dd <= 5.43)) {
+        const float orie = cc_atan2f_fdlibm(vy, vx);  // glibc's atan2f, operation for operation (cc_stats.h)
+        double fl = floor((dd - 5.43) / 1.01);
+        if (fl > CC_BITS_PER_LAYER - 1.0) fl = CC_BITS_PER_LAYER - 1.0;
+        o.ok = 1;
+        o.bit = (int)(fl + (double)(bl * CC_BITS_PER_LAYER));
+        o.r = dist;
+        o.theta = orie;
+      }
+    }
+    btmp[t] = o;
+  }
+  __syncthreads();
+  // The neighbour points are sorted through 32-bit proxies (bit_pos << 8 | slot, compared on bit_pos only): the replay of
+  // std::sort depends on the comparison outcomes alone, so the proxies end up in the order the reference's
+  // RelativePoint records would.
+  unsigned *bkey = (unsigned *)(R + 0);                            // [36][40] (T is dead now)
+  int *bcnt = (int *)(R + 5760);                                   // [36] points per anchor
+  // One WAVE per anchor (round 3: one lane per anchor, a lane-serial gather + sort replay + segment scan of dependent LDS
+  // reads, 26 us per scan whatever the scan): the <= 40 candidate neighbours sit one per lane, the valid ones are compacted
+  // with a ballot (slot order, as the serial loop appended them), sorted by the wave-parallel std::sort replay (cc_sort.h),
+  // segment starts found with a ballot.  Per-wave scratch behind the key tables in R2 (divs 5040 B + 3 x 36 ints end at 5488).
+  {
+    char *ws = R2 + 5504 + wave_id * 448;
+    unsigned short *lpos = (unsigned short *)ws, *rasc = lpos + CC_BCI_MAXPTS;   // 2 x 80 B
+    unsigned *tmp = (unsigned *)(ws + 160);                                        // 160 B
+    unsigned *seg = (unsigned *)(ws + 320);                                        // CC_SORT_STACK words = 104 B
+    static_assert(320 + CC_SORT_STACK * 4 <= 448 && CC_BCI_MAXPTS <= 64, "per-wave BCI scratch");
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int a = wave_id; a < NA; a += n_waves) {
+      const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+      unsigned *p = bkey + a * CC_BCI_MAXPTS;
+      bci_tmp o;
+      o.ok = 0;
+      o.bit = 0;
+      if (lane < CC_BCI_MAXPTS) o = btmp[a * CC_BCI_MAXPTS + lane];
+      const unsigned long long mok = __ballot(o.ok != 0);
+      const int n = __popcll(mok);
+      auto gather = [&]() {
+        if (o.ok) p[__popcll(mok & lt)] = ((unsigned)o.bit << 8) | (unsigned)lane;
+      };
+      gather();
+      // the 256-bit ring: word w = OR of the valid lanes' bits of that word
+      unsigned long long bw[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        unsigned long long v = (o.ok && (o.bit >> 6) == w) ? (1ull << (o.bit & 63)) : 0ull;
+        for (int sh_ = 32; sh_ > 0; sh_ >>= 1) v |= __shfl_xor(v, sh_);
+        bw[w] = v;
+      }
+      ccsort::std_sort_wave(p, n, [](unsigned x) { return x >> 8; }, gather, lane, lpos, rasc, tmp, seg);
+      cc_bci_t *ob = &desc->bcis[ll][seq];
+      // segment starts: positions where bit_pos changes, then n (contour_mng.h:871-883)
+      const bool head = lane < n && (lane == 0 || (p[lane] >> 8) != (p[lane - 1] >> 8));
+      const unsigned long long mh = __ballot(head);
+      const int nh = __popcll(mh), ns = n > 0 ? nh + 1 : 0;
+      if (head) ob->segs[__popcll(mh & lt)] = (uint16_t)lane;
+      if (lane == 0 && n > 0) ob->segs[nh] = (uint16_t)n;
+      if (lane >= ns && lane < CC_BCI_MAXPTS + 2) ob->segs[lane] = 0;
+      if (lane == 0) {
+        bcnt[a] = n;
+        ob->dist_bin[0] = bw[0];
+        ob->dist_bin[1] = bw[1];
+        ob->dist_bin[2] = bw[2];
+        ob->dist_bin[3] = bw[3];
+        // layer_key_bcis_ has piv_firsts_ entries per level (contour_mng.h:835-838): the record's slots beyond that stay all-zero
+        ob->piv_seq = seq < cfg.piv_firsts ? (int8_t)seq : (int8_t)0;
+        ob->level = seq < cfg.piv_firsts ? (int8_t)ll : (int8_t)0;
+        ob->n_pts = (uint8_t)n;
+        ob->n_segs = (uint8_t)ns;
+      }
+    }
+  }
+  __syncthreads();
+  // the point records, all threads
+  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
+    const int a = t / CC_BCI_MAXPTS, i = t - a * CC_BCI_MAXPTS;
+    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
+    unsigned w0 = 0u;
+    float r = 0.f, th = 0.f;
+    if (i < bcnt[a]) {
+      const unsigned k = bkey[a * CC_BCI_MAXPTS + i];
+      const int q = (int)(k & 0xFFu);
+      const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
+      // level (int8) | seq (int8) << 8 | bit_pos (int16) << 16
+      w0 = (unsigned)(q / CC_NDIST + 1) | ((unsigned)(q % CC_NDIST) << 8) | ((k >> 8) << 16);
+      r = o.r;
+      th = o.theta;
+    }
+    unsigned *dst = (unsigned *)&desc->bcis[ll][seq].pts[i];
+    dst[0] = w0;
+    dst[1] = __float_as_uint(r);
+    dst[2] = __float_as_uint(th);
+  }
+  CC_K2_STAMP(8);
+}
+
 // The kernel body.  NC = components per level it handles exactly; BIG = the per-component tables live in `bigtab` (global)
 // instead of LDS.  `scan` indexes the launch's inputs and outputs, `scr` is the scratch block to use.
 template <int NC, bool BIG>
@@ -206,11 +665,6 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
                                            cc_k2_big_tables *__restrict__ bigtab, cc_k2_big_queue *__restrict__ queue, int scan,
                                            cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
                                            char *smem) {
-  // optional phase timestamps (tuning aid): phase_clk[scan*CC_K2_NCLK + i], written by thread 0
-#define CC_K2_STAMP(i)                                                                     \
-  do {                                                                                     \
-    if (phase_clk && threadIdx.x == 0) phase_clk[(size_t)scan * CC_K2_NCLK + (i)] = (long long)wall_clock64(); \
-  } while (0)
   CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col, n_row = cfg.n_row;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -319,22 +773,6 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
   long long tsub = tmark;
   if (phase_clk && tid == 0)
     for (int j = 0; j < 6; j++) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + j] = 0;
-#define CC_K2_SUBLAP(j)                                                                   \
-  do {                                                                                    \
-    if (phase_clk) {                                                                      \
-      const long long now_ = (long long)wall_clock64();                                   \
-      if (tid == 0) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + (j)] += now_ - tsub; \
-      tsub = now_;                                                                        \
-    }                                                                                     \
-  } while (0)
-#define CC_K2_LAP(acc)                                     \
-  do {                                                     \
-    if (phase_clk) {                                       \
-      const long long now_ = (long long)wall_clock64();    \
-      acc += now_ - tmark;                                 \
-      tmark = now_;                                        \
-    }                                                      \
-  } while (0)
   unsigned *w_minc = W + NC, *w_maxc = W + 2 * NC, *w_area = W + 3 * NC, *w_cB = W + 4 * NC;
   // "has a second cell" / "has a third cell" bit per root (the kept test of a level), over the working arrays
   unsigned *bitA = (unsigned *)(R + 45056), *bitB = bitA + ((n_cell + 31) >> 5);
@@ -976,453 +1414,15 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
     phase_clk[(size_t)scan * CC_K2_NCLK + 3] = acc_walk;
   }
   CC_K2_STAMP(4);
-
-  // =========================== phase "order": region R re-carved ===========================
   __threadfence_block();
   __syncthreads();
-  int n_lev[CC_NLEV];
-  for (int l = 0; l < CC_NLEV; l++) n_lev[l] = sh[8 + l];
-  // lane-dependent level index: a select chain over the six registers (a lane-indexed array would live in scratch memory)
-#define CC_NLEV_AT(i) ((i) == 0 ? n_lev[0] : (i) == 1 ? n_lev[1] : (i) == 2 ? n_lev[2] : (i) == 3 ? n_lev[3] : (i) == 4 ? n_lev[4] : n_lev[5])
-  const int flags0 = sh[2];
-  __syncthreads();
-  cc_comp_t *T = BIG ? bigtab->T : (cc_comp_t *)R;                          // [6][NC] 30720 B
-  unsigned *skey = BIG ? bigtab->skey : (unsigned *)(R + 30720);            // [6][NC] u32 7680 B
-  unsigned *arr = BIG ? bigtab->arr : (unsigned *)(R + 30720 + 7680);       // [6][NC] u32 7680 B
-  cc_anchor_lds *top = (cc_anchor_lds *)(R + 30720 + 2 * 7680);             // [6][10] 1200 B
-  int *sh2 = (int *)(R + 30720 + 2 * 7680 + 1280);                          // scalars (64 ints)
-  char *R2 = R + 30720 + 2 * 7680 + 1280 + 256;                             // free for keys / BCI (~17.8 KB) -- see below
-  for (int l = 0; l < CC_NLEV; l++)
-    for (int k = tid; k < n_lev[l]; k += nt) T[l * NC + k] = scr->comp[l][k];
-  __syncthreads();
-  // insertion rank, bottom-up
-  for (int l = 0; l < CC_NLEV; l++) {
-    const int n = n_lev[l];
-    for (int k = tid; k < n; k += nt) {
-      const cc_comp_t cp = T[l * NC + k];
-      int py0 = 0, px0 = 0, prank = 0;
-      if (l > 0) {
-        unsigned p = cp.parent;
-        if (p < (unsigned)n_lev[l - 1]) {
-          const cc_comp_t pp = T[(l - 1) * NC + p];
-          py0 = pp.r0;
-          px0 = pp.c0;
-          prank = pp.rank;
-        }
-      }
-      const int rmin = cp.r0;
-      const int brow = (rmin - py0) >> 1;
-      const int ra = py0 + 2 * brow;
-      int cm = cp.cA;
-      if (ra == rmin && cp.cB < cm) cm = cp.cB;
-      const int bcol = (cm - px0) >> 1;
-      skey[l * NC + k] = ((unsigned)prank << 14) | ((unsigned)brow << 7) | (unsigned)bcol;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += nt >> 2) {  // four threads per component, every fourth key each (block-uniform trip count)
-      const int k = k0 + (tid >> 2), q = tid & 3;
-      const unsigned me = k < n ? skey[l * NC + k] : 0u;
-      int rk = 0;
-      for (int j = q; j < n; j += 4) rk += (skey[l * NC + j] < me) ? 1 : 0;
-      rk += __shfl_xor(rk, 1);
-      rk += __shfl_xor(rk, 2);
-      if (k < n && q == 0) {
-        T[l * NC + k].rank = (uint16_t)rk;
-        // pre-sort sequence: element at insertion position rk is component k
-        arr[l * NC + rk] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
-      }
-    }
-    __syncthreads();
-  }
-  // size sort, bigger first (contour_mng.h:596-599): libstdc++'s std::sort replayed by one WAVE per level (round 3: one
-  // lane per level, ~40 of a KITTI-shaped scan's 440 us): parallel partitions + stable rank, cc_sort.h.  The rank keys of
-  // the insertion order (skey) are dead by now: their rows hold the partitions' stopper lists, then the ranked copy.
-  for (int l = wave_id; l < CC_NLEV; l += n_waves) {
-    unsigned *a = arr + l * NC;
-    const int n = CC_NLEV_AT(l);
-    unsigned short *lpos = (unsigned short *)(skey + l * NC), *rasc = lpos + NC;
-    ccsort::std_sort_wave(
-        a, n, [](unsigned x) { return 0xFFFFu - (x >> 16); },
-        [&]() {
-          for (int k = lane; k < n; k += 64) a[T[l * NC + k].rank] = ((unsigned)T[l * NC + k].area << 16) | (unsigned)k;
-        },
-        lane, lpos, rasc, skey + l * NC, (unsigned *)R2 + l * CC_SORT_STACK);
-    int tot = 0;
-    for (int i = lane; i < n; i += 64) tot += (int)(a[i] >> 16);
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    if (lane == 0) sh2[l] = tot;
-  }
-  __syncthreads();
-  CC_K2_STAMP(5);
-  // emit sorted contour tables + header
-  for (int l = 0; l < CC_NLEV; l++) {
-    const int n = n_lev[l] < CC_MAXC ? n_lev[l] : CC_MAXC;
-    const int n_words = n * (int)(sizeof(cc_contour_t) / 4);
-    const unsigned *src = (const unsigned *)&scr->cont[l][0];
-    unsigned *dst = (unsigned *)&desc->cont[l][0];
-    for (int w = tid; w < n_words; w += nt) {
-      const int seq = w / 19, off = w - seq * 19;
-      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
-      dst[w] = src[k * 19 + off];
-    }
-    for (int seq = tid; seq < CC_NDIST && seq < n; seq += nt) {
-      const int k = (int)(arr[l * NC + seq] & 0xFFFFu);
-      const cc_contour_t *cv = &scr->cont[l][k];
-      cc_anchor_lds a;
-      a.pm[0] = cv->pos_mean[0];
-      a.pm[1] = cv->pos_mean[1];
-      a.ev[0] = cv->eig_vals[0];
-      a.ev[1] = cv->eig_vals[1];
-      a.cnt = cv->cell_cnt;
-      top[l * CC_NDIST + seq] = a;
-    }
-  }
-  if (tid < CC_NLEV) {
-    desc->n_cont[tid] = CC_NLEV_AT(tid);
-    desc->n_stored[tid] = CC_NLEV_AT(tid) < CC_MAXC ? CC_NLEV_AT(tid) : CC_MAXC;
-    desc->layer_cell_cnt[tid] = sh2[tid];
-  }
-  if (tid == 0) {
-    const cc_k1_scan_out k1 = k1_out[scan];
-    desc->max_bin_val = k1.max_bin_val;
-    desc->min_bin_val = k1.min_bin_val;
-    desc->n_pix = k1.n_pix;
-    int fl = flags0;
-    for (int l = 0; l < CC_NLEV; l++) fl |= n_lev[l] > CC_MAXC ? CC_DESC_TRUNCATED : 0;  // exact, the CC_MAXC largest are stored
-    desc->flags = fl;
-  }
-  if (labels_dbg) {
-    // component index -> seq (position after the size sort); skey is free now
-    for (int l = 0; l < CC_NLEV; l++)
-      for (int seq = tid; seq < n_lev[l]; seq += nt) skey[l * NC + (arr[l * NC + seq] & 0xFFFFu)] = (unsigned)seq;
-    __syncthreads();
-    for (int l = 0; l < CC_NLEV; l++) {
-      int16_t *ld = labels_dbg + ((size_t)scan * CC_NLEV + l) * n_cell;
-      for (int c = tid; c < n_cell; c += nt) {
-        int16_t v = ld[c];
-        if (v >= 0) ld[c] = (int16_t)skey[l * NC + v];
-      }
-    }
-  }
-  __syncthreads();
-
-  CC_K2_STAMP(6);
-  // =========================== phase "keys" (contour_mng.h:693-830) ===========================
-  // R2 layout: divs f32 [36][35] (5040) | cntp int[36] | valid int[36] | acc int[36] | bci tmp | bci pts
-  float *divs = (float *)R2;
-  int *cntp = (int *)(R2 + 5056);
-  int *valid = cntp + 36;
-  int *accum = valid + 36;
-  const int NA = CC_NLEV * CC_NPIV;
-  if (tid < NA) {
-    const int ll = tid / CC_NPIV, seq = tid - ll * CC_NPIV;
-    int ok = 0, acc = 0;
-    if (seq < cfg.piv_firsts) {
-      for (int s = 0; s <= seq; s++)
-        if (s < CC_NLEV_AT(ll)) acc += top[ll * CC_NDIST + s].cnt;  // accumulate_cell_cnt (contour_mng.h:705-706)
-      ok = (seq < CC_NLEV_AT(ll) && top[ll * CC_NDIST + seq].cnt >= cfg.min_cont_key_cnt) ? 1 : 0;
-    }
-    valid[tid] = ok;
-    accum[tid] = acc;
-    cntp[tid] = 0;
-  }
-  // the BCI phase's per-wave scratch (R2 + 5504 ...) is idle until then: the exp table and the list of valid anchors
-  double *exp_tab = (double *)(R2 + 5504);                    // 512 B
-  unsigned char *vlist = (unsigned char *)(R2 + 5504 + 512);  // [36] anchors with a key, ascending
-  if (tid >= 64 && tid < 128) exp_tab[tid - 64] = __longlong_as_double((long long)cc_exp2_tab64[tid - 64]);
-  __syncthreads();
-  int NV = 0;
-  for (int a = 0; a < CC_NLEV * CC_NPIV; a++) {  // uniform; 36 broadcast reads
-    const int ok = valid[a];
-    if (ok && tid == 0) vlist[NV] = (unsigned char)a;
-    NV += ok;
-  }
-  __syncthreads();
-  const int roi_pad = (int)ceilf(cfg.roi_radius + 1.f);
-  const float div_len = cfg.roi_radius / (float)(7 * 5);
-  const float bin_len = cfg.roi_radius / (float)7;
-  const double r_lim = (double)cfg.roi_radius - 1e-2;
-  // The 35 divisions of an anchor accumulate over the same cells (RoI cells above level 1 within the radius, in raster
-  // order; contour_mng.h:735-770): the cell list -- distance to the anchor, number of levels above -- is built once per
-  // anchor by a wave (ballot-ordered, so raster order is kept), then one lane per (anchor, division) walks it in LDS with
-  // the reference's f32 accumulation order.  Anchors are handled CC_KEYS_GRP at a time; the lists live where the
-  // ordering tables were.
-  {
-    const int CAP = CC_KEYS_CAP;
-    float *ldist = (float *)R;
-    unsigned char *lhi = (unsigned char *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 4);
-    int *lcnt = (int *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 5);
-    long long acc_klist = 0, acc_kexp = 0;
-    tmark = phase_clk ? (long long)wall_clock64() : 0;
-    // groups of CC_KEYS_GRP VALID anchors (a street scene has ~18 of the 36: two groups, not three)
-    for (int g0 = 0; g0 < NV; g0 += CC_KEYS_GRP) {
-      for (int av = g0 + wave_id; av < g0 + CC_KEYS_GRP && av < NV; av += n_waves) {
-        const int a = (int)vlist[av];
-        int n = 0;
-        {
-          const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-          const float vcx = top[ll * CC_NDIST + seq].pm[0], vcy = top[ll * CC_NDIST + seq].pm[1];
-          const int r_cen = (int)vcx, c_cen = (int)vcy;
-          const int r_min = r_cen - roi_pad > 0 ? r_cen - roi_pad : 0;
-          const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
-          const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
-          const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
-          const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
-          // nine 64-cell stretches (a 23 x 23 window) at a time: their level bytes and positions are fetched before any
-          // of them is compacted, so the L2 round trips of the positions overlap
-          const int KB = 9;
-          for (int base0 = 0; base0 < tot; base0 += 64 * KB) {
-            int lvv[KB];
-            float2 rcv[KB];
-#pragma unroll
-            for (int u = 0; u < KB; u++) {
-              const int idx = base0 + 64 * u + lane;
-              lvv[u] = 0;
-              rcv[u] = make_float2(0.f, 0.f);
-              if (idx < tot) {
-                const int ro = idx / W;
-                const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
-                // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
-                // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
-                lvv[u] = LV[cell];
-                if (lvv[u] >= 2) rcv[u] = pix[cell];
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < KB; u++) {
-              if (base0 + 64 * u >= tot) break;  // uniform
-              bool q = false;
-              float dist = 0.f;
-              if (lvv[u] >= 2) {
-                const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
-                dist = sqrtf(dx * dx + dy * dy);
-                q = (double)dist < r_lim;
-              }
-              const unsigned long long m = __ballot(q);
-              const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-              if (q && pos < CAP) {
-                ldist[(av - g0) * CAP + pos] = dist;
-                lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
-              }
-              n += __popcll(m);
-            }
-          }
-          if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
-        }
-        if (lane == 0) lcnt[av - g0] = n;
-      }
-      __syncthreads();
-      CC_K2_LAP(acc_klist);
-      for (int t = tid; t < CC_KEYS_GRP * 35; t += nt) {
-        const int al = t / 35, d = t - al * 35;
-        if (g0 + al >= NV) continue;
-        const int a = (int)vlist[g0 + al];
-        float acc = 0.f;
-        const int n = lcnt[al] < CAP ? lcnt[al] : CAP;
-        {
-          // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56): exp(-u^2/2) / sqrt(2 pi), here
-          // exp(...) * (1 / sqrt(2 pi)) -- one f64 rounding away from the quotient, gone in the conversion to f32
-          const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
-          for (int i = 0; i < n; i++) {
-            const float dist = ldist[al * CAP + i];
-            const int higher = lhi[al * CAP + i];
-            const float u = (xg - dist) / 1.0f;
-            const float pdf = (float)(cc_exp_nonpos(-0.5 * (double)u * (double)u, exp_tab) * 0.3989422804014327);
-            acc += (float)higher * pdf;
-          }
-        }
-        divs[a * 35 + d] = acc;
-        if (d == 0) cntp[a] = lcnt[al];
-      }
-      __syncthreads();
-      CC_K2_LAP(acc_kexp);
-    }
-    if (phase_clk && tid == 0) {
-      phase_clk[(size_t)scan * CC_K2_NCLK + 14] = acc_klist;
-      phase_clk[(size_t)scan * CC_K2_NCLK + 15] = acc_kexp;
-    }
-  }
-  for (int t = tid; t < NA * CC_KEY_DIM; t += nt) {
-    const int a = t / CC_KEY_DIM, kd = t - a * CC_KEY_DIM;
-    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-    float v = 0.f;
-    if (valid[a]) {
-      const cc_anchor_lds an = top[ll * CC_NDIST + seq];
-      if (kd == 0)
-        v = sqrtf(an.ev[1] * (float)an.cnt);
-      else if (kd == 1)
-        v = sqrtf(an.ev[0] * (float)an.cnt);
-      else if (kd == 2)
-        v = (float)sqrt((double)accum[a]);
-      else {
-        const int b = kd - 3;
-        float ring = 0.f;
-        for (int d = 0; d < 5; d++) ring += divs[a * 35 + b * 5 + d];
-        ring = (float)((double)ring * ((double)bin_len / sqrt((double)cntp[a])));
-        v = ring;
-      }
-    }
-    desc->keys[ll][seq][kd] = v;
-  }
-  __syncthreads();
-
-  CC_K2_STAMP(7);
-  // =========================== phase "BCI" (contour_mng.h:848-883) ===========================
-  struct bci_tmp {
-    int ok;
-    int bit;
-    float r, theta;
-  };
-  bci_tmp *btmp = (bci_tmp *)(R + 17280);                          // [36][40] 23040 B  (T/skey/arr dead; ends < top)
-  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
-    const int a = t / CC_BCI_MAXPTS, q = t - a * CC_BCI_MAXPTS;
-    const int bl = q / CC_NDIST, j = q - bl * CC_NDIST;
-    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-    bci_tmp o;
-    o.ok = 0;
-    o.bit = 0;
-    o.r = 0.f;
-    o.theta = 0.f;
-    const int lev = bl + 1;  // DIST_BIN_LAYERS = {1,2,3,4}
-    const int lim = cfg.dist_firsts < CC_NLEV_AT(lev) ? cfg.dist_firsts : CC_NLEV_AT(lev);
-    if (valid[a] && j < lim && !(ll == lev && j == seq)) {
-      const float vx = top[lev * CC_NDIST + j].pm[0] - top[ll * CC_NDIST + seq].pm[0];
-      const float vy = top[lev * CC_NDIST + j].pm[1] - top[ll * CC_NDIST + seq].pm[1];
-      const float dist = sqrtf(vx * vx + vy * vy);
-      const double dd = (double)dist;
-      if (!(dd > (CC_BITS_PER_LAYER - 1) * 1.01 + 5.43 - 1e-3 || dd <= 5.43)) {
-        const float orie = cc_atan2f_fdlibm(vy, vx);  // glibc's atan2f, operation for operation (cc_stats.h)
-        double fl = floor((dd - 5.43) / 1.01);
-        if (fl > CC_BITS_PER_LAYER - 1.0) fl = CC_BITS_PER_LAYER - 1.0;
-        o.ok = 1;
-        o.bit = (int)(fl + (double)(bl * CC_BITS_PER_LAYER));
-        o.r = dist;
-        o.theta = orie;
-      }
-    }
-    btmp[t] = o;
-  }
-  __syncthreads();
-  // The neighbour points are sorted through 32-bit proxies (bit_pos << 8 | slot, compared on bit_pos only): the replay of
-  // std::sort depends on the comparison outcomes alone, so the proxies end up in the order the reference's
-  // RelativePoint records would.
-  unsigned *bkey = (unsigned *)(R + 0);                            // [36][40] (T is dead now)
-  int *bcnt = (int *)(R + 5760);                                   // [36] points per anchor
-  // One WAVE per anchor (round 3: one lane per anchor, a lane-serial gather + sort replay + segment scan of dependent LDS
-  // reads, 26 us per scan whatever the scan): the <= 40 candidate neighbours sit one per lane, the valid ones are compacted
-  // with a ballot (slot order, as the serial loop appended them), sorted by the wave-parallel std::sort replay (cc_sort.h),
-  // segment starts found with a ballot.  Per-wave scratch behind the key tables in R2 (divs 5040 B + 3 x 36 ints end at 5488).
-  {
-    char *ws = R2 + 5504 + wave_id * 448;
-    unsigned short *lpos = (unsigned short *)ws, *rasc = lpos + CC_BCI_MAXPTS;   // 2 x 80 B
-    unsigned *tmp = (unsigned *)(ws + 160);                                        // 160 B
-    unsigned *seg = (unsigned *)(ws + 320);                                        // CC_SORT_STACK words = 104 B
-    static_assert(320 + CC_SORT_STACK * 4 <= 448 && CC_BCI_MAXPTS <= 64, "per-wave BCI scratch");
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int a = wave_id; a < NA; a += n_waves) {
-      const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-      unsigned *p = bkey + a * CC_BCI_MAXPTS;
-      bci_tmp o;
-      o.ok = 0;
-      o.bit = 0;
-      if (lane < CC_BCI_MAXPTS) o = btmp[a * CC_BCI_MAXPTS + lane];
-      const unsigned long long mok = __ballot(o.ok != 0);
-      const int n = __popcll(mok);
-      auto gather = [&]() {
-        if (o.ok) p[__popcll(mok & lt)] = ((unsigned)o.bit << 8) | (unsigned)lane;
-      };
-      gather();
-      // the 256-bit ring: word w = OR of the valid lanes' bits of that word
-      unsigned long long bw[4];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        unsigned long long v = (o.ok && (o.bit >> 6) == w) ? (1ull << (o.bit & 63)) : 0ull;
-        for (int sh_ = 32; sh_ > 0; sh_ >>= 1) v |= __shfl_xor(v, sh_);
-        bw[w] = v;
-      }
-      ccsort::std_sort_wave(p, n, [](unsigned x) { return x >> 8; }, gather, lane, lpos, rasc, tmp, seg);
-      cc_bci_t *ob = &desc->bcis[ll][seq];
-      // segment starts: positions where bit_pos changes, then n (contour_mng.h:871-883)
-      const bool head = lane < n && (lane == 0 || (p[lane] >> 8) != (p[lane - 1] >> 8));
-      const unsigned long long mh = __ballot(head);
-      const int nh = __popcll(mh), ns = n > 0 ? nh + 1 : 0;
-      if (head) ob->segs[__popcll(mh & lt)] = (uint16_t)lane;
-      if (lane == 0 && n > 0) ob->segs[nh] = (uint16_t)n;
-      if (lane >= ns && lane < CC_BCI_MAXPTS + 2) ob->segs[lane] = 0;
-      if (lane == 0) {
-        bcnt[a] = n;
-        ob->dist_bin[0] = bw[0];
-        ob->dist_bin[1] = bw[1];
-        ob->dist_bin[2] = bw[2];
-        ob->dist_bin[3] = bw[3];
-        // layer_key_bcis_ has piv_firsts_ entries per level (contour_mng.h:835-838): the record's slots beyond that stay all-zero
-        ob->piv_seq = seq < cfg.piv_firsts ? (int8_t)seq : (int8_t)0;
-        ob->level = seq < cfg.piv_firsts ? (int8_t)ll : (int8_t)0;
-        ob->n_pts = (uint8_t)n;
-        ob->n_segs = (uint8_t)ns;
-      }
-    }
-  }
-  __syncthreads();
-  // the point records, all threads
-  for (int t = tid; t < NA * CC_BCI_MAXPTS; t += nt) {
-    const int a = t / CC_BCI_MAXPTS, i = t - a * CC_BCI_MAXPTS;
-    const int ll = a / CC_NPIV, seq = a - ll * CC_NPIV;
-    unsigned w0 = 0u;
-    float r = 0.f, th = 0.f;
-    if (i < bcnt[a]) {
-      const unsigned k = bkey[a * CC_BCI_MAXPTS + i];
-      const int q = (int)(k & 0xFFu);
-      const bci_tmp o = btmp[a * CC_BCI_MAXPTS + q];
-      // level (int8) | seq (int8) << 8 | bit_pos (int16) << 16
-      w0 = (unsigned)(q / CC_NDIST + 1) | ((unsigned)(q % CC_NDIST) << 8) | ((k >> 8) << 16);
-      r = o.r;
-      th = o.theta;
-    }
-    unsigned *dst = (unsigned *)&desc->bcis[ll][seq].pts[i];
-    dst[0] = w0;
-    dst[1] = __float_as_uint(r);
-    dst[2] = __float_as_uint(th);
-  }
-  CC_K2_STAMP(8);
-}
-#undef CC_K2_STAMP
-
-// 4 waves per SIMD = two 512-thread workgroups (scans) per CU: at most 128 VGPRs
-__global__ void __launch_bounds__(CC_K2_BLOCK, 4)
-cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
-              const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
-              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
-              cc_k2_big_queue *__restrict__ queue) {
-  HIP_DYNAMIC_SHARED(char, smem)
-  cc_k2_body<CC_NC, false>(cfg, bev_in, pix_in, k1_out, scratch_all + blockIdx.x, nullptr, queue, (int)blockIdx.x, desc_out, labels_dbg, phase_clk,
-                           smem);
-}
-
-// The slow path: a few workgroups take the scans the fast launch has queued, one after the other, each with its own block
-// of global scratch.  Launched behind every fast launch (the host cannot know whether anything was queued without waiting
-// for it); with an empty queue it ends at once.
-__global__ void __launch_bounds__(CC_K2_BLOCK, 2)
-cc_k_contours_big(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
-                  const cc_k1_scan_out *__restrict__ k1_out, cc_k2_big_slot *__restrict__ slots, cc_k2_big_queue *__restrict__ queue,
-                  cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
-  HIP_DYNAMIC_SHARED(char, smem)
-  __shared__ int s_next;
-  for (;;) {
-    __syncthreads();  // the previous scan's LDS is no longer read
-    if (threadIdx.x == 0) s_next = atomicAdd(&queue->next, 1);
-    __syncthreads();
-    const int k = s_next;
-    if (k >= queue->n_flagged) {
-      // the last workgroup to leave resets the queue for the next call (no memset launch per ingest call)
-      if (threadIdx.x == 0 && atomicAdd(&queue->exited, 1) == (int)gridDim.x - 1) {
-        queue->n_flagged = 0;
-        queue->next = 0;
-        queue->exited = 0;
-      }
-      return;
-    }
-    cc_k2_body<CC_NC_BIG, true>(cfg, bev_in, pix_in, k1_out, &slots[blockIdx.x].scr, &slots[blockIdx.x].tab, nullptr, queue->scan[k], desc_out,
-                                labels_dbg, nullptr, smem);
-  }
+  int n_lev_f[CC_NLEV];
+  for (int l = 0; l < CC_NLEV; l++) n_lev_f[l] = sh[8 + l];
+  const int flags_f = sh[2];
+  cc_k2_levmap lm;
+  lm.LV = LV;
+  lm.bitmap = nullptr;
+  lm.cbase = nullptr;
+  lm.lev = nullptr;
+  cc_k2_back<NC, BIG, false>(cfg, pix, k1_out, scr, bigtab, scan, desc_out, labels_dbg, phase_clk, R, n_lev_f, flags_f, lm);
 }

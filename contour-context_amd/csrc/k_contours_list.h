@@ -1,0 +1,699 @@
+// K2, list front half (round 6): labelling of ALL six level sets at once on the raster-ordered list of the scan's active
+// cells, everything the passes touch resident in LDS.  Replaces, for scans of up to CC_K2L_NCAP active cells, the front
+// half of cc_k2_body (k_contours.h) -- the level loop, the member lists and the statistics walks; the back half
+// (cc_k2_back: insertion order, size sort, emit, keys, BCIs) is shared.  Same reference code as k_contours.h:
+//   ContourManager::makeContourRecursiveHelper   src/cont2/contour_mng.cpp:274-353
+//   RunningStatRecorder / ContourView::calcStatVals   contour.h:48-95,142-255
+//
+// Why: the original front half walks the levels top-down through one cell-indexed label image -- 7 barrier intervals per
+// level, 42 per scan, each bounded by LDS latency and not by work (a level of a nearly empty scan costs ~9 us) -- and keeps
+// six cells per thread in registers across that loop (128 VGPR + 160 B of scratch per lane), its per-level index images and
+// member lists in a global scratch block (2.5 x the kernel's algorithmic HBM traffic).  Here:
+//   * an ENTRY is an active cell (above the lowest level), entries are in raster order; entry i with level count L_i owns
+//     the SLOTS off[i] .. off[i] + L_i - 1, one per level set it belongs to (off = prefix sum of the level counts);
+//   * the label forest lives in slot space (u16 per slot): level l's components are labelled independently of the other
+//     levels' -- one pass over the adjacent pairs links a pair at every level both cells share -- so the whole labelling is
+//     ONE union pass, ONE flatten pass, ONE numbering pass (a dozen barrier intervals per scan instead of 42+);
+//   * a root is its component's smallest slot = its first cell in raster order, exactly as before, so components are
+//     numbered in the same order (OpenCV's label order restated) and every later stage sees the same input;
+//   * member lists (stable counting sort per level, one wave per level) and the heights / continuous positions the
+//     statistics walks read are in LDS; the only global scratch left are the component records and contour rows the back
+//     half reads.
+// A scan that does not fit (more than CC_K2L_NCAP active cells, CC_K2L_SCAP slots, CC_NC components on a level, or
+// min_cont_cell_cnt_ > 3) is queued for cc_k_contours_mid -- the original body, unchanged -- which in turn queues what IT
+// cannot number for cc_k_contours_big.
+#pragma once
+#include "k_contours.h"
+
+#define CC_K2L_NCAP 3072                          // entries (active cells) per scan
+#define CC_K2L_SCAP 10240                         // (entry, level) slots per scan (< 0x8000: labels carry a mark bit)
+#define CC_K2L_MEMB 11264                         // member-list entries incl. the lists' alignment padding
+#define CC_K2L_NSTR (CC_K2L_NCAP / 64)            // 64-entry stretches of the list (<= 64: one lane per stretch in the prefix)
+#define CC_K2L_NCHUNK ((CC_MAX_CELLS + 63) / 64)  // 64-cell chunks of the grid
+// LDS map (bytes).  Persistent through the back half: bit map, chunk bases, level bytes (the keys' RoI lookups).
+#define CC_K2L_O_BITMAP 0      // u64[352]: active cells of chunk b
+#define CC_K2L_O_CBASE 2816    // u16[352]: entries before chunk b
+#define CC_K2L_O_LEV 3584      // u8[NCAP]: level count of entry i
+#define CC_K2L_O_REST 6656     // what follows is the back half's region R (>= CC_K2_R_BYTES) once the walks are done
+#define CC_K2L_R_RC 0          // u16[NCAP]: (row << 8) | col of entry i
+#define CC_K2L_R_X 6144        // 36 864 B: labels + offsets + bit maps while the labelling runs, then heights + positions
+#define CC_K2L_R_MEMB 43008    // u16[MEMB] member lists (stage A: the level bytes per cell, u8[n_cell])
+#define CC_K2L_R_AREA 65536    // u16[6][NC] members per component
+#define CC_K2L_R_PTR 69376     // u16[6][NC] list write pointers (level-relative)
+#define CC_K2L_R_SH 73216      // int[128] scalars | u8[6][48] kept roots per stretch | u16[96] large components
+#define CC_K2L_LDS_BYTES (6656 + 73216 + 1024)
+#define CC_K2L_X_OFF 20480     // u16[NCAP + 1] slot offsets (behind the labels u16[SCAP])
+#define CC_K2L_X_BITA 26640    // u32[SCAP / 32]
+#define CC_K2L_X_BITB 27920
+#define CC_K2L_X_SBASE 29200   // stage A: u16[352] slots before chunk b
+#define CC_K2L_X_CLEV 29904    // stage A: u16[352] slots of chunk b
+#define CC_K2L_X_CCNT 30608    // stage A: u8[352] entries of chunk b
+static_assert(CC_K2L_SCAP < 0x8000 && CC_K2L_NSTR <= 64 && CC_NC * CC_NLEV * 2 == 3840, "list front half: table sizes");
+static_assert(CC_K2L_X_CCNT + CC_K2L_NCHUNK <= 36864 && CC_K2L_NCAP * 12 <= 36864 && CC_MAX_CELLS <= CC_K2L_MEMB * 2, "list front half: region X / stage A overlays");
+static_assert(CC_K2L_R_SH >= CC_K2_R_BYTES, "the back half's region");
+
+#ifdef CC_EMU  // CPU test harness only: say which scans leave the list kernel (tests assert on the path taken)
+#define CC_K2L_TRACE_BAIL() do { if (getenv("CC_EMU_TRACE_K2")) fprintf(stderr, "[k2 list] scan %d handed to the mid path (line %d)\n", scan, __LINE__); } while (0)
+#else
+#define CC_K2L_TRACE_BAIL() do { } while (0)
+#endif
+
+__device__ __forceinline__ int cc_k2l_idx_of(const unsigned long long *bitmap, const uint16_t *cbase, int cell) {
+  const unsigned long long m = bitmap[cell >> 6];
+  const int bit = cell & 63;
+  return ((m >> bit) & 1ull) ? (int)cbase[cell >> 6] + __popcll(m & ((1ull << bit) - 1ull)) : -1;
+}
+
+// Returns false when the scan was handed to the mid path (block-uniform); on true n_lev_out[] holds the levels' component
+// counts and scr->comp / scr->cont are written (visible after the caller's barrier).
+__device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+                                                 cc_k2_scratch *__restrict__ scr, cc_k2_big_queue *__restrict__ midq, int scan,
+                                                 cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg,
+                                                 long long *__restrict__ phase_clk, char *smem, int *n_lev_out) {
+  CC_K2_STAMP(0);
+  const int n_cell = cfg.n_cell, n_col = cfg.n_col;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  const int NC = CC_NC;
+#define CC_K2L_BAIL()                                                  \
+  do {                                                                 \
+    if (tid == 0) {                                                    \
+      CC_K2L_TRACE_BAIL();                                             \
+      midq->scan[atomicAdd(&midq->n_flagged, 1)] = scan;               \
+      desc_out[scan].flags = CC_DESC_INEXACT_COMPONENTS;               \
+    }                                                                  \
+    return false;                                                      \
+  } while (0)
+  if (cfg.min_cont_cell_cnt > 3) CC_K2L_BAIL();  // the exact-area renumbering of that configuration lives in the original body only
+
+  unsigned long long *bitmap = (unsigned long long *)(smem + CC_K2L_O_BITMAP);
+  uint16_t *cbase = (uint16_t *)(smem + CC_K2L_O_CBASE);
+  unsigned char *lev = (unsigned char *)(smem + CC_K2L_O_LEV);
+  char *R = smem + CC_K2L_O_REST;
+  uint16_t *rc = (uint16_t *)(R + CC_K2L_R_RC);
+  char *X = R + CC_K2L_R_X;
+  uint16_t *LAB = (uint16_t *)X;
+  uint16_t *off = (uint16_t *)(X + CC_K2L_X_OFF);
+  unsigned *bitA = (unsigned *)(X + CC_K2L_X_BITA), *bitB = (unsigned *)(X + CC_K2L_X_BITB);
+  uint16_t *sbase = (uint16_t *)(X + CC_K2L_X_SBASE), *clev = (uint16_t *)(X + CC_K2L_X_CLEV);
+  unsigned char *ccnt = (unsigned char *)(X + CC_K2L_X_CCNT);
+  uint16_t *memb = (uint16_t *)(R + CC_K2L_R_MEMB);
+  unsigned char *LVt = (unsigned char *)(R + CC_K2L_R_MEMB);
+  uint16_t *area = (uint16_t *)(R + CC_K2L_R_AREA);
+  uint16_t *ptr = (uint16_t *)(R + CC_K2L_R_PTR);
+  int *sh = (int *)(R + CC_K2L_R_SH);
+  unsigned char *scnt = (unsigned char *)(R + CC_K2L_R_SH + 512);
+  uint16_t *big = (uint16_t *)(R + CC_K2L_R_SH + 512 + 288);
+
+  const float *bev = bev_in + (size_t)scan * n_cell;
+  const float2 *pix = pix_in + (size_t)scan * n_cell;
+  long long acc_ccl = 0, acc_enum = 0, acc_walk = 0, tmark = phase_clk ? (long long)wall_clock64() : 0, tsub = tmark;
+  if (phase_clk && tid == 0)
+    for (int j = 0; j < 6; j++) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + j] = 0;
+
+  // ---- (A) level count of every cell (coalesced 16-byte loads of the BEV, four cells per lane), then the raster-ordered
+  //      list of the active cells: per 64-cell chunk six ballots (cells above level k) give the chunk's occupancy word,
+  //      its entry count and its slot count; a prefix over the 352 chunks (every wave makes all of it: no hand-over) gives
+  //      entry index and first slot of every active cell.
+  {
+    const float4 *bev4 = (const float4 *)bev;
+    const int n_quad = n_cell >> 2;
+#pragma unroll 6
+    for (int v = tid; v < n_quad; v += nt) {
+      const float4 h4 = bev4[v];
+      const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+      unsigned lv4 = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int lv = 0;
+        for (int e = 0; e < CC_NLEV; e++) lv += (hh[u] > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+        lv4 |= (unsigned)lv << (8 * u);
+      }
+      ((unsigned *)LVt)[v] = lv4;
+    }
+  }
+  if (tid < 128) sh[tid] = 0;
+  for (int i = tid; i < CC_NLEV * NC / 2; i += nt) ((unsigned *)area)[i] = 0u;
+  for (int i = tid; i < 2 * (CC_K2L_SCAP / 32); i += nt) bitA[i] = 0u;  // bitA and bitB are adjacent
+  if (labels_dbg)
+    for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
+  __syncthreads();
+  const int n_chunk = (n_cell + 63) >> 6;
+  for (int b = wave_id; b < n_chunk; b += n_waves) {
+    const int c = b * 64 + lane;
+    const int lvc = c < n_cell ? (int)LVt[c] : 0;
+    const unsigned long long m0 = __ballot(lvc > 0);
+    int levs = __popcll(m0);
+#pragma unroll
+    for (int k = 1; k < CC_NLEV; k++) levs += __popcll(__ballot(lvc > k));
+    if (lane == 0) {
+      bitmap[b] = m0;
+      ccnt[b] = (unsigned char)__popcll(m0);
+      clev[b] = (uint16_t)levs;
+    }
+  }
+  __syncthreads();
+  int n_act = 0, n_slot = 0;
+  for (int q = 0; q < n_chunk; q += 64) {
+    const int b = q + lane;
+    const int v1 = b < n_chunk ? (int)ccnt[b] : 0, v2 = b < n_chunk ? (int)clev[b] : 0;
+    int i1 = v1, i2 = v2;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int w1 = __shfl_up(i1, o), w2 = __shfl_up(i2, o);
+      if (lane >= o) {
+        i1 += w1;
+        i2 += w2;
+      }
+    }
+    if (b < n_chunk) {  // identical values from every wave
+      cbase[b] = (uint16_t)(n_act + i1 - v1);
+      const int s0 = n_slot + i2 - v2;
+      sbase[b] = (uint16_t)(s0 < 0xFFFF ? s0 : 0xFFFF);
+    }
+    n_act += __shfl(i1, 63);
+    n_slot += __shfl(i2, 63);
+  }
+#ifdef CC_EMU
+  if (tid == 0 && getenv("CC_EMU_TRACE_K2")) fprintf(stderr, "[k2 list] scan %d: %d active cells, %d slots\n", scan, n_act, n_slot);
+#endif
+  if (n_act > CC_K2L_NCAP || n_slot > CC_K2L_SCAP) CC_K2L_BAIL();
+  cc_wave_sync();  // a wave reads back what it wrote itself
+  for (int b = wave_id; b < n_chunk; b += n_waves) {
+    const int c = b * 64 + lane;
+    const int lvc = c < n_cell ? (int)LVt[c] : 0;
+    const unsigned long long m0 = __ballot(lvc > 0);
+    int so = (int)sbase[b] + __popcll(m0 & lane_lt);
+#pragma unroll
+    for (int k = 1; k < CC_NLEV; k++) so += __popcll(__ballot(lvc > k) & lane_lt);
+    if (lvc > 0) {
+      const int i = (int)cbase[b] + __popcll(m0 & lane_lt);
+      const int r = c / n_col;
+      rc[i] = (uint16_t)((r << 8) | (c - r * n_col));
+      lev[i] = (unsigned char)lvc;
+      off[i] = (uint16_t)so;
+      for (int l = 0; l < lvc; l++) LAB[so + l] = (uint16_t)(so + l);  // every slot starts as its own root
+    }
+  }
+  if (tid == 0) off[n_act] = (uint16_t)n_slot;
+  __syncthreads();
+  CC_K2_STAMP(9);
+  tmark = phase_clk ? (long long)wall_clock64() : 0;
+  tsub = tmark;
+
+  // ---- (B) 8-connected labelling of all level sets: one union per (adjacent pair, level both cells are in).  Backward
+  //      neighbours only (W, NW, N, NE): W is the previous entry if its cell is; the row above through the bit map.  Labels
+  //      are slot indices, parents point to smaller slots, so a root is its component's first cell in raster order whatever
+  //      the order of the unions.
+  for (int i = tid; i < n_act; i += nt) {
+    const unsigned rcv = rc[i];
+    const int r = (int)(rcv >> 8), cc = (int)(rcv & 255u);
+    const int c = r * n_col + cc;
+    const int Li = (int)lev[i], oi = (int)off[i];
+    int nj[4];
+    nj[0] = (cc > 0 && i > 0 && (unsigned)rc[i - 1] == rcv - 1u) ? i - 1 : -1;
+    nj[1] = (r > 0 && cc > 0) ? cc_k2l_idx_of(bitmap, cbase, c - n_col - 1) : -1;
+    nj[2] = r > 0 ? cc_k2l_idx_of(bitmap, cbase, c - n_col) : -1;
+    nj[3] = (r > 0 && cc < n_col - 1) ? cc_k2l_idx_of(bitmap, cbase, c - n_col + 1) : -1;
+    int shd[4], ojd[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      shd[d] = 0;
+      ojd[d] = 0;
+      if (nj[d] >= 0) {
+        const int Lj = (int)lev[nj[d]];
+        shd[d] = Lj < Li ? Lj : Li;
+        ojd[d] = (int)off[nj[d]];
+      }
+    }
+    for (int l = 0; l < Li; l++) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        if (l < shd[d]) {
+          const unsigned a = (unsigned)(oi + l), b = (unsigned)(ojd[d] + l);
+          // two slots with the same parent are in one tree already: two independent reads instead of two finds
+          if (cc_lds_vread16(LAB + a) != cc_lds_vread16(LAB + b)) cc_uf_union(LAB, a, b);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  CC_K2_SUBLAP(0);
+  // ---- (C) every slot is pointed at its root (an entry's finds advance hop by hop together); which roots own >= 3 cells:
+  //      a member that is not the root sets the root's bit in A, and in B if A was set already
+  const int need = cfg.min_cont_cell_cnt < 3 ? cfg.min_cont_cell_cnt : 3;
+  for (int i = tid; i < n_act; i += nt) {
+    const int Li = (int)lev[i], oi = (int)off[i];
+    unsigned x[CC_NLEV];
+#pragma unroll
+    for (int l = 0; l < CC_NLEV; l++) x[l] = (unsigned)(oi + l);
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int l = 0; l < CC_NLEV; l++) {
+        const unsigned pq = l < Li ? cc_lds_vread16(LAB + x[l]) : x[l];
+        more |= pq != x[l];
+        x[l] = pq;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < CC_NLEV; l++) {
+      if (l < Li && x[l] != (unsigned)(oi + l)) {
+        const unsigned rt = x[l];
+        LAB[oi + l] = (uint16_t)rt;
+        const unsigned bit = 1u << (rt & 31u);
+        if (atomicOr(&bitA[rt >> 5], bit) & bit) atomicOr(&bitB[rt >> 5], bit);
+      }
+    }
+  }
+  __syncthreads();
+  CC_K2_SUBLAP(1);
+  CC_K2_LAP(acc_ccl);
+  // ---- (D) kept roots, numbered per level in raster order of their first cells: ballots per 64-entry stretch (a wave
+  //      takes every n_waves-th stretch), a prefix over the <= 48 stretches per level in registers (one lane per stretch,
+  //      every wave makes it for itself), then the same ballots again give the numbers.
+#define CC_K2L_KEPT(s_) (need <= 1 || (((need == 2 ? bitA : bitB)[(s_) >> 5] >> ((s_) & 31)) & 1u))
+  const int n_str = (n_act + 63) >> 6;
+  for (int q = wave_id; q < n_str; q += n_waves) {
+    const int i = q * 64 + lane;
+    const int Li = i < n_act ? (int)lev[i] : 0, oi = i < n_act ? (int)off[i] : 0;
+#pragma unroll
+    for (int l = 0; l < CC_NLEV; l++) {
+      const bool kp = l < Li && (unsigned)LAB[oi + l] == (unsigned)(oi + l) && CC_K2L_KEPT(oi + l);
+      const unsigned long long m = __ballot(kp);
+      if (lane == 0) scnt[l * CC_K2L_NSTR + q] = (unsigned char)__popcll(m);
+    }
+  }
+  __syncthreads();
+  CC_K2_SUBLAP(2);
+  int nk[CC_NLEV], pre[CC_NLEV];
+  bool too_many = false;
+#pragma unroll
+  for (int l = 0; l < CC_NLEV; l++) {
+    const int v = lane < n_str ? (int)scnt[l * CC_K2L_NSTR + lane] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int w_ = __shfl_up(incl, o);
+      if (lane >= o) incl += w_;
+    }
+    pre[l] = incl - v;
+    nk[l] = __shfl(incl, 63);
+    too_many = too_many || nk[l] > NC;
+  }
+  if (too_many) CC_K2L_BAIL();  // more components on a level than the tables hold: the mid path decides (and queues for the big one)
+  for (int q = wave_id; q < n_str; q += n_waves) {
+    const int i = q * 64 + lane;
+    const int Li = i < n_act ? (int)lev[i] : 0, oi = i < n_act ? (int)off[i] : 0;
+#pragma unroll
+    for (int l = 0; l < CC_NLEV; l++) {
+      const bool kp = l < Li && (unsigned)LAB[oi + l] == (unsigned)(oi + l) && CC_K2L_KEPT(oi + l);
+      const unsigned long long m = __ballot(kp);
+      const int base = __builtin_amdgcn_readlane(pre[l], q);
+      if (kp) LAB[oi + l] = (uint16_t)(0x8000u | (unsigned)(base + __popcll(m & lane_lt)));
+    }
+  }
+  __syncthreads();
+  CC_K2_SUBLAP(3);
+  // ---- (E) component index of every slot, in place (a kept root carries 0x8000 | index; a member of a kept component
+  //      reads it from its root and carries it from here on); members counted per component; a root's parent is the
+  //      component its own cell belongs to one level down (the same entry's previous slot)
+  for (int i = tid; i < n_act; i += nt) {
+    const int Li = (int)lev[i], oi = (int)off[i];
+    int16_t *ld = nullptr;
+    int cell = 0;
+    if (labels_dbg) {
+      const unsigned rcv = rc[i];
+      cell = (int)(rcv >> 8) * n_col + (int)(rcv & 255u);
+      ld = labels_dbg + (size_t)scan * CC_NLEV * n_cell;
+    }
+    unsigned jprev = 0xFFFFu;
+    for (int l = 0; l < Li; l++) {
+      const unsigned v = LAB[oi + l];
+      unsigned j = CC_COMP_NONE;
+      if (v & 0x8000u) {  // a kept root (only its owner -- this thread -- ever writes the slot)
+        j = v & 0x7FFFu;
+        if (l > 0) scr->comp[l][j].parent = (uint16_t)jprev;
+      } else if (v != (unsigned)(oi + l)) {
+        const unsigned rv = LAB[v];  // roots are not rewritten in this pass
+        if (rv & 0x8000u) {
+          j = rv & 0x7FFFu;
+          LAB[oi + l] = (uint16_t)rv;
+        }
+      }
+      if (j != CC_COMP_NONE) {
+        const unsigned t = (unsigned)(l * NC) + j;
+        atomicAdd((unsigned *)area + (t >> 1), 1u << ((t & 1u) * 16));
+        if (ld) ld[(size_t)l * n_cell + cell] = (int16_t)j;
+      }
+      jprev = j == CC_COMP_NONE ? 0xFFFFu : j;
+    }
+  }
+  __syncthreads();
+  CC_K2_SUBLAP(4);
+  CC_K2_LAP(acc_enum);
+  // ---- (F) member lists: list starts (prefix of the areas, each rounded up to four entries: 8-byte aligned lists), then a
+  //      wave per level sweeps the list, 64 entries at a time, and gives every member its rank inside its component
+  //      (entries of one component meet through ballots; a running write pointer per component) -- a stable counting sort,
+  //      so every list is in raster order
+#define CC_K2L_NK(l_) ((l_) == 0 ? nk[0] : (l_) == 1 ? nk[1] : (l_) == 2 ? nk[2] : (l_) == 3 ? nk[3] : (l_) == 4 ? nk[4] : nk[5])
+  CC_K2_STAMP(10);
+  for (int l = wave_id; l < CC_NLEV; l += n_waves) {
+    const int n = CC_K2L_NK(l);
+    int run = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      const int k = k0 + lane;
+      const int a = k < n ? (int)area[l * NC + k] : 0;
+      const int a4 = (a + 3) & ~3;
+      int incl = a4;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (k < n) {
+        ptr[l * NC + k] = (uint16_t)(run + incl - a4);
+        if (a > CC_K2_BIG) big[atomicAdd(&sh[3], 1)] = (uint16_t)(l * NC + k);  // <= SCAP / (CC_K2_BIG + 1) = 79 of them
+      }
+      run += __shfl(incl, 63);
+    }
+    if (lane == 0) sh[16 + l] = run;
+  }
+  __syncthreads();
+  int lbase[CC_NLEV + 1];
+  lbase[0] = 0;
+#pragma unroll
+  for (int l = 0; l < CC_NLEV; l++) lbase[l + 1] = lbase[l] + sh[16 + l];
+  if (lbase[CC_NLEV] > CC_K2L_MEMB) CC_K2L_BAIL();  // (the padding of very many tiny components)
+#define CC_K2L_LBASE(l_) ((l_) == 0 ? lbase[0] : (l_) == 1 ? lbase[1] : (l_) == 2 ? lbase[2] : (l_) == 3 ? lbase[3] : (l_) == 4 ? lbase[4] : lbase[5])
+  // the heights and continuous positions the walks read: requested now (a thread's entries), stored behind the sweep's
+  // barrier -- they go where the labels are
+  float ch[CC_K2L_NCAP / CC_K2_BLOCK];
+  float2 cp[CC_K2L_NCAP / CC_K2_BLOCK];
+  static_assert(CC_K2L_NCAP % CC_K2_BLOCK == 0, "entries per thread");
+#pragma unroll
+  for (int u = 0; u < CC_K2L_NCAP / CC_K2_BLOCK; u++) {
+    const int i = tid + u * CC_K2_BLOCK;
+    ch[u] = 0.f;
+    cp[u] = make_float2(0.f, 0.f);
+    if (i < n_act) {
+      const unsigned rcv = rc[i];
+      const int cell = (int)(rcv >> 8) * n_col + (int)(rcv & 255u);
+      ch[u] = bev[cell];
+      cp[u] = pix[cell];
+    }
+  }
+  for (int l = wave_id; l < CC_NLEV; l += n_waves) {
+    uint16_t *ml = memb + CC_K2L_LBASE(l);
+    uint16_t *ptr_l = ptr + l * NC;
+    auto comp_of = [&](int i) -> unsigned {
+      if (i >= n_act || (int)lev[i] <= l) return CC_COMP_NONE;
+      const unsigned v = LAB[(int)off[i] + l];
+      return (v & 0x8000u) ? (v & 0x7FFFu) : CC_COMP_NONE;
+    };
+    unsigned jn = comp_of(lane);
+    for (int b0 = 0; b0 < n_act; b0 += 64) {
+      const unsigned j = jn;
+      const int i = b0 + lane;
+      jn = comp_of(i + 64);  // the next stretch travels while this one is filed
+      unsigned long long todo = __ballot(j != CC_COMP_NONE);
+      int rank = 0, total = 0;
+      bool last = false;
+      while (todo) {
+        const int src = __ffsll(todo) - 1;
+        const unsigned j0 = (unsigned)__builtin_amdgcn_readlane((int)j, src);  // src is wave-uniform
+        const unsigned long long m = __ballot(j == j0);
+        if (j == j0) {
+          rank = __popcll(m & lane_lt);
+          total = __popcll(m);
+          last = (m >> lane) == 1ull;
+        }
+        todo &= ~m;
+      }
+      int base = 0;
+      if (j != CC_COMP_NONE) {
+        base = (int)ptr_l[j];
+        ml[base + rank] = (uint16_t)i;
+      }
+      cc_wave_sync();  // every lane has read its pointer
+      if (j != CC_COMP_NONE && last) ptr_l[j] = (uint16_t)(base + total);
+      cc_wave_sync();
+    }
+  }
+  __syncthreads();
+  float *cbev = (float *)X;                              // [NCAP]
+  float2 *cpix = (float2 *)(X + CC_K2L_NCAP * 4);        // [NCAP]
+#pragma unroll
+  for (int u = 0; u < CC_K2L_NCAP / CC_K2_BLOCK; u++) {
+    const int i = tid + u * CC_K2_BLOCK;
+    if (i < n_act) {
+      cbev[i] = ch[u];
+      cpix[i] = cp[u];
+    }
+  }
+  __syncthreads();
+  CC_K2_STAMP(11);
+  // ---- (G) raster-order running statistics (contour_mng.cpp:317-331): ONE LANE per component walks its member list, eight
+  //      members per step -- their heights / positions fetched before any is added, the tail of the last step masked to +0.0
+  //      (every sum starts at +0.0 and never becomes -0.0, so x + 0.0 == x bit for bit) -- and finishes with calcStatVals;
+  //      the lane also finds what the insertion order needs of the component's shape: first row and its first column (the
+  //      first member), smallest column, first member column of the second row.
+  int lev_base[CC_NLEV + 1];
+  lev_base[0] = 0;
+#pragma unroll
+  for (int l = 0; l < CC_NLEV; l++) lev_base[l + 1] = lev_base[l] + nk[l];
+  const int n_tot = lev_base[CC_NLEV];
+  auto finish = [&](int l, int k, int a, const uint16_t *ml, const cc_running_stat &rec, int c0, int c1, int cB) {
+    const unsigned rc0 = rc[ml[0]], rcl = rc[ml[a - 1]];  // first member = the root; last member in raster order = poi_
+    cc_contour_t cvw;
+    cc_calc_stat_vals(cfg, rec, l, (int)(rcl >> 8), (int)(rcl & 255u), &cvw);
+    scr->cont[l][k] = cvw;
+    cc_comp_t *cpo = &scr->comp[l][k];  // (.parent was written in (E))
+    const unsigned root_cell = (rc0 >> 8) * (unsigned)n_col + (rc0 & 255u);
+    *(unsigned *)cpo = root_cell | ((unsigned)a << 16);
+    cpo->rank = 0;
+    cpo->r0 = (uint8_t)(rc0 >> 8);
+    cpo->r1 = 0;
+    cpo->c0 = (uint8_t)c0;
+    cpo->c1 = (uint8_t)c1;
+    cpo->cA = (uint8_t)(rc0 & 255u);
+    cpo->cB = (uint8_t)cB;
+    cpo->pad[0] = cpo->pad[1] = 0;
+  };
+  for (int w = tid; w < n_tot; w += nt) {
+    int l = 0;
+    for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
+    const int k = w - (l == 0 ? lev_base[0] : l == 1 ? lev_base[1] : l == 2 ? lev_base[2] : l == 3 ? lev_base[3] : l == 4 ? lev_base[4] : lev_base[5]);
+    const int a = (int)area[l * NC + k];
+    if (a > CC_K2_BIG) continue;  // left to the eight-lane pass below
+    const uint16_t *ml = memb + CC_K2L_LBASE(l) + (int)ptr[l * NC + k] - a;
+    const uint2 *ml2 = (const uint2 *)ml;
+    cc_running_stat rec;
+    rec.cnt = a;
+    rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
+    rec.vol3 = 0.f;
+    const int row1 = (int)(rc[ml[0]] >> 8) + 1;
+    int c0 = 255, c1 = 0, cB = 255;
+    uint2 nxa = ml2[0], nxb = a > 4 ? ml2[1] : make_uint2(0u, 0u);
+    for (int m0 = 0; m0 < a; m0 += 8) {
+      const unsigned wds[4] = {nxa.x, nxa.y, nxb.x, nxb.y};
+      if (m0 + 8 < a) nxa = ml2[(m0 >> 2) + 2];
+      if (m0 + 12 < a) nxb = ml2[(m0 >> 2) + 3];
+      const int nv = a - m0;
+      unsigned mk[8], rcu[8];
+      float hv[8];
+      float2 rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        mk[u] = (unsigned)-(int)(u < nv);  // all ones for a member, 0 for the list's padding (not initialised)
+        const unsigned iu = ((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & mk[u];
+        hv[u] = cbev[iu];
+        rv[u] = cpix[iu];
+        rcu[u] = rc[iu];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const float h = __uint_as_float(__float_as_uint(hv[u]) & mk[u]);
+        const double vr = (double)__uint_as_float(__float_as_uint(rv[u].x) & mk[u]);
+        const double vc = (double)__uint_as_float(__float_as_uint(rv[u].y) & mk[u]);
+        rec.ps_x += vr;
+        rec.ps_y += vc;
+        rec.t_xx += vr * vr;
+        rec.t_xy += vr * vc;
+        rec.t_yy += vc * vc;
+        rec.vol3 += h;
+        rec.tq_x += (double)h * vr;
+        rec.tq_y += (double)h * vc;
+        const int col = (int)(rcu[u] & 255u);
+        const int colm = mk[u] ? col : 255;
+        c0 = colm < c0 ? colm : c0;
+        c1 = (mk[u] && col > c1) ? col : c1;
+        cB = (mk[u] && (int)(rcu[u] >> 8) == row1 && cB == 255) ? col : cB;
+      }
+    }
+    finish(l, k, a, ml, rec, c0, c1, cB);
+  }
+  CC_K2_STAMP(12);
+  // The large components (a street scene's ground-connected blob): EIGHT LANES share one, one running sum each (a product
+  // a * b with (a, b) picked per lane, 1.0 for the plain sums: the same values added in the same order), the f32 height sum
+  // and the shape by every lane; lane 0 of the eight collects the sums and finishes.
+  {
+    const int n_big = sh[3];
+    const int role = tid & 7;
+    // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: nothing of its own)
+    const unsigned fa_h = role >= 5 ? ~0u : 0u, fa_y = (role == 1 || role == 4) ? ~0u : 0u, fa_x = ~(fa_h | fa_y);
+    const unsigned fb_1 = role < 2 ? ~0u : 0u, fb_x = (role == 2 || role == 5) ? ~0u : 0u, fb_y = ~(fb_1 | fb_x);
+    for (int g0 = 0; g0 < n_big; g0 += nt >> 3) {  // block-uniform trip count
+      const int g = g0 + (tid >> 3);
+      const bool on = g < n_big;
+      double acc = 0.0;
+      float vol3 = 0.f;
+      int l = 0, k = 0, a = 0, c0 = 255, c1 = 0, cB = 255;
+      const uint16_t *ml = memb;
+      if (on) {
+        const int t = (int)big[g];
+        l = t / NC;
+        k = t - l * NC;
+        a = (int)area[t];
+        ml = memb + CC_K2L_LBASE(l) + (int)ptr[t] - a;
+        const uint2 *ml2 = (const uint2 *)ml;
+        const int row1 = (int)(rc[ml[0]] >> 8) + 1;
+        uint2 nxa = ml2[0], nxb = ml2[1];
+        for (int m0 = 0; m0 < a; m0 += 8) {
+          const unsigned wds[4] = {nxa.x, nxa.y, nxb.x, nxb.y};
+          if (m0 + 8 < a) nxa = ml2[(m0 >> 2) + 2];
+          if (m0 + 12 < a) nxb = ml2[(m0 >> 2) + 3];
+          const int nv = a - m0;
+          unsigned mk[8], rcu[8];
+          float hv[8];
+          float2 rv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            mk[u] = (unsigned)-(int)(u < nv);
+            const unsigned iu = ((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & mk[u];
+            hv[u] = cbev[iu];
+            rv[u] = cpix[iu];
+            rcu[u] = rc[iu];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const unsigned hb = __float_as_uint(hv[u]) & mk[u], xb = __float_as_uint(rv[u].x) & mk[u], yb = __float_as_uint(rv[u].y) & mk[u];
+            const float fa = __uint_as_float((hb & fa_h) | (xb & fa_x) | (yb & fa_y));
+            const float fb = __uint_as_float((0x3F800000u & fb_1) | (xb & fb_x) | (yb & fb_y));
+            acc += (double)fa * (double)fb;  // a padding slot adds (+0.0) * fb = +0.0
+            vol3 += __uint_as_float(hb);
+            const int col = (int)(rcu[u] & 255u);
+            const int colm = mk[u] ? col : 255;
+            c0 = colm < c0 ? colm : c0;
+            c1 = (mk[u] && col > c1) ? col : c1;
+            cB = (mk[u] && (int)(rcu[u] >> 8) == row1 && cB == 255) ? col : cB;
+          }
+        }
+      }
+      cc_running_stat rec;
+      const int b8 = (tid & 63) & ~7;
+      rec.ps_x = __shfl(acc, b8 + 0);
+      rec.ps_y = __shfl(acc, b8 + 1);
+      rec.t_xx = __shfl(acc, b8 + 2);
+      rec.t_xy = __shfl(acc, b8 + 3);
+      rec.t_yy = __shfl(acc, b8 + 4);
+      rec.tq_x = __shfl(acc, b8 + 5);
+      rec.tq_y = __shfl(acc, b8 + 6);
+      rec.vol3 = vol3;
+      rec.cnt = a;
+      if (on && role == 0) finish(l, k, a, ml, rec, c0, c1, cB);
+    }
+  }
+  CC_K2_LAP(acc_walk);
+  if (phase_clk && tid == 0) {
+    phase_clk[(size_t)scan * CC_K2_NCLK + 1] = acc_ccl;
+    phase_clk[(size_t)scan * CC_K2_NCLK + 2] = acc_enum;
+    phase_clk[(size_t)scan * CC_K2_NCLK + 3] = acc_walk;
+  }
+  CC_K2_STAMP(4);
+#pragma unroll
+  for (int l = 0; l < CC_NLEV; l++) n_lev_out[l] = nk[l];
+  return true;
+#undef CC_K2L_BAIL
+#undef CC_K2L_KEPT
+#undef CC_K2L_NK
+#undef CC_K2L_LBASE
+}
+
+// 4 waves per SIMD = two 512-thread workgroups (scans) per CU: at most 128 VGPRs
+__global__ void __launch_bounds__(CC_K2_BLOCK, 4)
+cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+              const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
+              cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
+              cc_k2_big_queue *__restrict__ midq) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  const int scan = (int)blockIdx.x;
+  cc_k2_scratch *scr = scratch_all + scan;
+  int n_lev[CC_NLEV];
+  if (!cc_k2_front_list(cfg, bev_in, pix_in, scr, midq, scan, desc_out, labels_dbg, phase_clk, smem, n_lev)) return;
+  __threadfence_block();
+  __syncthreads();
+  cc_k2_levmap lm;
+  lm.LV = nullptr;
+  lm.bitmap = (const unsigned long long *)(smem + CC_K2L_O_BITMAP);
+  lm.cbase = (const uint16_t *)(smem + CC_K2L_O_CBASE);
+  lm.lev = (const unsigned char *)(smem + CC_K2L_O_LEV);
+  cc_k2_back<CC_NC, false, true>(cfg, pix_in + (size_t)scan * cfg.n_cell, k1_out, scr, nullptr, scan, desc_out, labels_dbg, phase_clk,
+                                 smem + CC_K2L_O_REST, n_lev, 0, lm);
+}
+
+// The scans the list kernel handed on (more active cells / slots / components than its LDS tables hold, or
+// min_cont_cell_cnt_ > 3): the original body with its cell-indexed label image, a scan at a time per workgroup.  Launched
+// behind every list launch; with an empty queue it ends at once.  What IT cannot number goes on to cc_k_contours_big.
+__global__ void __launch_bounds__(CC_K2_BLOCK, 2)
+cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+                  const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all, cc_k2_big_queue *__restrict__ midq,
+                  cc_k2_big_queue *__restrict__ bigq, cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  __shared__ int s_next;
+  for (;;) {
+    __syncthreads();  // the previous scan's LDS is no longer read
+    if (threadIdx.x == 0) s_next = atomicAdd(&midq->next, 1);
+    __syncthreads();
+    const int k = s_next;
+    if (k >= midq->n_flagged) {
+      if (threadIdx.x == 0 && atomicAdd(&midq->exited, 1) == (int)gridDim.x - 1) {
+        midq->n_flagged = 0;
+        midq->next = 0;
+        midq->exited = 0;
+      }
+      return;
+    }
+    const int scan = midq->scan[k];
+    cc_k2_body<CC_NC, false>(cfg, bev_in, pix_in, k1_out, scratch_all + scan, nullptr, bigq, scan, desc_out, labels_dbg, nullptr, smem);
+  }
+}
+
+// The slow path: a few workgroups take the scans the fast launch has queued, one after the other, each with its own block
+// of global scratch.  Launched behind every fast launch (the host cannot know whether anything was queued without waiting
+// for it); with an empty queue it ends at once.
+__global__ void __launch_bounds__(CC_K2_BLOCK, 2)
+cc_k_contours_big(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+                  const cc_k1_scan_out *__restrict__ k1_out, cc_k2_big_slot *__restrict__ slots, cc_k2_big_queue *__restrict__ queue,
+                  cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+  HIP_DYNAMIC_SHARED(char, smem)
+  __shared__ int s_next;
+  for (;;) {
+    __syncthreads();  // the previous scan's LDS is no longer read
+    if (threadIdx.x == 0) s_next = atomicAdd(&queue->next, 1);
+    __syncthreads();
+    const int k = s_next;
+    if (k >= queue->n_flagged) {
+      // the last workgroup to leave resets the queue for the next call (no memset launch per ingest call)
+      if (threadIdx.x == 0 && atomicAdd(&queue->exited, 1) == (int)gridDim.x - 1) {
+        queue->n_flagged = 0;
+        queue->next = 0;
+        queue->exited = 0;
+      }
+      return;
+    }
+    cc_k2_body<CC_NC_BIG, true>(cfg, bev_in, pix_in, k1_out, &slots[blockIdx.x].scr, &slots[blockIdx.x].tab, nullptr, queue->scan[k], desc_out,
+                                labels_dbg, nullptr, smem);
+  }
+}
+
+#undef CC_K2_STAMP
