@@ -22,7 +22,7 @@ import synth  # noqa: E402,F401
 import sharding  # noqa: E402,F401
 
 LIB_PATH = os.path.join(_HERE, "libcont2_amd.so")
-_SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_group.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "cc_fmath.h", "k_rasterize.h", "k_contours.h",
+_SRCS = ["cont2_amd.hip", "cc_dev.h", "cc_group.h", "cc_hostcfg.h", "cc_sort.h", "cc_stats.h", "cc_fmath.h", "k_rasterize.h", "k_contours.h", "k_contours_list.h",
          "k_knn.h", "k_check.h", "k_merge.h", "k_gmm.h", "cc_hostdb.h", "cc_db_api.inc", "cc_comm.inc"]
 
 

@@ -25,6 +25,25 @@ __device__ __forceinline__ void cc_wave_sync() {
 }
 
 
+// bits of a wave-wide mask below the caller's lane: popcount(m & ((1 << lane) - 1)) as the two v_mbcnt instructions it is (the
+// generic expression costs two ANDs and two bit counts; with the mask in scalar registers nothing else)
+__device__ __forceinline__ int cc_mbcnt(unsigned long long m) {
+#ifndef CC_EMU
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+#else
+  return __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+#endif
+}
+// the wave's index inside its workgroup as a SCALAR (threadIdx.x >> 6 is a vector value to the compiler: loops over "my wave's
+// chunks" then run on exec masks, and every ballot result they use sits in vector registers)
+__device__ __forceinline__ int cc_wave_id() {
+#ifndef CC_EMU
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  return (int)(threadIdx.x >> 6);
+#endif
+}
+
 // Volatile reads of LDS words that other lanes are changing (the union-find forest of K2).  A plain `volatile T *` made from a
 // generic pointer keeps the GENERIC address space -- the address-space inference leaves volatile accesses alone -- and is
 // compiled to flat_load + s_waitcnt vmcnt(0) per access (round 4's labelling ran on those); spelled with the LDS address
@@ -38,11 +57,15 @@ __device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) {
 __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) {
   return *(const volatile __attribute__((address_space(3))) unsigned *)p;
 }
+__device__ __forceinline__ void cc_lds_vwrite16(uint16_t *p, unsigned v) {
+  *(volatile __attribute__((address_space(3))) uint16_t *)p = (uint16_t)v;
+}
 #pragma clang diagnostic pop
 __device__ __forceinline__ double cc_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }  // v_rsq_f64
 #else
 __device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) { return *(const volatile uint16_t *)p; }
 __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) { return *(const volatile unsigned *)p; }
+__device__ __forceinline__ void cc_lds_vwrite16(uint16_t *p, unsigned v) { *(volatile uint16_t *)p = (uint16_t)v; }
 __device__ __forceinline__ double cc_rsq_seed(double x) { return 1.0 / sqrt(x); }
 #endif
 

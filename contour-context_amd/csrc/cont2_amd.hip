@@ -360,7 +360,7 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
     std::vector<long long> h(CC_K2_NCLK * (size_t)c->max_batch);
     HIPCHK(hipMemcpy(h.data(), c->d_phase_clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
     const int n = c->max_batch < 256 ? c->max_batch : 256;
-    double ph[9] = {0}, sub[8] = {0}, lv[6] = {0};
+    double ph[9] = {0}, sub[8] = {0}, lv[6] = {0}, sa[4] = {0};
     for (int i = 0; i < n; i++) {
       const long long *p = &h[(size_t)i * CC_K2_NCLK];
       ph[0] += p[1] * 0.01;
@@ -378,11 +378,21 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
       sub[4] += p[14] * 0.01;            // keys: RoI lists
       sub[5] += p[15] * 0.01;            // keys: division sums
       for (int j = 0; j < 6; j++) lv[j] += p[16 + j] * 0.01;
+      sa[0] += (p[22] - p[0]) * 0.01;
+      sa[1] += (p[23] - p[22]) * 0.01;
+      sa[2] += (p[24] - p[23]) * 0.01;
+      sa[3] += (p[9] - p[24]) * 0.01;
     }
     fprintf(stderr, "[cc_k_contours phases, mean us over %d scans] ccl %.1f  enum+bbox %.1f  walk %.1f  order+sort %.1f  emit %.1f  keys %.1f  bci %.1f  | total %.1f\n",
             n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
     fprintf(stderr, "[cc_k_contours sub-phases] fill+list %.1f | walk: member lists %.1f  lane walk %.1f  eight-lane walk %.1f | keys: RoI lists %.1f  division sums %.1f\n",
             sub[0] / n, sub[1] / n, sub[2] / n, sub[3] / n, sub[4] / n, sub[5] / n);
+    {
+      cc_k2_big_queue hq;
+      HIPCHK(hipMemcpy(&hq, c->main.d_midq, sizeof(hq), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[cc_k_contours] scans handed to the mid path so far: %d (configuration %d, cells / slots %d, components %d, list padding %d)\n", hq.total, hq.why[0], hq.why[1], hq.why[2], hq.why[3]);
+    }
+    fprintf(stderr, "[cc_k_contours list stage A] levels %.1f  chunk ballots %.1f  prefix %.1f  entries + run labels %.1f\n", sa[0] / n, sa[1] / n, sa[2] / n, sa[3] / n);
     fprintf(stderr, "[cc_k_contours level loop, summed over the levels] unions %.1f  flatten+count %.1f  kept roots %.1f  rank %.1f  bbox/area %.1f  records %.1f\n",
             lv[0] / n, lv[1] / n, lv[2] / n, lv[3] / n, lv[4] / n, lv[5] / n);
   }

@@ -66,7 +66,8 @@ struct cc_k2_big_slot {  // one workgroup of the slow path
   cc_k2_big_tables tab;
 };
 struct cc_k2_big_queue {  // filled by the fast launch, drained by the slow one (whose last workgroup leaves it empty again)
-  int n_flagged, next, exited, pad_;
+  int n_flagged, next, exited, total;  // total: scans ever queued (statistics, never reset)
+  int why[4];   // ... by reason (list kernel: configuration, cells / slots, components per level, list padding)
   int scan[1];  // [max_batch] follows
 };
 #define CC_K2_NCLK 32    // phase-clock slots per scan (tuning aid)
@@ -716,7 +717,7 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
   }
   if (tid < 40) sh[tid] = 0;
   __syncthreads();
-  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  const int wave_id = cc_wave_id(), lane = tid & 63, n_waves = nt >> 6;
   int n_act;
   {
     const int per_wave = (((n_cell + n_waves - 1) / n_waves) + 63) & ~63;

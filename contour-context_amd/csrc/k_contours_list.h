@@ -26,8 +26,13 @@
 #include "k_contours.h"
 
 #define CC_K2L_NCAP 3072                          // entries (active cells) per scan
-#define CC_K2L_SCAP 10240                         // (entry, level) slots per scan (< 0x8000: labels carry a mark bit)
-#define CC_K2L_MEMB 11264                         // member-list entries incl. the lists' alignment padding
+#define CC_K2L_SCAP 12800                         // (entry, level) slots per scan (< 0x8000: labels carry a mark bit)
+#ifndef CC_K2L_MEMB
+#define CC_K2L_MEMB 11264
+#endif
+//                        // member-list entries incl. the lists' alignment padding
+#define CC_K2L_BIG 64                             // components of this many cells and more are walked by eight lanes
+#define CC_K2L_WL_CAP (CC_K2L_MEMB / 2)            // link items the work list holds (the member lists' block, 4 bytes per item)
 #define CC_K2L_NSTR (CC_K2L_NCAP / 64)            // 64-entry stretches of the list (<= 64: one lane per stretch in the prefix)
 #define CC_K2L_NCHUNK ((CC_MAX_CELLS + 63) / 64)  // 64-cell chunks of the grid
 // LDS map (bytes).  Persistent through the back half: bit map, chunk bases, level bytes (the keys' RoI lookups).
@@ -38,18 +43,18 @@
 #define CC_K2L_R_RC 0          // u16[NCAP]: (row << 8) | col of entry i
 #define CC_K2L_R_X 6144        // 36 864 B: labels + offsets + bit maps while the labelling runs, then heights + positions
 #define CC_K2L_R_MEMB 43008    // u16[MEMB] member lists (stage A: the level bytes per cell, u8[n_cell])
-#define CC_K2L_R_AREA 65536    // u16[6][NC] members per component
-#define CC_K2L_R_PTR 69376     // u16[6][NC] list write pointers (level-relative)
-#define CC_K2L_R_SH 73216      // int[128] scalars | u8[6][48] kept roots per stretch | u16[96] large components
-#define CC_K2L_LDS_BYTES (6656 + 73216 + 1024)
-#define CC_K2L_X_OFF 20480     // u16[NCAP + 1] slot offsets (behind the labels u16[SCAP])
-#define CC_K2L_X_BITA 26640    // u32[SCAP / 32]
-#define CC_K2L_X_BITB 27920
-#define CC_K2L_X_SBASE 29200   // stage A: u16[352] slots before chunk b
-#define CC_K2L_X_CLEV 29904    // stage A: u16[352] slots of chunk b
-#define CC_K2L_X_CCNT 30608    // stage A: u8[352] entries of chunk b
-static_assert(CC_K2L_SCAP < 0x8000 && CC_K2L_NSTR <= 64 && CC_NC * CC_NLEV * 2 == 3840, "list front half: table sizes");
-static_assert(CC_K2L_X_CCNT + CC_K2L_NCHUNK <= 36864 && CC_K2L_NCAP * 12 <= 36864 && CC_MAX_CELLS <= CC_K2L_MEMB * 2, "list front half: region X / stage A overlays");
+#define CC_K2L_R_AREA (CC_K2L_R_MEMB + 2 * CC_K2L_MEMB)  // u16[6][NC] members per component
+#define CC_K2L_R_PTR (CC_K2L_R_AREA + 3840)              // u16[6][NC] list write pointers (level-relative)
+#define CC_K2L_R_SH (CC_K2L_R_PTR + 3840)                // int[128] scalars | u8[6][48] kept roots per stretch | u16[96] large components
+#define CC_K2L_LDS_BYTES (CC_K2L_O_REST + CC_K2L_R_SH + 1024)
+#define CC_K2L_X_OFF (2 * CC_K2L_SCAP)                          // u16[NCAP + 1] slot offsets (behind the labels u16[SCAP])
+#define CC_K2L_X_BITA (CC_K2L_X_OFF + 2 * CC_K2L_NCAP + 16)     // u32[SCAP / 32]
+#define CC_K2L_X_BITB (CC_K2L_X_BITA + CC_K2L_SCAP / 8)
+#define CC_K2L_X_SBASE CC_K2L_X_BITA                            // stage A (over the bit maps, which are cleared in stage B): u16[352] slots before chunk b
+#define CC_K2L_X_CLEV (CC_K2L_X_SBASE + 2 * CC_K2L_NCHUNK)      // stage A: u16[352] slots of chunk b
+#define CC_K2L_X_CCNT (CC_K2L_X_CLEV + 2 * CC_K2L_NCHUNK)       // stage A: u8[352] entries of chunk b
+static_assert(CC_K2L_SCAP / CC_K2L_BIG <= 256 && CC_K2L_BIG == 64 && CC_K2L_SCAP % 32 == 0 && CC_K2L_X_BITA % 4 == 0 && CC_K2L_SCAP < 0x8000 && CC_K2L_NSTR <= 64 && CC_NC * CC_NLEV * 2 == 3840, "list front half: table sizes");
+static_assert(CC_K2L_X_CCNT + 2 * CC_K2L_NCHUNK <= CC_K2L_X_BITB + CC_K2L_SCAP / 8 && CC_K2L_X_BITB + CC_K2L_SCAP / 8 <= 36864 && CC_K2L_NCAP * 12 <= 36864 && CC_MAX_CELLS <= CC_K2L_MEMB * 2 + 7680, "list front half: region X / stage A overlays");
 static_assert(CC_K2L_R_SH >= CC_K2_R_BYTES, "the back half's region");
 
 #ifdef CC_EMU  // CPU test harness only: say which scans leave the list kernel (tests assert on the path taken)
@@ -64,6 +69,48 @@ __device__ __forceinline__ int cc_k2l_idx_of(const unsigned long long *bitmap, c
   return ((m >> bit) & 1ull) ? (int)cbase[cell >> 6] + __popcll(m & ((1ull << bit) - 1ull)) : -1;
 }
 
+// find with path halving: every second cell of the path is pointed at its grandparent (a 16-bit store to a cell that is not a
+// root: the CAS of a concurrent link compares the whole 32-bit word and retries).  The list kernel labels every level set from
+// single runs, in whatever order the threads come by -- without it a component's tree grows as deep as the component is tall.
+__device__ __forceinline__ unsigned cc_uf_find_h(uint16_t *LAB, unsigned x) {
+  for (;;) {
+    const unsigned p = cc_lds_vread16(LAB + x);
+    if (p == x) return x;
+    const unsigned gp = cc_lds_vread16(LAB + p);
+    if (gp == p) return p;
+    cc_lds_vwrite16(LAB + x, gp);
+    x = gp;
+  }
+}
+__device__ __forceinline__ void cc_uf_union_h(uint16_t *LAB, unsigned a, unsigned b) {
+  a = cc_uf_find_h(LAB, a);
+  b = cc_uf_find_h(LAB, b);
+  while (a != b) {
+    if (a < b) {
+      const unsigned t = a;
+      a = b;
+      b = t;
+    }
+    unsigned *w = (unsigned *)LAB + (a >> 1);  // a > b: hang root a under b, provided a is still a root
+    const int shf = (a & 1) * 16;
+    unsigned old = cc_lds_vread32(w);
+    unsigned cur;
+    while (true) {
+      cur = (old >> shf) & 0xFFFFu;
+      if (cur != a) break;
+      const unsigned got = atomicCAS(w, old, (old & ~(0xFFFFu << shf)) | (b << shf));
+      if (got == old) {
+        cur = b;
+        break;
+      }
+      old = got;
+    }
+    if (cur == b) break;
+    a = cc_uf_find_h(LAB, cur);
+    b = cc_uf_find_h(LAB, b);
+  }
+}
+
 // Returns false when the scan was handed to the mid path (block-uniform); on true n_lev_out[] holds the levels' component
 // counts and scr->comp / scr->cont are written (visible after the caller's barrier).
 __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
@@ -73,19 +120,21 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int wave_id = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  const int wave_id = cc_wave_id(), lane = tid & 63, n_waves = nt >> 6;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int NC = CC_NC;
-#define CC_K2L_BAIL()                                                  \
+#define CC_K2L_BAIL(why_)                                                \
   do {                                                                 \
     if (tid == 0) {                                                    \
       CC_K2L_TRACE_BAIL();                                             \
       midq->scan[atomicAdd(&midq->n_flagged, 1)] = scan;               \
+      atomicAdd(&midq->total, 1);                                      \
+      atomicAdd(&midq->why[why_], 1);                                  \
       desc_out[scan].flags = CC_DESC_INEXACT_COMPONENTS;               \
     }                                                                  \
     return false;                                                      \
   } while (0)
-  if (cfg.min_cont_cell_cnt > 3) CC_K2L_BAIL();  // the exact-area renumbering of that configuration lives in the original body only
+  if (cfg.min_cont_cell_cnt > 3) CC_K2L_BAIL(0);  // the exact-area renumbering of that configuration lives in the original body only
 
   unsigned long long *bitmap = (unsigned long long *)(smem + CC_K2L_O_BITMAP);
   uint16_t *cbase = (uint16_t *)(smem + CC_K2L_O_CBASE);
@@ -98,13 +147,15 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   unsigned *bitA = (unsigned *)(X + CC_K2L_X_BITA), *bitB = (unsigned *)(X + CC_K2L_X_BITB);
   uint16_t *sbase = (uint16_t *)(X + CC_K2L_X_SBASE), *clev = (uint16_t *)(X + CC_K2L_X_CLEV);
   unsigned char *ccnt = (unsigned char *)(X + CC_K2L_X_CCNT);
+  unsigned char *cflag = ccnt + CC_K2L_NCHUNK;  // stage A: chunk has an active cell
   uint16_t *memb = (uint16_t *)(R + CC_K2L_R_MEMB);
+  unsigned *wl = (unsigned *)(R + CC_K2L_R_MEMB);  // stage B: the work list of links (slot a | slot b << 16)
   unsigned char *LVt = (unsigned char *)(R + CC_K2L_R_MEMB);
   uint16_t *area = (uint16_t *)(R + CC_K2L_R_AREA);
   uint16_t *ptr = (uint16_t *)(R + CC_K2L_R_PTR);
   int *sh = (int *)(R + CC_K2L_R_SH);
   unsigned char *scnt = (unsigned char *)(R + CC_K2L_R_SH + 512);
-  uint16_t *big = (uint16_t *)(R + CC_K2L_R_SH + 512 + 288);
+  uint16_t *big = (uint16_t *)(R + CC_K2L_R_SH + 512);  // (over scnt: the stretch counts are dead by then) 256 entries
 
   const float *bev = bev_in + (size_t)scan * n_cell;
   const float2 *pix = pix_in + (size_t)scan * n_cell;
@@ -119,41 +170,63 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   {
     const float4 *bev4 = (const float4 *)bev;
     const int n_quad = n_cell >> 2;
+    // (sixteen lanes = one 64-cell chunk: the chunk's "any cell active" flag comes out of the loop that makes the level bytes,
+    // and the two chunk passes below only visit the chunks that have something -- a tenth to a half of the 352)
 #pragma unroll 6
-    for (int v = tid; v < n_quad; v += nt) {
-      const float4 h4 = bev4[v];
-      const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+    for (int v0 = 0; v0 < n_quad; v0 += nt) {
+      const int v = v0 + tid;
       unsigned lv4 = 0;
+      if (v < n_quad) {
+        const float4 h4 = bev4[v];
+        const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        int lv = 0;
-        for (int e = 0; e < CC_NLEV; e++) lv += (hh[u] > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
-        lv4 |= (unsigned)lv << (8 * u);
+        for (int u = 0; u < 4; u++) {
+          int lv = 0;
+          for (int e = 0; e < CC_NLEV; e++) lv += (hh[u] > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+          lv4 |= (unsigned)lv << (8 * u);
+        }
+        ((unsigned *)LVt)[v] = lv4;
       }
-      ((unsigned *)LVt)[v] = lv4;
+      const unsigned long long many = __ballot(lv4 != 0u);
+      if ((lane & 15) == 0 && v < n_quad) cflag[v >> 4] = (unsigned char)(((many >> lane) & 0xFFFFull) != 0ull);
     }
   }
   if (tid < 128) sh[tid] = 0;
-  for (int i = tid; i < CC_NLEV * NC / 2; i += nt) ((unsigned *)area)[i] = 0u;
-  for (int i = tid; i < 2 * (CC_K2L_SCAP / 32); i += nt) bitA[i] = 0u;  // bitA and bitB are adjacent
   if (labels_dbg)
     for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
   __syncthreads();
+  CC_K2_STAMP(22);
   const int n_chunk = (n_cell + 63) >> 6;
-  for (int b = wave_id; b < n_chunk; b += n_waves) {
-    const int c = b * 64 + lane;
-    const int lvc = c < n_cell ? (int)LVt[c] : 0;
-    const unsigned long long m0 = __ballot(lvc > 0);
-    int levs = __popcll(m0);
+  const int cpw = (n_chunk + n_waves - 1) / n_waves;  // chunks per wave (44 <= 64: one lane per chunk); wave w takes chunks w, w + n_waves, ...:
+                                                      // the active cells sit around the sensor, a block of consecutive rows per wave would be uneven
+  {
+    const int b = wave_id + lane * n_waves;
+    const bool mine = lane < cpw && b < n_chunk;
+    const bool full = mine && cflag[b] != 0;
+    if (mine && !full) {
+      bitmap[b] = 0ull;
+      ccnt[b] = 0;
+      clev[b] = 0;
+    }
+    unsigned long long todo = __ballot(full);
+    while (todo) {  // wave-uniform
+      const int bb = wave_id + (__ffsll(todo) - 1) * n_waves;
+      todo &= todo - 1ull;
+      const int c = bb * 64 + lane;
+      const int lvc = c < n_cell ? (int)LVt[c] : 0;
+      const unsigned long long m0 = __ballot(lvc > 0);
+      int levs = __popcll(m0);
 #pragma unroll
-    for (int k = 1; k < CC_NLEV; k++) levs += __popcll(__ballot(lvc > k));
-    if (lane == 0) {
-      bitmap[b] = m0;
-      ccnt[b] = (unsigned char)__popcll(m0);
-      clev[b] = (uint16_t)levs;
+      for (int k = 1; k < CC_NLEV; k++) levs += __popcll(__ballot(lvc > k));
+      if (lane == 0) {
+        bitmap[bb] = m0;
+        ccnt[bb] = (unsigned char)__popcll(m0);
+        clev[bb] = (uint16_t)levs;
+      }
     }
   }
   __syncthreads();
+  CC_K2_STAMP(23);
   int n_act = 0, n_slot = 0;
   for (int q = 0; q < n_chunk; q += 64) {
     const int b = q + lane;
@@ -177,23 +250,55 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
 #ifdef CC_EMU
   if (tid == 0 && getenv("CC_EMU_TRACE_K2")) fprintf(stderr, "[k2 list] scan %d: %d active cells, %d slots\n", scan, n_act, n_slot);
 #endif
-  if (n_act > CC_K2L_NCAP || n_slot > CC_K2L_SCAP) CC_K2L_BAIL();
+  if (n_act > CC_K2L_NCAP || n_slot > CC_K2L_SCAP) CC_K2L_BAIL(1);
   cc_wave_sync();  // a wave reads back what it wrote itself
-  for (int b = wave_id; b < n_chunk; b += n_waves) {
+  CC_K2_STAMP(24);
+  // Every slot starts pointing at the first cell of its horizontal RUN at its level (cells of one row, side by side, all in
+  // the level set): the run starts of a chunk are bit operations on the ballots, the start's slot comes by a shuffle.  The
+  // union pass below then only links runs of adjacent rows (and runs that continue across a chunk border).
+  const unsigned long long lane_le = lane_lt | (1ull << lane);
+  unsigned long long todo4 = __ballot(lane < cpw && wave_id + lane * n_waves < n_chunk && cflag[wave_id + lane * n_waves < n_chunk ? wave_id + lane * n_waves : 0] != 0);
+  while (todo4) {  // wave-uniform: the chunks of this wave's block that have active cells
+    const int b = wave_id + (__ffsll(todo4) - 1) * n_waves;
+    todo4 &= todo4 - 1ull;
+    const unsigned long long m0 = bitmap[b];
     const int c = b * 64 + lane;
     const int lvc = c < n_cell ? (int)LVt[c] : 0;
-    const unsigned long long m0 = __ballot(lvc > 0);
-    int so = (int)sbase[b] + __popcll(m0 & lane_lt);
+    const int r = c / n_col, cc = c - r * n_col;
+    const unsigned long long not_row_start = ~__ballot(cc == 0);
+    unsigned long long mk[CC_NLEV];
+    mk[0] = m0;
+    int so = (int)sbase[b] + cc_mbcnt(m0);
 #pragma unroll
-    for (int k = 1; k < CC_NLEV; k++) so += __popcll(__ballot(lvc > k) & lane_lt);
+    for (int k = 1; k < CC_NLEV; k++) {
+      mk[k] = __ballot(lvc > k);
+      so += cc_mbcnt(mk[k]);
+    }
     if (lvc > 0) {
-      const int i = (int)cbase[b] + __popcll(m0 & lane_lt);
-      const int r = c / n_col;
-      rc[i] = (uint16_t)((r << 8) | (c - r * n_col));
+      const int i = (int)cbase[b] + cc_mbcnt(m0);
+      rc[i] = (uint16_t)((r << 8) | cc);
       lev[i] = (unsigned char)lvc;
       off[i] = (uint16_t)so;
-      for (int l = 0; l < lvc; l++) LAB[so + l] = (uint16_t)(so + l);  // every slot starts as its own root
     }
+    // (the six levels without a branch between them: their shuffles are in flight together; an empty level set stores nothing)
+#if defined(CC_K2L_ABL) && CC_K2L_ABL == 1
+    for (int k = 0; k < CC_NLEV; k++)
+      if (lvc > k) LAB[so + k] = (uint16_t)(so + k);
+    (void)lane_le; (void)not_row_start;
+#elif defined(CC_K2L_ABL) && CC_K2L_ABL == 2
+    (void)lane_le; (void)not_row_start;
+#else
+    int so_start[CC_NLEV];
+#pragma unroll
+    for (int k = 0; k < CC_NLEV; k++) {
+      const unsigned long long starts = mk[k] & ~((mk[k] << 1) & not_row_start);
+      const int ys = 63 - __clzll((long long)(starts & lane_le));  // (lanes outside the level set: any lane, value unused)
+      so_start[k] = __shfl(so, ys & 63);
+    }
+#pragma unroll
+    for (int k = 0; k < CC_NLEV; k++)
+      if (lvc > k) LAB[so + k] = (uint16_t)(so_start[k] + k);
+#endif
   }
   if (tid == 0) off[n_act] = (uint16_t)n_slot;
   __syncthreads();
@@ -205,36 +310,97 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   //      neighbours only (W, NW, N, NE): W is the previous entry if its cell is; the row above through the bit map.  Labels
   //      are slot indices, parents point to smaller slots, so a root is its component's first cell in raster order whatever
   //      the order of the unions.
+  for (int i = tid; i < CC_NLEV * NC / 2; i += nt) ((unsigned *)area)[i] = 0u;  // (stage A's level bytes reached into this table)
+  for (int i = tid; i < 2 * (CC_K2L_SCAP / 32); i += nt) bitA[i] = 0u;           // bitA and bitB are adjacent (stage A's chunk tables lay here)
   for (int i = tid; i < n_act; i += nt) {
     const unsigned rcv = rc[i];
     const int r = (int)(rcv >> 8), cc = (int)(rcv & 255u);
     const int c = r * n_col + cc;
     const int Li = (int)lev[i], oi = (int)off[i];
-    int nj[4];
-    nj[0] = (cc > 0 && i > 0 && (unsigned)rc[i - 1] == rcv - 1u) ? i - 1 : -1;
-    nj[1] = (r > 0 && cc > 0) ? cc_k2l_idx_of(bitmap, cbase, c - n_col - 1) : -1;
-    nj[2] = r > 0 ? cc_k2l_idx_of(bitmap, cbase, c - n_col) : -1;
-    nj[3] = (r > 0 && cc < n_col - 1) ? cc_k2l_idx_of(bitmap, cbase, c - n_col + 1) : -1;
-    int shd[4], ojd[4];
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      shd[d] = 0;
-      ojd[d] = 0;
-      if (nj[d] >= 0) {
-        const int Lj = (int)lev[nj[d]];
-        shd[d] = Lj < Li ? Lj : Li;
-        ojd[d] = (int)off[nj[d]];
-      }
+    // Which links this cell has to make (the others are somebody else's or already there):
+    //  * W: inside a chunk the run labels have it; a run that continues across a chunk border is linked here;
+    //  * row above: if N is in the level set, NW and NE (when they are) belong to N's run -- one link; else NW and NE each;
+    //  * of the cells of my run that touch the same run above only the leftmost links: with W in my run and NW in the level
+    //    set, W's own link (its N is my NW) has joined the two runs.
+    // NW, N, NE are three consecutive cells: one look at the occupancy words (the field may straddle two of them) and one
+    // chunk base give all three entry indices -- the list is in raster order, so they are consecutive among the active ones.
+    int sh_w = 0, o_w = 0, sh_nw = 0, o_nw = 0, sh_n = 0, o_n = 0, sh_ne = 0, o_ne = 0;
+    if (cc > 0 && i > 0 && (unsigned)rc[i - 1] == rcv - 1u) {
+      const int Lj = (int)lev[i - 1];
+      sh_w = Lj < Li ? Lj : Li;
+      o_w = (int)off[i - 1];
     }
-    for (int l = 0; l < Li; l++) {
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        if (l < shd[d]) {
-          const unsigned a = (unsigned)(oi + l), b = (unsigned)(ojd[d] + l);
-          // two slots with the same parent are in one tree already: two independent reads instead of two finds
-          if (cc_lds_vread16(LAB + a) != cc_lds_vread16(LAB + b)) cc_uf_union(LAB, a, b);
+    if (r > 0) {
+      const int q0 = c - n_col - 1;        // the NW cell; -1 for the first cell of row 1 (then the field starts at N)
+      const int qb = q0 < 0 ? 0 : q0;
+      const int wb = qb >> 6, bit = qb & 63;
+      const unsigned long long w0 = bitmap[wb], w1 = bitmap[wb + 1 < CC_K2L_NCHUNK ? wb + 1 : wb];
+      unsigned raw = (unsigned)(w0 >> bit);
+      if (bit > 61) raw |= (unsigned)(w1 << (64 - bit));
+      raw = q0 < 0 ? (raw << 1) & 6u : raw & 7u;  // bit 0 NW, 1 N, 2 NE
+      unsigned f3 = raw;
+      if (cc == 0) f3 &= 6u;          // no NW (the cell there is the previous row's last)
+      if (cc == n_col - 1) f3 &= 3u;  // no NE
+      if (f3) {
+        const int j_nw = (int)cbase[wb] + __popcll(w0 & ((1ull << bit) - 1ull));  // entries before the field's first cell
+        const int j_n = j_nw + (int)(raw & 1u), j_ne = j_n + (int)((raw >> 1) & 1u);
+        if (f3 & 1u) {
+          const int Lj = (int)lev[j_nw];
+          sh_nw = Lj < Li ? Lj : Li;
+          o_nw = (int)off[j_nw];
+        }
+        if (f3 & 2u) {
+          const int Lj = (int)lev[j_n];
+          sh_n = Lj < Li ? Lj : Li;
+          o_n = (int)off[j_n];
+        }
+        if (f3 & 4u) {
+          const int Lj = (int)lev[j_ne];
+          sh_ne = Lj < Li ? Lj : Li;
+          o_ne = (int)off[j_ne];
         }
       }
+    }
+    // the levels at which each link is this cell's to make, as bit masks (bit l = level l)
+    const unsigned b_w = (1u << sh_w) - 1u, b_nw = (1u << sh_nw) - 1u, b_n = (1u << sh_n) - 1u, b_ne = (1u << sh_ne) - 1u;
+    unsigned m_w = ((c & 63) == 0) ? b_w : 0u;
+    unsigned m_n = b_n & ~(b_w & b_nw);
+    unsigned m_nw = b_nw & ~b_n & ~b_w;
+    unsigned m_ne = b_ne & ~b_n;
+    // The links go on a work list (slot pair per item) that the whole workgroup works off below: linked here, a wave would run
+    // the union code whenever ONE of its lanes has a link to make, at every turn of every lane's level loop.
+    const int cnt = __popc(m_w) + __popc(m_n) + __popc(m_nw) + __popc(m_ne);
+    if (cnt) {
+      int pos = atomicAdd(&sh[5], cnt);
+      const bool fits = pos + cnt <= CC_K2L_WL_CAP;
+#define CC_K2L_LINKS(mask_, o_)                                                                       \
+  while (mask_) {                                                                                     \
+    const int l_ = __ffs((int)mask_) - 1;                                                             \
+    mask_ &= mask_ - 1u;                                                                              \
+    const unsigned a_ = (unsigned)(oi + l_), b_ = (unsigned)((o_) + l_);                              \
+    if (fits)                                                                                         \
+      wl[pos++] = a_ | (b_ << 16);                                                                    \
+    else {                                                                                            \
+      if (pos < CC_K2L_WL_CAP) wl[pos] = 0u; /* a no-op item where the list still had room */         \
+      pos++;                                                                                          \
+      if (cc_lds_vread16(LAB + a_) != cc_lds_vread16(LAB + b_)) cc_uf_union_h(LAB, a_, b_);           \
+    }                                                                                                 \
+  }
+      CC_K2L_LINKS(m_w, o_w)
+      CC_K2L_LINKS(m_n, o_n)
+      CC_K2L_LINKS(m_nw, o_nw)
+      CC_K2L_LINKS(m_ne, o_ne)
+#undef CC_K2L_LINKS
+    }
+  }
+  __syncthreads();
+  {
+    const int n_items = sh[5] < CC_K2L_WL_CAP ? sh[5] : CC_K2L_WL_CAP;
+    for (int j = tid; j < n_items; j += nt) {
+      const unsigned it = wl[j];
+      const unsigned a_ = it & 0xFFFFu, b_ = it >> 16;
+      // two slots with the same parent are in one tree already: two independent reads instead of two finds
+      if (cc_lds_vread16(LAB + a_) != cc_lds_vread16(LAB + b_)) cc_uf_union_h(LAB, a_, b_);
     }
   }
   __syncthreads();
@@ -301,7 +467,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     nk[l] = __shfl(incl, 63);
     too_many = too_many || nk[l] > NC;
   }
-  if (too_many) CC_K2L_BAIL();  // more components on a level than the tables hold: the mid path decides (and queues for the big one)
+  if (too_many) CC_K2L_BAIL(2);  // more components on a level than the tables hold: the mid path decides (and queues for the big one)
   for (int q = wave_id; q < n_str; q += n_waves) {
     const int i = q * 64 + lane;
     const int Li = i < n_act ? (int)lev[i] : 0, oi = i < n_act ? (int)off[i] : 0;
@@ -310,7 +476,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       const bool kp = l < Li && (unsigned)LAB[oi + l] == (unsigned)(oi + l) && CC_K2L_KEPT(oi + l);
       const unsigned long long m = __ballot(kp);
       const int base = __builtin_amdgcn_readlane(pre[l], q);
-      if (kp) LAB[oi + l] = (uint16_t)(0x8000u | (unsigned)(base + __popcll(m & lane_lt)));
+      if (kp) LAB[oi + l] = (uint16_t)(0x8000u | (unsigned)(base + cc_mbcnt(m)));
     }
   }
   __syncthreads();
@@ -352,7 +518,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   __syncthreads();
   CC_K2_SUBLAP(4);
   CC_K2_LAP(acc_enum);
-  // ---- (F) member lists: list starts (prefix of the areas, each rounded up to four entries: 8-byte aligned lists), then a
+  // ---- (F) member lists: list starts (prefix of the areas, each rounded up to two entries: 4-byte aligned lists), then a
   //      wave per level sweeps the list, 64 entries at a time, and gives every member its rank inside its component
   //      (entries of one component meet through ballots; a running write pointer per component) -- a stable counting sort,
   //      so every list is in raster order
@@ -364,7 +530,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     for (int k0 = 0; k0 < n; k0 += 64) {
       const int k = k0 + lane;
       const int a = k < n ? (int)area[l * NC + k] : 0;
-      const int a4 = (a + 3) & ~3;
+      const int a4 = (a + 1) & ~1;  // lists start on a 4-byte boundary
       int incl = a4;
       for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o);
@@ -372,7 +538,10 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       }
       if (k < n) {
         ptr[l * NC + k] = (uint16_t)(run + incl - a4);
-        if (a > CC_K2_BIG) big[atomicAdd(&sh[3], 1)] = (uint16_t)(l * NC + k);  // <= SCAP / (CC_K2_BIG + 1) = 79 of them
+        // size class = floor(log2 area), 7 = CC_K2L_BIG cells and more (eight-lane walk): counted here, placed below -- the
+        // lane walk takes the components largest first, so the 64 lanes of a wave walk lists of similar length
+        const int cls = a >= CC_K2L_BIG ? 7 : 31 - __clz(a);
+        atomicAdd(&sh[32 + cls], 1);
       }
       run += __shfl(incl, 63);
     }
@@ -383,7 +552,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   lbase[0] = 0;
 #pragma unroll
   for (int l = 0; l < CC_NLEV; l++) lbase[l + 1] = lbase[l] + sh[16 + l];
-  if (lbase[CC_NLEV] > CC_K2L_MEMB) CC_K2L_BAIL();  // (the padding of very many tiny components)
+  if (lbase[CC_NLEV] > CC_K2L_MEMB) CC_K2L_BAIL(3);  // (the padding of very many tiny components)
 #define CC_K2L_LBASE(l_) ((l_) == 0 ? lbase[0] : (l_) == 1 ? lbase[1] : (l_) == 2 ? lbase[2] : (l_) == 3 ? lbase[3] : (l_) == 4 ? lbase[4] : lbase[5])
   // the heights and continuous positions the walks read: requested now (a thread's entries), stored behind the sweep's
   // barrier -- they go where the labels are
@@ -402,9 +571,32 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       cp[u] = pix[cell];
     }
   }
+  // walk order: position of every component in the size-ordered sequence (big ones first in their own list), in the scan's
+  // scratch block (2 bytes per component; read back behind two barriers)
+  {
+    int cbase_[7];
+    cbase_[6] = 0;  // (classes 6 and 7 are the same list now: CC_K2L_BIG = 2^6)
+#pragma unroll
+    for (int cI = 5; cI >= 0; cI--) cbase_[cI] = cbase_[cI + 1] + (cI == 5 ? 0 : sh[32 + cI + 1]);  // classes 5 .. 0 behind each other
+    // (by the waves the sweep below leaves idle -- there are six levels -- or by everybody if the workgroup has no such waves)
+    const int t0 = n_waves > CC_NLEV ? tid - CC_NLEV * 64 : tid, tn = n_waves > CC_NLEV ? nt - CC_NLEV * 64 : nt;
+    if (t0 >= 0)
+      for (int l = 0; l < CC_NLEV; l++) {
+        for (int k = t0; k < CC_K2L_NK(l); k += tn) {
+          const int a = (int)area[l * NC + k];
+          const int cls = a >= CC_K2L_BIG ? 7 : 31 - __clz(a);
+          const int p = atomicAdd(&sh[40 + cls], 1);
+          if (cls == 7)
+            big[p] = (uint16_t)(l * NC + k);  // <= SCAP / CC_K2L_BIG = 200 of them
+          else
+            scr->act[(cls == 0 ? cbase_[0] : cls == 1 ? cbase_[1] : cls == 2 ? cbase_[2] : cls == 3 ? cbase_[3] : cls == 4 ? cbase_[4] : cbase_[5]) + p] = (uint16_t)(l * NC + k);
+        }
+      }
+  }
   for (int l = wave_id; l < CC_NLEV; l += n_waves) {
     uint16_t *ml = memb + CC_K2L_LBASE(l);
     uint16_t *ptr_l = ptr + l * NC;
+    const int n_bits = 32 - __clz(CC_K2L_NK(l) > 1 ? CC_K2L_NK(l) - 1 : 1);  // bits of this level's component indices (wave-uniform)
     auto comp_of = [&](int i) -> unsigned {
       if (i >= n_act || (int)lev[i] <= l) return CC_COMP_NONE;
       const unsigned v = LAB[(int)off[i] + l];
@@ -415,20 +607,20 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       const unsigned j = jn;
       const int i = b0 + lane;
       jn = comp_of(i + 64);  // the next stretch travels while this one is filed
-      unsigned long long todo = __ballot(j != CC_COMP_NONE);
-      int rank = 0, total = 0;
-      bool last = false;
-      while (todo) {
-        const int src = __ffsll(todo) - 1;
-        const unsigned j0 = (unsigned)__builtin_amdgcn_readlane((int)j, src);  // src is wave-uniform
-        const unsigned long long m = __ballot(j == j0);
-        if (j == j0) {
-          rank = __popcll(m & lane_lt);
-          total = __popcll(m);
-          last = (m >> lane) == 1ull;
-        }
-        todo &= ~m;
+      // the stretch's entries of one component find each other without a loop over the components: M = lanes whose index
+      // agrees with mine in every bit (a ballot per index bit; a loop over the distinct components was 15 turns of dependent
+      // scalar work per stretch on a street scene, 30 us of the scan)
+      const bool valid = j != CC_COMP_NONE;
+      unsigned long long M = __ballot(valid);
+      if (M == 0ull) continue;  // wave-uniform: nothing of this level in the stretch (the upper levels are sparse)
+      static_assert(CC_NC <= 512, "nine index bits");
+      for (int bq = 0; bq < n_bits; bq++) {
+        const bool bit = (j >> bq) & 1u;
+        const unsigned long long B = __ballot(valid && bit);
+        M &= bit ? B : ~B;
       }
+      const int rank = cc_mbcnt(M), total = __popcll(M);
+      const bool last = (M >> lane) == 1ull;
       int base = 0;
       if (j != CC_COMP_NONE) {
         base = (int)ptr_l[j];
@@ -439,6 +631,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       cc_wave_sync();
     }
   }
+  __threadfence_block();
   __syncthreads();
   float *cbev = (float *)X;                              // [NCAP]
   float2 *cpix = (float2 *)(X + CC_K2L_NCAP * 4);        // [NCAP]
@@ -462,11 +655,14 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
 #pragma unroll
   for (int l = 0; l < CC_NLEV; l++) lev_base[l + 1] = lev_base[l] + nk[l];
   const int n_tot = lev_base[CC_NLEV];
-  auto finish = [&](int l, int k, int a, const uint16_t *ml, const cc_running_stat &rec, int c0, int c1, int cB) {
-    const unsigned rc0 = rc[ml[0]], rcl = rc[ml[a - 1]];  // first member = the root; last member in raster order = poi_
+  auto finish_stats = [&](int l, int k, int a, const uint16_t *ml, const cc_running_stat &rec) {
+    const unsigned rcl = rc[ml[a - 1]];  // last member in raster order = poi_
     cc_contour_t cvw;
     cc_calc_stat_vals(cfg, rec, l, (int)(rcl >> 8), (int)(rcl & 255u), &cvw);
     scr->cont[l][k] = cvw;
+  };
+  auto finish_shape = [&](int l, int k, int a, const uint16_t *ml, int c0, int c1, int cB) {
+    const unsigned rc0 = rc[ml[0]];     // first member = the root
     cc_comp_t *cpo = &scr->comp[l][k];  // (.parent was written in (E))
     const unsigned root_cell = (rc0 >> 8) * (unsigned)n_col + (rc0 & 255u);
     *(unsigned *)cpo = root_cell | ((unsigned)a << 16);
@@ -479,25 +675,53 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     cpo->cB = (uint8_t)cB;
     cpo->pad[0] = cpo->pad[1] = 0;
   };
-  for (int w = tid; w < n_tot; w += nt) {
-    int l = 0;
-    for (int e = 1; e < CC_NLEV; e++) l += (w >= lev_base[e]) ? 1 : 0;
-    const int k = w - (l == 0 ? lev_base[0] : l == 1 ? lev_base[1] : l == 2 ? lev_base[2] : l == 3 ? lev_base[3] : l == 4 ? lev_base[4] : lev_base[5]);
-    const int a = (int)area[l * NC + k];
-    if (a > CC_K2_BIG) continue;  // left to the eight-lane pass below
-    const uint16_t *ml = memb + CC_K2L_LBASE(l) + (int)ptr[l * NC + k] - a;
-    const uint2 *ml2 = (const uint2 *)ml;
+  const int n_big = sh[40 + 7];
+  for (int g = tid; g < n_big; g += nt) {  // the large components' shape (their sums: the eight-lane pass below)
+    const int t_ = (int)big[g];
+    const int l = t_ / NC, k = t_ - l * NC;
+    const int a = (int)area[t_];
+    const uint16_t *ml = memb + CC_K2L_LBASE(l) + (int)ptr[t_] - a;
+    const unsigned *mlw = (const unsigned *)ml;
+    const int row1 = (int)(rc[ml[0]] >> 8) + 1;
+    int c0 = 255, c1 = 0, cB = 255;
+    for (int m0 = 0; m0 < a; m0 += 8) {
+      const unsigned wds[4] = {mlw[m0 >> 1], mlw[(m0 >> 1) + 1], mlw[(m0 >> 1) + 2], mlw[(m0 >> 1) + 3]};  // (reads past the list's end stay inside the LDS block)
+      const int nv = a - m0;
+      unsigned rcu[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) rcu[u] = rc[((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & (unsigned)-(int)(u < nv)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int col = (int)(rcu[u] & 255u);
+        if (u < nv) {
+          c0 = col < c0 ? col : c0;
+          c1 = col > c1 ? col : c1;
+          cB = ((int)(rcu[u] >> 8) == row1 && col < cB) ? col : cB;
+        }
+      }
+    }
+    finish_shape(l, k, a, ml, c0, c1, cB);
+  }
+  const int n_small = n_tot - n_big;
+  for (int w = tid; w < n_small; w += nt) {
+    const int t_ = (int)scr->act[w];
+    const int l = t_ / NC, k = t_ - l * NC;
+    const int a = (int)area[t_];
+    const uint16_t *ml = memb + CC_K2L_LBASE(l) + (int)ptr[t_] - a;
+    const unsigned *mlw = (const unsigned *)ml;
     cc_running_stat rec;
     rec.cnt = a;
     rec.ps_x = rec.ps_y = rec.t_xx = rec.t_xy = rec.t_yy = rec.tq_x = rec.tq_y = 0.0;
     rec.vol3 = 0.f;
     const int row1 = (int)(rc[ml[0]] >> 8) + 1;
     int c0 = 255, c1 = 0, cB = 255;
-    uint2 nxa = ml2[0], nxb = a > 4 ? ml2[1] : make_uint2(0u, 0u);
+    unsigned nx[4] = {mlw[0], mlw[1], mlw[2], mlw[3]};  // (reads past the list's end stay inside the LDS block)
     for (int m0 = 0; m0 < a; m0 += 8) {
-      const unsigned wds[4] = {nxa.x, nxa.y, nxb.x, nxb.y};
-      if (m0 + 8 < a) nxa = ml2[(m0 >> 2) + 2];
-      if (m0 + 12 < a) nxb = ml2[(m0 >> 2) + 3];
+      const unsigned wds[4] = {nx[0], nx[1], nx[2], nx[3]};
+      if (m0 + 8 < a) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) nx[u] = mlw[(m0 >> 1) + 4 + u];
+      }
       const int nv = a - m0;
       unsigned mk[8], rcu[8];
       float hv[8];
@@ -530,14 +754,14 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
         cB = (mk[u] && (int)(rcu[u] >> 8) == row1 && cB == 255) ? col : cB;
       }
     }
-    finish(l, k, a, ml, rec, c0, c1, cB);
+    finish_stats(l, k, a, ml, rec);
+    finish_shape(l, k, a, ml, c0, c1, cB);
   }
   CC_K2_STAMP(12);
   // The large components (a street scene's ground-connected blob): EIGHT LANES share one, one running sum each (a product
   // a * b with (a, b) picked per lane, 1.0 for the plain sums: the same values added in the same order), the f32 height sum
-  // and the shape by every lane; lane 0 of the eight collects the sums and finishes.
+  // by every lane; lane 0 of the eight collects the sums and finishes.
   {
-    const int n_big = sh[3];
     const int role = tid & 7;
     // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: nothing of its own)
     const unsigned fa_h = role >= 5 ? ~0u : 0u, fa_y = (role == 1 || role == 4) ? ~0u : 0u, fa_x = ~(fa_h | fa_y);
@@ -547,7 +771,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       const bool on = g < n_big;
       double acc = 0.0;
       float vol3 = 0.f;
-      int l = 0, k = 0, a = 0, c0 = 255, c1 = 0, cB = 255;
+      int l = 0, k = 0, a = 0;
       const uint16_t *ml = memb;
       if (on) {
         const int t = (int)big[g];
@@ -555,15 +779,16 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
         k = t - l * NC;
         a = (int)area[t];
         ml = memb + CC_K2L_LBASE(l) + (int)ptr[t] - a;
-        const uint2 *ml2 = (const uint2 *)ml;
-        const int row1 = (int)(rc[ml[0]] >> 8) + 1;
-        uint2 nxa = ml2[0], nxb = ml2[1];
+        const unsigned *mlw = (const unsigned *)ml;
+        unsigned nx[4] = {mlw[0], mlw[1], mlw[2], mlw[3]};
         for (int m0 = 0; m0 < a; m0 += 8) {
-          const unsigned wds[4] = {nxa.x, nxa.y, nxb.x, nxb.y};
-          if (m0 + 8 < a) nxa = ml2[(m0 >> 2) + 2];
-          if (m0 + 12 < a) nxb = ml2[(m0 >> 2) + 3];
+          const unsigned wds[4] = {nx[0], nx[1], nx[2], nx[3]};
+          if (m0 + 8 < a) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) nx[u] = mlw[(m0 >> 1) + 4 + u];
+          }
           const int nv = a - m0;
-          unsigned mk[8], rcu[8];
+          unsigned mk[8];
           float hv[8];
           float2 rv[8];
 #pragma unroll
@@ -572,7 +797,6 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
             const unsigned iu = ((wds[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu) & mk[u];
             hv[u] = cbev[iu];
             rv[u] = cpix[iu];
-            rcu[u] = rc[iu];
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
@@ -581,11 +805,6 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
             const float fb = __uint_as_float((0x3F800000u & fb_1) | (xb & fb_x) | (yb & fb_y));
             acc += (double)fa * (double)fb;  // a padding slot adds (+0.0) * fb = +0.0
             vol3 += __uint_as_float(hb);
-            const int col = (int)(rcu[u] & 255u);
-            const int colm = mk[u] ? col : 255;
-            c0 = colm < c0 ? colm : c0;
-            c1 = (mk[u] && col > c1) ? col : c1;
-            cB = (mk[u] && (int)(rcu[u] >> 8) == row1 && cB == 255) ? col : cB;
           }
         }
       }
@@ -600,7 +819,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       rec.tq_y = __shfl(acc, b8 + 6);
       rec.vol3 = vol3;
       rec.cnt = a;
-      if (on && role == 0) finish(l, k, a, ml, rec, c0, c1, cB);
+      if (on && role == 0) finish_stats(l, k, a, ml, rec);
     }
   }
   CC_K2_LAP(acc_walk);
