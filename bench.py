@@ -65,12 +65,14 @@ def main():
     ap.add_argument("--sync-query", action="store_true",
                     help="cc_db_query_batch per step (collects every batch before the next one is queued) instead of cc_db_query_submit + one cc_db_query_wait")
     ap.add_argument("--lanes", type=int, default=0, help="query chunks in flight inside cc_db_query_batch (1..4; 0 = library default 2)")
-    ap.add_argument("--workload", choices=("sparse", "dense", "kitti", "seq"), default="sparse",
-                    help="sparse: SURVEY.md 8(d)'s world (1 object / 150 m2), the headline configuration; dense: the cluttered "
-                         "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level; "
-                         "kitti: the KITTI-shaped town (street grid, porous vegetation, rough ground: 4-6 k occupied cells, ~100 "
+    ap.add_argument("--workload", choices=("sparse", "dense", "kitti", "seq"), default="kitti",
+                    help="kitti (the default, the workload BASELINE.json's target is stated on): the KITTI-shaped town (street grid, "
+                         "porous vegetation, rough ground: SURVEY.md 8(d)'s value distributions -- 4-6 k occupied cells, ~100 "
                          "contours on the low levels, 18 valid keys per scan) driven as a random walk, so that ~10 % of the query "
                          "scans revisit a DB place and the others end without a candidate; "
+                         "sparse: a world of 1 object / 150 m2 (2 k occupied cells, ~14 contours per level: lighter than 8(d) asks "
+                         "for; rounds 1-5 quoted their headline on it, now in `extra`); dense: the cluttered "
+                         "world (vegetation, walls, relief, HDL-64E beam table) with several times the contours per level; "
                          "seq: BASELINE config 2's shape -- the reference's ONLINE loop (test/batch_bin_test.cpp:131-237) over one "
                          "long sequence of the dense world from an empty DB: per sub-batch ingest -> addScan/pushAndBalance -> query "
                          "(scan i against epoch i), the DB update INSIDE the timed region; a step = one sub-batch of --seq-batch scans")
@@ -421,7 +423,9 @@ def main():
                      "event_sampling": "query-side stage events on every %d. chunk launch of the timed region, ingest events on every step; "
                                        "isolated: %d extra untimed steps, one stream, every launch" % (PROF_EVERY, ISO_STEPS),
                      "query_protocol": "cc_db_query_batch per step" if (args.sync_query or kms_iso is None) else "cc_db_query_submit per step, one cc_db_query_wait inside the timed region",
-                     "value_over_ingest_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))})
+                     "value_over_ingest_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (P * 16)),
+                     # scans/s over what the HBM could stream if ingest did nothing but read the points once (8 TB/s / 1.92 MB = 4.17 M scans/s)
+                     "ingest_frac": value / world / (HBM_PEAK_GBS * 1e9 / (P * 16))})
         out = {
             "metric": "scans/sec ingest+query (120k-pt scan vs 5k-scan DB); max-F1 parity",
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -432,7 +436,8 @@ def main():
                                    "the batch, the DB update (addScan/pushAndBalance) is outside the timed step"
                                    % (args.beams, args.azim, P, args.workload, n_db, B, "the drive goes on through the town: about a tenth of the query scans revisit a DB place"
                                       if args.workload == "kitti" else "queries revisit DB places", n_found, K * B),
-                       "world": args.workload, "workload_stats": wl_stats, "dtype_note": DTYPE_NOTE,
+                       "world": args.workload, "occupied_cells_mean": wl_stats["occupied_cells_mean"],
+                       "contours_per_level_mean": wl_stats["contours_per_level_mean"], "workload_stats": wl_stats, "dtype_note": DTYPE_NOTE,
                        "shape_limits": "6 levels, grid <= 150x150, nnk <= 64, dist_firsts <= 10; the 320 largest contours of a level are stored, a scan with more components on a level goes through the exact slow path (cc_k_contours_big)",
                        "db_scans": n_db, "batch": B, "global_batch": B * world, "points_per_scan": P,
                        "parallelism": "scan-sharded x%d%s" % (world, ", batch descriptors all-gathered" if share else "")},
@@ -474,21 +479,20 @@ def main():
             except Exception as e:  # the headline stands on its own
                 out["extra"]["dropin_loop"] = {"error": repr(e)}
             # the other single-GPU configurations of BASELINE.json, 8 timed steps each (same pipeline as the headline)
-            if args.db_scans == 5000 and args.workload == "sparse":
+            if args.db_scans == 5000 and args.workload == "kitti":
                 try:
                     del batches
                     db.close()
                     db = None
                     torch.cuda.empty_cache()
-                    big, rec50 = measure_config(cc, ctx, dev, wld, 50000, B, 8, 2, P, first_query=60000)
+                    sparse = cc.synth.World()
+                    big, rec50 = measure_config(cc, ctx, dev, sparse, 50000, B, 8, 2, P, first_query=60000)
                     out["extra"]["db_50k_sparse"] = big
-                    out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, wld, 20000, B, 8, 2, P, first_query=60000, rec=rec50)[0]
+                    out["extra"]["db_20k_sparse"] = measure_config(cc, ctx, dev, sparse, 20000, B, 8, 2, P, first_query=60000, rec=rec50)[0]
                     del rec50
                     out["extra"]["db_5k_dense"] = measure_config(cc, ctx, dev, cc.synth.World(dense=True), 5000, B, 8, 2, P)[0]
-                    # SURVEY.md 8(d)'s value distributions on a drive with a realistic revisit rate (the KITTI-shaped town)
-                    out["extra"]["db_5k_kitti_shaped"] = measure_config(cc, ctx, dev, cc.synth.World(kitti=True), 5000, B, 16, 2, P,
-                                                                         kernels=True, workload="kitti",
-                                                                         cpu_sample=0 if (args.no_cpu or args.cpu_sample <= 0) else 96)[0]
+                    # rounds 1-5's headline world (2 k occupied cells, ~14 contours per level, every query revisits a DB place)
+                    out["extra"]["db_5k_sparse"] = measure_config(cc, ctx, dev, sparse, 5000, B, 16, 2, P, kernels=True, workload="sparse")[0]
                 except Exception as e:
                     out["extra"]["other_configs_error"] = repr(e)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:

@@ -283,6 +283,13 @@ class ContourDB {
     if (specDepth() > 0) hub_token_ = cc_host::lookahead().subscribe([this](const void *src) {
       if (src == source_) dropReadAhead();  // (another source's scans are not among the ones this database has worked ahead on)
     });
+    if (hub_token_ >= 0) cc_host::lookahead().subscribeRelease(hub_token_, [this](cc_scan *h) {
+      for (const Spec &sp : spec_)
+        if (sp.scan == h) {  // a scan this database has worked ahead on dies before the driver added it: its handle's address may come back
+          dropReadAhead();
+          break;
+        }
+    });
   }
   ContourDB(const ContourDB &) = delete;
   ContourDB &operator=(const ContourDB &) = delete;

@@ -195,7 +195,20 @@ struct ScanLookahead {
     on_invalidate[next_token] = std::move(f);
     return next_token++;
   }
-  void unsubscribe(int token) { on_invalidate.erase(token); }
+  void unsubscribe(int token) {
+    on_invalidate.erase(token);
+    on_release.erase(token);
+  }
+  // A scan handle is about to be released (its ContourManager dies): a database whose queued work refers to the handle drops
+  // that work -- the address may be handed out again for a later scan, and a queued answer must never be matched by address
+  // against a different scan (driver thread only, like invalidate()).
+  std::map<int, std::function<void(cc_scan *)>> on_release;
+  void subscribeRelease(int token, std::function<void(cc_scan *)> f) { on_release[token] = std::move(f); }
+  void released(cc_scan *scan) {
+    if (!scan) return;
+    for (auto &f : on_release) f.second(scan);
+    popFront(scan);
+  }
   void push(cc_scan *scan, double ts, const void *source) {
     std::lock_guard<std::mutex> lk(mu);
     upcoming.push_back({scan, ts, source});
@@ -250,7 +263,10 @@ class ContourManager {
     ccfg_ = cc_host::to_c(cfg_);
   }
 
-  ~ContourManager() { cc_scan_release(scan_); }
+  ~ContourManager() {
+    cc_host::lookahead().released(scan_);  // (nobody may keep matching queued work against this address)
+    cc_scan_release(scan_);
+  }
   ContourManager(const ContourManager &) = delete;
   ContourManager &operator=(const ContourManager &) = delete;
 

@@ -1,5 +1,7 @@
 """Randomised ingest parity campaign on the CPU harness (not collected by pytest; run by hand):
-    python tests/fuzz_emu.py <seed0> <n_iter>
+    python tests/fuzz_emu.py <seed0> <n_iter> [fit]
+"fit": every scan is lowered / thinned at random so that most draws have few enough cells above the lowest level for K2's list
+kernel (csrc/k_contours_list.h: <= 3 072 active cells); without it most draws are dense and take the original body behind it.
 Every iteration draws one scan from a family of generators and compares BEV, continuous pixel positions, integer labels
 and the whole descriptor of the emulated kernels with the oracle, bit for bit."""
 import sys
@@ -73,6 +75,9 @@ def main():
     for it in range(n_it):
         rng = np.random.default_rng(seed0 + it)
         kind, s = gen(rng)
+        if len(sys.argv) > 3 and sys.argv[3] == "fit":
+            s = s[rng.random(len(s)) < rng.uniform(0.15, 1.0)].copy()
+            s[:, 2] -= np.float32(rng.uniform(0.5, 2.5))
         if len(s) <= 10:
             continue
         o = oracle.Scan(s)

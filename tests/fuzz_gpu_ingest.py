@@ -1,5 +1,7 @@
 """Randomised ingest parity campaign ON THE GPU (not collected by pytest; run by hand on the GPU box):
-    python tests/fuzz_gpu_ingest.py <seed0> <n_iter>
+    python tests/fuzz_gpu_ingest.py <seed0> <n_iter> [fit]
+("fit": two scans of three are lowered / thinned at random so that they fit K2's list kernel, csrc/k_contours_list.h; the campaign
+counts how many scans that kernel kept -- by its capacities, from the oracle's images -- and how many went on to the bodies behind it)
 The scan generators of tests/fuzz_emu.py (terrain, uniform clouds, blobs, cell borders, walls, heights exactly at the level
 thresholds, duplicates and far outliers), 24 scans of different sizes per cc_ingest_batch call, a ContourManagerConfig drawn per
 batch (shipped / MulRan levels, grids, resolutions, contour / key / RoI settings), every descriptor against the oracle: integers, contour rows and BCIs bit for bit, keys to the last bits of the f64 exp."""
@@ -21,7 +23,8 @@ def main():
     seed0, n_it = int(sys.argv[1]), int(sys.argv[2])
     cc = cc_amd.load()
     L = oracle.L
-    n_bad = n_flag = n_scan = n_big = 0
+    n_bad = n_flag = n_scan = n_big = n_list = 0
+    fit = len(sys.argv) > 3 and sys.argv[3] == "fit"
     for it in range(n_it):
         rng = np.random.default_rng(seed0 + it)
         # a ContourManagerConfig per batch: the shipped one, the MulRan level set, other grids and resolutions (the
@@ -47,14 +50,20 @@ def main():
         scans = []
         while len(scans) < 24:
             kind, s = gen(rng)
+            if fit and len(scans) % 3 != 2:
+                s = s[rng.random(len(s)) < rng.uniform(0.15, 1.0)].copy()
+                s[:, 2] -= np.float32(rng.uniform(0.5, 2.5))
             if len(s) > 10:
                 scans.append((kind, s))
         offs = np.concatenate([[0], np.cumsum([len(s) for _, s in scans])]).astype(np.int64)
         x = torch.from_numpy(np.concatenate([s for _, s in scans], 0)).cuda()
         desc = cc.desc_to_numpy(ctx.ingest(x, offs))   # a scan that exceeds a capacity comes back flagged, the call succeeds
         for k, (kind, s) in enumerate(scans):
-            od = oracle.Scan(s, cfg=mcfg).desc()[0]
+            osc = oracle.Scan(s, cfg=mcfg)
+            od = osc.desc()[0]
             n_scan += 1
+            lvl = (osc.bev()[0][None, :] > np.asarray(list(mcfg.lv_grads), np.float32)[:, None]).sum(0)   # level count per cell
+            n_list += int(mcfg.min_cont_cell_cnt <= 3 and (lvl > 0).sum() <= 3072 and lvl.sum() <= 12800 and int(od["n_cont"].max()) <= L.MAXC)
             if desc[k]["flags"] & 6:   # CC_DESC_INEXACT_*: since round 5 only an over-full key RoI (roi_radius_ > 10) can do that
                 n_flag += 1
                 if desc[k]["flags"] & 2:
@@ -69,8 +78,8 @@ def main():
                 n_bad += 1
         ctx.close()
         if it % 10 == 9:
-            print("... %d batches, %d scans, %d through the slow path, %d flagged, %d bad" % (it + 1, n_scan, n_big, n_flag, n_bad), flush=True)
-    print("done: %d bad of %d scans (%d with more than CC_MAXC components on a level, compared; %d flagged inexact)" % (n_bad, n_scan, n_big, n_flag))
+            print("... %d batches, %d scans, %d within the list kernel's capacities, %d through the slow path, %d flagged, %d bad" % (it + 1, n_scan, n_list, n_big, n_flag, n_bad), flush=True)
+    print("done: %d bad of %d scans (%d within the list kernel's capacities, %d with more than CC_MAXC components on a level, compared; %d flagged inexact)" % (n_bad, n_scan, n_list, n_big, n_flag))
     return 1 if n_bad else 0
 
 

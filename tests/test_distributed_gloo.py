@@ -128,7 +128,7 @@ def _bench_on_harness(world, extra):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1", "--db-scans", "13",
-           "--beams", "16", "--azim", "450"] + extra
+           "--beams", "16", "--azim", "450", "--workload", "sparse"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -195,3 +195,85 @@ def test_more_components_than_cc_maxc_take_the_exact_slow_path(oracle):
     assert d["n_cont"][0].max() > 320 and d["n_cont"][2].max() > 320, d["n_cont"]
     assert d["flags"][0] == 1 and d["flags"][1] == 0 and d["flags"][2] == 1, d["flags"]
     assert (d["n_stored"][0] <= 320).all()
+
+
+# ---- the list front half of K2 (csrc/k_contours_list.h): which scans it takes, and that what it takes is bit-exact ----
+def _list_trace(capfd):
+    """(scans the list kernel kept, scans it handed to the mid path) from the harness build's trace lines."""
+    err = capfd.readouterr().err
+    seen = {int(l.split("scan")[1].split(":")[0]) for l in err.splitlines() if l.startswith("[k2 list] scan") and "active cells" in l}
+    handed = {int(l.split("scan")[1].split()[0]) for l in err.splitlines() if "handed to the mid path" in l}
+    return seen - handed, handed
+
+
+def _thin_terrain(seed, n, scale, z_shift, quant=None):
+    """A terrain scan lowered by z_shift: fewer cells above the lowest level, so that the scan fits the list kernel."""
+    s = terrain_scan(seed, n=n, scale=scale, quant=quant)
+    s[:, 2] -= z_shift
+    return s
+
+
+def test_list_kernel_takes_what_fits_and_hands_on_the_rest(oracle, capfd, monkeypatch):
+    """Scans of up to 3 072 active cells / 12 800 (cell, level) slots are labelled by the list kernel, larger ones by the
+    original body behind it (cc_k_contours_mid); both are compared with the oracle like every other scan."""
+    monkeypatch.setenv("CC_EMU_TRACE_K2", "1")
+    fits = [_thin_terrain(11, 9000, 1.5, 1.2), _thin_terrain(12, 14000, 2.5, 2.0, quant=0.25)]
+    too_big = [terrain_scan(13, n=40000, scale=1.6)]
+    capfd.readouterr()
+    d = _check(oracle, fits + too_big)
+    kept, handed = _list_trace(capfd)
+    assert kept == {0, 1} and handed == {2}, (kept, handed)
+    assert (d["flags"] == 0).all() and d["n_cont"][:2].max() > 8
+
+
+def test_list_kernel_scan_family(oracle, capfd, monkeypatch):
+    """Scans that fit the list kernel, of several kinds: smooth terrain at different densities, plateaus exactly at the level
+    thresholds, long thin walls (one-cell-wide runs, many run contacts), blobs that straddle the 64-cell chunk borders and
+    the row ends (column 0 / 149 cells are not neighbours of the previous / next row's last / first cell)."""
+    monkeypatch.setenv("CC_EMU_TRACE_K2", "1")
+    rng = np.random.default_rng(77)
+    scans = [_thin_terrain(21 + i, int(rng.integers(3000, 16000)), float(rng.uniform(0.8, 3.0)), float(rng.uniform(1.4, 2.6)),
+                           quant=[None, 0.1, 0.5][i % 3]) for i in range(5)]
+    n = 6000
+    p = np.zeros((n, 4), np.float32)  # plateau steps exactly at the thresholds (strict `>` must hold), sparse enough to fit
+    p[:, :2] = rng.uniform(-40, 40, (n, 2))
+    lv = np.array([1.5, 2.0, 2.5, 3.0, 3.5, 4.0], np.float32) - 2.0
+    p[:, 2] = lv[rng.integers(0, 6, n)] + rng.choice([0.0, 1e-6, -1e-6], n).astype(np.float32)
+    scans.append(p)
+    k = 18
+    a = rng.uniform(-70, 70, (k, 2))
+    b = a + rng.uniform(-60, 60, (k, 2))
+    i = rng.integers(0, k, 9000)
+    t = rng.random(9000)[:, None]
+    w = np.zeros((9000, 4), np.float32)  # walls
+    w[:, :2] = a[i] * (1 - t) + b[i] * t + rng.normal(0, 0.3, (9000, 2))
+    w[:, 2] = rng.integers(0, 5, 9000) * 1.0 - 0.5
+    scans.append(w)
+    e = np.zeros((12000, 4), np.float32)  # the map's left / right border columns and rows around the chunk borders
+    e[:, 0] = rng.uniform(-74, 74, 12000)
+    e[:, 1] = np.where(rng.random(12000) < 0.5, rng.uniform(-74.9, -70, 12000), rng.uniform(70, 74.9, 12000))
+    e[:, 2] = rng.uniform(-1.0, 3.0, 12000)
+    scans.append(e)
+    capfd.readouterr()
+    _check(oracle, scans)
+    kept, handed = _list_trace(capfd)
+    assert len(kept) >= 6, (kept, handed)   # (a dense draw may go to the mid path: still compared above)
+
+
+def test_list_kernel_min_cont_cell_cnt_one_and_two(oracle, capfd, monkeypatch):
+    """min_cont_cell_cnt_ of 1 and 2 (the kept test is "has a second cell" / every root); 4 and more is the mid path's."""
+    monkeypatch.setenv("CC_EMU_TRACE_K2", "1")
+    rng = np.random.default_rng(5)
+    k = 14
+    c = rng.uniform(-60, 60, (k, 2))
+    i = rng.integers(0, k, 12000)
+    blobs = np.zeros((12000, 4), np.float32)  # dense blobs of different heights plus a few lone cells: tens of components, not hundreds
+    blobs[:, :2] = c[i] + rng.normal(0, 1, (12000, 2)) * rng.uniform(1.0, 4.0, k)[i, None]
+    blobs[:, 2] = rng.uniform(-0.3, 3.0, k)[i] + rng.normal(0, 0.3, 12000)
+    for mc in (1, 2):
+        cfg = oracle.L.default_manager_cfg()
+        cfg.min_cont_cell_cnt = mc
+        capfd.readouterr()
+        d = _check(oracle, [blobs], cfg=cfg)
+        kept, handed = _list_trace(capfd)
+        assert kept == {0} and not handed, (kept, handed, d["n_cont"])

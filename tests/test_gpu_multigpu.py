@@ -19,7 +19,7 @@ def _run(extra):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--db-scans", "1664", "--batch", "256", "--steps", "2",
-           "--warmup", "1", "--no-cpu", "--no-extra"] + extra
+           "--warmup", "1", "--no-cpu", "--no-extra", "--workload", "sparse"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
