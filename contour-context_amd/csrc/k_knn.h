@@ -752,7 +752,11 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
 // the final order is (distance, key id): hit lists are bit-identical to cc_k_knn's.  The sorted view carries |k|^2 as an
 // 11th row (cc_k_ksort_merge).
 // ------------------------------------------------------------------------------------------------
-#define CC_KNN_TILE_MIN_KEYS 60000  // cc_db picks the tiled search from this many keys in a layer on (~10 000 scans)
+#define CC_KNN_TILE_MIN_KEYS 24000  // cc_db picks the tiled search from this many keys in a layer on (~4 000 scans).  Round 6: 60 000 before;
+                                    // at the 5 000-scan DB (30 k keys per layer) the tiled search gives the KITTI-shaped step +2.3 % (420-425 k ->
+                                    // 431-434 k scans/s: no faster alone, but it leaves more of the chip to the other streams) and costs the
+                                    // sparse world 0.5 % (482-486 k -> 481-483 k: every query there has its own keys in the DB bit for bit and the
+                                    // walk's radius collapses at once) -- profiles/r6/ab_knn_mode.txt
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
 #define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
 #define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round
