@@ -219,3 +219,28 @@ __device__ __forceinline__ int cc_row_shl1(int v) {
   return sl < 15 ? o : 0;
 }
 #endif
+
+// inclusive prefix sum over the wave's 64 lanes: a Hillis-Steele scan inside each 16-lane row on DPP row shifts (register to
+// register), then the three row totals added to the rows behind them -- ~12 instructions where six ds_bpermute round trips
+// (__shfl_up) are six dependent LDS-crossbar latencies
+__device__ __forceinline__ int cc_wave_scan_incl(int v) {
+  v += cc_row_shr<1>(v);
+  v += cc_row_shr<2>(v);
+  v += cc_row_shr<4>(v);
+  v += cc_row_shr<8>(v);
+#ifndef CC_EMU
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+#else
+  const int t0 = __shfl(v, 15), t1 = __shfl(v, 31), t2 = __shfl(v, 47);
+#endif
+  const int lane = (int)(threadIdx.x & 63);
+  return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+// the whole wave's sum of v given its inclusive scan
+__device__ __forceinline__ int cc_wave_scan_total(int incl) {
+#ifndef CC_EMU
+  return __builtin_amdgcn_readlane(incl, 63);
+#else
+  return __shfl(incl, 63);
+#endif
+}

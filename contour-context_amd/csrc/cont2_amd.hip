@@ -71,6 +71,7 @@ struct cc_ctx {
     int n_bigslots = 0;
     cc_k2_big_queue *d_bigq = nullptr;
     cc_k2_big_queue *d_midq = nullptr;  // scans the list kernel hands to the original body (cc_k_contours_mid)
+    cc_k1_list_out list;                // K1 -> K2: the scans' active cells as raster-ordered lists (k_rasterize.h)
     cc_k2_big_slot *d_bigslots = nullptr;
     hipEvent_t ev_last = nullptr;
     hipStream_t last_stream = nullptr;
@@ -160,6 +161,11 @@ static int scratch_alloc(cc_ctx *c, cc_ctx::Scratch &S, int cap, int n_bigslots)
   HIPCHK(hipMalloc(&S.d_bigq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)cap));
   HIPCHK(hipMemset(S.d_bigq, 0, sizeof(cc_k2_big_queue)));  // the slow launch leaves it empty again
   HIPCHK(hipMalloc(&S.d_midq, sizeof(cc_k2_big_queue) + sizeof(int) * (size_t)cap));
+  HIPCHK(hipMalloc(&S.list.hdr, sizeof(int4) * (size_t)cap));
+  HIPCHK(hipMalloc(&S.list.rc, sizeof(uint16_t) * (size_t)CC_LIST_CAP * cap));
+  HIPCHK(hipMalloc(&S.list.lev, (size_t)CC_LIST_CAP * cap));
+  HIPCHK(hipMalloc(&S.list.h, sizeof(float) * (size_t)CC_LIST_CAP * cap));
+  HIPCHK(hipMalloc(&S.list.pix, sizeof(float2) * (size_t)CC_LIST_CAP * cap));
   HIPCHK(hipMemset(S.d_midq, 0, sizeof(cc_k2_big_queue)));
   S.n_bigslots = n_bigslots < cap ? n_bigslots : cap;
   HIPCHK(hipMalloc(&S.d_bigslots, sizeof(cc_k2_big_slot) * S.n_bigslots));
@@ -177,6 +183,11 @@ static void scratch_free(cc_ctx::Scratch &S) {
   hipFree(S.d_offsets);
   hipFree(S.d_bigq);
   hipFree(S.d_midq);
+  hipFree(S.list.hdr);
+  hipFree(S.list.rc);
+  hipFree(S.list.lev);
+  hipFree(S.list.h);
+  hipFree(S.list.pix);
   hipFree(S.d_bigslots);
   if (S.ev_last) hipEventDestroy(S.ev_last);
   S = cc_ctx::Scratch();
@@ -314,7 +325,7 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   }
   if (getenv("CC_K2_PHASES"))  // (a channel launch brings up to CC_SCAN_BATCH_MAX scans whatever max_batch_scans is)
     CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * (size_t)(max_batch_scans > CC_SCAN_BATCH_MAX ? max_batch_scans : CC_SCAN_BATCH_MAX)));
-  c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64;
+  c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64 + CC_K1_EMIT_LDS_BYTES;
   c->lds2 = CC_K2_LDS_BYTES(nc);
   {
     const char *e = getenv("CC_K2_LDS_PAD");  // tuning aid, read once: extra bytes asked for (above 80 KB one scan per CU instead of two)
@@ -482,22 +493,22 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
       }
       if (c->dcfg.reso_pow2 && !c->k1_div)
         hipLaunchKernelGGL((cc_k_rasterize<4, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list);
       else
         hipLaunchKernelGGL((cc_k_rasterize<4, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list);
       hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)S.d_offsets, S.k1_part, S.d_bev,
-                         S.d_pix, S.d_k1);
+                         S.d_pix, S.d_k1, S.list);
     } else if (c->dcfg.reso_pow2 && !c->k1_div)
       hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part());
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list);
     else
       hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part());
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list);
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK), (size_t)CC_K2L_LDS_BYTES, stream, c->dcfg, (const float *)S.d_bev,
-                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_midq);
+                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_midq, S.list);
     // the scans the list kernel handed on (more active cells / components than its LDS tables hold): the original body
     hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < 512 ? nb : 512), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
                        (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab);

@@ -962,13 +962,9 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
       const int n_str = (((n_act + nt - 1) / nt) * nt) >> 6;  // stretches written above
       for (int q = 0; q < n_str; q += 64) {
         const int v = q + lane < n_str ? (int)scnt[q + lane] : 0;
-        int incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-          const int w_ = __shfl_up(incl, o);
-          if (lane >= o) incl += w_;
-        }
+        const int incl = cc_wave_scan_incl(v);
         if (q + lane < n_str) sbase[q + lane] = (uint16_t)(n_kept + incl - v);
-        n_kept += __shfl(incl, 63);
+        n_kept += cc_wave_scan_total(incl);
       }
     }
     cc_wave_sync();
@@ -1152,13 +1148,9 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
       for (int k0 = 0; k0 < n; k0 += 64) {
         const int k = k0 + lane;
         const int a8 = k < n ? ((int)scr->comp[l][k].area + 7) >> 3 : 0;
-        int incl = a8;
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o);
-          if (lane >= o) incl += v;
-        }
+        const int incl = cc_wave_scan_incl(a8);
         if (k < n) moff[l * NC + k] = (uint16_t)(run + incl - a8);
-        run += __shfl(incl, 63);
+        run += cc_wave_scan_total(incl);
       }
     }
     __syncthreads();

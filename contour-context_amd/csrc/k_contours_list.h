@@ -25,7 +25,7 @@
 #pragma once
 #include "k_contours.h"
 
-#define CC_K2L_NCAP 3072                          // entries (active cells) per scan
+#define CC_K2L_NCAP CC_LIST_CAP                   // entries (active cells) per scan: what K1 lists (k_rasterize.h)
 #define CC_K2L_SCAP 12800                         // (entry, level) slots per scan (< 0x8000: labels carry a mark bit)
 #ifndef CC_K2L_MEMB
 #define CC_K2L_MEMB 11264
@@ -50,11 +50,8 @@
 #define CC_K2L_X_OFF (2 * CC_K2L_SCAP)                          // u16[NCAP + 1] slot offsets (behind the labels u16[SCAP])
 #define CC_K2L_X_BITA (CC_K2L_X_OFF + 2 * CC_K2L_NCAP + 16)     // u32[SCAP / 32]
 #define CC_K2L_X_BITB (CC_K2L_X_BITA + CC_K2L_SCAP / 8)
-#define CC_K2L_X_SBASE CC_K2L_X_BITA                            // stage A (over the bit maps, which are cleared in stage B): u16[352] slots before chunk b
-#define CC_K2L_X_CLEV (CC_K2L_X_SBASE + 2 * CC_K2L_NCHUNK)      // stage A: u16[352] slots of chunk b
-#define CC_K2L_X_CCNT (CC_K2L_X_CLEV + 2 * CC_K2L_NCHUNK)       // stage A: u8[352] entries of chunk b
 static_assert(CC_K2L_SCAP / CC_K2L_BIG <= 256 && CC_K2L_BIG == 64 && CC_K2L_SCAP % 32 == 0 && CC_K2L_X_BITA % 4 == 0 && CC_K2L_SCAP < 0x8000 && CC_K2L_NSTR <= 64 && CC_NC * CC_NLEV * 2 == 3840, "list front half: table sizes");
-static_assert(CC_K2L_X_CCNT + 2 * CC_K2L_NCHUNK <= CC_K2L_X_BITB + CC_K2L_SCAP / 8 && CC_K2L_X_BITB + CC_K2L_SCAP / 8 <= 36864 && CC_K2L_NCAP * 12 <= 36864 && CC_MAX_CELLS <= CC_K2L_MEMB * 2 + 7680, "list front half: region X / stage A overlays");
+static_assert(CC_K2L_X_BITB + CC_K2L_SCAP / 8 <= 36864 && CC_K2L_NCAP * 12 <= 36864, "list front half: region X / stage A overlays");
 static_assert(CC_K2L_R_SH >= CC_K2_R_BYTES, "the back half's region");
 
 #ifdef CC_EMU  // CPU test harness only: say which scans leave the list kernel (tests assert on the path taken)
@@ -116,7 +113,7 @@ __device__ __forceinline__ void cc_uf_union_h(uint16_t *LAB, unsigned a, unsigne
 __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
                                                  cc_k2_scratch *__restrict__ scr, cc_k2_big_queue *__restrict__ midq, int scan,
                                                  cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg,
-                                                 long long *__restrict__ phase_clk, char *smem, int *n_lev_out) {
+                                                 long long *__restrict__ phase_clk, char *smem, int *n_lev_out, const cc_k1_list_out &list) {
   CC_K2_STAMP(0);
   const int n_cell = cfg.n_cell, n_col = cfg.n_col;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -145,12 +142,8 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   uint16_t *LAB = (uint16_t *)X;
   uint16_t *off = (uint16_t *)(X + CC_K2L_X_OFF);
   unsigned *bitA = (unsigned *)(X + CC_K2L_X_BITA), *bitB = (unsigned *)(X + CC_K2L_X_BITB);
-  uint16_t *sbase = (uint16_t *)(X + CC_K2L_X_SBASE), *clev = (uint16_t *)(X + CC_K2L_X_CLEV);
-  unsigned char *ccnt = (unsigned char *)(X + CC_K2L_X_CCNT);
-  unsigned char *cflag = ccnt + CC_K2L_NCHUNK;  // stage A: chunk has an active cell
   uint16_t *memb = (uint16_t *)(R + CC_K2L_R_MEMB);
   unsigned *wl = (unsigned *)(R + CC_K2L_R_MEMB);  // stage B: the work list of links (slot a | slot b << 16)
-  unsigned char *LVt = (unsigned char *)(R + CC_K2L_R_MEMB);
   uint16_t *area = (uint16_t *)(R + CC_K2L_R_AREA);
   uint16_t *ptr = (uint16_t *)(R + CC_K2L_R_PTR);
   int *sh = (int *)(R + CC_K2L_R_SH);
@@ -163,142 +156,88 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   if (phase_clk && tid == 0)
     for (int j = 0; j < 6; j++) phase_clk[(size_t)scan * CC_K2_NCLK + 16 + j] = 0;
 
-  // ---- (A) level count of every cell (coalesced 16-byte loads of the BEV, four cells per lane), then the raster-ordered
-  //      list of the active cells: per 64-cell chunk six ballots (cells above level k) give the chunk's occupancy word,
-  //      its entry count and its slot count; a prefix over the 352 chunks (every wave makes all of it: no hand-over) gives
-  //      entry index and first slot of every active cell.
-  {
-    const float4 *bev4 = (const float4 *)bev;
-    const int n_quad = n_cell >> 2;
-    // (sixteen lanes = one 64-cell chunk: the chunk's "any cell active" flag comes out of the loop that makes the level bytes,
-    // and the two chunk passes below only visit the chunks that have something -- a tenth to a half of the 352)
-#pragma unroll 6
-    for (int v0 = 0; v0 < n_quad; v0 += nt) {
-      const int v = v0 + tid;
-      unsigned lv4 = 0;
-      if (v < n_quad) {
-        const float4 h4 = bev4[v];
-        const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int lv = 0;
-          for (int e = 0; e < CC_NLEV; e++) lv += (hh[u] > cfg.lv_grads[e]) ? 1 : 0;  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
-          lv4 |= (unsigned)lv << (8 * u);
-        }
-        ((unsigned *)LVt)[v] = lv4;
-      }
-      const unsigned long long many = __ballot(lv4 != 0u);
-      if ((lane & 15) == 0 && v < n_quad) cflag[v >> 4] = (unsigned char)(((many >> lane) & 0xFFFFull) != 0ull);
-    }
-  }
-  if (tid < 128) sh[tid] = 0;
-  if (labels_dbg)
-    for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
-  __syncthreads();
-  CC_K2_STAMP(22);
-  const int n_chunk = (n_cell + 63) >> 6;
-  const int cpw = (n_chunk + n_waves - 1) / n_waves;  // chunks per wave (44 <= 64: one lane per chunk); wave w takes chunks w, w + n_waves, ...:
-                                                      // the active cells sit around the sensor, a block of consecutive rows per wave would be uneven
-  {
-    const int b = wave_id + lane * n_waves;
-    const bool mine = lane < cpw && b < n_chunk;
-    const bool full = mine && cflag[b] != 0;
-    if (mine && !full) {
-      bitmap[b] = 0ull;
-      ccnt[b] = 0;
-      clev[b] = 0;
-    }
-    unsigned long long todo = __ballot(full);
-    while (todo) {  // wave-uniform
-      const int bb = wave_id + (__ffsll(todo) - 1) * n_waves;
-      todo &= todo - 1ull;
-      const int c = bb * 64 + lane;
-      const int lvc = c < n_cell ? (int)LVt[c] : 0;
-      const unsigned long long m0 = __ballot(lvc > 0);
-      int levs = __popcll(m0);
-#pragma unroll
-      for (int k = 1; k < CC_NLEV; k++) levs += __popcll(__ballot(lvc > k));
-      if (lane == 0) {
-        bitmap[bb] = m0;
-        ccnt[bb] = (unsigned char)__popcll(m0);
-        clev[bb] = (uint16_t)levs;
-      }
-    }
-  }
-  __syncthreads();
-  CC_K2_STAMP(23);
-  int n_act = 0, n_slot = 0;
-  for (int q = 0; q < n_chunk; q += 64) {
-    const int b = q + lane;
-    const int v1 = b < n_chunk ? (int)ccnt[b] : 0, v2 = b < n_chunk ? (int)clev[b] : 0;
-    int i1 = v1, i2 = v2;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int w1 = __shfl_up(i1, o), w2 = __shfl_up(i2, o);
-      if (lane >= o) {
-        i1 += w1;
-        i2 += w2;
-      }
-    }
-    if (b < n_chunk) {  // identical values from every wave
-      cbase[b] = (uint16_t)(n_act + i1 - v1);
-      const int s0 = n_slot + i2 - v2;
-      sbase[b] = (uint16_t)(s0 < 0xFFFF ? s0 : 0xFFFF);
-    }
-    n_act += __shfl(i1, 63);
-    n_slot += __shfl(i2, 63);
-  }
+  // ---- (A) the scan's active cells come as a raster-ordered list from K1 (k_rasterize.h: cc_k1_emit -- it has every cell's
+  //      height in LDS when it writes the image): (row, col) and level count per entry.  Here: the occupancy bit map and
+  //      chunk bases (cell -> entry, for the neighbour and RoI lookups), the slot offsets (prefix of the level counts) and
+  //      the initial labels -- every slot starts pointing at the first cell of its horizontal RUN at its level (entries side by
+  //      side in one row, all in the level set): per 64-entry stretch the run starts are bit operations on ballots, the
+  //      start's slot comes by a shuffle.  The union pass below then only links runs of adjacent rows (and runs that
+  //      continue across a stretch border).
+  const int4 hd = list.hdr[scan];
+  const int n_act = hd.x, n_slot = hd.y;
 #ifdef CC_EMU
   if (tid == 0 && getenv("CC_EMU_TRACE_K2")) fprintf(stderr, "[k2 list] scan %d: %d active cells, %d slots\n", scan, n_act, n_slot);
 #endif
   if (n_act > CC_K2L_NCAP || n_slot > CC_K2L_SCAP) CC_K2L_BAIL(1);
-  cc_wave_sync();  // a wave reads back what it wrote itself
-  CC_K2_STAMP(24);
-  // Every slot starts pointing at the first cell of its horizontal RUN at its level (cells of one row, side by side, all in
-  // the level set): the run starts of a chunk are bit operations on the ballots, the start's slot comes by a shuffle.  The
-  // union pass below then only links runs of adjacent rows (and runs that continue across a chunk border).
-  const unsigned long long lane_le = lane_lt | (1ull << lane);
-  unsigned long long todo4 = __ballot(lane < cpw && wave_id + lane * n_waves < n_chunk && cflag[wave_id + lane * n_waves < n_chunk ? wave_id + lane * n_waves : 0] != 0);
-  while (todo4) {  // wave-uniform: the chunks of this wave's block that have active cells
-    const int b = wave_id + (__ffsll(todo4) - 1) * n_waves;
-    todo4 &= todo4 - 1ull;
-    const unsigned long long m0 = bitmap[b];
-    const int c = b * 64 + lane;
-    const int lvc = c < n_cell ? (int)LVt[c] : 0;
-    const int r = c / n_col, cc = c - r * n_col;
-    const unsigned long long not_row_start = ~__ballot(cc == 0);
-    unsigned long long mk[CC_NLEV];
-    mk[0] = m0;
-    int so = (int)sbase[b] + cc_mbcnt(m0);
-#pragma unroll
-    for (int k = 1; k < CC_NLEV; k++) {
-      mk[k] = __ballot(lvc > k);
-      so += cc_mbcnt(mk[k]);
+  const int n_chunk = (n_cell + 63) >> 6;
+  const int n_str = (n_act + 63) >> 6;
+  uint16_t *ssum = (uint16_t *)scnt;  // slots per stretch (stage A; the kept-root counts of stage D come later)
+  {
+    const uint16_t *g_rc = list.rc + (size_t)scan * CC_LIST_CAP;
+    const unsigned char *g_lev = list.lev + (size_t)scan * CC_LIST_CAP;
+    for (int i = tid; i < n_act; i += nt) {
+      rc[i] = g_rc[i];
+      lev[i] = g_lev[i];
     }
-    if (lvc > 0) {
-      const int i = (int)cbase[b] + cc_mbcnt(m0);
-      rc[i] = (uint16_t)((r << 8) | cc);
-      lev[i] = (unsigned char)lvc;
-      off[i] = (uint16_t)so;
+    for (int i = tid; i < n_chunk; i += nt) bitmap[i] = 0ull;
+    if (tid < 128) sh[tid] = 0;
+    if (labels_dbg)
+      for (int i = tid; i < CC_NLEV * n_cell; i += nt) labels_dbg[(size_t)scan * CC_NLEV * n_cell + i] = (int16_t)-1;
+  }
+  __syncthreads();
+  CC_K2_STAMP(22);
+  for (int i = tid; i < n_act; i += nt) {
+    const unsigned rcv = rc[i];
+    const int c = (int)(rcv >> 8) * n_col + (int)(rcv & 255u);
+    atomicOr(&bitmap[c >> 6], 1ull << (c & 63));
+    bool first = i == 0;
+    if (!first) {
+      const unsigned rp = rc[i - 1];
+      first = (((int)(rp >> 8) * n_col + (int)(rp & 255u)) >> 6) != (c >> 6);
     }
-    // (the six levels without a branch between them: their shuffles are in flight together; an empty level set stores nothing)
-#if defined(CC_K2L_ABL) && CC_K2L_ABL == 1
-    for (int k = 0; k < CC_NLEV; k++)
-      if (lvc > k) LAB[so + k] = (uint16_t)(so + k);
-    (void)lane_le; (void)not_row_start;
-#elif defined(CC_K2L_ABL) && CC_K2L_ABL == 2
-    (void)lane_le; (void)not_row_start;
-#else
-    int so_start[CC_NLEV];
-#pragma unroll
-    for (int k = 0; k < CC_NLEV; k++) {
-      const unsigned long long starts = mk[k] & ~((mk[k] << 1) & not_row_start);
-      const int ys = 63 - __clzll((long long)(starts & lane_le));  // (lanes outside the level set: any lane, value unused)
-      so_start[k] = __shfl(so, ys & 63);
+    if (first) cbase[c >> 6] = (uint16_t)i;  // entries before the chunk = index of its first entry (empty chunks are never looked up)
+  }
+  for (int q = wave_id; q < n_str; q += n_waves) {
+    const int i = q * 64 + lane;
+    int v = i < n_act ? (int)lev[i] : 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) ssum[q] = (uint16_t)v;
+  }
+  __syncthreads();
+  CC_K2_STAMP(23);
+  {
+    const unsigned long long lane_le = lane_lt | (1ull << lane);
+    int spre;  // slots before stretch `lane` (every wave makes the prefix for itself: <= 48 stretches, one lane each)
+    {
+      const int v = lane < n_str ? (int)ssum[lane] : 0;
+      const int incl = cc_wave_scan_incl(v);
+      spre = incl - v;
     }
+    CC_K2_STAMP(24);
+    for (int q = wave_id; q < n_str; q += n_waves) {
+      const int i = q * 64 + lane;
+      const bool valid = i < n_act;
+      const int lvc = valid ? (int)lev[i] : 0;
+      const unsigned rcv = valid ? (unsigned)rc[i] : 0xFFFFu;
+      const int incl = cc_wave_scan_incl(lvc);
+      const int so = __builtin_amdgcn_readlane(spre, q) + incl - lvc;
+      if (valid) off[i] = (uint16_t)so;
+      // entry x continues entry x - 1's run: same row, next column (lane 0 never does: a run that crosses the stretch border is
+      // linked in the union pass)
+      const unsigned rcp = (unsigned)__shfl_up((int)rcv, 1);
+      const unsigned long long adj = __ballot(valid && lane > 0 && rcv == rcp + 1u);
+      int so_start[CC_NLEV];
 #pragma unroll
-    for (int k = 0; k < CC_NLEV; k++)
-      if (lvc > k) LAB[so + k] = (uint16_t)(so_start[k] + k);
-#endif
+      for (int k = 0; k < CC_NLEV; k++) {  // (the six levels without a branch between them: their shuffles are in flight together)
+        const unsigned long long mk = __ballot(lvc > k);
+        const unsigned long long starts = mk & ~((mk << 1) & adj);
+        const int ys = 63 - __clzll((long long)(starts & lane_le));  // (lanes outside the level set: any lane, value unused)
+        so_start[k] = __shfl(so, ys & 63);
+      }
+#pragma unroll
+      for (int k = 0; k < CC_NLEV; k++)
+        if (lvc > k) LAB[so + k] = (uint16_t)(so_start[k] + k);
+    }
   }
   if (tid == 0) off[n_act] = (uint16_t)n_slot;
   __syncthreads();
@@ -318,7 +257,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     const int c = r * n_col + cc;
     const int Li = (int)lev[i], oi = (int)off[i];
     // Which links this cell has to make (the others are somebody else's or already there):
-    //  * W: inside a chunk the run labels have it; a run that continues across a chunk border is linked here;
+    //  * W: inside a 64-entry stretch the run labels have it; a run that continues across a stretch border is linked here;
     //  * row above: if N is in the level set, NW and NE (when they are) belong to N's run -- one link; else NW and NE each;
     //  * of the cells of my run that touch the same run above only the leftmost links: with W in my run and NW in the level
     //    set, W's own link (its N is my NW) has joined the two runs.
@@ -342,7 +281,9 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       if (cc == 0) f3 &= 6u;          // no NW (the cell there is the previous row's last)
       if (cc == n_col - 1) f3 &= 3u;  // no NE
       if (f3) {
-        const int j_nw = (int)cbase[wb] + __popcll(w0 & ((1ull << bit) - 1ull));  // entries before the field's first cell
+        // entries before the field's first cell (a chunk base exists for chunks that have entries: with none in this word the
+        // field's active cells are the next word's first ones)
+        const int j_nw = w0 != 0ull ? (int)cbase[wb] + __popcll(w0 & ((1ull << bit) - 1ull)) : (int)cbase[wb + 1];
         const int j_n = j_nw + (int)(raw & 1u), j_ne = j_n + (int)((raw >> 1) & 1u);
         if (f3 & 1u) {
           const int Lj = (int)lev[j_nw];
@@ -363,7 +304,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     }
     // the levels at which each link is this cell's to make, as bit masks (bit l = level l)
     const unsigned b_w = (1u << sh_w) - 1u, b_nw = (1u << sh_nw) - 1u, b_n = (1u << sh_n) - 1u, b_ne = (1u << sh_ne) - 1u;
-    unsigned m_w = ((c & 63) == 0) ? b_w : 0u;
+    unsigned m_w = ((i & 63) == 0) ? b_w : 0u;
     unsigned m_n = b_n & ~(b_w & b_nw);
     unsigned m_nw = b_nw & ~b_n & ~b_w;
     unsigned m_ne = b_ne & ~b_n;
@@ -440,7 +381,6 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
   //      takes every n_waves-th stretch), a prefix over the <= 48 stretches per level in registers (one lane per stretch,
   //      every wave makes it for itself), then the same ballots again give the numbers.
 #define CC_K2L_KEPT(s_) (need <= 1 || (((need == 2 ? bitA : bitB)[(s_) >> 5] >> ((s_) & 31)) & 1u))
-  const int n_str = (n_act + 63) >> 6;
   for (int q = wave_id; q < n_str; q += n_waves) {
     const int i = q * 64 + lane;
     const int Li = i < n_act ? (int)lev[i] : 0, oi = i < n_act ? (int)off[i] : 0;
@@ -458,13 +398,9 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
 #pragma unroll
   for (int l = 0; l < CC_NLEV; l++) {
     const int v = lane < n_str ? (int)scnt[l * CC_K2L_NSTR + lane] : 0;
-    int incl = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int w_ = __shfl_up(incl, o);
-      if (lane >= o) incl += w_;
-    }
+    const int incl = cc_wave_scan_incl(v);
     pre[l] = incl - v;
-    nk[l] = __shfl(incl, 63);
+    nk[l] = cc_wave_scan_total(incl);
     too_many = too_many || nk[l] > NC;
   }
   if (too_many) CC_K2L_BAIL(2);  // more components on a level than the tables hold: the mid path decides (and queues for the big one)
@@ -531,11 +467,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       const int k = k0 + lane;
       const int a = k < n ? (int)area[l * NC + k] : 0;
       const int a4 = (a + 1) & ~1;  // lists start on a 4-byte boundary
-      int incl = a4;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-      }
+      const int incl = cc_wave_scan_incl(a4);
       if (k < n) {
         ptr[l * NC + k] = (uint16_t)(run + incl - a4);
         // size class = floor(log2 area), 7 = CC_K2L_BIG cells and more (eight-lane walk): counted here, placed below -- the
@@ -543,7 +475,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
         const int cls = a >= CC_K2L_BIG ? 7 : 31 - __clz(a);
         atomicAdd(&sh[32 + cls], 1);
       }
-      run += __shfl(incl, 63);
+      run += cc_wave_scan_total(incl);
     }
     if (lane == 0) sh[16 + l] = run;
   }
@@ -564,11 +496,9 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     const int i = tid + u * CC_K2_BLOCK;
     ch[u] = 0.f;
     cp[u] = make_float2(0.f, 0.f);
-    if (i < n_act) {
-      const unsigned rcv = rc[i];
-      const int cell = (int)(rcv >> 8) * n_col + (int)(rcv & 255u);
-      ch[u] = bev[cell];
-      cp[u] = pix[cell];
+    if (i < n_act) {  // (coalesced: K1 wrote them in list order)
+      ch[u] = list.h[(size_t)scan * CC_LIST_CAP + i];
+      cp[u] = list.pix[(size_t)scan * CC_LIST_CAP + i];
     }
   }
   // walk order: position of every component in the size-ordered sequence (big ones first in their own list), in the scan's
@@ -843,12 +773,12 @@ __global__ void __launch_bounds__(CC_K2_BLOCK, 4)
 cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
               const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all,
               cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg, long long *__restrict__ phase_clk,
-              cc_k2_big_queue *__restrict__ midq) {
+              cc_k2_big_queue *__restrict__ midq, cc_k1_list_out list) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int scan = (int)blockIdx.x;
   cc_k2_scratch *scr = scratch_all + scan;
   int n_lev[CC_NLEV];
-  if (!cc_k2_front_list(cfg, bev_in, pix_in, scr, midq, scan, desc_out, labels_dbg, phase_clk, smem, n_lev)) return;
+  if (!cc_k2_front_list(cfg, bev_in, pix_in, scr, midq, scan, desc_out, labels_dbg, phase_clk, smem, n_lev, list)) return;
   __threadfence_block();
   __syncthreads();
   cc_k2_levmap lm;

@@ -55,17 +55,112 @@ struct cc_k1_part {
   unsigned *red;   // [n_scans * CC_K1_SPLIT][2]: max key, min key
 };
 
-// grid = n_scans (PART: n_scans * CC_K1_SPLIT), block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 bytes.
+// The scan's ACTIVE cells (above the lowest level) as a raster-ordered list -- what K2's list kernel (k_contours_list.h) starts
+// from: K1 has every cell's height in LDS when it writes the dense image, so it lists the active ones on the way out
+// instead of K2 re-reading 90 KB of image to find the ~2 500 cells it wants (round 6).  Per scan: header (entries, (cell,
+// level) slots), and for the first CC_LIST_CAP entries (row << 8 | col), level count, height, continuous position.
+#define CC_LIST_CAP 3072
+#define CC_K1_NCHUNK ((CC_MAX_CELLS + 63) / 64)
+struct cc_k1_list_out {
+  int4 *hdr;            // [n_scans]: x = entries (all of them, also beyond the capacity), y = slots = sum of the level counts
+  uint16_t *rc;         // [n_scans][CC_LIST_CAP]
+  unsigned char *lev;   // same
+  float *h;             // same
+  float2 *pix;          // same
+};
+#define CC_K1_EMIT_LDS_BYTES (CC_K1_NCHUNK * 2 * 3 + 16)  // u16 entries per chunk | u16 entries before the chunk | u16 slots per chunk | totals
+
+// The output pass shared by the one-sweep kernel and the merge kernel.  keyfn(c) / idxfn(c): the cell's height key and the
+// scan-relative index of the point that owns it (asked for occupied cells only).  Two sweeps over the cells, a wave
+// on 64 consecutive cells at a time: (1) active cells per chunk (one ballot), prefix by wave 0; (2) the
+// dense image, the continuous position of every occupied cell, and the list entries at their raster-order positions.
+// Returns this thread's count of occupied cells.  tab: CC_K1_EMIT_LDS_BYTES of LDS.
+template <typename KeyFn, typename IdxFn>
+__device__ __forceinline__ int cc_k1_emit(const cc_dev_cfg &cfg, KeyFn keyfn, IdxFn idxfn, const float4 *__restrict__ P, float *__restrict__ bev,
+                                          float2 *__restrict__ pix, const cc_k1_list_out &L, int scan, char *tab) {
+  const int n_cell = cfg.n_cell, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
+  uint16_t *ccnt = (uint16_t *)tab, *cbase = ccnt + CC_K1_NCHUNK;
+  int *tot = (int *)(tab + CC_K1_NCHUNK * 6);
+  const int n_chunk = (n_cell + 63) >> 6;
+  // (1) active cells per 64-cell chunk: one compare and one ballot per cell (a wave is on 64 consecutive cells)
+  for (int c0 = 0; c0 < n_cell; c0 += nt) {  // block-uniform trip count: the ballots see whole waves
+    const int c = c0 + tid;
+    const float h = c < n_cell ? cc_funkey(keyfn(c)) : CC_BEV_EMPTY;
+    const unsigned long long m0 = __ballot(h > cfg.lv_grads[0]);
+    if (lane == 0 && c < n_cell) ccnt[c >> 6] = (uint16_t)__popcll(m0);
+  }
+  if (tid == 0) tot[1] = 0;
+  __syncthreads();
+  if (tid < 64) {  // prefix over the chunks, one wave
+    int n_act = 0;
+    for (int q = 0; q < n_chunk; q += 64) {
+      const int b = q + lane;
+      const int v1 = b < n_chunk ? (int)ccnt[b] : 0;
+      const int i1 = cc_wave_scan_incl(v1);
+      if (b < n_chunk) cbase[b] = (uint16_t)(n_act + i1 - v1);
+      n_act += cc_wave_scan_total(i1);
+    }
+    if (lane == 0) tot[0] = n_act;
+  }
+  __syncthreads();
+  uint16_t *l_rc = L.rc + (size_t)scan * CC_LIST_CAP;
+  unsigned char *l_lev = L.lev + (size_t)scan * CC_LIST_CAP;
+  float *l_h = L.h + (size_t)scan * CC_LIST_CAP;
+  float2 *l_pix = L.pix + (size_t)scan * CC_LIST_CAP;
+  int npix = 0, nslot = 0;
+  // (2) the dense image, the continuous position of every occupied cell, the list entries at their raster-order positions
+  for (int c0 = 0; c0 < n_cell; c0 += nt) {
+    const int c = c0 + tid;
+    const unsigned key = c < n_cell ? keyfn(c) : KEY_EMPTY;
+    const float h = cc_funkey(key);
+    const bool act = h > cfg.lv_grads[0];  // cv::threshold BINARY is strict `>` (contour_mng.cpp:283)
+    const unsigned long long m0 = __ballot(act);
+    if (c < n_cell) {
+      bev[c] = h;
+      if (key != KEY_EMPTY) {
+        const float4 q = P[idxfn(c)];
+        // pointToContRowCol: x / reso + n_row/2 - 0.5f, left to right in f32
+        float2 rcf;
+        rcf.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
+        rcf.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;
+        pix[c] = rcf;
+        npix++;
+        if (act) {
+          int lv = 1;
+          for (int e = 1; e < CC_NLEV; e++) lv += (h > cfg.lv_grads[e]) ? 1 : 0;
+          nslot += lv;
+          const int i = (int)cbase[c >> 6] + cc_mbcnt(m0);
+          if (i < CC_LIST_CAP) {
+            const int r = c / cfg.n_col;
+            l_rc[i] = (uint16_t)((r << 8) | (c - r * cfg.n_col));
+            l_lev[i] = (unsigned char)lv;
+            l_h[i] = h;
+            l_pix[i] = rcf;
+          }
+        }
+      }
+    }
+  }
+  nslot = cc_wave_sum(nslot);
+  if (lane == 0 && nslot) atomicAdd(&tot[1], nslot);
+  __syncthreads();
+  if (tid == 0) L.hdr[scan] = make_int4(tot[0], tot[1], 0, 0);
+  return npix;
+}
+
+// grid = n_scans (PART: n_scans * CC_K1_SPLIT), block = multiple of 64.  dynamic LDS: n_cell*4 + ((n_cell+2)/3)*8 + 16 + CC_K1_EMIT_LDS_BYTES bytes.
 template <int CC_K1_U, bool CC_K1_POW2, bool PART = false>
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
-               float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out, cc_k1_part part = cc_k1_part()) {
+               float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out, cc_k1_part part, cc_k1_list_out list_out) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int n_cell = cfg.n_cell;
   unsigned *hmax = (unsigned *)smem;
   const int n_w3 = (n_cell + 2) / 3;
   unsigned long long *idx3 = (unsigned long long *)(smem + (((size_t)n_cell * 4 + 15) & ~(size_t)15));
   unsigned *red = (unsigned *)(idx3 + n_w3);  // [0]=max key [1]=min key [2]=n_pix
+  char *emit_tab = (char *)(red + 4);          // CC_K1_EMIT_LDS_BYTES: the output pass' chunk tables
 
   const int scan = PART ? (int)blockIdx.x / CC_K1_SPLIT : (int)blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -209,22 +304,14 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   // ---- outputs ----
   float *bev = bev_out + (size_t)scan * n_cell;
   float2 *pix = pix_out + (size_t)scan * n_cell;
-  int npix = 0;
-  for (int c = tid; c < n_cell; c += nt) {
-    unsigned k = hmax[c];
-    bev[c] = cc_funkey(k);
-    if (k != KEY_EMPTY) {
-      const int w = c / 3, sh = (c - 3 * w) * CC_K1_IDX_BITS;
-      int j = (int)((idx3[w] >> sh) & CC_K1_IDX_MASK);
-      float4 q = P[j];
-      // pointToContRowCol: x / reso + n_row/2 - 0.5f, left to right in f32
-      float2 rc;
-      rc.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
-      rc.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;
-      pix[c] = rc;
-      npix++;
-    }
-  }
+  int npix = cc_k1_emit(
+      cfg,
+      [&](int c) { return hmax[c]; },
+      [&](int c) {
+        const int w = c / 3, sh = (c - 3 * w) * CC_K1_IDX_BITS;
+        return (int)((idx3[w] >> sh) & CC_K1_IDX_MASK);
+      },
+      P, bev, pix, list_out, scan, emit_tab);
   npix = cc_wave_sum(npix);
   if ((tid & 63) == 0) atomicAdd(&red[2], (unsigned)npix);
   __syncthreads();
@@ -244,8 +331,9 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
 // grid = n_scans, block = multiple of 64
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize_merge(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets, cc_k1_part part,
-                     float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out) {
+                     float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out, cc_k1_list_out list_out) {
   __shared__ unsigned red[3];
+  __shared__ __attribute__((aligned(16))) char emit_tab[CC_K1_EMIT_LDS_BYTES];
   const int scan = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, n_cell = cfg.n_cell;
   const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
   const float4 *P = pts + offsets[scan];
@@ -263,30 +351,31 @@ cc_k_rasterize_merge(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long 
   __syncthreads();
   float *bev = bev_out + (size_t)scan * n_cell;
   float2 *pix = pix_out + (size_t)scan * n_cell;
-  int npix = 0;
-  for (int c = tid; c < n_cell; c += nt) {
-    unsigned k[CC_K1_SPLIT];
+  int npix = cc_k1_emit(
+      cfg,
+      [&](int c) {  // the largest of the ranges' keys
+        unsigned best = KEY_EMPTY;
 #pragma unroll
-    for (int p = 0; p < CC_K1_SPLIT; p++) k[p] = part.key[((size_t)scan * CC_K1_SPLIT + p) * n_cell + c];
-    unsigned best = KEY_EMPTY;
-    int bp = -1;
+        for (int p = 0; p < CC_K1_SPLIT; p++) {
+          const unsigned k = part.key[((size_t)scan * CC_K1_SPLIT + p) * n_cell + c];
+          best = (k != KEY_EMPTY && (best == KEY_EMPTY || k > best)) ? k : best;
+        }
+        return best;
+      },
+      [&](int c) {  // ... and among equals the FIRST range's point (ranges are in file order)
+        unsigned best = KEY_EMPTY;
+        int bp = 0;
 #pragma unroll
-    for (int p = 0; p < CC_K1_SPLIT; p++)
-      if (k[p] != KEY_EMPTY && (bp < 0 || k[p] > best)) {
-        best = k[p];
-        bp = p;
-      }
-    bev[c] = cc_funkey(best);
-    if (bp >= 0) {
-      const int j = part.idx[((size_t)scan * CC_K1_SPLIT + bp) * n_cell + c];
-      const float4 q = P[j];
-      float2 rc;
-      rc.x = q.x / cfg.reso_row + (float)cfg.half_row - 0.5f;
-      rc.y = q.y / cfg.reso_col + (float)cfg.half_col - 0.5f;
-      pix[c] = rc;
-      npix++;
-    }
-  }
+        for (int p = 0; p < CC_K1_SPLIT; p++) {
+          const unsigned k = part.key[((size_t)scan * CC_K1_SPLIT + p) * n_cell + c];
+          if (k != KEY_EMPTY && (best == KEY_EMPTY || k > best)) {
+            best = k;
+            bp = p;
+          }
+        }
+        return part.idx[((size_t)scan * CC_K1_SPLIT + bp) * n_cell + c];
+      },
+      P, bev, pix, list_out, scan, emit_tab);
   npix = cc_wave_sum(npix);
   if ((tid & 63) == 0) atomicAdd(&red[2], (unsigned)npix);
   __syncthreads();

@@ -3,7 +3,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/q1
-timeout 300 rocprofv3 --kernel-include-regex "cc_k_" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/q1 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-overlap --steps 2 --warmup 1 --db-scans 2000 > /dev/null 2> $OUT/pmc.err
+timeout 300 rocprofv3 --kernel-include-regex "cc_k_" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/q1 -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-overlap --steps 2 --warmup 1 --db-scans 5000 --workload ${WL:-kitti} > /dev/null 2> $OUT/pmc.err
 F=$(find /tmp/q1 -name "*counter_collection.csv" | head -1)
 python - <<PY
 import csv, collections

@@ -57,6 +57,7 @@ struct uint4 {
   unsigned x, y, z, w;
 };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return {a, b, c, d}; }
 struct double2 {
   double x, y;
 };
