@@ -229,6 +229,9 @@ struct cc_k2_levmap {
   const unsigned long long *bitmap;  // bit c & 63 of word c >> 6: cell c is active
   const uint16_t *cbase;             // active cells before chunk c >> 6
   const unsigned char *lev;          // level count per list entry
+  const uint16_t *g_rc;              // the scan's entry list in global memory (k_rasterize.h): (row << 8) | col ...
+  const float2 *g_pix;               // ... and continuous position per entry
+  int n_act;                         // entries
 };
 template <bool LISTED>
 __device__ __forceinline__ int cc_k2_lev_at(const cc_k2_levmap &M, int cell) {
@@ -438,44 +441,94 @@ __device__ __forceinline__ void cc_k2_back(const cc_dev_cfg &cfg, const float2 *
           const int r_max = r_cen + roi_pad < n_row - 1 ? r_cen + roi_pad : n_row - 1;
           const int c_min = c_cen - roi_pad > 0 ? c_cen - roi_pad : 0;
           const int c_max = c_cen + roi_pad < n_col - 1 ? c_cen + roi_pad : n_col - 1;
-          const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
-          // nine 64-cell stretches (a 23 x 23 window) at a time: their level bytes and positions are fetched before any
-          // of them is compacted, so the L2 round trips of the positions overlap
-          const int KB = 9;
-          for (int base0 = 0; base0 < tot; base0 += 64 * KB) {
-            int lvv[KB];
-            float2 rcv[KB];
+          if (LISTED) {
+            // The list front half's scans: the window's rows are ONE stretch of the raster-ordered entry list (first entry at or
+            // after the first row's first cell .. last entry of the last row), so the wave reads entries -- (row, col), level
+            // count, position, side by side in memory -- instead of probing 23 x 23 cells through the occupancy words; the
+            // column test keeps the window's cells, in the same raster order.
+            auto before = [&](int cell) {  // entries before `cell` (cell <= n_cell)
+              if (cell >= n_cell) return lm.n_act;
+              return (int)lm.cbase[cell >> 6] + (int)__popcll(lm.bitmap[cell >> 6] & ((1ull << (cell & 63)) - 1ull));
+            };
+            const int i_lo = before(r_min * n_col), i_hi = before((r_max + 1) * n_col);
+            const int KB = 9;
+            for (int base0 = i_lo; base0 < i_hi; base0 += 64 * KB) {
+              int lvv[KB];
+              float2 rcv[KB];
 #pragma unroll
-            for (int u = 0; u < KB; u++) {
-              const int idx = base0 + 64 * u + lane;
-              lvv[u] = 0;
-              rcv[u] = make_float2(0.f, 0.f);
-              if (idx < tot) {
-                const int ro = idx / W;
-                const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
-                // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
-                // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
-                lvv[u] = cc_k2_lev_at<LISTED>(lm, cell);
-                if (lvv[u] >= 2) rcv[u] = pix[cell];
+              for (int u = 0; u < KB; u++) {
+                const int idx = base0 + 64 * u + lane;
+                lvv[u] = 0;
+                rcv[u] = make_float2(0.f, 0.f);
+                if (idx < i_hi) {
+                  // (column and position requested together -- both coalesced; a position fetched only for the cells that pass
+                  // the column and level tests would be a second global round trip behind the first)
+                  const int col = (int)(lm.g_rc[idx] & 255u);
+                  rcv[u] = lm.g_pix[idx];
+                  // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> level count >= 2;
+                  // "higher" = #{e >= 1 : h > lv_grads[e]} = level count - 1
+                  if (col >= c_min && col <= c_max) lvv[u] = (int)lm.lev[idx];
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < KB; u++) {
+                if (base0 + 64 * u >= i_hi) break;  // uniform
+                bool q = false;
+                float dist = 0.f;
+                if (lvv[u] >= 2) {
+                  const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
+                  dist = sqrtf(dx * dx + dy * dy);
+                  q = (double)dist < r_lim;
+                }
+                const unsigned long long m = __ballot(q);
+                const int pos = n + cc_mbcnt(m);
+                if (q && pos < CAP) {
+                  ldist[(av - g0) * CAP + pos] = dist;
+                  lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+                }
+                n += __popcll(m);
               }
             }
+          } else {
+            const int W = c_max - c_min + 1, tot = W * (r_max - r_min + 1);
+            // nine 64-cell stretches (a 23 x 23 window) at a time: their level bytes and positions are fetched before any
+            // of them is compacted, so the L2 round trips of the positions overlap
+            const int KB = 9;
+            for (int base0 = 0; base0 < tot; base0 += 64 * KB) {
+              int lvv[KB];
+              float2 rcv[KB];
 #pragma unroll
-            for (int u = 0; u < KB; u++) {
-              if (base0 + 64 * u >= tot) break;  // uniform
-              bool q = false;
-              float dist = 0.f;
-              if (lvv[u] >= 2) {
-                const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
-                dist = sqrtf(dx * dx + dy * dy);
-                q = (double)dist < r_lim;
+              for (int u = 0; u < KB; u++) {
+                const int idx = base0 + 64 * u + lane;
+                lvv[u] = 0;
+                rcv[u] = make_float2(0.f, 0.f);
+                if (idx < tot) {
+                  const int ro = idx / W;
+                  const int cell = (r_min + ro) * n_col + c_min + (idx - ro * W);
+                  // `h < g1 -> skip`, then `h > g1` (contour_mng.h:742-748): together h > lv_grads[1] <=> LV >= 2;
+                  // "higher" = #{e >= 1 : h > lv_grads[e]} = LV - 1
+                  lvv[u] = cc_k2_lev_at<LISTED>(lm, cell);
+                  if (lvv[u] >= 2) rcv[u] = pix[cell];
+                }
               }
-              const unsigned long long m = __ballot(q);
-              const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-              if (q && pos < CAP) {
-                ldist[(av - g0) * CAP + pos] = dist;
-                lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+#pragma unroll
+              for (int u = 0; u < KB; u++) {
+                if (base0 + 64 * u >= tot) break;  // uniform
+                bool q = false;
+                float dist = 0.f;
+                if (lvv[u] >= 2) {
+                  const float dx = rcv[u].x - vcx, dy = rcv[u].y - vcy;
+                  dist = sqrtf(dx * dx + dy * dy);
+                  q = (double)dist < r_lim;
+                }
+                const unsigned long long m = __ballot(q);
+                const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (q && pos < CAP) {
+                  ldist[(av - g0) * CAP + pos] = dist;
+                  lhi[(av - g0) * CAP + pos] = (unsigned char)(lvv[u] - 1);
+                }
+                n += __popcll(m);
               }
-              n += __popcll(m);
             }
           }
           if (n > CAP && lane == 0) atomicOr((unsigned *)&desc->flags, 4u);  // more RoI cells than the list holds: keys not exact
@@ -1417,5 +1470,8 @@ __device__ __forceinline__ void cc_k2_body(const cc_dev_cfg &cfg, const float *_
   lm.bitmap = nullptr;
   lm.cbase = nullptr;
   lm.lev = nullptr;
+  lm.g_rc = nullptr;
+  lm.g_pix = nullptr;
+  lm.n_act = 0;
   cc_k2_back<NC, BIG, false>(cfg, pix, k1_out, scr, bigtab, scan, desc_out, labels_dbg, phase_clk, R, n_lev_f, flags_f, lm);
 }

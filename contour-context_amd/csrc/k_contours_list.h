@@ -190,12 +190,6 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     const unsigned rcv = rc[i];
     const int c = (int)(rcv >> 8) * n_col + (int)(rcv & 255u);
     atomicOr(&bitmap[c >> 6], 1ull << (c & 63));
-    bool first = i == 0;
-    if (!first) {
-      const unsigned rp = rc[i - 1];
-      first = (((int)(rp >> 8) * n_col + (int)(rp & 255u)) >> 6) != (c >> 6);
-    }
-    if (first) cbase[c >> 6] = (uint16_t)i;  // entries before the chunk = index of its first entry (empty chunks are never looked up)
   }
   for (int q = wave_id; q < n_str; q += n_waves) {
     const int i = q * 64 + lane;
@@ -212,6 +206,14 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       const int v = lane < n_str ? (int)ssum[lane] : 0;
       const int incl = cc_wave_scan_incl(v);
       spre = incl - v;
+    }
+    // entries before every 64-cell chunk (every wave makes all of it and writes the same values: no hand-over)
+    for (int q = 0, run = 0; q < n_chunk; q += 64) {
+      const int b = q + lane;
+      const int v = b < n_chunk ? __popcll(bitmap[b]) : 0;
+      const int incl = cc_wave_scan_incl(v);
+      if (b < n_chunk) cbase[b] = (uint16_t)(run + incl - v);
+      run += cc_wave_scan_total(incl);
     }
     CC_K2_STAMP(24);
     for (int q = wave_id; q < n_str; q += n_waves) {
@@ -281,9 +283,7 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
       if (cc == 0) f3 &= 6u;          // no NW (the cell there is the previous row's last)
       if (cc == n_col - 1) f3 &= 3u;  // no NE
       if (f3) {
-        // entries before the field's first cell (a chunk base exists for chunks that have entries: with none in this word the
-        // field's active cells are the next word's first ones)
-        const int j_nw = w0 != 0ull ? (int)cbase[wb] + __popcll(w0 & ((1ull << bit) - 1ull)) : (int)cbase[wb + 1];
+        const int j_nw = (int)cbase[wb] + __popcll(w0 & ((1ull << bit) - 1ull));  // entries before the field's first cell
         const int j_n = j_nw + (int)(raw & 1u), j_ne = j_n + (int)((raw >> 1) & 1u);
         if (f3 & 1u) {
           const int Lj = (int)lev[j_nw];
@@ -605,8 +605,15 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     cpo->cB = (uint8_t)cB;
     cpo->pad[0] = cpo->pad[1] = 0;
   };
+  // The two kinds of walk run SIDE BY SIDE (round 6: one after the other before, 16 + 11 us per street scene): the lower half of the
+  // workgroup takes the lane walks -- the ~500 components largest first, so its first round holds everything of any length --
+  // and the large components' shapes, the upper half the eight-lane walks of the large components (a few dozen).
   const int n_big = sh[40 + 7];
-  for (int g = tid; g < n_big; g += nt) {  // the large components' shape (their sums: the eight-lane pass below)
+  const int half = nt >> 1;
+  const bool lane_walker = tid < half || nt < 128;
+  const int wt = nt < 128 ? tid : (tid < half ? tid : tid - half), wn = nt < 128 ? nt : half;  // index / count inside the thread's half
+  if (lane_walker)
+  for (int g = wt; g < n_big; g += wn) {  // the large components' shape (their sums: the eight-lane pass)
     const int t_ = (int)big[g];
     const int l = t_ / NC, k = t_ - l * NC;
     const int a = (int)area[t_];
@@ -633,7 +640,8 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     finish_shape(l, k, a, ml, c0, c1, cB);
   }
   const int n_small = n_tot - n_big;
-  for (int w = tid; w < n_small; w += nt) {
+  if (lane_walker)
+  for (int w = wt; w < n_small; w += wn) {
     const int t_ = (int)scr->act[w];
     const int l = t_ / NC, k = t_ - l * NC;
     const int a = (int)area[t_];
@@ -696,8 +704,9 @@ __device__ __forceinline__ bool cc_k2_front_list(const cc_dev_cfg &cfg, const fl
     // role: 0 ps_x  1 ps_y  2 t_xx  3 t_xy  4 t_yy  5 tq_x  6 tq_y  (7: nothing of its own)
     const unsigned fa_h = role >= 5 ? ~0u : 0u, fa_y = (role == 1 || role == 4) ? ~0u : 0u, fa_x = ~(fa_h | fa_y);
     const unsigned fb_1 = role < 2 ? ~0u : 0u, fb_x = (role == 2 || role == 5) ? ~0u : 0u, fb_y = ~(fb_1 | fb_x);
-    for (int g0 = 0; g0 < n_big; g0 += nt >> 3) {  // block-uniform trip count
-      const int g = g0 + (tid >> 3);
+    if (!lane_walker || nt < 128)
+    for (int g0 = 0; g0 < n_big; g0 += wn >> 3) {  // uniform trip count over the waves that are here
+      const int g = g0 + (wt >> 3);
       const bool on = g < n_big;
       double acc = 0.0;
       float vol3 = 0.f;
@@ -786,6 +795,9 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
   lm.bitmap = (const unsigned long long *)(smem + CC_K2L_O_BITMAP);
   lm.cbase = (const uint16_t *)(smem + CC_K2L_O_CBASE);
   lm.lev = (const unsigned char *)(smem + CC_K2L_O_LEV);
+  lm.g_rc = list.rc + (size_t)scan * CC_LIST_CAP;
+  lm.g_pix = list.pix + (size_t)scan * CC_LIST_CAP;
+  lm.n_act = list.hdr[scan].x;
   cc_k2_back<CC_NC, false, true>(cfg, pix_in + (size_t)scan * cfg.n_cell, k1_out, scr, nullptr, scan, desc_out, labels_dbg, phase_clk,
                                  smem + CC_K2L_O_REST, n_lev, 0, lm);
 }
