@@ -816,8 +816,8 @@ def _read_kernel_ms(cc, ctx, db, B):
 def algorithmic_bytes(d, res, B, P, n_db):
     """ALGORITHMIC bytes per step and kernel group (DESIGN.md "Kernels"): what the step has to move, independent of how.
     d = descriptors of (a sample of) the step's scans, res = the step's query results.
-      K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions;
-      K2 reads those and emits the descriptor used downstream;
+      K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions + the list of active cells;
+      K2 reads that list and emits the descriptor used downstream;
       K3 reads the layers' key matrices once and, per anchor key, the 40-B key and <= nnk 12-B hits;
       K4 reads, per KNN hit, the hit and two contour records, per anchor-similar pair the two 256-bit rings, per check that
          reaches the pairing the two 600-B BCIs, and writes a 104-B record per pass;
@@ -830,15 +830,19 @@ def algorithmic_bytes(d, res, B, P, n_db):
     f = {k: float(res[k].mean()) for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check3", "n_cand_tidy")}
     n_keys_db = 3 * 6 * n_db
     bev = 22500 * 4 + n_pix * 8
-    alg = {"cc_k_rasterize": B * (P * 16 + bev),
-           "cc_k_contours": B * (bev + desc_emit),
+    # round 6: K1 also lists the scan's active cells (above the lowest level) for K2 -- 15 B per entry ((row, col), level count,
+    # height, continuous position) + a 16-B header -- and K2 starts from that list instead of re-reading the image.  The entry
+    # count is not in the descriptor; the level-0 contours' cells (>= 3-cell components of the same level set) are a lower bound
+    active_list = 16 + 15 * float(d["layer_cell_cnt"][:, 0].mean())
+    alg = {"cc_k_rasterize": B * (P * 16 + bev + active_list),
+           "cc_k_contours": B * (active_list + desc_emit),
            "cc_k_knn": n_keys_db * 44 + B * 18 * 40 + B * f["n_knn_hits"] * 12,
            "cc_k_check": B * (f["n_knn_hits"] * (12 + 2 * 76) + f["cand_aft_check1"] * (64 + 2 * 600) + f["cand_aft_check3"] * 104),
            "cc_k_merge": B * f["cand_aft_check3"] * 104,
            "cc_k_gmm": B * f["n_cand_tidy"] * (2 * 45 * 32 + 64),
            "cc_k_final": B * 64}
     compulsory = B * P * 16 + B * desc_emit + n_keys_db * 44 + B * 18 * 40 + B * 64
-    intermediate = 2 * B * bev
+    intermediate = B * bev + 2 * B * active_list   # the dense image K1 leaves (debug / the mid and big paths read it) + the list both ways
     split = {"compulsory": compulsory, "intermediate": intermediate, "logical_gather": sum(alg.values()) - compulsory - intermediate}
     return alg, split
 
@@ -1130,7 +1134,7 @@ def pmc_traffic(kernel, batch, db_scans, workload):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))  # round tags sort by name
     parts = {"cc_k_check": ["cc_k_check_a", "cc_k_check_b1", "cc_k_compact_cstl", "cc_k_check_b2", "cc_k_check_c"],
              "cc_k_gmm": ["cc_k_gmm_init", "cc_k_select", "cc_k_gmm_refine"]}.get(kernel, [kernel])
-    optional = {"cc_k_contours": ["cc_k_contours_big"]}.get(kernel, [])  # (the slow path's launch: in the summaries since round 5)
+    optional = {"cc_k_contours": ["cc_k_contours_mid", "cc_k_contours_big"]}.get(kernel, [])  # (the launches behind the list kernel, usually with empty queues)
     d = ks = None
     for f in reversed(files):   # the newest summary taken on this configuration
         try:

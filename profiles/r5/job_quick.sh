@@ -2,7 +2,7 @@
 TAG=${1:-r5q}
 mkdir -p gpurun_out/$TAG
 ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > gpurun_out/$TAG/pytest_gpu.log 2>&1
-timeout 600 python bench.py --no-cpu --no-extra --steps 30 --warmup 3 2> gpurun_out/$TAG/bench_sparse.err | grep '^{' > gpurun_out/$TAG/bench_sparse.json
+timeout 600 python bench.py --no-cpu --no-extra --workload sparse --steps 30 --warmup 3 2> gpurun_out/$TAG/bench_sparse.err | grep '^{' > gpurun_out/$TAG/bench_sparse.json
 timeout 600 python bench.py --no-cpu --no-extra --workload kitti --steps 30 --warmup 3 2> gpurun_out/$TAG/bench_kitti.err | grep '^{' > gpurun_out/$TAG/bench_kitti.json
 tail -5 gpurun_out/$TAG/pytest_gpu.log
 python - <<PY
