@@ -44,6 +44,57 @@ __device__ __forceinline__ int cc_wave_id() {
 #endif
 }
 
+// (m << 1) | (sign bit of x): a comparison result appended to a bit string by ONE instruction (v_alignbit_b32) instead of a
+// compare plus a conditional OR
+__device__ __forceinline__ unsigned cc_push_sign(unsigned m, float x) {
+#ifndef CC_EMU
+  return __builtin_amdgcn_alignbit(m, __float_as_uint(x), 31);
+#else
+  return (m << 1) | (__float_as_uint(x) >> 31);
+#endif
+}
+// two f32 values per lane and instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
+#ifndef CC_EMU
+typedef float cc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cc_f2 cc_pk_fma(cc_f2 a, cc_f2 b, cc_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ unsigned cc_brev(unsigned v) { return __brev(v); }
+#else
+struct cc_f2 {
+  float x, y;
+};
+inline cc_f2 operator+(cc_f2 a, cc_f2 b) { return cc_f2{a.x + b.x, a.y + b.y}; }
+inline cc_f2 operator-(cc_f2 a, cc_f2 b) { return cc_f2{a.x - b.x, a.y - b.y}; }
+inline cc_f2 operator*(cc_f2 a, cc_f2 b) { return cc_f2{a.x * b.x, a.y * b.y}; }
+inline cc_f2 operator-(cc_f2 a) { return cc_f2{-a.x, -a.y}; }
+inline cc_f2 cc_pk_fma(cc_f2 a, cc_f2 b, cc_f2 c) { return cc_f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+inline unsigned cc_brev(unsigned v) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+#endif
+
+// a value that is the same in every lane of the wave, handed to the compiler as a SCALAR (loaded through a vector load it is a
+// vector value to the compiler, and every address built from it costs vector registers and vector arithmetic)
+__device__ __forceinline__ int cc_uniform_i(int v) {
+#ifndef CC_EMU
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ T *cc_uniform_ptr(T *p) {
+#ifndef CC_EMU
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+#else
+  return p;
+#endif
+}
+
 // Volatile reads of LDS words that other lanes are changing (the union-find forest of K2).  A plain `volatile T *` made from a
 // generic pointer keeps the GENERIC address space -- the address-space inference leaves volatile accesses alone -- and is
 // compiled to flat_load + s_waitcnt vmcnt(0) per access (round 4's labelling ran on those); spelled with the LDS address
@@ -60,9 +111,15 @@ __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) {
 __device__ __forceinline__ void cc_lds_vwrite16(uint16_t *p, unsigned v) {
   *(volatile __attribute__((address_space(3))) uint16_t *)p = (uint16_t)v;
 }
+// Request the cache line of a global address without using the value: a volatile load is issued where it stands, nothing
+// waits for it (its destination register is not reused before it has arrived: the compiler tracks that like any load).
+__device__ __forceinline__ void cc_touch_global(const void *p) {
+  (void)*(const volatile __attribute__((address_space(1))) unsigned *)p;
+}
 #pragma clang diagnostic pop
 __device__ __forceinline__ double cc_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }  // v_rsq_f64
 #else
+__device__ __forceinline__ void cc_touch_global(const void *) {}
 __device__ __forceinline__ unsigned cc_lds_vread16(const uint16_t *p) { return *(const volatile uint16_t *)p; }
 __device__ __forceinline__ unsigned cc_lds_vread32(const unsigned *p) { return *(const volatile unsigned *)p; }
 __device__ __forceinline__ void cc_lds_vwrite16(uint16_t *p, unsigned v) { *(volatile uint16_t *)p = (uint16_t)v; }

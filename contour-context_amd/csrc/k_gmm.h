@@ -42,6 +42,15 @@
 // input, ~3 000 pairs x ~40 evaluations per problem, it LOSES: four waves repeat the serial line-search code,
 // cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk.  Not launched.)
 
+// The long problems are listed by length class, longest first: the 64-lane refinement starts them in that order, so the
+// waves that are still running when the launch runs dry hold the SHORT lists.  (In list order, a chunk's ~3 000 one-wave
+// problems ran as one full round of 2 048 and a second, under-filled one: the launch lasted two problem lengths, 383 us,
+// where its instructions fill the SIMDs for 225.)
+#define CC_GMM_NCLS 8
+__device__ __forceinline__ int cc_gmm_len_class(int np) {
+  return np > 1400 ? 0 : (np > 1100 ? 1 : (np > 950 ? 2 : (np > 850 ? 3 : (np > 750 ? 4 : (np > 650 ? 5 : (np > 500 ? 6 : 7))))));
+}
+
 struct cc_gmm_result {
   double corr_init;
   double corr_opt;
@@ -52,7 +61,7 @@ struct cc_gmm_result {
   int flags;       // bit0: a scan kept only its first CC_GMM_ECAP_L ellipses of a level (cannot happen while CC_GMM_ECAP_L == CC_MAXC), bit1: the pair pool was full,
                    // bit2: contour table truncated (CC_MAXC)
   int n_pairs;     // selected (src, tgt) ellipse pairs
-  int pad;
+  int code_seg;    // first segment of the problem's pair-code list in the chunk's code pool (cc_k_gmm_init), -1: none
 };
 
 struct cc_ell {  // values are f32 in the reference too (getManualCov, pos_mean_, cell_cnt_), widened to f64 at use
@@ -234,7 +243,62 @@ struct cc_gpair {
   double pad_;
   float smx, smy, tmx, tmy;
 };  // 80 B: five 16-byte units (sd sb | a00 a11 | as ap | w - | means)
-static_assert(sizeof(cc_gpair) == 80, "five 16-byte loads per pair");
+static_assert(sizeof(cc_gpair) == 80, "the pose-independent half of a term, in registers");
+// What the refinement keeps of a pair between its evaluations: the two ellipses' f32 values as they are (56 B instead of
+// the 80 B of the combined record above; cc_gmm_make_pair is repeated by every evaluation).  Round 6: with ~2 000 problems
+// of ~800 pairs in flight, each streaming its records once per evaluation, the 64-lane refinement ran at the HBM's
+// bandwidth (1.8 GB per chunk in 0.38 ms), not at the f64 rate -- bytes per pair are what it costs.
+// Unit by unit -- pair i's k-th unit at unit index k * n + i -- so that the 64 lanes of a load or store touch ONE
+// contiguous kilobyte (records side by side cost a 16-byte piece of 40 different cache lines per instruction).
+struct cc_graw {
+  float4 s;  // src covariance c00 c01 c10 c11
+  float4 t;  // tgt covariance
+  float4 m;  // src mean, tgt mean
+  float2 w;  // src weight, tgt weight
+};
+#define CC_GRAW_BYTES 56
+// the first pairs of a problem stay in LDS (CC_GMM_NL of a 64-lane problem, a quarter of that for each of the four
+// problems of a 16-lane wave), the rest goes through the global pool
+#ifndef CC_GMM_NL
+#define CC_GMM_NL 128
+#endif
+struct cc_gsrc {       // where a problem's records are
+  float4 *lds;         // [3][nl_cap] float4 | [nl_cap] float2 (this problem's part of the workgroup's block)
+  char *glb;           // units of the pairs >= nl: [3][ng_alloc] float4 | [ng_alloc] float2, 16-byte aligned
+  int nl_cap, nl, ng_alloc;
+};
+__device__ __forceinline__ cc_graw cc_gsrc_load(const cc_gsrc &Q, int i) {
+  cc_graw r;
+  if (i < Q.nl) {
+    r.s = Q.lds[i];
+    r.t = Q.lds[Q.nl_cap + i];
+    r.m = Q.lds[2 * Q.nl_cap + i];
+    r.w = ((const float2 *)(Q.lds + 3 * Q.nl_cap))[i];
+  } else {
+    const int j = i - Q.nl;
+    const float4 *g = (const float4 *)Q.glb + j;
+    r.s = g[0];
+    r.t = g[Q.ng_alloc];
+    r.m = g[2 * (size_t)Q.ng_alloc];
+    r.w = ((const float2 *)((const float4 *)Q.glb + 3 * (size_t)Q.ng_alloc))[j];
+  }
+  return r;
+}
+__device__ __forceinline__ void cc_gsrc_store(const cc_gsrc &Q, int i, const cc_graw &r) {
+  if (i < Q.nl) {
+    Q.lds[i] = r.s;
+    Q.lds[Q.nl_cap + i] = r.t;
+    Q.lds[2 * Q.nl_cap + i] = r.m;
+    ((float2 *)(Q.lds + 3 * Q.nl_cap))[i] = r.w;
+  } else {
+    const int j = i - Q.nl;
+    float4 *g = (float4 *)Q.glb + j;
+    g[0] = r.s;
+    g[Q.ng_alloc] = r.t;
+    g[2 * (size_t)Q.ng_alloc] = r.m;
+    ((float2 *)((float4 *)Q.glb + 3 * (size_t)Q.ng_alloc))[j] = r.w;
+  }
+}
 
 // sum over the lanes of a problem, result in every lane
 template <int G>
@@ -245,31 +309,13 @@ __device__ __forceinline__ double cc_gsum(double v) {
   }
   return cc_group_sum_d(v);
 }
-// the four sums of an evaluation (cost, gradient).  G = 256: a problem owns a whole workgroup of four waves; the waves'
-// partial sums meet in LDS and every lane adds them in the same order, so all 256 lanes hold bit-identical results and
-// take the same branches of the line search (two barriers per evaluation of several thousand cycles).
+// the four sums of an evaluation (cost, gradient)
 template <int G>
 __device__ __forceinline__ void cc_gsum4(double &a, double &b, double &c, double &d) {
   a = cc_gsum<G>(a);
   b = cc_gsum<G>(b);
   c = cc_gsum<G>(c);
   d = cc_gsum<G>(d);
-  if (G == 256) {
-    __shared__ double part[4][4];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-      part[w][0] = a;
-      part[w][1] = b;
-      part[w][2] = c;
-      part[w][3] = d;
-    }
-    __syncthreads();
-    a = ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0];
-    b = ((part[0][1] + part[1][1]) + part[2][1]) + part[3][1];
-    c = ((part[0][2] + part[1][2]) + part[2][2]) + part[3][2];
-    d = ((part[0][3] + part[1][3]) + part[2][3]) + part[3][3];
-    __syncthreads();
-  }
 }
 
 // One term of GMMPair::operator() (correlation.h:123-160) and its gradient, in closed form.  The reference builds the
@@ -327,33 +373,40 @@ __device__ __forceinline__ bool cc_gmm_pair_near(double dx, double dy, float sma
   if (x > y2 * (1.0 + 1e-12)) return false;
   return sqrt(x) < y;
 }
-__device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_ell &et) {
-  const double s00 = (double)es.c00, s01 = (double)es.c01, s10 = (double)es.c10, s11 = (double)es.c11;
+__device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_graw &r) {
+  const double s00 = (double)r.s.x, s01 = (double)r.s.y, s10 = (double)r.s.z, s11 = (double)r.s.w;
   const double sm = 0.5 * (s00 + s11), sa = 0.5 * (s10 - s01);
-  const double a01 = 2.0 * ((double)et.c01 - sa), a10 = 2.0 * ((double)et.c10 + sa);
+  const double a01 = 2.0 * ((double)r.t.y - sa), a10 = 2.0 * ((double)r.t.z + sa);
   cc_gpair P;
   P.sd = 0.5 * (s00 - s11);
   P.sb = 0.5 * (s01 + s10);
-  P.a00 = 2.0 * (sm + (double)et.c00);
-  P.a11 = 2.0 * (sm + (double)et.c11);
+  P.a00 = 2.0 * (sm + (double)r.t.x);
+  P.a11 = 2.0 * (sm + (double)r.t.w);
   P.as = a01 + a10;
   P.ap = a01 * a10;
-  P.w = (double)es.w * (double)et.w;
-  P.smx = es.mx;
-  P.smy = es.my;
-  P.tmx = et.mx;
-  P.tmy = et.my;
+  P.w = (double)r.w.x * (double)r.w.y;
+  P.smx = r.m.x;
+  P.smy = r.m.y;
+  P.tmx = r.m.z;
+  P.tmy = r.m.w;
   P.pad_ = 0.0;
   return P;
 }
+__device__ __forceinline__ cc_graw cc_gmm_raw_of(const cc_ell &es, const cc_ell &et) {
+  cc_graw r;
+  r.s = make_float4(es.c00, es.c01, es.c10, es.c11);
+  r.t = make_float4(et.c00, et.c01, et.c10, et.c11);
+  r.m = make_float4(es.mx, es.my, et.mx, et.my);
+  r.w = make_float2(es.w, et.w);
+  return r;
+}
+__device__ __forceinline__ cc_gpair cc_gmm_make_pair(const cc_ell &es, const cc_ell &et) { return cc_gmm_make_pair(cc_gmm_raw_of(es, et)); }
 
 // hand-off between the G lanes of a problem through memory (lockstep on the GPU: a compiler fence; the CPU test harness
 // needs its threads to meet)
 template <int G>
 __device__ __forceinline__ void cc_gsync() {
-  if (G == 256) {
-    __syncthreads();
-  } else if (G == 64) {
+  if (G == 64) {
     cc_wave_sync();
   } else {
     cc_group_sync();
@@ -372,10 +425,19 @@ __device__ __forceinline__ void cc_gsync() {
 // evaluation, pool record) runs on full lanes.  Round 3 tested every pair in f64 and balloted once per tgt: K5's largest
 // part on contour-rich scans (0.66 ms of cc_k_gmm_init per 1 024 KITTI-shaped queries).
 #define CC_GMM_TCHUNK 64
+#ifdef CC_TUNE_GMM_CLK
+__device__ unsigned long long cc_gmm_scan_clk[8];  // tuning aid: cycles of the scan's parts, summed over the 64-lane problems (fill, f32 sweep, f64 tests, filing, flush, count)
+#define CC_CLK_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CC_CLK_ADD(i, a, b) do { clk_acc[i] += (b) - (a); } while (0)
+#else
+#define CC_CLK_T(v)
+#define CC_CLK_ADD(i, a, b)
+#endif
 #define CC_GMM_LIST_CAP 256
 #define CC_GMM_PRE_MARGIN 0.01f
-struct cc_gmm_scan_lds {
-  float4 T[CC_GMM_TCHUNK];  // (mx, my, maj, 3 maj + margin) of the current tgt chunk
+struct alignas(16) cc_gmm_scan_lds {
+  float Tx[CC_GMM_TCHUNK], Ty[CC_GMM_TCHUNK], Tw[CC_GMM_TCHUNK], Tm[CC_GMM_TCHUNK];  // mean, 3 maj + margin, maj of the current tgt chunk
+                                                                                     // (slots beyond the chunk: a mean no src comes near)
   unsigned code[CC_GMM_LIST_CAP];
 };
 static_assert(CC_GMM_ECAP_L <= 512 && CC_GMM_LEVELS <= 4, "pair codes are level:2 | src:9 | tgt:9 bits");
@@ -401,98 +463,175 @@ __device__ __forceinline__ int cc_gbcast_i(int v, int src) {
   return G == 64 ? __shfl(v, src) : cc_group_bcast(v, src);
 }
 
-// returns the number of selected pairs; flush(n) consumes L.code[0..n)
+// returns the number of selected pairs; flush(n, last) consumes L.code[0..n) (last: the sweep's final call)
 template <int G, typename Flush>
 __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__ fsrc, const cc_gmm_feat *__restrict__ ftgt, double tx, double ty,
                                                  double ct0, double st0, cc_gmm_scan_lds &L, int sl, Flush flush) {
   int cnt = 0, total = 0;
-  for (int li = 0; li < CC_GMM_LEVELS; li++) {
-    const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
-    if (ns <= 0) continue;
-    for (int t0 = 0; t0 < ntg; t0 += CC_GMM_TCHUNK) {
-      const int tn = ntg - t0 < CC_GMM_TCHUNK ? ntg - t0 : CC_GMM_TCHUNK;
-      cc_gsync<G>();  // the previous chunk is no longer read
-      for (int j = sl; j < tn; j += G) {
-        const cc_ell *pt = &ftgt->ell[li][t0 + j];
-        L.T[j] = make_float4(pt->mx, pt->my, pt->maj, 3.f * pt->maj + CC_GMM_PRE_MARGIN);
-      }
-      cc_gsync<G>();
-      for (int s0 = 0; s0 < ns; s0 += G) {
-        const int si = s0 + sl;
-        unsigned long long mask = 0ull;
-        if (si < ns) {
-          const cc_ell *ps = &fsrc->ell[li][si];
-          const double mx = (double)ps->mx, my = (double)ps->my;
-          const double sx = ct0 * mx + (-st0) * my + tx;  // T_init applied to the src mean, as written at correlation.h:87-90
-          const double sy = st0 * mx + ct0 * my + ty;
-          const float smaj = ps->maj;
-          const float sxf = (float)sx, syf = (float)sy, s3 = 3.f * smaj;
-          const bool pre_ok = fabsf(sxf) < 4096.f && fabsf(syf) < 4096.f;
-          // pass 1, branch-free: the f32 test of all tn tgts, eight per step (LDS reads in flight together), into a
-          // candidate mask.  A branch to the f64 test inside this loop would be taken by the WAVE whenever any of its
-          // 64 lanes has a candidate among the step's tgts -- nearly always -- although ~1 % of the pairs are candidates.
-          unsigned long long cand = 0ull;
-          for (int tb = 0; tb < tn; tb += 8) {
-            unsigned m8 = 0u;
+#ifdef CC_TUNE_GMM_CLK
+  unsigned long long clk_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  // The tgt chunks of all levels in one sequence, each chunk's (mean, major axis) values requested a chunk ahead: what a
+  // chunk boundary costs is then the LDS hand-over, not a memory round trip.  A lane holds TPL tgts of the next chunk.
+  constexpr int TPL = CC_GMM_TCHUNK / G;
+  float nx_[TPL], ny_[TPL], nm_[TPL];
+  auto request = [&](int li, int t0) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const float4 t = L.T[tb + u < tn ? tb + u : tn - 1];
-              const float dxf = sxf - t.x, dyf = syf - t.y, r = s3 + t.w;
-              m8 |= (dxf * dxf + dyf * dyf <= r * r) ? (1u << u) : 0u;
-            }
-            if (tb + 8 > tn) m8 &= (1u << (tn - tb)) - 1u;
-            cand |= (unsigned long long)m8 << tb;
+    for (int u = 0; u < TPL; u++) {
+      const int j = t0 + sl + u * G;
+      nx_[u] = 3.0e38f;  // beyond the chunk: dx^2 overflows to +inf, the test fails
+      ny_[u] = 0.f;
+      nm_[u] = 0.f;
+      if (li < CC_GMM_LEVELS && j < ftgt->n_ell[li]) {
+        const cc_ell *pt = &ftgt->ell[li][j];
+        nx_[u] = pt->mx;
+        ny_[u] = pt->my;
+        nm_[u] = pt->maj;
+      }
+    }
+  };
+  auto next_chunk = [&](int &li, int &t0) {  // the chunk after (li, t0) that has src and tgt ellipses, or li = CC_GMM_LEVELS
+    t0 += CC_GMM_TCHUNK;
+    while (li < CC_GMM_LEVELS && (fsrc->n_ell[li] <= 0 || t0 >= ftgt->n_ell[li])) {
+      li++;
+      t0 = 0;
+    }
+  };
+  int li = 0, t0 = -CC_GMM_TCHUNK;
+  next_chunk(li, t0);
+  request(li, t0);
+  while (li < CC_GMM_LEVELS) {
+    const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
+    const int tn = ntg - t0 < CC_GMM_TCHUNK ? ntg - t0 : CC_GMM_TCHUNK;
+    CC_CLK_T(c_f0);
+    cc_gsync<G>();  // the previous chunk is no longer read
+#pragma unroll
+    for (int u = 0; u < TPL; u++) {
+      const int j = sl + u * G;
+      L.Tx[j] = nx_[u];
+      L.Ty[j] = ny_[u];
+      L.Tm[j] = nm_[u];
+      L.Tw[j] = 3.f * nm_[u] + CC_GMM_PRE_MARGIN;
+    }
+    cc_gsync<G>();
+    int li_n = li, t0_n = t0;
+    next_chunk(li_n, t0_n);
+    request(li_n, t0_n);
+    CC_CLK_T(c_f1);
+    CC_CLK_ADD(0, c_f0, c_f1);
+    // the src block after this one is requested while this one is swept
+    float pmx = 0.f, pmy = 0.f, pmaj = 0.f;
+    if (sl < ns) {
+      const cc_ell *ps = &fsrc->ell[li][sl];
+      pmx = ps->mx, pmy = ps->my, pmaj = ps->maj;
+    }
+    for (int s0 = 0; s0 < ns; s0 += G) {
+      const int si = s0 + sl;
+      unsigned long long mask = 0ull;
+      CC_CLK_T(c_p0);
+      unsigned long long c_p1v = 0;
+      const float cmx = pmx, cmy = pmy, smaj = pmaj;
+      if (si + G < ns) {
+        const cc_ell *ps = &fsrc->ell[li][si + G];
+        pmx = ps->mx, pmy = ps->my, pmaj = ps->maj;
+      }
+      if (si < ns) {
+        const double mx = (double)cmx, my = (double)cmy;
+        const double sx = ct0 * mx + (-st0) * my + tx;  // T_init applied to the src mean, as written at correlation.h:87-90
+        const double sy = st0 * mx + ct0 * my + ty;
+        const float sxf = (float)sx, syf = (float)sy, s3 = 3.f * smaj;
+        const bool pre_ok = fabsf(sxf) < 4096.f && fabsf(syf) < 4096.f;
+        // pass 1, branch-free: the f32 test of the chunk's tgts, two per instruction (packed f32), eight per step (LDS reads
+        // in flight together), the outcome pushed into a bit string by its sign (r^2 - d^2 < 0: no candidate).  A branch
+        // to the f64 test inside this loop would be taken by the WAVE whenever any of its 64 lanes has a candidate among
+        // the step's tgts -- nearly always -- although ~1 % of the pairs are candidates.
+        unsigned long long cand = 0ull;
+        const cc_f2 sx2 = {sxf, sxf}, sy2 = {syf, syf}, s32 = {s3, s3};
+        for (int tb = 0; tb < tn; tb += 8) {
+          unsigned m8 = 0u;
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            const cc_f2 x2 = *(const cc_f2 *)&L.Tx[tb + u], y2 = *(const cc_f2 *)&L.Ty[tb + u], w2 = *(const cc_f2 *)&L.Tw[tb + u];
+            const cc_f2 d = sx2 - x2, e = sy2 - y2, r = s32 + w2;
+            const cc_f2 q = cc_pk_fma(e, e, d * d);
+            const cc_f2 z = cc_pk_fma(r, r, -q);  // >= 0: candidate (the margin of the conservative test covers the fused rounding)
+            m8 = cc_push_sign(m8, z.x);
+            m8 = cc_push_sign(m8, z.y);
           }
-          if (!pre_ok) cand = tn >= 64 ? ~0ull : (1ull << tn) - 1ull;
-          // pass 2: the reference's f64 expression on the candidates (a handful per lane)
-          while (cand) {
-            const int tj = __ffsll((unsigned long long)cand) - 1;
-            cand &= cand - 1;
-            const float4 t = L.T[tj];
-            if (cc_gmm_pair_near(sx - (double)t.x, sy - (double)t.y, smaj, t.z)) mask |= 1ull << tj;
-          }
+          // the string holds the step's eight outcomes first tgt highest, 1 = no candidate
+          cand |= (unsigned long long)((cc_brev(~m8) >> 24) & 0xffu) << tb;
         }
-        const int c = __popcll(mask);
-        const int incl = cc_gscan_incl<G>(c, sl);
-        const int tot = cc_gbcast_i<G>(incl, G - 1);
-        if (tot == 0) continue;
-        if (cnt + tot > CC_GMM_LIST_CAP) {
-          flush(cnt);
-          total += cnt;
-          cnt = 0;
+        if (!pre_ok) cand = tn >= 64 ? ~0ull : (1ull << tn) - 1ull;
+#ifdef CC_TUNE_GMM_CLK
+        c_p1v = __builtin_readcyclecounter();
+#endif
+        // pass 2: the reference's f64 expression on the candidates (a handful per lane)
+        while (cand) {
+          const int tj = __ffsll((unsigned long long)cand) - 1;
+          cand &= cand - 1;
+          if (tj < tn && cc_gmm_pair_near(sx - (double)L.Tx[tj], sy - (double)L.Ty[tj], smaj, L.Tm[tj])) mask |= 1ull << tj;
         }
-        if (tot <= CC_GMM_LIST_CAP) {
-          int pos = cnt + incl - c;
-          while (mask) {
-            const int tj = __ffsll((unsigned long long)mask) - 1;
-            mask &= mask - 1;
-            L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
+      }
+      CC_CLK_T(c_p2);
+#ifdef CC_TUNE_GMM_CLK
+      if (c_p1v) { CC_CLK_ADD(1, c_p0, c_p1v); CC_CLK_ADD(2, c_p1v, c_p2); }
+#endif
+      const int c = __popcll(mask);
+      const int incl = cc_gscan_incl<G>(c, sl);
+      const int tot = cc_gbcast_i<G>(incl, G - 1);
+      if (tot == 0) continue;
+      if (cnt + tot > CC_GMM_LIST_CAP) {
+        CC_CLK_T(c_q0);
+        flush(cnt, false);
+        CC_CLK_T(c_q1);
+        CC_CLK_ADD(4, c_q0, c_q1);
+        total += cnt;
+        cnt = 0;
+      }
+      CC_CLK_T(c_p3);
+      if (tot <= CC_GMM_LIST_CAP) {
+        int pos = cnt + incl - c;
+        while (mask) {
+          const int tj = __ffsll((unsigned long long)mask) - 1;
+          mask &= mask - 1;
+          L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
+        }
+        cnt += tot;
+        CC_CLK_T(c_p4);
+        CC_CLK_ADD(3, c_p3, c_p4);
+      } else {  // one (src chunk, tgt chunk) block with more hits than the list holds: lane by lane (a lane has <= 64)
+        for (int l = 0; l < G; l++) {
+          const int cl = cc_gbcast_i<G>(c, l);
+          if (cl == 0) continue;
+          if (cnt + cl > CC_GMM_LIST_CAP) {
+            flush(cnt, false);
+            total += cnt;
+            cnt = 0;
           }
-          cnt += tot;
-        } else {  // one (src chunk, tgt chunk) block with more hits than the list holds: lane by lane (a lane has <= 64)
-          for (int l = 0; l < G; l++) {
-            const int cl = cc_gbcast_i<G>(c, l);
-            if (cl == 0) continue;
-            if (cnt + cl > CC_GMM_LIST_CAP) {
-              flush(cnt);
-              total += cnt;
-              cnt = 0;
+          if (sl == l) {
+            int pos = cnt;
+            while (mask) {
+              const int tj = __ffsll((unsigned long long)mask) - 1;
+              mask &= mask - 1;
+              L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
             }
-            if (sl == l) {
-              int pos = cnt;
-              while (mask) {
-                const int tj = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                L.code[pos++] = (unsigned)((li << 18) | (si << 9) | (t0 + tj));
-              }
-            }
-            cnt += cl;
           }
+          cnt += cl;
         }
       }
     }
+    li = li_n;
+    t0 = t0_n;
   }
-  if (cnt > 0) flush(cnt);
+  CC_CLK_T(c_q2);
+  if (cnt > 0) flush(cnt, true);
+  CC_CLK_T(c_q3);
+  CC_CLK_ADD(4, c_q2, c_q3);
+  CC_CLK_ADD(5, 0ull, 1ull);
+#ifdef CC_TUNE_GMM_CLK
+  if (G == 64 && sl == 0)
+    for (int i = 0; i < 6; i++) atomicAdd(&cc_gmm_scan_clk[i], clk_acc[i]);
+#endif
   return total + cnt;
 }
 
@@ -501,28 +640,113 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
 // problems than the launch has waves; a whole wave per problem otherwise (contour-rich scans with few candidates: ~1 100
 // problems of ~30 000 grid cells each per 1 024 KITTI-shaped queries -- with 16 lanes each they occupied 290 waves of a GPU
 // that holds thousands, and the kernel lasted as long as the largest grid).
+// The (level, src, tgt) codes of the selected pairs are kept, so that the refinement of a problem reads its pair list
+// instead of sweeping the ellipse grid a second time (round 6: the second sweep was a third of cc_k_gmm_refine's time on
+// contour-rich scans).  A problem's codes go to BLOCKS of the chunk's code pool -- {n, next block, n codes}: the first
+// holds CC_GMM_BLK0 codes (most problems of a sparse scene need no more), the following ones CC_GMM_BLK, so a long list is
+// a few long contiguous runs.  A block is taken with one atomic, issued BEFORE it is needed (the first at the problem's
+// start, the next when the current one is half full): what these phases cost is memory round trips, not instructions.
+// A full code pool marks the pair pool full as well: every refinement of the chunk is then skipped and the host reports
+// CC_ECAPACITY (chunk_status).
+#define CC_GMM_BLK0 CC_GMM_LIST_CAP
+#define CC_GMM_BLK 1024
+struct cc_gmm_code_pool {
+  unsigned *codes;
+  int cap;
+  int *head;       // next free entry of codes[]
+  int *pair_head;  // the refinement's pair pool head (see above)
+  int pair_cap;
+};
+__device__ __forceinline__ cc_ell cc_gmm_ell_of(const cc_gmm_feat *f, int li, int i) {
+  return f->ell[li][i];
+}
 template <int G>
 __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
                                                 const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl,
-                                                const double *exp_tab) {
+                                                const double *exp_tab, const cc_gmm_code_pool &CPL) {
   const cc_gmm_problem pb = probs[pidx];
   const cc_gmm_feat *fsrc = db_feat + pb.gidx;
   const cc_gmm_feat *ftgt = qfeat + pb.q;
+  // the first block is requested now and bound at the first flush
+  int raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK0 + 2) : 0;  // lane 0: the requested block
+  int raw_cap = CC_GMM_BLK0;
+  bool have_raw = true;
   const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
   const double c2 = ct0 * ct0 - st0 * st0, s2 = 2.0 * st0 * ct0;
   double acc = 0.0;
-  const int np = cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
+  int first_blk = -1, blk = -1, blk_n = 0, blk_cap = 0;
+  bool pool_full = false;
+  const int np = cc_gmm_scan_pairs<G>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n, bool last) {
     cc_gsync<G>();
-    for (int e = sl; e < n; e += G) {
-      const int code = (int)L.code[e];
-      const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
-      const cc_gpair P = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
+    // the step's first pairs are on their way while the block bookkeeping runs
+    int e = sl;
+    unsigned code = 0u;
+    cc_ell es = {}, et = {};
+    if (e < n) {
+      code = L.code[e];
+      es = cc_gmm_ell_of(fsrc, (int)code >> 18, ((int)code >> 9) & 511);
+      et = cc_gmm_ell_of(ftgt, (int)code >> 18, (int)code & 511);
+    }
+    if (blk < 0 || blk_n + n > blk_cap) {  // (uniform over the problem's lanes) bind the requested block, or take one now
+      if (!have_raw) {
+        raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
+        raw_cap = CC_GMM_BLK;
+      }
+      const int nb = cc_gbcast_i<G>(raw_blk, 0);
+      have_raw = false;
+      if (nb + raw_cap + 2 > CPL.cap) pool_full = true;
+      if (!pool_full) {
+        if (blk >= 0) {
+          if (sl == 0) {
+            CPL.codes[blk] = (unsigned)blk_n;
+            CPL.codes[blk + 1] = (unsigned)nb;
+          }
+        } else {
+          first_blk = nb;
+        }
+      }
+      blk = nb;
+      blk_n = 0;
+      blk_cap = raw_cap;
+    }
+    // (the codes go out in a loop of their own: a loop that mixes loads and stores waits for ALL of them at every use of a
+    // loaded value -- one counter serves both on gfx9 and the two kinds complete out of order)
+    if (!pool_full) {
+      unsigned *dst = CPL.codes + blk + 2 + blk_n;
+      for (int k = sl; k < n; k += G) dst[k] = L.code[k];
+    }
+    while (e < n) {
+      const int e2 = e + G;
+      unsigned code2 = 0u;
+      cc_ell es2 = es, et2 = et;
+      if (e2 < n) {
+        code2 = L.code[e2];
+        es2 = cc_gmm_ell_of(fsrc, (int)code2 >> 18, ((int)code2 >> 9) & 511);
+        et2 = cc_gmm_ell_of(ftgt, (int)code2 >> 18, (int)code2 & 511);
+      }
+      const cc_gpair P = cc_gmm_make_pair(es, et);
       acc += cc_gmm_term(P, pb.tf[0], pb.tf[1], ct0, st0, c2, s2, exp_tab).v;
+      e = e2;
+      code = code2;
+      es = es2;
+      et = et2;
+    }
+    blk_n += n;
+    if (!last && !have_raw && 2 * blk_n >= blk_cap) {  // the next block, ahead of its use
+      raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
+      raw_cap = CC_GMM_BLK;
+      have_raw = true;
     }
     cc_gsync<G>();
   });
   const double cost = cc_gsum<G>(acc);
   if (sl == 0) {
+    if (pool_full) {
+      atomicMax(CPL.pair_head, CPL.pair_cap + 1);
+    } else if (blk >= 0) {
+      CPL.codes[blk] = (unsigned)blk_n;
+      CPL.codes[blk + 1] = 0xffffffffu;
+    }
     cc_gmm_result R;
     R.corr_init = -cost / sqrt(fsrc->ac * ftgt->ac);
     R.corr_opt = R.corr_init;
@@ -534,71 +758,52 @@ __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict
     R.termination = 0;
     R.flags = (fsrc->flags | ftgt->flags) & 5;
     R.n_pairs = np;
-    R.pad = 0;
+    R.code_seg = pool_full ? -1 : first_blk;
     results[pidx] = R;
   }
 }
 // grid = any (grid-stride over the device-side problem count), block = 64
 __global__ void __launch_bounds__(64)
 cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
-              const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results) {
+              const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results,
+              cc_gmm_code_pool CPL) {
   __shared__ cc_gmm_scan_lds lds[64 / CC_G];
   __shared__ double exp_tab[64];
   exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
   cc_wave_sync();
   const int n_prob = *n_prob_p;
   if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
-    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab);
+    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL);
     return;
   }
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
   for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
-    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab);
+    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL);
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes
 template <int G>
-__device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, int np, int sl, const double p[3], double *cost,
-                                            double grad[3], const double *exp_tab) {
+__device__ __forceinline__ void cc_gmm_eval(const cc_gsrc &Q, int np, int sl, const double p[3], double *cost, double grad[3],
+                                            const double *exp_tab) {
   double c, s;
   sincos(p[2], &s, &c);
   const double c2 = c * c - s * s, s2 = 2.0 * s * c;
   double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
-  // the next pair's record is requested before this pair's ~95 f64 instructions are issued: with one wave per SIMD (few,
-  // long problems) nothing else hides the L2 round trip
-  double2 w0 = make_double2(0.0, 0.0), w1 = w0, w2 = w0, w3 = w0;
-  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (sl < np) {
-    const double2 *g2 = (const double2 *)(pairs + sl);
-    w0 = g2[0], w1 = g2[1], w2 = g2[2], w3 = g2[3];
-    w4 = *(const float4 *)(g2 + 4);
-  }
+  // the next pair's record is requested before this pair's ~120 f64 instructions are issued
+  cc_graw w = {};
+  if (sl < np) w = cc_gsrc_load(Q, sl);
   for (int i = sl; i < np; i += G) {
-    double2 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
-    float4 n4 = w4;
-    if (i + G < np) {
-      const double2 *g2 = (const double2 *)(pairs + i + G);
-      n0 = g2[0], n1 = g2[1], n2 = g2[2], n3 = g2[3];
-      n4 = *(const float4 *)(g2 + 4);
-    }
-    cc_gpair P;
-    P.sd = w0.x;
-    P.sb = w0.y;
-    P.a00 = w1.x;
-    P.a11 = w1.y;
-    P.as = w2.x;
-    P.ap = w2.y;
-    P.w = w3.x;
-    P.smx = w4.x;
-    P.smy = w4.y;
-    P.tmx = w4.z;
-    P.tmy = w4.w;
+    cc_graw n = w;
+#ifdef CC_TUNE_GMM_NOLOAD
+    if (i + G < np && p[0] == 1.2345e-300) n = cc_gsrc_load(Q, i + G);
+#else
+    if (i + G < np) n = cc_gsrc_load(Q, i + G);
+#endif
+    const cc_gpair P = cc_gmm_make_pair(w);
     const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2, exp_tab);
 #ifdef CC_TUNE_GMM_TWICE  // tuning aid: the pair arithmetic twice (what it costs = this build's K5 minus the product's)
     {
-      cc_gpair P2 = P;
-      P2.w = P.w * 1.0000001;
-      const cc_gterm t2 = cc_gmm_term(P2, p[0], p[1], c, s, c2, s2, exp_tab);
+      const cc_gterm t2 = cc_gmm_term(P, p[0] + 1e-9, p[1], c * 1.000000001, s, c2 * 1.000000001, s2, exp_tab);  // nothing in common with the first but the loads
       a += 1e-300 * (t2.v + t2.gx + t2.gy + t2.gt);
     }
 #endif
@@ -606,7 +811,83 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
     ax += t.gx;
     ay += t.gy;
     at += t.gt;
-    w0 = n0, w1 = n1, w2 = n2, w3 = n3, w4 = n4;
+    w = n;
+  }
+  cc_gsum4<G>(a, ax, ay, at);
+  *cost = a;
+  grad[0] = ax;
+  grad[1] = ay;
+  grad[2] = at;
+}
+
+// The FIRST evaluation of a refined problem (at the initial pose) also files the problem's pair records: the codes
+// cc_k_gmm_init left are read block by block, the two ellipses of a pair gathered, the record stored for the evaluations
+// that follow and the term taken from it right away.  Codes are requested a sub-batch ahead, the next block's header a
+// block ahead.  A lane takes the positions it takes in cc_gmm_eval (position = lane, mod G): the sums are those of a
+// plain evaluation over the filed records, bit for bit.
+template <int G>
+__device__ __forceinline__ void cc_gmm_eval_first(const unsigned *__restrict__ codes, int blk, const cc_gmm_feat *__restrict__ fsrc,
+                                                  const cc_gmm_feat *__restrict__ ftgt, const cc_gsrc &Q, int sl, const double p[3],
+                                                  double *cost, double grad[3], const double *exp_tab) {
+  double c, s;
+  sincos(p[2], &s, &c);
+  const double c2 = c * c - s * s, s2 = 2.0 * s * c;
+  double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
+  int done = 0, n = 0, nxt = -1;
+  if (blk >= 0) {
+    n = (int)codes[blk];
+    nxt = (int)codes[blk + 1];
+  }
+  while (blk >= 0) {
+    int n2 = 0, nxt2 = -1;
+    if (nxt >= 0) {
+      n2 = (int)codes[nxt];
+      nxt2 = (int)codes[nxt + 1];
+    }
+    const unsigned *cb = codes + blk + 2;
+    int e0 = sl - done % G;
+    e0 = e0 < 0 ? e0 + G : e0;
+    // U steps at a time: their codes were requested a sub-batch ago, their 2 U ellipses are requested together, then the
+    // U records are stored and evaluated.  (Loads and stores share one counter and complete out of order: a step-by-step
+    // pipeline waits for its own stores at every step -- measured: 4 700 cycles per step instead of ~1 100.)
+    constexpr int U = 2;
+    unsigned cc_[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) cc_[u] = e0 + u * G < n ? cb[e0 + u * G] : 0u;
+    for (; e0 < n; e0 += U * G) {
+      cc_ell es[U], et[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        es[u] = cc_ell{};
+        et[u] = cc_ell{};
+        if (e0 + u * G < n) {
+          es[u] = cc_gmm_ell_of(fsrc, (int)cc_[u] >> 18, ((int)cc_[u] >> 9) & 511);
+          et[u] = cc_gmm_ell_of(ftgt, (int)cc_[u] >> 18, (int)cc_[u] & 511);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int en = e0 + (U + u) * G;
+        cc_[u] = en < n ? cb[en] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (e0 + u * G < n) {
+          const cc_graw r = cc_gmm_raw_of(es[u], et[u]);
+          cc_gsrc_store(Q, done + e0 + u * G, r);
+          const cc_gpair P = cc_gmm_make_pair(r);
+          const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2, exp_tab);
+          a += t.v;
+          ax += t.gx;
+          ay += t.gy;
+          at += t.gt;
+        }
+      }
+    }
+    done += n;
+    blk = nxt;
+    n = n2;
+    nxt = nxt2;
   }
   cc_gsum4<G>(a, ax, ay, at);
   *cost = a;
@@ -616,10 +897,20 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gpair *__restrict__ pairs, 
 }
 
 struct cc_gmm_ctx {  // what a line-search evaluation needs
-  const cc_gpair *pairs;
+  cc_gsrc Q;
   const double *exp_tab;  // cc_exp2_tab64 in LDS
   int np, sl;
+#ifdef CC_TUNE_GMM_CLK
+  unsigned long long *ev_clk;  // tuning aid: cycles spent in evaluations, their count
+  int *n_ev;
+#endif
 };
+#ifdef CC_TUNE_GMM_CLK  // tuning aid: per refined problem {np | G << 20 | iterations << 40 | evaluations << 48, cycles, cycles in evaluations, cycles filing pairs}
+#define CC_GMM_CLK_CAP 65536
+__device__ unsigned long long cc_gmm_clk[CC_GMM_CLK_CAP * 4];
+__device__ unsigned long long cc_gmm_clk2[CC_GMM_CLK_CAP * 4];  // wall clock (100 MHz) at start / end, HW_ID, -
+__device__ int cc_gmm_clk_n;
+#endif
 // ---- Ceres 2.x line search pieces (see oracle/orc_gmm.h for the provenance notes) ----
 struct cc_fs {  // FunctionSample; vector_x is not kept (it is pos + x * dir, recomputed where needed)
   double x, value, gradient;
@@ -888,7 +1179,14 @@ __device__ __forceinline__ void cc_ls_eval(const cc_gmm_ctx &S, const double pos
   o->x = x;
   double vx[3];
   for (int i = 0; i < 3; i++) vx[i] = pos[i] + x * dir[i];
-  cc_gmm_eval<G>(S.pairs, S.np, S.sl, vx, &o->value, o->vg, S.exp_tab);
+#ifdef CC_TUNE_GMM_CLK
+  const unsigned long long t_ev = __builtin_readcyclecounter();
+#endif
+  cc_gmm_eval<G>(S.Q, S.np, S.sl, vx, &o->value, o->vg, S.exp_tab);
+#ifdef CC_TUNE_GMM_CLK
+  *S.ev_clk += __builtin_readcyclecounter() - t_ev;
+  *S.n_ev += 1;
+#endif
   o->value_ok = isfinite(o->value);
   o->grad_ok = o->value_ok && isfinite(o->vg[0]) && isfinite(o->vg[1]) && isfinite(o->vg[2]);
   o->gradient = dir[0] * o->vg[0] + dir[1] * o->vg[1] + dir[2] * o->vg[2];
@@ -993,77 +1291,98 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 // K5b: calcCorrelation (correlation.h:206-238) for the problems cc_k_select listed: LineSearchMinimizer, LBFGS rank 20,
 // Wolfe / cubic interpolation, <= 10 iterations.  G lanes per problem.
 // grid = any (grid-stride over the device-side list), block = 64
-// G = 16: four problems per wave; 64: one wave per problem; 256: one workgroup of four waves per problem (the long pair
-// lists of contour-rich scans -- ~1 500 pairs per problem on KITTI-shaped input, where a chunk has only ~1 000 problems to
-// refine: one wave each left three quarters of the SIMDs idle and the kernel lasted as long as its longest chain).
+// G = 16: four problems per wave; 64: one wave per problem.
 template <int G>
-__global__ void __launch_bounds__(G == 256 ? 256 : 64) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
                 const int *__restrict__ n_mid_p, const int *__restrict__ mid_list, const int *__restrict__ n_other_p,
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
-                cc_gpair *__restrict__ pool, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results) {
-  constexpr int NP = G >= 64 ? 1 : 64 / G;  // problems per workgroup
+                char *__restrict__ pool /*[pool_cap] records of CC_GRAW_BYTES*/, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results,
+                const unsigned *__restrict__ codes, const int *__restrict__ cls_list /*the own list by length class (64-lane instance) or nullptr*/,
+                const int *__restrict__ cls_cnt, int sel_stride) {
+  constexpr int NP = 64 / G;                // problems per workgroup
+  constexpr int NLCAP = CC_GMM_NL / NP;     // records of a problem that stay in LDS
+  static_assert(NLCAP % 2 == 0, "a problem's LDS block is 3 NLCAP float4 + NLCAP float2");
   __shared__ double hist_all[NP][80];  // L-BFGS history: dx[10][3] | dg[10][3] | dx.dg[10] | alpha[10]  (group-uniform values)
-  __shared__ cc_gmm_scan_lds scan_lds[NP];
-  __shared__ int s_off;
+  __shared__ float4 rec_lds[NP][NLCAP > 0 ? NLCAP * 7 / 2 : 1];
   __shared__ double exp_tab[64];
-  if (threadIdx.x < 64) exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
-  if (G == 256) __syncthreads(); else cc_wave_sync();
+  exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
+  cc_wave_sync();
   const int sub = threadIdx.x / G, sl = threadIdx.x % G;
   double *hist = hist_all[sub];
-  cc_gmm_scan_lds &L = scan_lds[sub];
   // this instance's own list, then the in-between problems if the chunk's problem count sends them here
   const int n_own = *n_sel_p, n_mid = *n_mid_p;
   const bool mid_here = ((n_own + n_mid + *n_other_p) >= CC_GMM_PACK_MIN_PROBLEMS) == (G == 16);
   const int n_sel = n_own + (mid_here ? n_mid : 0);
   for (int k = blockIdx.x * NP + sub; k < n_sel; k += gridDim.x * NP) {
-    const int pidx = k < n_own ? sel_list[k] : mid_list[k - n_own];
+    int pidx;
+    if (k >= n_own) {
+      pidx = mid_list[k - n_own];
+    } else if (cls_list == nullptr) {
+      pidx = sel_list[k];
+    } else {  // the k-th problem in class order (the class counts add up to n_own: cc_k_select has finished)
+      int c = 0, kk = k;
+#pragma unroll
+      for (int j = 0; j < CC_GMM_NCLS - 1; j++) {
+        const int cj = cls_cnt[j];
+        if (c == j && kk >= cj) {
+          kk -= cj;
+          c = j + 1;
+        }
+      }
+      pidx = cls_list[(size_t)c * sel_stride + kk];
+    }
     cc_gmm_result R = results[pidx];
     if ((float)R.corr_init < corr_lb) continue;
     const cc_gmm_problem pb = probs[pidx];
     const cc_gmm_feat *fsrc = db_feat + pb.gidx;
     const cc_gmm_feat *ftgt = qfeat + pb.q;
-    // ---- the problem's pair list into the pool (any fixed order: the evaluations sum it lane-strided)
-    const int np = R.n_pairs;
-    int off = 0;
-    if (sl == 0) off = atomicAdd(pool_head, np);
-    if (G == 256) {
-      __syncthreads();  // the previous problem's s_off has been read by everyone
-      if (sl == 0) s_off = off;
-      __syncthreads();
-      off = s_off;
-    } else {
-      off = G == 64 ? __shfl(off, 0) : cc_group_bcast(off, 0);
+    const int np = G >= 64 ? cc_uniform_i(R.n_pairs) : R.n_pairs;  // one problem per wave: counts and strides are scalars
+    // The ellipse tables of the two scans were swept by cc_k_gmm_init a few thousand problems ago and have left the L2 since
+    // (a chunk's problems touch ~250 MB of them): their cache lines (four ellipses each) are requested now, all at once,
+    // so that the gathers of the first evaluation find them in the L2 instead of paying an HBM round trip per step.
+#pragma unroll
+    for (int li = 0; li < CC_GMM_LEVELS; li++) {
+      for (int i = sl * 4; i < fsrc->n_ell[li]; i += G * 4) cc_touch_global(&fsrc->ell[li][i]);
+      for (int i = sl * 4; i < ftgt->n_ell[li]; i += G * 4) cc_touch_global(&ftgt->ell[li][i]);
     }
-    if (off + np > pool_cap) {
+    // ---- where the problem's records go: the first NLCAP in LDS, the rest in the pool (an even count: 16-byte units)
+    cc_gmm_ctx S;
+    S.Q.lds = rec_lds[sub];
+    S.Q.nl_cap = NLCAP;
+    S.Q.nl = np < NLCAP ? np : NLCAP;
+    S.Q.ng_alloc = (np - S.Q.nl + 1) & ~1;
+    int off = 0;
+    if (sl == 0 && S.Q.ng_alloc > 0) off = atomicAdd(pool_head, S.Q.ng_alloc);
+    off = G == 64 ? cc_uniform_i(__shfl(off, 0)) : cc_group_bcast(off, 0);
+    if (off + S.Q.ng_alloc > pool_cap) {
       if (sl == 0) results[pidx].flags = R.flags | 2;
       continue;
     }
-    if (G != 256 || threadIdx.x < 64) {  // G = 256: the first wave files the pairs, all four evaluate them
-      constexpr int GS = G == 256 ? 64 : G;
-      const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
-      int done = 0;
-      cc_gmm_scan_pairs<GS>(fsrc, ftgt, pb.tf[0], pb.tf[1], ct0, st0, L, sl, [&](int n) {
-        cc_gsync<GS>();
-        for (int e = sl; e < n; e += GS) {
-          const int code = (int)L.code[e];
-          const int li = code >> 18, si = (code >> 9) & 511, ti = code & 511;
-          pool[off + done + e] = cc_gmm_make_pair(fsrc->ell[li][si], ftgt->ell[li][ti]);
-        }
-        done += n;
-        cc_gsync<GS>();
-      });
-    }
-    __threadfence_block();  // the pairs are read back by all lanes of the problem
-    cc_gsync<G>();
-    cc_gmm_ctx S;
-    S.pairs = pool + off;
+    S.Q.glb = pool + (size_t)off * CC_GRAW_BYTES;
+#ifdef CC_TUNE_GMM_CLK
+    const unsigned long long t_p0 = __builtin_readcyclecounter();
+    const unsigned long long t_w0 = wall_clock64();
+    unsigned long long ev_clk = 0;
+    int n_ev = 0;
+#endif
     S.exp_tab = exp_tab;
     S.np = np;
     S.sl = sl;
+#ifdef CC_TUNE_GMM_CLK
+    S.ev_clk = &ev_clk;
+    S.n_ev = &n_ev;
+#endif
+    cc_gsync<G>();  // the previous problem's records in LDS are no longer read
     double x[3] = {pb.tf[0], pb.tf[1], pb.tf[2]};
     double cost, g[3];
-    cc_gmm_eval<G>(S.pairs, S.np, S.sl, x, &cost, g, S.exp_tab);
+    // the evaluation at the initial pose files the pair records (from the code list cc_k_gmm_init left) on its way
+    cc_gmm_eval_first<G>(codes, R.code_seg, fsrc, ftgt, S.Q, sl, x, &cost, g, exp_tab);
+    __threadfence_block();  // the records are read back by other lanes of the problem
+    cc_gsync<G>();
+#ifdef CC_TUNE_GMM_CLK
+    const unsigned long long t_p1 = __builtin_readcyclecounter();
+#endif
     const double denom = sqrt(fsrc->ac * ftgt->ac);
     {
     // ---- calcCorrelation (correlation.h:206-238): LineSearchMinimizer, LBFGS rank 20, Wolfe/cubic, <= 10 iterations
@@ -1176,6 +1495,22 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     R.tf_opt[2] = x[2];
     }
     if (sl == 0) results[pidx] = R;
+#ifdef CC_TUNE_GMM_CLK
+    if (sl == 0) {
+      const unsigned long long t_p2 = __builtin_readcyclecounter();
+      const int e = atomicAdd(&cc_gmm_clk_n, 1);
+      if (e < CC_GMM_CLK_CAP) {
+        cc_gmm_clk[e * 4 + 0] = (unsigned long long)np | ((unsigned long long)G << 20) | ((unsigned long long)R.iterations << 40) | ((unsigned long long)n_ev << 48);
+        cc_gmm_clk[e * 4 + 1] = t_p2 - t_p0;
+        cc_gmm_clk[e * 4 + 2] = ev_clk;
+        cc_gmm_clk[e * 4 + 3] = t_p1 - t_p0;
+        cc_gmm_clk2[e * 4 + 0] = t_w0;
+        cc_gmm_clk2[e * 4 + 1] = wall_clock64();
+        cc_gmm_clk2[e * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+        cc_gmm_clk2[e * 4 + 3] = (unsigned long long)blockIdx.x;
+      }
+    }
+#endif
   }
 }
 // tidyUpCandidates' order-changing compaction (contour_db.h:580-592) followed by fineOptimize's std::sort on the
@@ -1243,7 +1578,8 @@ __device__ __forceinline__ int cc_tidy_order(int nc, const unsigned char *has, u
 __global__ void __launch_bounds__(64)
 cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
             const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[3][sel_stride]*/, int sel_stride,
-            int *__restrict__ n_sel /*[2]*/, int *__restrict__ n_sel_wide, const unsigned short *__restrict__ perm_tab) {
+            int *__restrict__ n_sel /*[2]*/, int *__restrict__ n_sel_wide, const unsigned short *__restrict__ perm_tab,
+            int *__restrict__ cls_list /*[CC_GMM_NCLS][sel_stride]: the long problems by length class*/, int *__restrict__ cls_cnt /*[CC_GMM_NCLS]*/) {
   __shared__ unsigned short idx[CC_MAXCAND];
   __shared__ unsigned short scr[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
@@ -1290,7 +1626,18 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
                small = i < pre && !wide && !big;
     const unsigned long long mw = __ballot(wide), mbig = __ballot(big), msm = __ballot(small);
     if (wide) sel_list[2 * (size_t)sel_stride + o_wide + __popcll(mw & lt)] = g;
-    if (big) sel_list[(size_t)sel_stride + o_big + __popcll(mbig & lt)] = g;
+    if (mbig) {  // (uniform) a handful per query: one atomic per class that occurs
+      const int c = big ? cc_gmm_len_class(np) : -1;
+      for (unsigned long long left = mbig; left;) {
+        const int c0 = __shfl(c, __ffsll(left) - 1);
+        const unsigned long long mc = __ballot(c == c0);
+        int base = 0;
+        if (lane == __ffsll(mc) - 1) base = atomicAdd(&cls_cnt[c0], __popcll(mc));
+        base = __shfl(base, __ffsll(mc) - 1);
+        if (c == c0) cls_list[(size_t)c0 * sel_stride + base + __popcll(mc & lt)] = g;
+        left &= ~mc;
+      }
+    }
     if (small) sel_list[o_small + __popcll(msm & lt)] = g;
     o_wide += __popcll(mw);
     o_big += __popcll(mbig);
