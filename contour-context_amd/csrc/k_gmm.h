@@ -47,6 +47,9 @@
 // problems ran as one full round of 2 048 and a second, under-filled one: the launch lasted two problem lengths, 383 us,
 // where its instructions fill the SIMDs for 225.)
 #define CC_GMM_NCLS 8
+#ifndef CC_GMM_WPE
+#define CC_GMM_WPE 2  // waves per SIMD the refinement is compiled for
+#endif
 __device__ __forceinline__ int cc_gmm_len_class(int np) {
   return np > 1400 ? 0 : (np > 1100 ? 1 : (np > 950 ? 2 : (np > 850 ? 3 : (np > 750 ? 4 : (np > 650 ? 5 : (np > 500 ? 6 : 7))))));
 }
@@ -663,12 +666,12 @@ __device__ __forceinline__ cc_ell cc_gmm_ell_of(const cc_gmm_feat *f, int li, in
 template <int G>
 __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
                                                 const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl,
-                                                const double *exp_tab, const cc_gmm_code_pool &CPL) {
+                                                const double *exp_tab, const cc_gmm_code_pool &CPL, int blk0 /*the problem's first block*/, int dyn0 /*where the blocks taken with the atomic start*/) {
   const cc_gmm_problem pb = probs[pidx];
   const cc_gmm_feat *fsrc = db_feat + pb.gidx;
   const cc_gmm_feat *ftgt = qfeat + pb.q;
   // the first block is requested now and bound at the first flush
-  int raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK0 + 2) : 0;  // lane 0: the requested block
+  int raw_blk = sl != 0 ? 0 : blk0;  // lane 0: the requested block
   int raw_cap = CC_GMM_BLK0;
   bool have_raw = true;
   const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
@@ -689,7 +692,7 @@ __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict
     }
     if (blk < 0 || blk_n + n > blk_cap) {  // (uniform over the problem's lanes) bind the requested block, or take one now
       if (!have_raw) {
-        raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
+        raw_blk = sl == 0 ? dyn0 + atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
         raw_cap = CC_GMM_BLK;
       }
       const int nb = cc_gbcast_i<G>(raw_blk, 0);
@@ -733,7 +736,7 @@ __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict
     }
     blk_n += n;
     if (!last && !have_raw && 2 * blk_n >= blk_cap) {  // the next block, ahead of its use
-      raw_blk = sl == 0 ? atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
+      raw_blk = sl == 0 ? dyn0 + atomicAdd(CPL.head, CC_GMM_BLK + 2) : 0;
       raw_cap = CC_GMM_BLK;
       have_raw = true;
     }
@@ -772,13 +775,18 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
   exp_tab[threadIdx.x] = __longlong_as_double((long long)cc_exp2_tab64[threadIdx.x]);
   cc_wave_sync();
   const int n_prob = *n_prob_p;
+  // The FIRST code block of the i-th problem of the chunk's list is block i of the pool -- no atomic (a chunk of a sparse
+  // scene has ~30 000 problems; one atomic each on the pool's head, all waves asking at once, cost 36-54 us per chunk: a
+  // third of this kernel); the blocks long lists add come from the head, which counts from behind those n_prob blocks.
+  const int dyn0 = n_prob * (CC_GMM_BLK0 + 2);
   if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
-    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL);
+    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x)
+      cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL, pi * (CC_GMM_BLK0 + 2), dyn0);
     return;
   }
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
   for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
-    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL);
+    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL, pi * (CC_GMM_BLK0 + 2), dyn0);
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes
@@ -1293,11 +1301,11 @@ __device__ bool cc_wolfe(const cc_gmm_ctx &S, const double pos[3], const double 
 // grid = any (grid-stride over the device-side list), block = 64
 // G = 16: four problems per wave; 64: one wave per problem.
 template <int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CC_GMM_WPE)))
 cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ n_sel_p, const int *__restrict__ sel_list,
                 const int *__restrict__ n_mid_p, const int *__restrict__ mid_list, const int *__restrict__ n_other_p,
                 const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, float corr_lb,
-                char *__restrict__ pool /*[pool_cap] records of CC_GRAW_BYTES*/, int pool_cap, int *__restrict__ pool_head, cc_gmm_result *__restrict__ results,
+                char *__restrict__ pool /*[pool_cap] records of CC_GRAW_BYTES*/, int pool_cap, const int *__restrict__ pool_off /*[problem slot], cc_k_select*/, cc_gmm_result *__restrict__ results,
                 const unsigned *__restrict__ codes, const int *__restrict__ cls_list /*the own list by length class (64-lane instance) or nullptr*/,
                 const int *__restrict__ cls_cnt, int sel_stride) {
   constexpr int NP = 64 / G;                // problems per workgroup
@@ -1352,9 +1360,8 @@ cc_k_gmm_refine(const cc_gmm_problem *__restrict__ probs, const int *__restrict_
     S.Q.nl_cap = NLCAP;
     S.Q.nl = np < NLCAP ? np : NLCAP;
     S.Q.ng_alloc = (np - S.Q.nl + 1) & ~1;
-    int off = 0;
-    if (sl == 0 && S.Q.ng_alloc > 0) off = atomicAdd(pool_head, S.Q.ng_alloc);
-    off = G == 64 ? cc_uniform_i(__shfl(off, 0)) : cc_group_bcast(off, 0);
+    int off = S.Q.ng_alloc > 0 ? pool_off[pidx] : 0;
+    if (G == 64) off = cc_uniform_i(off);
     if (off + S.Q.ng_alloc > pool_cap) {
       if (sl == 0) results[pidx].flags = R.flags | 2;
       continue;
@@ -1579,12 +1586,13 @@ __global__ void __launch_bounds__(64)
 cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restrict__ cands_all, const cc_qstate *__restrict__ qstate,
             const cc_gmm_result *__restrict__ gres, int *__restrict__ sel_list /*[3][sel_stride]*/, int sel_stride,
             int *__restrict__ n_sel /*[2]*/, int *__restrict__ n_sel_wide, const unsigned short *__restrict__ perm_tab,
-            int *__restrict__ cls_list /*[CC_GMM_NCLS][sel_stride]: the long problems by length class*/, int *__restrict__ cls_cnt /*[CC_GMM_NCLS]*/) {
+            int *__restrict__ cls_list /*[CC_GMM_NCLS][sel_stride]: the long problems by length class*/, int *__restrict__ cls_cnt /*[CC_GMM_NCLS]*/,
+            int *__restrict__ pool_head, int *__restrict__ pool_off /*[problem slot]: where a selected problem's records go in the pair pool*/) {
   __shared__ unsigned short idx[CC_MAXCAND];
   __shared__ unsigned short scr[CC_MAXCAND];
   __shared__ unsigned char has[CC_MAXCAND];
   __shared__ int gm[CC_MAXCAND];
-  __shared__ int s_off[3];
+  __shared__ int s_off[4];
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
   const cc_cand_out *cands = cands_all + (size_t)q * CC_MAXCAND;
@@ -1603,25 +1611,44 @@ cc_k_select(int nq, float corr_lb, int max_fine_opt, const cc_cand_out *__restri
   // one or the other by the chunk's problem count (cc_k_gmm_refine)
   // (one atomic per list and query, not one per problem: same-address atomics are served one after the other)
   const unsigned long long lt = (1ull << lane) - 1ull;
-  int n_big = 0, n_wide = 0;
+  // ... and the pair pool is handed out here as well (the part of a problem's records that does not stay in LDS, an even
+  // count): a problem that asked for its share itself, at the start of the refinement, stood in a queue of thousands
+  // (same-address atomics are served ~9 ns apart: the 64-lane launch took 30 us to get its 2 048 waves going)
+  int n_big = 0, n_wide = 0, need_tot = 0;
   for (int i0 = 0; i0 < pre; i0 += 64) {
     const int i = i0 + lane;
     const int np = i < pre ? gres[gm[idx[i]]].n_pairs : 0;
-    n_big += __popcll(__ballot(np > CC_GMM_MID_MAX_PAIRS));
+    const bool big = np > CC_GMM_MID_MAX_PAIRS;
+    n_big += __popcll(__ballot(big));
     n_wide += __popcll(__ballot(np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_MID_MAX_PAIRS));
+    const int nl = big ? CC_GMM_NL : CC_GMM_NL / (64 / CC_G);  // (an in-between problem: the smaller share, whichever instance takes it)
+    int need = i < pre && np > nl ? ((np - nl + 1) & ~1) : 0;
+    for (int o = 32; o > 0; o >>= 1) need += __shfl_xor(need, o);
+    need_tot += need;
   }
   const int n_small = pre - n_big - n_wide;
-  if (lane == 0) {
-    s_off[0] = n_small ? atomicAdd(&n_sel[0], n_small) : 0;
-    s_off[1] = n_big ? atomicAdd(&n_sel[1], n_big) : 0;
-    s_off[2] = n_wide ? atomicAdd(n_sel_wide, n_wide) : 0;
+  {  // the four requests at once, from four lanes
+    int *const dst = lane == 0 ? &n_sel[0] : (lane == 1 ? &n_sel[1] : (lane == 2 ? n_sel_wide : pool_head));
+    const int amt = lane == 0 ? n_small : (lane == 1 ? n_big : (lane == 2 ? n_wide : need_tot));
+    if (lane < 4) s_off[lane] = amt ? atomicAdd(dst, amt) : 0;
   }
   __syncthreads();
-  int o_small = s_off[0], o_big = s_off[1], o_wide = s_off[2];
+  int o_small = s_off[0], o_big = s_off[1], o_wide = s_off[2], o_pool = s_off[3];
   for (int i0 = 0; i0 < pre; i0 += 64) {
     const int i = i0 + lane;
     const int g = i < pre ? gm[idx[i]] : 0;
     const int np = i < pre ? gres[g].n_pairs : 0;
+    {
+      const int nl = np > CC_GMM_MID_MAX_PAIRS ? CC_GMM_NL : CC_GMM_NL / (64 / CC_G);
+      const int need = i < pre && np > nl ? ((np - nl + 1) & ~1) : 0;
+      int incl = need;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (i < pre) pool_off[g] = o_pool + incl - need;
+      o_pool += __shfl(incl, 63);
+    }
     const bool wide = i < pre && np > CC_GMM_G16_MAX_PAIRS && np <= CC_GMM_MID_MAX_PAIRS /* the in-between list */, big = i < pre && np > CC_GMM_MID_MAX_PAIRS,
                small = i < pre && !wide && !big;
     const unsigned long long mw = __ballot(wide), mbig = __ballot(big), msm = __ballot(small);
