@@ -107,8 +107,12 @@ __device__ __forceinline__ float cc_norm2f(float x, float y) { return sqrtf(x * 
 
 // Stage A (one lane per check slot of the chunk; a wave's 64 slots are the 64 hit positions of one anchor key): (1/4)
 // anchor ContourView::checkSim and the popcount part of (2/4) BCI::checkConstellSim (ovlp_sum / max_one bars).
-// grid = nq * CC_CHK_STRIDE / 256, block = 256
-__global__ void __launch_bounds__(256)
+// grid = ceil(nq * CC_CHK_STRIDE / CC_CHKA_BLOCK), block = CC_CHKA_BLOCK
+// (1 024 threads: the list append below costs one returning atomic per workgroup on ONE address, and those are served
+// ~11.5 ns apart whatever else the chip does -- profiles/r6/micro/atomic_convoy.hip; with 256-thread workgroups the 4 608
+// atomics of a chunk WERE this kernel: 55 of its 69 us)
+#define CC_CHKA_BLOCK 1024
+__global__ void __launch_bounds__(CC_CHKA_BLOCK)
 cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_hot_desc_t *__restrict__ db_hot,
              int nq, const cc_knn_hit_t *__restrict__ hits, const int *__restrict__ hit_cnt, cc_chk_item *__restrict__ items,
              int *__restrict__ cnt, unsigned char *__restrict__ pass_ok, int *__restrict__ pass_cnt /*[nq][4]*/,
@@ -169,7 +173,8 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
   // grouped by expected work: stage B1 gives four consecutive checks to the four 16-lane groups of a wave, which advance
   // together, so a wave takes as long as its largest check -- the potential pairs grow with the overlap count, and
   // checks of one size class sit side by side (the order of the list never shows: results are slot-indexed).
-  __shared__ int s_bcnt[4][4], s_base;  // [size class][wave]
+  constexpr int NW = CC_CHKA_BLOCK / 64;
+  __shared__ int s_bcnt[4][NW], s_base;  // [size class][wave]; after the hand-over: exclusive prefix in (class, wave) order
   const int bk = !keep ? -1 : (sc_sum < P.size_class[0] ? 0 : (sc_sum < P.size_class[1] ? 1 : (sc_sum < P.size_class[2] ? 2 : 3)));
   const unsigned long long ma = __ballot(anchor_ok);
   const unsigned long long mb0 = __ballot(bk == 0), mb1 = __ballot(bk == 1), mb2 = __ballot(bk == 2), mb3 = __ballot(bk == 3);
@@ -182,17 +187,21 @@ cc_k_check_a(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const cc
     if (ma) atomicAdd(&pass_cnt[q * 4 + 1], __popcll(ma));
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int b = 0; b < 4; b++)
-      for (int w = 0; w < 4; w++) tot += s_bcnt[b][w];
-    s_base = tot ? atomicAdd(&cnt[CC_CNT_CHK], tot) : 0;
+  if (threadIdx.x < 64) {  // 4 NW <= 64 counts: prefix by one wave, the total to the list head
+    static_assert(4 * NW <= 64, "one wave scans the (class, wave) counts");
+    const int v = lane < 4 * NW ? (&s_bcnt[0][0])[lane] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    const int tot = __shfl(incl, 63);
+    if (lane < 4 * NW) (&s_bcnt[0][0])[lane] = incl - v;
+    if (lane == 0) s_base = tot ? atomicAdd(&cnt[CC_CNT_CHK], tot) : 0;
   }
   __syncthreads();
   if (keep) {
-    int pos = s_base;
-    for (int b = 0; b < 4; b++)
-      for (int w = 0; w < 4; w++) pos += (b < bk || (b == bk && w < wave)) ? s_bcnt[b][w] : 0;
+    const int pos = s_base + s_bcnt[bk][wave];
     const unsigned long long mine = bk == 0 ? mb0 : (bk == 1 ? mb1 : (bk == 2 ? mb2 : mb3));
     cc_chk_item it;
     it.q = q;
@@ -681,10 +690,11 @@ cc_k_check_b1(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
 }
 
 // The constellations that passed, as a dense index list for stage B2 (order irrelevant: results are slot-indexed).
-// One global atomic per workgroup.  grid = ceil(n_chk_max / 256) (device-side bound check), block = 256
-__global__ void __launch_bounds__(256)
+// One global atomic per workgroup.  grid = ceil(n_chk_max / CC_CHKA_BLOCK) (device-side bound check), block = CC_CHKA_BLOCK
+__global__ void __launch_bounds__(CC_CHKA_BLOCK)
 cc_k_compact_cstl(cc_check_params P, const cc_cstl_item *__restrict__ cstl, int *__restrict__ cnt, int *__restrict__ cstl_idx) {
-  __shared__ int s_bcnt[4][4], s_base;  // [size class][wave]: stage B2's groups advance four to a wave, like stage B1's
+  constexpr int NW = CC_CHKA_BLOCK / 64;
+  __shared__ int s_bcnt[4][NW], s_base;  // [size class][wave]: stage B2's groups advance four to a wave, like stage B1's
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_in = i < cnt[CC_CNT_CHK] ? (int)cstl[i].n_in : 0;
@@ -698,17 +708,20 @@ cc_k_compact_cstl(cc_check_params P, const cc_cstl_item *__restrict__ cstl, int 
     s_bcnt[3][wave] = __popcll(mb3);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int b = 0; b < 4; b++)
-      for (int w = 0; w < 4; w++) tot += s_bcnt[b][w];
-    s_base = tot ? atomicAdd(&cnt[CC_CNT_CSTL], tot) : 0;
+  if (threadIdx.x < 64) {
+    const int v = lane < 4 * NW ? (&s_bcnt[0][0])[lane] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    const int tot = __shfl(incl, 63);
+    if (lane < 4 * NW) (&s_bcnt[0][0])[lane] = incl - v;
+    if (lane == 0) s_base = tot ? atomicAdd(&cnt[CC_CNT_CSTL], tot) : 0;
   }
   __syncthreads();
   if (ok) {
-    int pos = s_base;
-    for (int b = 0; b < 4; b++)
-      for (int w = 0; w < 4; w++) pos += (b < bk || (b == bk && w < wave)) ? s_bcnt[b][w] : 0;
+    const int pos = s_base + s_bcnt[bk][wave];
     const unsigned long long mine = bk == 0 ? mb0 : (bk == 1 ? mb1 : (bk == 2 ? mb2 : mb3));
     cstl_idx[pos + __popcll(mine & ((1ull << lane) - 1ull))] = i;
   }
