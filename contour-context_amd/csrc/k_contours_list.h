@@ -811,6 +811,10 @@ cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2
                   cc_k2_big_queue *__restrict__ bigq, cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
   HIP_DYNAMIC_SHARED(char, smem)
   __shared__ int s_next;
+  // An empty queue (the usual case) is left alone: its counters are zero already, and the two atomics every workgroup would
+  // spend on finding that out are served one after the other (512 workgroups: 12 us behind every ingest launch).  A queue
+  // that holds scans is reset only after EVERY workgroup has counted itself out, so none can see the zero of the reset here.
+  if (midq->n_flagged == 0) return;
   for (;;) {
     __syncthreads();  // the previous scan's LDS is no longer read
     if (threadIdx.x == 0) s_next = atomicAdd(&midq->next, 1);
@@ -838,6 +842,7 @@ cc_k_contours_big(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2
                   cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
   HIP_DYNAMIC_SHARED(char, smem)
   __shared__ int s_next;
+  if (queue->n_flagged == 0) return;  // as in cc_k_contours_mid
   for (;;) {
     __syncthreads();  // the previous scan's LDS is no longer read
     if (threadIdx.x == 0) s_next = atomicAdd(&queue->next, 1);
