@@ -71,6 +71,7 @@ struct cc_ctx {
     int n_bigslots = 0;
     cc_k2_big_queue *d_bigq = nullptr;
     cc_k2_big_queue *d_midq = nullptr;  // scans the list kernel hands to the original body (cc_k_contours_mid)
+    int *h_mid_seen = nullptr;          // pinned: the queue length the last cc_k_contours_mid launch found (-1: none has run yet)
     cc_k1_list_out list;                // K1 -> K2: the scans' active cells as raster-ordered lists (k_rasterize.h)
     cc_k2_big_slot *d_bigslots = nullptr;
     hipEvent_t ev_last = nullptr;
@@ -167,6 +168,8 @@ static int scratch_alloc(cc_ctx *c, cc_ctx::Scratch &S, int cap, int n_bigslots)
   HIPCHK(hipMalloc(&S.list.h, sizeof(float) * (size_t)CC_LIST_CAP * cap));
   HIPCHK(hipMalloc(&S.list.pix, sizeof(float2) * (size_t)CC_LIST_CAP * cap));
   HIPCHK(hipMemset(S.d_midq, 0, sizeof(cc_k2_big_queue)));
+  HIPCHK(hipHostMalloc((void **)&S.h_mid_seen, sizeof(int), hipHostMallocDefault));
+  *S.h_mid_seen = -1;
   S.n_bigslots = n_bigslots < cap ? n_bigslots : cap;
   HIPCHK(hipMalloc(&S.d_bigslots, sizeof(cc_k2_big_slot) * S.n_bigslots));
   HIPCHK(hipEventCreateWithFlags(&S.ev_last, hipEventDisableTiming));
@@ -183,6 +186,7 @@ static void scratch_free(cc_ctx::Scratch &S) {
   hipFree(S.d_offsets);
   hipFree(S.d_bigq);
   hipFree(S.d_midq);
+  if (S.h_mid_seen) hipHostFree(S.h_mid_seen);
   hipFree(S.list.hdr);
   hipFree(S.list.rc);
   hipFree(S.list.lev);
@@ -509,9 +513,15 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK), (size_t)CC_K2L_LDS_BYTES, stream, c->dcfg, (const float *)S.d_bev,
                        (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, d_out + b0, lab, c->d_phase_clk, S.d_midq, S.list);
-    // the scans the list kernel handed on (more active cells / components than its LDS tables hold): the original body
-    hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < 512 ? nb : 512), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
-                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab);
+    // the scans the list kernel handed on (more active cells / components than its LDS tables hold): the original body.
+    // Its workgroups need 78 KB of LDS each to START, even those that find the queue empty and leave at once: behind a
+    // pipelined ingest 512 of them waited 0.13 ms for their turns (the other streams' kernels hold the LDS).  So the
+    // launch is sized by what the previous one found: 16 workgroups while the queue stays empty (they take whatever shows
+    // up, one scan after the other, and the next launch is a full one again), 512 otherwise and at first.
+    const int mid_seen = *(volatile int *)S.h_mid_seen;
+    const int mid_wgs = mid_seen == 0 ? 16 : 512;
+    hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < mid_wgs ? nb : mid_wgs), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
+                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab, S.h_mid_seen);
     // the scans the launch above could not number (more than CC_MAXC components on a level): exact, slow, usually none
     hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < S.n_bigslots ? nb : S.n_bigslots), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
                        (const float *)S.d_bev, (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_bigslots, S.d_bigq, d_out + b0, lab);

@@ -808,13 +808,17 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
 __global__ void __launch_bounds__(CC_K2_BLOCK, 2)
 cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
                   const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all, cc_k2_big_queue *__restrict__ midq,
-                  cc_k2_big_queue *__restrict__ bigq, cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg) {
+                  cc_k2_big_queue *__restrict__ bigq, cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg,
+                  int *__restrict__ seen /*pinned host memory: how many scans this launch found queued (the host sizes the NEXT launch by it)*/) {
   HIP_DYNAMIC_SHARED(char, smem)
   __shared__ int s_next;
   // An empty queue (the usual case) is left alone: its counters are zero already, and the two atomics every workgroup would
   // spend on finding that out are served one after the other (512 workgroups: 12 us behind every ingest launch).  A queue
   // that holds scans is reset only after EVERY workgroup has counted itself out, so none can see the zero of the reset here.
-  if (midq->n_flagged == 0) return;
+  if (midq->n_flagged == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *seen = 0;
+    return;
+  }
   for (;;) {
     __syncthreads();  // the previous scan's LDS is no longer read
     if (threadIdx.x == 0) s_next = atomicAdd(&midq->next, 1);
@@ -822,6 +826,7 @@ cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2
     const int k = s_next;
     if (k >= midq->n_flagged) {
       if (threadIdx.x == 0 && atomicAdd(&midq->exited, 1) == (int)gridDim.x - 1) {
+        *seen = midq->n_flagged;
         midq->n_flagged = 0;
         midq->next = 0;
         midq->exited = 0;
