@@ -666,12 +666,12 @@ __device__ __forceinline__ cc_ell cc_gmm_ell_of(const cc_gmm_feat *f, int li, in
 template <int G>
 __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
                                                 const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl,
-                                                const double *exp_tab, const cc_gmm_code_pool &CPL, int blk0 /*the problem's first block*/, int dyn0 /*where the blocks taken with the atomic start*/) {
+                                                const double *exp_tab, const cc_gmm_code_pool &CPL, int blk0 /*the problem's first block, or -1: from the head*/, int dyn0 /*where the blocks taken with the atomic start*/) {
   const cc_gmm_problem pb = probs[pidx];
   const cc_gmm_feat *fsrc = db_feat + pb.gidx;
   const cc_gmm_feat *ftgt = qfeat + pb.q;
   // the first block is requested now and bound at the first flush
-  int raw_blk = sl != 0 ? 0 : blk0;  // lane 0: the requested block
+  int raw_blk = sl != 0 ? 0 : (blk0 >= 0 ? blk0 : dyn0 + atomicAdd(CPL.head, CC_GMM_BLK0 + 2));  // lane 0: the requested block
   int raw_cap = CC_GMM_BLK0;
   bool have_raw = true;
   const double ct0 = cos(pb.tf[2]), st0 = sin(pb.tf[2]);
@@ -766,7 +766,7 @@ __device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict
   }
 }
 // grid = any (grid-stride over the device-side problem count), block = 64
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ prob_list, const int *__restrict__ n_prob_p,
               const cc_gmm_feat *__restrict__ qfeat, const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results,
               cc_gmm_code_pool CPL) {
@@ -777,16 +777,21 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
   const int n_prob = *n_prob_p;
   // The FIRST code block of the i-th problem of the chunk's list is block i of the pool -- no atomic (a chunk of a sparse
   // scene has ~30 000 problems; one atomic each on the pool's head, all waves asking at once, cost 36-54 us per chunk: a
-  // third of this kernel); the blocks long lists add come from the head, which counts from behind those n_prob blocks.
-  const int dyn0 = n_prob * (CC_GMM_BLK0 + 2);
+  // third of this kernel).  Half of the pool is set aside for such blocks; problems beyond that many (a 50 000-scan DB
+  // brings ~160 000 per chunk) take their first block from the head like every further block, and the head counts from
+  // behind the static ones.
+  const int n_static = n_prob < CPL.cap / 2 / (CC_GMM_BLK0 + 2) ? n_prob : CPL.cap / 2 / (CC_GMM_BLK0 + 2);
+  const int dyn0 = n_static * (CC_GMM_BLK0 + 2);
   if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
     for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x)
-      cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL, pi * (CC_GMM_BLK0 + 2), dyn0);
+      cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL,
+                          pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
     return;
   }
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
   for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
-    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL, pi * (CC_GMM_BLK0 + 2), dyn0);
+    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL,
+                          pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes

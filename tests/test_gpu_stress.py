@@ -147,6 +147,15 @@ def test_pair_pool_overflow_is_reported(cc, monkeypatch):
     with pytest.raises(cc.CCError, match="pool"):
         db.check_hints(d[0], hints)
     monkeypatch.delenv("CC_GMM_POOL_PAIRS")
+    # ... and the pool of pair codes cc_k_gmm_init files for the refinement (round 6): 1 024 entries hold one first block
+    # (258) in their static half and none of the 1 026-entry blocks a long list goes on with
+    monkeypatch.setenv("CC_GMM_POOL_CODES", "1024")
+    db3 = cc.Database(ctx, capacity=8)
+    db3.add_scans(d[:1], np.zeros(1), np.zeros(1, np.int32))
+    with pytest.raises(cc.CCError, match="pool"):
+        db3.check_hints(d[0], hints)
+    monkeypatch.delenv("CC_GMM_POOL_CODES")
+    db3.close()
     db2 = cc.Database(ctx, capacity=8)
     db2.add_scans(d[:1], np.zeros(1), np.zeros(1, np.int32))
     r, sc = db2.check_hints(d[0], hints)
