@@ -478,24 +478,43 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
   // chunk boundary costs is then the LDS hand-over, not a memory round trip.  A lane holds TPL tgts of the next chunk.
   constexpr int TPL = CC_GMM_TCHUNK / G;
   float nx_[TPL], ny_[TPL], nm_[TPL];
+  float fsx_ = 0.f, fsy_ = 0.f, fsm_ = 0.f;  // ... and the first src block of the next chunk's level
+  // the levels' ellipse counts, read once (the stores to the code pool in between keep the compiler from holding on to them)
+  int ns4[CC_GMM_LEVELS], nt4[CC_GMM_LEVELS];
+#pragma unroll
+  for (int l = 0; l < CC_GMM_LEVELS; l++) {
+    ns4[l] = fsrc->n_ell[l];
+    nt4[l] = ftgt->n_ell[l];
+  }
+  auto cnt_of = [&](const int (&a)[CC_GMM_LEVELS], int l) {  // a[l], l in 0 .. CC_GMM_LEVELS (register array: no dynamic index)
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < CC_GMM_LEVELS; k++) v = l == k ? a[k] : v;
+    return v;
+  };
   auto request = [&](int li, int t0) {
+    const int ntl = cnt_of(nt4, li), nsl = cnt_of(ns4, li);  // 0 for li == CC_GMM_LEVELS
 #pragma unroll
     for (int u = 0; u < TPL; u++) {
       const int j = t0 + sl + u * G;
       nx_[u] = 3.0e38f;  // beyond the chunk: dx^2 overflows to +inf, the test fails
       ny_[u] = 0.f;
       nm_[u] = 0.f;
-      if (li < CC_GMM_LEVELS && j < ftgt->n_ell[li]) {
+      if (j < ntl) {
         const cc_ell *pt = &ftgt->ell[li][j];
         nx_[u] = pt->mx;
         ny_[u] = pt->my;
         nm_[u] = pt->maj;
       }
     }
+    if (sl < nsl) {
+      const cc_ell *ps = &fsrc->ell[li][sl];
+      fsx_ = ps->mx, fsy_ = ps->my, fsm_ = ps->maj;
+    }
   };
   auto next_chunk = [&](int &li, int &t0) {  // the chunk after (li, t0) that has src and tgt ellipses, or li = CC_GMM_LEVELS
     t0 += CC_GMM_TCHUNK;
-    while (li < CC_GMM_LEVELS && (fsrc->n_ell[li] <= 0 || t0 >= ftgt->n_ell[li])) {
+    while (li < CC_GMM_LEVELS && (cnt_of(ns4, li) <= 0 || t0 >= cnt_of(nt4, li))) {
       li++;
       t0 = 0;
     }
@@ -504,7 +523,7 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
   next_chunk(li, t0);
   request(li, t0);
   while (li < CC_GMM_LEVELS) {
-    const int ns = fsrc->n_ell[li], ntg = ftgt->n_ell[li];
+    const int ns = cnt_of(ns4, li), ntg = cnt_of(nt4, li);
     const int tn = ntg - t0 < CC_GMM_TCHUNK ? ntg - t0 : CC_GMM_TCHUNK;
     CC_CLK_T(c_f0);
     cc_gsync<G>();  // the previous chunk is no longer read
@@ -517,17 +536,13 @@ __device__ __forceinline__ int cc_gmm_scan_pairs(const cc_gmm_feat *__restrict__
       L.Tw[j] = 3.f * nm_[u] + CC_GMM_PRE_MARGIN;
     }
     cc_gsync<G>();
+    // this chunk's first src block came with the chunk; the block after it is requested while this one is swept
+    float pmx = fsx_, pmy = fsy_, pmaj = fsm_;
     int li_n = li, t0_n = t0;
     next_chunk(li_n, t0_n);
     request(li_n, t0_n);
     CC_CLK_T(c_f1);
     CC_CLK_ADD(0, c_f0, c_f1);
-    // the src block after this one is requested while this one is swept
-    float pmx = 0.f, pmy = 0.f, pmaj = 0.f;
-    if (sl < ns) {
-      const cc_ell *ps = &fsrc->ell[li][sl];
-      pmx = ps->mx, pmy = ps->my, pmaj = ps->maj;
-    }
     for (int s0 = 0; s0 < ns; s0 += G) {
       const int si = s0 + sl;
       unsigned long long mask = 0ull;
@@ -664,10 +679,9 @@ __device__ __forceinline__ cc_ell cc_gmm_ell_of(const cc_gmm_feat *f, int li, in
   return f->ell[li][i];
 }
 template <int G>
-__device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem *__restrict__ probs, int pidx, const cc_gmm_feat *__restrict__ qfeat,
+__device__ __forceinline__ void cc_gmm_init_one(const cc_gmm_problem &pb, int pidx, const cc_gmm_feat *__restrict__ qfeat,
                                                 const cc_gmm_feat *__restrict__ db_feat, cc_gmm_result *__restrict__ results, cc_gmm_scan_lds &L, int sl,
                                                 const double *exp_tab, const cc_gmm_code_pool &CPL, int blk0 /*the problem's first block, or -1: from the head*/, int dyn0 /*where the blocks taken with the atomic start*/) {
-  const cc_gmm_problem pb = probs[pidx];
   const cc_gmm_feat *fsrc = db_feat + pb.gidx;
   const cc_gmm_feat *ftgt = qfeat + pb.q;
   // the first block is requested now and bound at the first flush
@@ -783,15 +797,21 @@ cc_k_gmm_init(const cc_gmm_problem *__restrict__ probs, const int *__restrict__ 
   const int n_static = n_prob < CPL.cap / 2 / (CC_GMM_BLK0 + 2) ? n_prob : CPL.cap / 2 / (CC_GMM_BLK0 + 2);
   const int dyn0 = n_static * (CC_GMM_BLK0 + 2);
   if (n_prob <= (int)gridDim.x) {  // a wave per problem (uniform over the launch)
-    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x)
-      cc_gmm_init_one<64>(probs, prob_list[pi], qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL,
-                          pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
+    for (int pi = blockIdx.x; pi < n_prob; pi += gridDim.x) {
+      const int pidx = prob_list[pi];
+      const cc_gmm_problem pb = probs[pidx];
+      cc_gmm_init_one<64>(pb, pidx, qfeat, db_feat, results, lds[0], (int)threadIdx.x, exp_tab, CPL, pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
+    }
     return;
   }
   const int sub = threadIdx.x / CC_G, sl = threadIdx.x % CC_G;
-  for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G))
-    cc_gmm_init_one<CC_G>(probs, prob_list[pi], qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL,
-                          pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
+  // (the list entry two problems ahead and the record one ahead, held in registers across a problem: measured, 73 -> 80 us per
+  // chunk of a sparse scene -- the kernel is at its register limit and spills what it is asked to keep)
+  for (int pi = blockIdx.x * (64 / CC_G) + sub; pi < n_prob; pi += gridDim.x * (64 / CC_G)) {
+    const int pidx = prob_list[pi];
+    const cc_gmm_problem pb = probs[pidx];
+    cc_gmm_init_one<CC_G>(pb, pidx, qfeat, db_feat, results, lds[sub], sl, exp_tab, CPL, pi < n_static ? pi * (CC_GMM_BLK0 + 2) : -1, dyn0);
+  }
 }
 
 // cost and gradient at p over a problem's pair list, summed over its G lanes
