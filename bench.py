@@ -464,7 +464,15 @@ def main():
                 "data_path_collectives_in_timed_step": 1 if share else 0}
         if world == 1 and c_comm is not None:  # --comm-owner c on one GPU: the library's RCCL call with a world of one
             out["comm_owner_c_world1"] = {"collective": "cc_comm_allgather_packed (ncclAllGather, world = 1)", "bytes": exchange_bytes, "ms": exchange_ms}
-        batch_cpu = batches[W % len(batches)]
+        # the CPU leg's sample: scans spread evenly over the TIMED batches (every (K * B / n)-th scan of the timed drive), so that it
+        # sees the drive's mix of first passes and revisits -- the first scans of the first timed batch can be all of one kind
+        # (with --warmup 5 every one of them revisits a DB place: 12 ms of L2 optimisation per scan, 64 scans/s instead of ~270)
+        n_cpu = min(args.cpu_sample, B)
+        if not args.no_cpu and n_cpu > 0 and world == 1:
+            t_idx = [int(j) * (K * B) // n_cpu for j in range(n_cpu)]
+            batch_cpu = torch.cat([batches[(W + t // B) % len(batches)][(t % B) * P:((t % B) + 1) * P] for t in t_idx])
+        else:
+            batch_cpu = batches[W % len(batches)]
         if world == 1 and not args.no_extra:
             # the reference's online loop on the scans already resident: from an empty DB, per 512-scan sub-batch
             # ingest -> add -> query at the scan's own epoch; with the DB update inside the timed region and without
@@ -1224,7 +1232,7 @@ def cpu_baseline(cc, db_desc, n_db, batch0, P, n_q, all_cores=True):
         odb.push_and_balance(n_db + i, (n_db + i) / 10.0)
     t_upd = time.perf_counter() - t_upd
     out = {"value": n_q / dt, "unit": "scans/s", "cores": 1, "kind": "port",
-           "sample": "first %d scans of the first timed batch: ingest + query against the same %d-scan DB (CPU-side DB rebuilt "
+           "sample": "%d scans of the timed batches (spread evenly over the timed drive in the default run): ingest + query against the same %d-scan DB (CPU-side DB rebuilt "
                      "from the scans' descriptors, untimed, %.1f s; kd-tree=%s); %d loop closures found"
                      % (n_q, n_db, t_build, "reference nanoflann (oracle/_ref)" if kd else "exact scan", found),
            "seconds_per_scan": {"make bev": t_ing / n_q, "KNN search": tq["KNN search"] / n_q, "Constell": tq["Constell"] / n_q,
