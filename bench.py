@@ -289,17 +289,22 @@ def main():
                     dist.all_gather_into_tensor(gathered, rec_q)
                     e1.record()
                     share_ev.append((e0, e1))
+            t_h = time.perf_counter()
             if args.sync_query or args.no_overlap:
                 res = db.query(q, epochs)
             else:  # queue the batch; its chunks are collected when their lanes are needed again, the last ones below
                 res = db.query_submit(q, epochs)
+            run_steps.host_submit_s += time.perf_counter() - t_h
             pending.append(res)
+        t_h = time.perf_counter()
         db.query_wait()
+        run_steps.host_wait_s += time.perf_counter() - t_h
         for res in pending:
             found += int((res["n_res"] > 0).sum())
         run_steps.last = pending[-1]
         return found
 
+    run_steps.host_submit_s = run_steps.host_wait_s = 0.0
     run_steps(0, W)
     sync()
     if world > 1:
@@ -309,6 +314,7 @@ def main():
         cc.lib().cc_db_profile_enable(db.h, PROF_EVERY)  # stage events on every 3rd chunk launch (alternating lanes)
     share_ev.clear()
     sync()
+    run_steps.host_submit_s = run_steps.host_wait_s = 0.0
     t0 = time.perf_counter()
     n_found = run_steps(W, K)
     res = run_steps.last
@@ -316,6 +322,9 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("CC_BENCH_HOSTPROF") and rank == 0:  # tuning aid: where the host thread spent the timed region
+        print("host: %.3f ms per step inside cc_db_query_submit (lane collection included), %.3f ms in the final cc_db_query_wait, "
+              "%.3f ms per step elapsed" % (run_steps.host_submit_s / K * 1e3, run_steps.host_wait_s * 1e3, elapsed / K * 1e3), file=sys.stderr)
     if args.stats and rank == 0:
         for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check2", "cand_aft_check3", "n_cand_pose", "n_cand_tidy"):
             print("funnel %-16s mean %8.1f  max %6d" % (k, float(res[k].mean()), int(res[k].max())), file=sys.stderr)
