@@ -822,16 +822,7 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gsrc &Q, int np, int sl, co
   sincos(p[2], &s, &c);
   const double c2 = c * c - s * s, s2 = 2.0 * s * c;
   double a = 0.0, ax = 0.0, ay = 0.0, at = 0.0;
-  // the next pair's record is requested before this pair's ~120 f64 instructions are issued
-  cc_graw w = {};
-  if (sl < np) w = cc_gsrc_load(Q, sl);
-  for (int i = sl; i < np; i += G) {
-    cc_graw n = w;
-#ifdef CC_TUNE_GMM_NOLOAD
-    if (i + G < np && p[0] == 1.2345e-300) n = cc_gsrc_load(Q, i + G);
-#else
-    if (i + G < np) n = cc_gsrc_load(Q, i + G);
-#endif
+  auto add_term = [&](const cc_graw &w) {
     const cc_gpair P = cc_gmm_make_pair(w);
     const cc_gterm t = cc_gmm_term(P, p[0], p[1], c, s, c2, s2, exp_tab);
 #ifdef CC_TUNE_GMM_TWICE  // tuning aid: the pair arithmetic twice (what it costs = this build's K5 minus the product's)
@@ -844,6 +835,40 @@ __device__ __forceinline__ void cc_gmm_eval(const cc_gsrc &Q, int np, int sl, co
     ax += t.gx;
     ay += t.gy;
     at += t.gt;
+  };
+  // A lane's pairs in ascending position: those in LDS, then those in the pool -- two loops (one loop that picks the
+  // source per step carried a branch, sixteen register moves and seven lane reads per pair)
+  for (int i = sl; i < Q.nl; i += G) {
+    cc_graw w;
+    w.s = Q.lds[i];
+    w.t = Q.lds[Q.nl_cap + i];
+    w.m = Q.lds[2 * Q.nl_cap + i];
+    w.w = ((const float2 *)(Q.lds + 3 * Q.nl_cap))[i];
+    add_term(w);
+  }
+  // (Q.nl is np or a multiple of G: the lane's first pool position is its lane index)
+  const int ng = np - Q.nl;
+  const float4 *gb = (const float4 *)Q.glb;
+  const float2 *gw = (const float2 *)(gb + 3 * (size_t)Q.ng_alloc);
+  auto load = [&](int j) {  // (scalar bases + a 32-bit lane offset: the kernel has no scalar registers left, they came back through six lane reads per step)
+    cc_graw r;
+    r.s = gb[j];
+    r.t = gb[Q.ng_alloc + j];
+    r.m = gb[2 * (size_t)Q.ng_alloc + j];
+    r.w = gw[j];
+    return r;
+  };
+  // the next pair's record is requested before this pair's ~150 f64 instructions are issued
+  cc_graw w = {};
+  if (sl < ng) w = load(sl);
+  for (int j = sl; j < ng; j += G) {
+    cc_graw n = w;
+#ifdef CC_TUNE_GMM_NOLOAD
+    if (j + G < ng && p[0] == 1.2345e-300) n = load(j + G);
+#else
+    if (j + G < ng) n = load(j + G);
+#endif
+    add_term(w);
     w = n;
   }
   cc_gsum4<G>(a, ax, ay, at);
