@@ -117,6 +117,28 @@ def test_capacities_are_flagged_never_silent(oracle):
     assert abs(eres["correlation"] - res["correlation"]) < 1e-6 and np.abs(eres["tf"] - res["tf"]).max() < 1e-6
 
 
+def test_correlation_pools_running_out_is_an_error(oracle, monkeypatch):
+    """The correlation's two pools (round 6: the pair codes cc_k_gmm_init files for every problem, the pair records the
+    refinement keeps beyond what stays in LDS) are sized per query lane (CC_GMM_POOL_CODES / CC_GMM_POOL_PAIRS, read when the
+    lane comes into use): a chunk that needs more gets CC_ECAPACITY, never a shorter pair list."""
+    L = oracle.L
+    api = emu_api.EmuApi(L)
+    ctx = api.create(max_batch=2)
+    many = _many_ellipses(_base_desc(oracle))   # 200 ellipses on a level: thousands of selected pairs against itself
+    hints = [(1, 0, 0), (2, 0, 0), (3, 0, 0)]
+    for var, val in (("CC_GMM_POOL_CODES", "1024"), ("CC_GMM_POOL_PAIRS", "32")):
+        monkeypatch.setenv(var, val)
+        db = api.db_create(ctx, cap=4)
+        api.db_add(db, many, np.zeros(1), np.zeros(1, np.int32))
+        rc, res, sc = _check(api, L, db, many, hints)
+        monkeypatch.delenv(var)
+        assert rc == CC_ECAPACITY and b"pool" in api.lib.cc_last_error(), (var, rc, api.lib.cc_last_error())
+    db = api.db_create(ctx, cap=4)
+    api.db_add(db, many, np.zeros(1), np.zeros(1, np.int32))
+    rc, res, sc = _check(api, L, db, many, hints)
+    assert rc == 0 and res["flags"] == 0 and res["n_res"] == 1
+
+
 def test_hint_must_name_existing_contours_on_both_sides(oracle):
     """cc_db_check_hints validates seq_src against the DB scan and seq_tgt against the (device-resident) query scan: a hint
     naming a contour that does not exist is CC_EINVAL, not a comparison against zero-filled rows."""
