@@ -310,6 +310,11 @@ int orc_ingest_batch(const float *xyzi, const int64_t *offsets, int n_scans, con
 void orc_atan2f(const float *y, const float *x, float *out, long n) {
   for (long i = 0; i < n; i++) out[i] = std::atan2(y[i], x[i]);
 }
+// device's acosf replica (tests/test_atan2f_replica.py): this libm's acosf on an array
+void orc_acosf(const float *x, float *out, long n) {
+  for (long i = 0; i < n; i++) out[i] = std::acos(x[i]);
+}
+
 void orc_eigen2f(const float m[4] /*a00 a01 a10 a11*/, float evals[2], float evecs[4] /*row-major*/) {
   M2F mm, ev;
   mm.a[0][0] = m[0];

@@ -112,4 +112,8 @@ void emu_eigen2f(const float m[3], float ev[2], float vec[4]) { cc_eigen2f(m[0],
 void emu_atan2f(const float *y, const float *x, float *out, long n) {
   for (long i = 0; i < n; i++) out[i] = cc_atan2f_fdlibm(y[i], x[i]);
 }
+// ... and the acosf replica
+void emu_acosf(const float *x, float *out, long n) {
+  for (long i = 0; i < n; i++) out[i] = cc_acosf_fdlibm(x[i]);
+}
 }
