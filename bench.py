@@ -49,8 +49,8 @@ DTYPE_NOTE = "as the reference: f32 raster / moments / key sums / kNN distances 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 8; --workload seq: the whole sequence)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --workload seq: the whole sequence)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5; --workload seq: 2)")
     ap.add_argument("--db-scans", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=1024, help="query scans per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="query scans timed by the CPU baseline (0 = skip)")
@@ -102,8 +102,10 @@ def main():
     args = ap.parse_args()
     steps_given = args.steps is not None
     if args.steps is None:
-        args.steps = 8
+        args.steps = 20   # (the round-end driver passes --steps 20 --warmup 5; a timed region of 8 steps is a quarter pipeline fill and drain)
     args.steps_given = steps_given
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "seq" else 5
 
     # `python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run
     # (one process per GPU, RCCL over xGMI) and let rank 0's JSON line through.
