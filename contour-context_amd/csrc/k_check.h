@@ -954,8 +954,44 @@ cc_k_check_b2(cc_check_params P, const cc_hot_desc_t *__restrict__ qhot, const c
     s01 = cc_group_sum_d(s01) * one_over_n;
     s10 = cc_group_sum_d(s10) * one_over_n;
     s11 = cc_group_sum_d(s11) * one_over_n;
-    const double sn2 = s10 - s01, cs_ = s00 + s11;
-    const double nrm = sqrt(sn2 * sn2 + cs_ * cs_);
+    double sn2 = s10 - s01, cs_ = s00 + s11;
+    double nrm = sqrt(sn2 * sn2 + cs_ * cs_);
+    if (nrm < 1e-6) {  // (group-uniform)
+      // A constellation whose cross-covariance cancels (every src contour of a pair set paired with every tgt contour: the
+      // sums are products of sums of deviations, i.e. zero) leaves rounding noise in sn2 and cs_, and the rotation is THAT
+      // noise's angle: it depends on the association of the sums.  Such a case is summed again in the reference's
+      // sequential order (contour_mng.h:1252-1277 as the oracle restates it), by every lane for itself, so that the same
+      // noise comes out (round 6: fuzz drive 201965 -- angle exactly 0 here, 0.09 rad there, a candidate kept on one side only).
+      smx = smy = dmx = dmy = 0;
+      for (int e = 0; e < ncs; e++) {
+        const int o = L.keepf[e];
+        smx += (double)L.spm[o][0];
+        smy += (double)L.spm[o][1];
+        dmx += (double)L.tpm[o][0];
+        dmy += (double)L.tpm[o][1];
+      }
+      smx = smx * one_over_n;
+      smy = smy * one_over_n;
+      dmx = dmx * one_over_n;
+      dmy = dmy * one_over_n;
+      s00 = s01 = s10 = s11 = 0;
+      for (int e = 0; e < ncs; e++) {
+        const int o = L.keepf[e];
+        const double ax = (double)L.spm[o][0] - smx, ay = (double)L.spm[o][1] - smy;
+        const double bx = (double)L.tpm[o][0] - dmx, by = (double)L.tpm[o][1] - dmy;
+        s00 += bx * ax;
+        s01 += bx * ay;
+        s10 += by * ax;
+        s11 += by * ay;
+      }
+      s00 *= one_over_n;
+      s01 *= one_over_n;
+      s10 *= one_over_n;
+      s11 *= one_over_n;
+      sn2 = s10 - s01;
+      cs_ = s00 + s11;
+      nrm = sqrt(sn2 * sn2 + cs_ * cs_);
+    }
     double r00 = 1, r10 = 0;
     if (nrm > 0) {
       r00 = cs_ / nrm;
