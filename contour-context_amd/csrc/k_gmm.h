@@ -3,13 +3,16 @@
 //
 //   cc_k_gmm_prep    per scan, once: the ellipses GMMPair's ctor selects and the scan's auto-correlation term
 //   cc_k_gmm_init    every (query, candidate) problem: pair pre-selection and the initial correlation in one sweep over
-//                    the ellipse grid -- nothing is stored but the correlation and the pair count
-//   cc_k_select      the <= max_fine_opt_ candidates per query the reference refines, split by pair count
-//   cc_k_gmm_refine  those problems: the selected pairs' constants are written to a pool (64 B per pair, streamed
-//                    coalesced by every evaluation), then Ceres' LineSearchMinimizer restated (L-BFGS + Wolfe / cubic).
+//                    the ellipse grid; the selected pairs' (level, src, tgt) codes are filed in the chunk's code pool
+//   cc_k_select      the <= max_fine_opt_ candidates per query the reference refines, split by pair count (the long ones by
+//                    length class); hands out the pair pool
+//   cc_k_gmm_refine  those problems: Ceres' LineSearchMinimizer restated (L-BFGS + Wolfe / cubic).  The first evaluation
+//                    reads the problem's codes and files a 56-byte record per pair (the first CC_GMM_NL in LDS, the rest in
+//                    the pair pool, unit by unit), every further evaluation streams those records.
 //                    Two instances: 16 lanes per problem (4 problems per wave) and 64 lanes for the long pair lists.
 //   cc_k_final       tidyUp compaction, fineOptimize ordering, result record
-// No capacity anywhere on this path: ellipse tables are read where they lie, pair lists take what they need of the pool.
+// The ellipse tables are read where they lie; the two pools are sized per query lane (cc_db_api.inc) and running out of
+// either is reported (CC_ECAPACITY), never a shorter pair list.
 #pragma once
 #include "cc_dev.h"
 #include "cc_group.h"
@@ -38,9 +41,9 @@
 #ifndef CC_GMM_PACK_MIN_PROBLEMS
 #define CC_GMM_PACK_MIN_PROBLEMS 3072   // selected problems of a chunk from which the in-between ones are packed four to a wave
 #endif
-// (A 256-lane instance -- a workgroup per problem, template value 256 below -- exists for very long lists; measured on KITTI-shaped
-// input, ~3 000 pairs x ~40 evaluations per problem, it LOSES: four waves repeat the serial line-search code,
-// cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk.  Not launched.)
+// (A 256-lane instance -- a workgroup per problem -- existed until round 6; measured on KITTI-shaped input it LOST twice: four
+// waves repeat the serial line-search code, and a 256-thread workgroup at 250 registers leaves room for 512 problems on the
+// chip instead of 2 048: cc_k_gmm_refine<64> 503 us -> <64> 175 + <256> 672 us per chunk in round 5, K5 0.65 -> 0.90 ms in round 6.)
 
 // The long problems are listed by length class, longest first: the 64-lane refinement starts them in that order, so the
 // waves that are still running when the launch runs dry hold the SHORT lists.  (In list order, a chunk's ~3 000 one-wave
