@@ -26,8 +26,8 @@ struct cc_dev_cfg {
 
 // order-preserving map f32 -> u32 (total order of finite floats), used for LDS atomicMax on heights
 __device__ __forceinline__ unsigned cc_fkey(float f) {
-  unsigned b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);  // negative: ~b, else b | sign bit
 }
 __device__ __forceinline__ float cc_funkey(unsigned k) {
   unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
@@ -41,12 +41,14 @@ __device__ __forceinline__ float cc_funkey(unsigned k) {
 template <bool POW2 = false>
 __device__ __forceinline__ int cc_point_cell(const cc_dev_cfg &c, float x, float y) {
   // written so that a NaN coordinate is rejected (the reference's int(floor(NaN)) is undefined behaviour); identical to
-  // `x < lo || x > hi || ...` for every other value
-  if (!(x >= c.x_lo && x <= c.x_hi && y >= c.y_lo && y <= c.y_hi) || (y * y + x * x) < c.blind_sq) return -1;
-  int row = (int)floorf(POW2 ? x * c.inv_row : x / c.reso_row) + c.half_row;
-  int col = (int)floorf(POW2 ? y * c.inv_col : y / c.reso_col) + c.half_col;
-  if (row <= 0) return -1;
-  return row * c.n_col + col;
+  // `x < lo || x > hi || ...` for every other value.  Selects, no early return: K1 runs this per point and the branches an
+  // early return compiles to cost more than the few instructions they skip (round 6).  A rejected point's row / col are
+  // computed from whatever it holds and dropped (the float -> int conversion saturates).
+  const bool ok = (x >= c.x_lo) & (x <= c.x_hi) & (y >= c.y_lo) & (y <= c.y_hi) & !((y * y + x * x) < c.blind_sq);  // `&`: no short-circuit branches
+  const int row = (int)floorf(POW2 ? x * c.inv_row : x / c.reso_row) + c.half_row;
+  const int col = (int)floorf(POW2 ? y * c.inv_col : y / c.reso_col) + c.half_col;
+  const int cell = __mul24(row, c.n_col) + col;  // |row| <= 75 + 150 for an accepted point, n_col <= 150
+  return (ok & (row > 0)) ? cell : -1;
 }
 
 // value of `v` in lane `src_lane` (wave-uniform index), e.g. the lane found by ffs of a ballot mask

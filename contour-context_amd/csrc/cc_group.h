@@ -256,6 +256,14 @@ __device__ __forceinline__ T cc_group_bcast(T v, int src) {
 }
 #endif
 
+// this lane's bit of a wave-uniform 64-bit mask, as a condition (the mask stays in scalar registers: a select on it is one
+// v_cndmask with the register pair as its condition)
+#ifndef CC_EMU
+__device__ __forceinline__ bool cc_mask_lane(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+#else
+__device__ __forceinline__ bool cc_mask_lane(unsigned long long m) { return (m >> (threadIdx.x & 63)) & 1ull; }
+#endif
+
 // value of the lane D places to the left / one place to the right inside the 16-lane row; 0 beyond the row's ends
 #ifndef CC_EMU
 template <int D>

@@ -128,6 +128,7 @@ struct cc_ctx {
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
   int k1_nosplit = 0;  // CC_K1_NOSPLIT=1: one workgroup per scan also for calls of a few scans (A/B aid)
+  int k1_dense = 0;    // CC_K1_DENSE=1: K1 writes the dense image / positions of every scan (A/B aid; round 5's behaviour)
   // optional per-kernel timing (cc_profile_*)
   bool prof = false;
   std::vector<hipEvent_t> ev;  // triplets (before K1, between, after K2)
@@ -329,21 +330,23 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
   }
   if (getenv("CC_K2_PHASES"))  // (a channel launch brings up to CC_SCAN_BATCH_MAX scans whatever max_batch_scans is)
     CREATE_CHK(hipMalloc(&c->d_phase_clk, sizeof(long long) * CC_K2_NCLK * (size_t)(max_batch_scans > CC_SCAN_BATCH_MAX ? max_batch_scans : CC_SCAN_BATCH_MAX)));
-  c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64 + CC_K1_EMIT_LDS_BYTES;
+  c->lds1 = ((nc * 4 + 15) & ~(size_t)15) + ((nc + 2) / 3) * 8 + 64 + ((CC_K1_EMIT_LDS_BYTES + 15) & ~15);
   c->lds2 = CC_K2_LDS_BYTES(nc);
   {
     const char *e = getenv("CC_K2_LDS_PAD");  // tuning aid, read once: extra bytes asked for (above 80 KB one scan per CU instead of two)
     if (e && atoi(e) > 0 && atoi(e) <= 65536) c->lds2 += (size_t)atoi(e);
   }
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
-  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<CC_K1_U_DEFAULT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<CC_K1_U_DEFAULT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<CC_K1_U_DEFAULT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
+  CREATE_CHK(hipFuncSetAttribute((const void *)cc_k_rasterize<CC_K1_U_DEFAULT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds1));
   {
     const char *e = getenv("CC_K1_DIV");  // tuning aid, read once
     c->k1_div = (e && atoi(e) == 1) ? 1 : 0;
     const char *e2 = getenv("CC_K1_NOSPLIT");
     c->k1_nosplit = (e2 && atoi(e2) == 1) ? 1 : 0;
+    const char *e3 = getenv("CC_K1_DENSE");
+    c->k1_dense = (e3 && atoi(e3) == 1) ? 1 : 0;
   }
   if (nc > (size_t)CC_MAX_CELLS) {
     cc_destroy(c);
@@ -420,6 +423,14 @@ int cc_profile_read(cc_ctx *c, double ms_out[2], int *n_launches) {
 }
 
 int cc_destroy(cc_ctx *c) {
+#ifdef CC_TUNE_K1_CLK
+  {
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(cc_k1_clk), sizeof h) == hipSuccess)
+      fprintf(stderr, "[cc_k_rasterize clocks, ticks of 10 ns summed over workgroups (thread 0)] init %llu | A %llu | barrier %llu | B %llu | barrier %llu | emit %llu\n", h[0], h[1], h[2],
+              h[3], h[4], h[5]);
+  }
+#endif
   if (!c) return CC_OK;
   hipSetDevice(c->device);
   for (auto &e : c->ev) hipEventDestroy(e);
@@ -477,6 +488,9 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
     HIPCHK(hipEventRecord(c->off_ev[slot], stream));
     c->off_busy[slot] = true;
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
+    // K1's dense image / positions: for the debug outputs, for a configuration K2's list kernel hands on as a whole
+    // (min_cont_cell_cnt_ > 3), CC_K1_DENSE=1 (tuning aid); otherwise only for scans whose active cells overflow the list
+    const int want_dense = ((dbg && (dbg->d_bev || dbg->d_pix_rc)) || c->dcfg.min_cont_cell_cnt > 3 || c->k1_dense) ? 1 : 0;
     if (dbg && dbg->d_pix_rc)
       hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)S.d_pix, -1.f, nc * 2 * nb);
     hipEvent_t *pe = nullptr;
@@ -496,19 +510,19 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
         HIPCHK(hipMalloc(&S.k1_part.red, sizeof(unsigned) * np * 2));
       }
       if (c->dcfg.reso_pow2 && !c->k1_div)
-        hipLaunchKernelGGL((cc_k_rasterize<4, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list);
+        hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense);
       else
-        hipLaunchKernelGGL((cc_k_rasterize<4, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list);
+        hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense);
       hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)S.d_offsets, S.k1_part, S.d_bev,
-                         S.d_pix, S.d_k1, S.list);
+                         S.d_pix, S.d_k1, S.list, want_dense);
     } else if (c->dcfg.reso_pow2 && !c->k1_div)
-      hipLaunchKernelGGL((cc_k_rasterize<4, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list);
+      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense);
     else
-      hipLaunchKernelGGL((cc_k_rasterize<4, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list);
+      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense);
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK), (size_t)CC_K2L_LDS_BYTES, stream, c->dcfg, (const float *)S.d_bev,
@@ -520,8 +534,8 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
     // up, one scan after the other, and the next launch is a full one again), 512 otherwise and at first.
     const int mid_seen = *(volatile int *)S.h_mid_seen;
     const int mid_wgs = mid_seen == 0 ? 16 : 512;
-    hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < mid_wgs ? nb : mid_wgs), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, (const float *)S.d_bev,
-                       (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab, S.h_mid_seen);
+    hipLaunchKernelGGL(cc_k_contours_mid, dim3(nb < mid_wgs ? nb : mid_wgs), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg, S.d_bev, S.d_pix,
+                       (const cc_k1_scan_out *)S.d_k1, S.d_scr, S.d_midq, S.d_bigq, d_out + b0, lab, S.h_mid_seen, S.list);
     // the scans the launch above could not number (more than CC_MAXC components on a level): exact, slow, usually none
     hipLaunchKernelGGL(cc_k_contours_big, dim3(nb < S.n_bigslots ? nb : S.n_bigslots), dim3(CC_K2_BLOCK), c->lds2, stream, c->dcfg,
                        (const float *)S.d_bev, (const float2 *)S.d_pix, (const cc_k1_scan_out *)S.d_k1, S.d_bigslots, S.d_bigq, d_out + b0, lab);

@@ -806,10 +806,11 @@ cc_k_contours(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__
 // min_cont_cell_cnt_ > 3): the original body with its cell-indexed label image, a scan at a time per workgroup.  Launched
 // behind every list launch; with an empty queue it ends at once.  What IT cannot number goes on to cc_k_contours_big.
 __global__ void __launch_bounds__(CC_K2_BLOCK, 2)
-cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2 *__restrict__ pix_in,
+cc_k_contours_mid(cc_dev_cfg cfg, float *bev_io, float2 *pix_io /*written here for a scan K1 left without them, then read*/,
                   const cc_k1_scan_out *__restrict__ k1_out, cc_k2_scratch *__restrict__ scratch_all, cc_k2_big_queue *__restrict__ midq,
                   cc_k2_big_queue *__restrict__ bigq, cc_scan_desc_t *__restrict__ desc_out, int16_t *__restrict__ labels_dbg,
-                  int *__restrict__ seen /*pinned host memory: how many scans this launch found queued (the host sizes the NEXT launch by it)*/) {
+                  int *__restrict__ seen /*pinned host memory: how many scans this launch found queued (the host sizes the NEXT launch by it)*/,
+                  cc_k1_list_out list) {
   HIP_DYNAMIC_SHARED(char, smem)
   __shared__ int s_next;
   // An empty queue (the usual case) is left alone: its counters are zero already, and the two atomics every workgroup would
@@ -834,7 +835,32 @@ cc_k_contours_mid(cc_dev_cfg cfg, const float *__restrict__ bev_in, const float2
       return;
     }
     const int scan = midq->scan[k];
-    cc_k2_body<CC_NC, false>(cfg, bev_in, pix_in, k1_out, scratch_all + scan, nullptr, bigq, scan, desc_out, labels_dbg, nullptr, smem);
+    // K1 writes the dense image and positions only on request or when its list overflows (k_rasterize.h: cc_k1_emit); a scan
+    // that comes here without them gets them from its (complete) list: every cell the body looks at beyond a threshold test
+    // is an active one, the others only have to stay below the lowest level
+    const int4 hd = list.hdr[scan];
+    if (hd.z == 0) {
+#ifdef CC_EMU
+      if (threadIdx.x == 0 && getenv("CC_EMU_TRACE_K2")) fprintf(stderr, "[k2 mid] scan %d: dense image rebuilt from the list (%d entries)\n", scan, hd.x);
+#endif
+      float *bev = bev_io + (size_t)scan * cfg.n_cell;
+      float2 *pix = pix_io + (size_t)scan * cfg.n_cell;
+      for (int c = threadIdx.x; c < cfg.n_cell; c += blockDim.x) bev[c] = CC_BEV_EMPTY;
+      __threadfence_block();
+      __syncthreads();
+      const uint16_t *l_rc = list.rc + (size_t)scan * CC_LIST_CAP;
+      const float *l_h = list.h + (size_t)scan * CC_LIST_CAP;
+      const float2 *l_pix = list.pix + (size_t)scan * CC_LIST_CAP;
+      for (int i = threadIdx.x; i < hd.x; i += blockDim.x) {
+        const int rc = (int)l_rc[i], c = (rc >> 8) * cfg.n_col + (rc & 255);
+        bev[c] = l_h[i];
+        pix[c] = l_pix[i];
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (threadIdx.x == 0) list.hdr[scan].z = 1;
+    }
+    cc_k2_body<CC_NC, false>(cfg, bev_io, pix_io, k1_out, scratch_all + scan, nullptr, bigq, scan, desc_out, labels_dbg, nullptr, smem);
   }
 }
 

@@ -232,6 +232,8 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
+static inline int __mul24(int a, int b) { return (int)((unsigned)(((a << 8) >> 8) * (long long)((b << 8) >> 8))); }  // low 32 bits of the product of the low 24 bits, sign-extended
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 

@@ -15,7 +15,11 @@ def _check(oracle, scans, cfg=None):
     api = emu_api.EmuApi(oracle.L)
     ctx = api.create(cfg=cfg, max_batch=len(scans))
     offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
+    # first WITHOUT the debug outputs, on the fresh context: K1 then writes its dense image / positions only for scans whose
+    # active cells overflow its list, and a scan the list kernel hands on gets them rebuilt from the list (cc_k_contours_mid)
+    plain = api.ingest(ctx, np.concatenate(scans, 0), offs)
     desc, dbg = api.ingest(ctx, np.concatenate(scans, 0), offs, debug=True)
+    assert plain.tobytes() == desc.tobytes(), "descriptors with and without the dense debug outputs differ"
     for i, s in enumerate(scans):
         o = oracle.Scan(s, cfg=cfg)
         ob, opix = o.bev()
@@ -195,6 +199,21 @@ def test_more_components_than_cc_maxc_take_the_exact_slow_path(oracle):
     assert d["n_cont"][0].max() > 320 and d["n_cont"][2].max() > 320, d["n_cont"]
     assert d["flags"][0] == 1 and d["flags"][1] == 0 and d["flags"][2] == 1, d["flags"]
     assert (d["n_stored"][0] <= 320).all()
+
+
+def test_mid_path_rebuilds_the_dense_image_from_the_list(oracle, capfd, monkeypatch):
+    """K1 writes the dense max-height image and the dense positions only on request (debug outputs) or when a scan's active
+    cells overflow its list.  A scan that fits the list but not the list kernel's tables (more than 320 components on a
+    level) reaches cc_k_contours_mid without them: it rebuilds both from the list.  `_check` ingests without debug outputs
+    first, on a fresh context, and compares those descriptors too."""
+    monkeypatch.setenv("CC_EMU_TRACE_K2", "1")
+    scenes = [_blob_scene(3, n_blobs=420, pitch=6), _thin_terrain(11, 9000, 1.5, 1.2)]
+    capfd.readouterr()
+    d = _check(oracle, scenes)
+    err = capfd.readouterr().err
+    rebuilt = {int(l.split("scan")[1].split(":")[0]) for l in err.splitlines() if l.startswith("[k2 mid]") and "rebuilt" in l}
+    assert rebuilt == {0}, (rebuilt, d["n_cont"])
+    assert d["n_cont"][0].max() > 320
 
 
 # ---- the list front half of K2 (csrc/k_contours_list.h): which scans it takes, and that what it takes is bit-exact ----

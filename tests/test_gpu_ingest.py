@@ -14,9 +14,13 @@ def _run(cc, oracle, scans, cfg=None):
     ctx = cc.Context(0, cfg, max_batch=8)
     offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int64)
     x = torch.from_numpy(np.concatenate(scans, 0)).cuda()
+    # first WITHOUT the debug outputs, on the fresh context: K1 then writes its dense image / positions only for scans whose
+    # active cells overflow its list, and a scan the list kernel hands on gets them rebuilt from the list (cc_k_contours_mid)
+    plain = ctx.ingest(x, offs).clone()
     desc, dbg = ctx.ingest(x, offs, debug=True)
     torch.cuda.synchronize()
     d = cc.desc_to_numpy(desc)
+    dp = cc.desc_to_numpy(plain)
     report = []
     for i, s in enumerate(scans):
         o = oracle.Scan(s, cfg)
@@ -28,6 +32,7 @@ def _run(cc, oracle, scans, cfg=None):
         if not np.array_equal(o.labels(), dbg["labels"][i].cpu().numpy()):
             report.append("scan %d: canonical label images differ" % i)
         report += ["scan %d: %s" % (i, m) for m in compare_desc(o.desc()[0], d[i], float_exact=False)]
+        report += ["scan %d (no debug outputs): %s" % (i, m) for m in compare_desc(o.desc()[0], dp[i], float_exact=False)]
     ctx.close()
     return report, d
 
