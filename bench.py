@@ -835,25 +835,25 @@ def _read_kernel_ms(cc, ctx, db, B):
 def algorithmic_bytes(d, res, B, P, n_db):
     """ALGORITHMIC bytes per step and kernel group (DESIGN.md "Kernels"): what the step has to move, independent of how.
     d = descriptors of (a sample of) the step's scans, res = the step's query results.
-      K1 streams the xyzi records once (16 B/point) and emits the dense BEV + per-cell continuous positions + the list of active cells;
+      K1 streams the xyzi records once (16 B/point) and emits the list of the scan's active cells (the dense BEV + per-cell
+         positions only on request or when the list overflows: neither happens in this workload);
       K2 reads that list and emits the descriptor used downstream;
       K3 reads the layers' key matrices once and, per anchor key, the 40-B key and <= nnk 12-B hits;
       K4 reads, per KNN hit, the hit and two contour records, per anchor-similar pair the two 256-bit rings, per check that
          reaches the pairing the two 600-B BCIs, and writes a 104-B record per pass;
       merge reads those records; K5 reads two ellipse tables (32 B/ellipse) per problem and writes 64 B.
     Returns (per-group bytes, split): the split sorts the same bytes into `compulsory` (point stream in, descriptors out, the
-    key matrices and query keys once, results out), `intermediate` (the BEV that goes from K1 to K2 through HBM) and
+    key matrices and query keys once, results out), `intermediate` (the active-cell list that goes from K1 to K2 through HBM) and
     `logical_gather` (per-hit / per-check / per-problem reads of DB records, mostly served by L2 / Infinity Cache)."""
     n_pix = float(d["n_pix"].mean())
     desc_emit = float(np.mean(72 + 16 + 1440 + 36 * 600 + d["n_stored"].sum(1) * 76))
     f = {k: float(res[k].mean()) for k in ("n_knn_hits", "cand_aft_check1", "cand_aft_check3", "n_cand_tidy")}
     n_keys_db = 3 * 6 * n_db
-    bev = 22500 * 4 + n_pix * 8
     # round 6: K1 also lists the scan's active cells (above the lowest level) for K2 -- 15 B per entry ((row, col), level count,
     # height, continuous position) + a 16-B header -- and K2 starts from that list instead of re-reading the image.  The entry
     # count is not in the descriptor; the level-0 contours' cells (>= 3-cell components of the same level set) are a lower bound
     active_list = 16 + 15 * float(d["layer_cell_cnt"][:, 0].mean())
-    alg = {"cc_k_rasterize": B * (P * 16 + bev + active_list),
+    alg = {"cc_k_rasterize": B * (P * 16 + active_list),   # (rounds 1-6a: + bev, the dense image and positions nobody read)
            "cc_k_contours": B * (active_list + desc_emit),
            "cc_k_knn": n_keys_db * 44 + B * 18 * 40 + B * f["n_knn_hits"] * 12,
            "cc_k_check": B * (f["n_knn_hits"] * (12 + 2 * 76) + f["cand_aft_check1"] * (64 + 2 * 600) + f["cand_aft_check3"] * 104),
@@ -861,7 +861,7 @@ def algorithmic_bytes(d, res, B, P, n_db):
            "cc_k_gmm": B * f["n_cand_tidy"] * (2 * 45 * 32 + 64),
            "cc_k_final": B * 64}
     compulsory = B * P * 16 + B * desc_emit + n_keys_db * 44 + B * 18 * 40 + B * 64
-    intermediate = B * bev + 2 * B * active_list   # the dense image K1 leaves (debug / the mid and big paths read it) + the list both ways
+    intermediate = 2 * B * active_list   # the list, both ways (K1 writes the dense image only on request / list overflow since round 6)
     split = {"compulsory": compulsory, "intermediate": intermediate, "logical_gather": sum(alg.values()) - compulsory - intermediate}
     return alg, split
 
