@@ -805,8 +805,11 @@ struct cc_knn_tlds {
 // so every key that can still make the result passes r <= x.  SLACK = 0 gives exactly the nnk-th smallest distance (more
 // than nnk are kept only when distances tie there); a few more kept candidates cost nothing and save most of the
 // bisection's ~31 rounds.  One wave, cnt <= 64 * R.
+// Round 6: the bisection starts from the data's own range -- lo = the smallest distance in the buffer, hi = the search's
+// current radius `ub` (every candidate was admitted under it) -- instead of [0, inf): the first ~20 of its rounds only found
+// the distances' exponent and leading mantissa bits (cut-backs were a quarter of cc_k_knn_tile at a 5 000-scan DB).
 template <int R, int SLACK>
-__device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt, int nnk, int lane, int &kept) {
+__device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt, int nnk, int lane, int &kept, float ub) {
   unsigned long long v[R];
   unsigned d[R];
   cc_wave_sync();
@@ -815,7 +818,17 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
     v[a] = (a * 64 + lane < cnt) ? buf[a * 64 + lane] : ~0ull;
     d[a] = (unsigned)(v[a] >> 32);  // squared distances are >= 0: their bit patterns order like the values
   }
-  unsigned lo = 0u, hi = 0x7F800000u;  // invariant: #(d <= hi) >= nnk, #(d < lo) < nnk
+  unsigned lo = 0xFFFFFFFFu, hi = __float_as_uint(ub);  // invariant: #(d <= hi) >= nnk, #(d < lo) < nnk
+#pragma unroll
+  for (int a = 0; a < R; a++) lo = d[a] < lo ? d[a] : lo;  // (the padding's ~0 does not win)
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned o_ = (unsigned)__shfl_xor((int)lo, o);
+    lo = o_ < lo ? o_ : lo;
+  }
+  if (!(hi <= 0x7F800000u) || lo > hi) {  // not a radius every candidate lies under (cannot happen): the whole range
+    lo = 0u;
+    hi = 0x7F800000u;
+  }
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo) >> 1);
     int c = 0;
@@ -843,9 +856,9 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
 
 // A search's buffer of cnt <= CC_KNN_TCAP candidates cut back to those within its nnk-th smallest distance (a few more,
 // see cc_knn_select); returns that distance, `kept` candidates stay at buf[0..kept), kept <= 64.
-__device__ __forceinline__ float cc_knn_cut(unsigned long long *buf, int cnt, int nnk, int lane, int &kept) {
-  float nub = cnt <= 128 ? cc_knn_select<2, 12>(buf, cnt, nnk, lane, kept)
-                         : (cnt <= 256 ? cc_knn_select<4, 12>(buf, cnt, nnk, lane, kept) : cc_knn_select<6, 12>(buf, cnt, nnk, lane, kept));
+__device__ __forceinline__ float cc_knn_cut(unsigned long long *buf, int cnt, int nnk, int lane, int &kept, float ub /*the search's radius so far*/) {
+  float nub = cnt <= 128 ? cc_knn_select<2, 12>(buf, cnt, nnk, lane, kept, ub)
+                         : (cnt <= 256 ? cc_knn_select<4, 12>(buf, cnt, nnk, lane, kept, ub) : cc_knn_select<6, 12>(buf, cnt, nnk, lane, kept, ub));
   if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
                     // in the result -- order them and drop the rest, so that the buffer bound holds
     unsigned long long first;
@@ -1189,7 +1202,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
           due &= due - 1ull;
           const int cnt = __builtin_amdgcn_readlane(cnt_l, jj);
           int kept;
-          const float nub = cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept);
+          const float nub = cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept, L.st[jj].ub);
           if (lane == 0) {
             L.st[jj].ub = nub;
             L.st[jj].cnt = kept;
@@ -1212,7 +1225,7 @@ cc_k_knn_tile(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, const cc_
     int cnt = __builtin_amdgcn_readfirstlane(L.st[jj].cnt);
     if (cnt > 128) {  // what is within the nnk-th distance fits the smaller sorting network
       int kept;
-      cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept);
+      cc_knn_cut(L.buf[jj], cnt, nnk, lane, kept, L.st[jj].ub);
       cnt = kept;
     }
     unsigned long long first;
