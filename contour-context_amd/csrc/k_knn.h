@@ -760,14 +760,24 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
 #define CC_KNN_TQ 16      // searches per workgroup = columns of a 16x16x4 tile
 #define CC_KNN_TW 8       // waves per workgroup: half of them walk upwards, half downwards
 #define CC_KNN_TSTRIDE (64 * (CC_KNN_TW / 2))  // keys a direction advances by per round
+#ifndef CC_KNN_TREP
 #define CC_KNN_TREP 2     // 64-key steps a wave takes per round
+#endif
+#ifndef CC_KNN_TTRIG
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
+#endif
+#ifndef CC_KNN_TPASS
 #define CC_KNN_TPASS 256  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one (round 3:
                           // 128 -- a pass every 1.5 rounds, each one a round trip to the keys with the whole workgroup waiting)
+#endif
+#ifndef CC_KNN_TCAP
 #define CC_KNN_TCAP 384   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
+#endif
+#ifndef CC_KNN_TWL
 #define CC_KNN_TWL 320    // queue per wave: a wave stops queueing once fewer than 64 places are left and carries the rest of its
                           // step's pairs over to the next round -- by then a pass has run: a queue that full holds CC_KNN_TPASS pairs
                           // (round 3 sized the queues for a step in which all 1 024 pairs pass: 38 KB that were never used)
+#endif
 // LDS: 48 KB of buffers + 10 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
 static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS + 64 <= CC_KNN_TWL &&
