@@ -767,21 +767,22 @@ cc_k_knn_order(cc_knn_params P, const cc_hot_desc_t *__restrict__ qhot, int nq, 
 #define CC_KNN_TTRIG 128  // a buffer holding this many candidates is cut back after a pass of the queue
 #endif
 #ifndef CC_KNN_TPASS
-#define CC_KNN_TPASS 256  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one (round 3:
-                          // 128 -- a pass every 1.5 rounds, each one a round trip to the keys with the whole workgroup waiting)
+#define CC_KNN_TPASS 384  // pairs worked off per pass (threads 0 .. CC_KNN_TPASS - 1), and the queue length that starts one (round 3:
+                          // 128 -- a pass every 1.5 rounds, each one a round trip to the keys with the whole workgroup waiting; rounds 4-6a:
+                          // 256; 128 / 192 / 256 / 320 / 384 measured in round 6: cc_k_knn 0.49 / 0.44 / 0.42 / 0.40 / 0.39 ms at the 5 000-scan DB)
 #endif
 #ifndef CC_KNN_TCAP
-#define CC_KNN_TCAP 384   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
+#define CC_KNN_TCAP 512   // candidate buffer per search: < CC_KNN_TTRIG kept + CC_KNN_TPASS from one pass
 #endif
 #ifndef CC_KNN_TWL
-#define CC_KNN_TWL 320    // queue per wave: a wave stops queueing once fewer than 64 places are left and carries the rest of its
+#define CC_KNN_TWL 448    // queue per wave: a wave stops queueing once fewer than 64 places are left and carries the rest of its
                           // step's pairs over to the next round -- by then a pass has run: a queue that full holds CC_KNN_TPASS pairs
                           // (round 3 sized the queues for a step in which all 1 024 pairs pass: 38 KB that were never used)
 #endif
-// LDS: 48 KB of buffers + 10 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
+// LDS: 64 KB of buffers + 14 KB of queues + 1.3 KB; with ~115 registers per lane two workgroups (16 waves) fit a CU
 typedef float cc_f32x4 __attribute__((__vector_size__(4 * sizeof(float))));
 static_assert(CC_KNN_TTRIG >= 2 * CC_KNN_MAX && CC_KNN_TTRIG - 1 + CC_KNN_TPASS <= CC_KNN_TCAP && CC_KNN_TPASS + 64 <= CC_KNN_TWL &&
-                  CC_KNN_TPASS <= 64 * CC_KNN_TW && CC_KNN_TCAP <= 384, "cc_k_knn_tile: buffer bounds");
+                  CC_KNN_TPASS <= 64 * CC_KNN_TW && CC_KNN_TCAP <= 512, "cc_k_knn_tile: buffer bounds");
 
 // |value of the fmaf chain - real squared distance| for every key whose real distance is within radius^2 = ub of the
 // search: the chain sums 12 products of magnitude <= (|q| + |k|)^2 in total with one rounding each (<= 13 * 2^-24 relative
@@ -868,7 +869,8 @@ __device__ __forceinline__ float cc_knn_select(unsigned long long *buf, int cnt,
 // see cc_knn_select); returns that distance, `kept` candidates stay at buf[0..kept), kept <= 64.
 __device__ __forceinline__ float cc_knn_cut(unsigned long long *buf, int cnt, int nnk, int lane, int &kept, float ub /*the search's radius so far*/) {
   float nub = cnt <= 128 ? cc_knn_select<2, 12>(buf, cnt, nnk, lane, kept, ub)
-                         : (cnt <= 256 ? cc_knn_select<4, 12>(buf, cnt, nnk, lane, kept, ub) : cc_knn_select<6, 12>(buf, cnt, nnk, lane, kept, ub));
+                         : (cnt <= 256 ? cc_knn_select<4, 12>(buf, cnt, nnk, lane, kept, ub)
+                                        : (cnt <= 384 ? cc_knn_select<6, 12>(buf, cnt, nnk, lane, kept, ub) : cc_knn_select<8, 12>(buf, cnt, nnk, lane, kept, ub)));
   if (kept > 64) {  // a crowd of exactly equal distances at the radius: only the nnk smallest (distance, key id) can end up
                     // in the result -- order them and drop the rest, so that the buffer bound holds
     unsigned long long first;

@@ -177,7 +177,11 @@ __device__ __forceinline__ int cc_k1_emit(const cc_dev_cfg &cfg, KeyFn keyfn, Id
         key[e] = cc[e] >= 0 ? keyfn(cc[e]) : KEY_EMPTY;
       }
 #pragma unroll
+#ifdef CC_TUNE_K1_NOB
+      for (int e = 0; e < CC_K1_LB; e++) xy[e] = *(const float2 *)(P + (cc[e] >= 0 ? idxfn(cc[e]) % n_pts : 0));
+#else
       for (int e = 0; e < CC_K1_LB; e++) xy[e] = *(const float2 *)(P + (cc[e] >= 0 ? idxfn(cc[e]) : 0));  // (an active cell has an owner: n_pts > 0)
+#endif
 #pragma unroll
       for (int e = 0; e < CC_K1_LB; e++) {
         const int i = i0 + e * nt + tid, c = cc[e];
@@ -397,6 +401,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
     // step B: which of this lane's points hold their cell's maximum (four reads in flight), then ONE loop in which a lane
     // works off its winners one CAS attempt per turn -- a retry and the next winner's first attempt share a turn
     unsigned pend = 0u;
+#ifndef CC_TUNE_K1_NOB  // (tuning aid: the sweep without its index pass -- wrong owners, for timing only)
     {
       unsigned hm[CC_K1_U];
 #pragma unroll
@@ -404,6 +409,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
 #pragma unroll
       for (int u = 0; u < CC_K1_U; u++) pend |= (cell[u] >= 0 && key[u] == hm[u] && key[u] != KEY_EMPTY) ? (1u << u) : 0u;
     }
+#endif
     {
       bool busy = false;
       int w = 0, sh = 0;
