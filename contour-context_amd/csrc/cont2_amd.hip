@@ -267,10 +267,46 @@ static hipError_t stream_take(int device, hipStream_t *out) {
   }
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
+// A query lane's stream.  CC_QUERY_CUS = "a/b" (a of every b CUs of each XCD) or "xa/b" (a of every b XCDs) keeps the
+// lanes' kernels off the other CUs (hipExtStreamCreateWithCUMask; bit i of the mask is CU i / 8 of XCD i % 8: the driver
+// deals the bits out to the XCDs in turn): in a pipelined loop the ingest stream is the critical path and its big
+// workgroups (79-158 KB of LDS) wait for CUs that many small query workgroups keep occupied.  Unset: the pool's stream.
+static std::vector<hipStream_t> g_masked_streams;  // (never pooled: their mask is part of them)
+static hipError_t lane_stream_take(int device, hipStream_t *out) {
+  const char *e = getenv("CC_QUERY_CUS");
+  if (e && *e && *e != '-') {
+    const bool by_xcd = e[0] == 'x';
+    int a = 0, b = 0;
+    if (sscanf(by_xcd ? e + 1 : e, "%d/%d", &a, &b) == 2 && a > 0 && b >= a) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) {
+        const int n_cu = pr.multiProcessorCount, n_xcd = 8;
+        std::vector<uint32_t> words((size_t)(n_cu + 31) / 32, 0u);
+        for (int i = 0; i < n_cu; i++) {
+          const int unit = by_xcd ? i % n_xcd : i / n_xcd;
+          if (unit % b < a) words[(size_t)i / 32] |= 1u << (i % 32);
+        }
+        const hipError_t r = hipExtStreamCreateWithCUMask(out, (uint32_t)words.size(), words.data());
+        if (r == hipSuccess) {
+          std::lock_guard<std::mutex> lk(g_rt_mu);
+          g_masked_streams.push_back(*out);
+        }
+        return r;
+      }
+    }
+  }
+  return stream_take(device, out);
+}
 static void stream_give(int device, hipStream_t s) {
   hipStreamSynchronize(s);
   if (device >= 0 && device < CC_RT_MAX_DEV) {
     std::lock_guard<std::mutex> lk(g_rt_mu);
+    for (size_t i = 0; i < g_masked_streams.size(); i++)
+      if (g_masked_streams[i] == s) {
+        g_masked_streams.erase(g_masked_streams.begin() + (long)i);
+        hipStreamDestroy(s);
+        return;
+      }
     if (g_stream_pool[device].size() < 32) {
       g_stream_pool[device].push_back(s);
       return;

@@ -809,6 +809,9 @@ struct cc_knn_tlds {
   // per round parity (a wave may be one round ahead of another between two barriers):
   int wn[2][CC_KNN_TW];                // pairs pending in each wave's queue
   int go[2][CC_KNN_TW];                // the wave's sub-walk (every other step of its direction) still has a search to serve
+#ifdef CC_KNN_TPAD
+  char pad[CC_KNN_TPAD];               // tuning aid: LDS nobody uses (how many workgroups share a CU, and with whom)
+#endif
 };
 
 // Cut a search's buffer back: keep the candidates with distance <= x for an x with nnk <= #kept <= nnk + SLACK (bisection
