@@ -128,6 +128,8 @@ struct cc_ctx {
   size_t lds1 = 0, lds2 = 0;
   int k1_div = 0;  // CC_K1_DIV=1: keep the IEEE divisions even for power-of-two resolutions (A/B aid)
   int k1_nosplit = 0;  // CC_K1_NOSPLIT=1: one workgroup per scan also for calls of a few scans (A/B aid)
+  int k1_wgs = 0;      // CC_K1_WGS: workgroups of a many-scan K1 launch, each taking scans b, b + grid, ... (0 = one per scan, the default:
+                       // 256 persistent workgroups make K1 0.55 -> 0.49 ms inside the pipelined step and K2 1.15 -> 1.22, the step 1.79 -> 1.82)
   int k1_dense = 0;    // CC_K1_DENSE=1: K1 writes the dense image / positions of every scan (A/B aid; round 5's behaviour)
   // optional per-kernel timing (cc_profile_*)
   bool prof = false;
@@ -381,6 +383,8 @@ int cc_create(int device, const cc_manager_cfg_t *cfg, int max_batch_scans, cc_c
     c->k1_div = (e && atoi(e) == 1) ? 1 : 0;
     const char *e2 = getenv("CC_K1_NOSPLIT");
     c->k1_nosplit = (e2 && atoi(e2) == 1) ? 1 : 0;
+    const char *e4 = getenv("CC_K1_WGS");
+    c->k1_wgs = (e4 && atoi(e4) > 0) ? atoi(e4) : 0;
     const char *e3 = getenv("CC_K1_DENSE");
     c->k1_dense = (e3 && atoi(e3) == 1) ? 1 : 0;
   }
@@ -526,6 +530,8 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
     const float4 *pts = (const float4 *)d_xyzi + h_offsets[b0];
     // K1's dense image / positions: for the debug outputs, for a configuration K2's list kernel hands on as a whole
     // (min_cont_cell_cnt_ > 3), CC_K1_DENSE=1 (tuning aid); otherwise only for scans whose active cells overflow the list
+    // CC_K1_WGS: fewer K1 workgroups, each keeping its CU for scans b, b + grid, ... (k_rasterize.h; tuning aid)
+    const int k1_grid = (c->k1_wgs > 0 && nb > c->k1_wgs) ? c->k1_wgs : nb;
     const int want_dense = ((dbg && (dbg->d_bev || dbg->d_pix_rc)) || c->dcfg.min_cont_cell_cnt > 3 || c->k1_dense) ? 1 : 0;
     if (dbg && dbg->d_pix_rc)
       hipLaunchKernelGGL(cc_k_fill_f32, dim3(512), dim3(256), 0, stream, (float *)S.d_pix, -1.f, nc * 2 * nb);
@@ -547,18 +553,18 @@ static int ingest_on(cc_ctx *c, cc_ctx::Scratch &S, const float *d_xyzi, const i
       }
       if (c->dcfg.reso_pow2 && !c->k1_div)
         hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, true, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense, nb * CC_K1_SPLIT);
       else
         hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, false, true>), dim3(nb * CC_K1_SPLIT), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts,
-                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense);
+                           (const long long *)S.d_offsets, S.d_bev, S.d_pix, S.d_k1, S.k1_part, S.list, want_dense, nb * CC_K1_SPLIT);
       hipLaunchKernelGGL(cc_k_rasterize_merge, dim3(nb), dim3(1024), 0, stream, c->dcfg, pts, (const long long *)S.d_offsets, S.k1_part, S.d_bev,
                          S.d_pix, S.d_k1, S.list, want_dense);
     } else if (c->dcfg.reso_pow2 && !c->k1_div)
-      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, true>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense);
+      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, true>), dim3(k1_grid), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense, nb);
     else
-      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, false>), dim3(nb), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
-                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense);
+      hipLaunchKernelGGL((cc_k_rasterize<CC_K1_U_DEFAULT, false>), dim3(k1_grid), dim3(CC_INGEST_BLOCK), c->lds1, stream, c->dcfg, pts, (const long long *)S.d_offsets,
+                         S.d_bev, S.d_pix, S.d_k1, cc_k1_part(), S.list, want_dense, nb);
     if (pe) HIPCHK(hipEventRecord(pe[1], stream));
     int16_t *lab = (dbg && dbg->d_labels) ? dbg->d_labels + (size_t)b0 * CC_NLEV * nc : nullptr;
     hipLaunchKernelGGL(cc_k_contours, dim3(nb), dim3(CC_K2_BLOCK), (size_t)CC_K2L_LDS_BYTES, stream, c->dcfg, (const float *)S.d_bev,

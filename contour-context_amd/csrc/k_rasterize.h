@@ -269,7 +269,7 @@ template <int CC_K1_U, bool CC_K1_POW2, bool PART = false>
 __global__ void __launch_bounds__(1024)
 cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *__restrict__ offsets,
                float *__restrict__ bev_out, float2 *__restrict__ pix_out, cc_k1_scan_out *__restrict__ scan_out, cc_k1_part part, cc_k1_list_out list_out,
-               int want_dense) {
+               int want_dense, int n_units /*scans (PART: scans * CC_K1_SPLIT); workgroup b takes units b, b + gridDim.x, ...*/) {
   HIP_DYNAMIC_SHARED(char, smem)
   const int n_cell = cfg.n_cell;
   unsigned *hmax = (unsigned *)smem;
@@ -280,13 +280,21 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   unsigned *idle = (unsigned *)(emit_tab + CC_K1_EMIT_TAB_BYTES);  // [blockDim]: where a lane with nothing to send aims its atomicMax (the sweep's; the output pass has its cell list there)
   static_assert(CC_LIST_CAP * 2 >= 4 * 1024 && CC_K1_EMIT_TAB_BYTES % 4 == 0, "cc_k_rasterize: the idle words fit the list's cells");
 
-  const int scan = PART ? (int)blockIdx.x / CC_K1_SPLIT : (int)blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef CC_TUNE_K1_CLK
+  long long k1_t_ = 0, k1_acc_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  // A workgroup takes units b, b + gridDim.x, ...: the host normally launches one per unit; CC_K1_WGS brings fewer, each
+  // keeping its CU (a K1 workgroup needs one to itself) for several scans -- measured: K1's own in-step time falls, K2's rises
+  // by as much (profiles/r6/notes_negative_results.md).
+  for (int unit = (int)blockIdx.x; unit < n_units; unit += (int)gridDim.x) {
+  if (unit != (int)blockIdx.x) __syncthreads();  // the previous scan's output pass has read the grid
+  const int scan = PART ? unit / CC_K1_SPLIT : unit;
   long long p0 = offsets[scan];
   int n_pts = (int)(offsets[scan + 1] - p0);
   int idx_base = 0;  // scan-relative index of this workgroup's first point
   if (PART) {
-    const int per = (n_pts + CC_K1_SPLIT - 1) / CC_K1_SPLIT, pi = (int)blockIdx.x % CC_K1_SPLIT;
+    const int per = (n_pts + CC_K1_SPLIT - 1) / CC_K1_SPLIT, pi = unit % CC_K1_SPLIT;
     idx_base = pi * per < n_pts ? pi * per : n_pts;
     n_pts = n_pts - idx_base < per ? n_pts - idx_base : per;
     p0 += idx_base;
@@ -294,7 +302,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   const float4 *P = pts + p0;
 
 #ifdef CC_TUNE_K1_CLK
-  long long k1_t_ = (long long)wall_clock64(), k1_acc_[6] = {0, 0, 0, 0, 0, 0};
+  k1_t_ = (long long)wall_clock64();
 #endif
   const unsigned KEY_EMPTY = cc_fkey(CC_BEV_EMPTY);
   for (int i = tid; i < n_cell; i += nt) hmax[i] = KEY_EMPTY;
@@ -449,8 +457,8 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
   __syncthreads();
 
   if (PART) {  // this range's grid to the scratch; cc_k_rasterize_merge combines the ranges
-    unsigned *pk = part.key + (size_t)blockIdx.x * n_cell;
-    int *pj = part.idx + (size_t)blockIdx.x * n_cell;
+    unsigned *pk = part.key + (size_t)unit * n_cell;
+    int *pj = part.idx + (size_t)unit * n_cell;
     unsigned kmx = KEY_EMPTY;
     for (int c = tid; c < n_cell; c += nt) {
       const unsigned k = hmax[c];
@@ -467,10 +475,10 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
     if ((tid & 63) == 0) atomicMax(&red[0], kmx);
     __syncthreads();
     if (tid == 0) {
-      part.red[(size_t)blockIdx.x * 2] = red[0];
-      part.red[(size_t)blockIdx.x * 2 + 1] = red[1];
+      part.red[(size_t)unit * 2] = red[0];
+      part.red[(size_t)unit * 2 + 1] = red[1];
     }
-    return;
+    continue;
   }
   // ---- outputs ----
   float *bev = bev_out + (size_t)scan * n_cell;
@@ -496,6 +504,7 @@ cc_k_rasterize(cc_dev_cfg cfg, const float4 *__restrict__ pts, const long long *
     scan_out[scan] = o;
   }
   CC_K1_STAMP(5)
+  }  // units of this workgroup
 #ifdef CC_TUNE_K1_CLK
   if (tid == 0)
     for (int i = 0; i < 6; i++) atomicAdd(&cc_k1_clk[i], (unsigned long long)k1_acc_[i]);

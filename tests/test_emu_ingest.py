@@ -216,6 +216,15 @@ def test_mid_path_rebuilds_the_dense_image_from_the_list(oracle, capfd, monkeypa
     assert d["n_cont"][0].max() > 320
 
 
+def test_k1_workgroups_take_several_scans(oracle, monkeypatch):
+    """A many-scan launch brings one K1 workgroup per CU, and a workgroup takes scans b, b + grid, ... one after the other
+    (csrc/k_rasterize.h): two workgroups for five scans here, the LDS grid re-initialised between a workgroup's scans."""
+    monkeypatch.setenv("CC_K1_WGS", "2")
+    scans = [terrain_scan(31, n=6000), _thin_terrain(32, 5000, 1.5, 1.2), terrain_scan(33, n=900), np.full((40, 4), 1000.0, np.float32),
+             terrain_scan(34, n=12000, scale=2.0)]
+    _check(oracle, scans)
+
+
 # ---- the list front half of K2 (csrc/k_contours_list.h): which scans it takes, and that what it takes is bit-exact ----
 def _list_trace(capfd):
     """(scans the list kernel kept, scans it handed to the mid path) from the harness build's trace lines."""
