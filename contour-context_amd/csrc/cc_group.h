@@ -256,6 +256,17 @@ __device__ __forceinline__ T cc_group_bcast(T v, int src) {
 }
 #endif
 
+// value of lane Q of this lane's quad (lanes 4 k .. 4 k + 3)
+#ifndef CC_EMU
+template <int Q>
+__device__ __forceinline__ float cc_quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), Q | (Q << 2) | (Q << 4) | (Q << 6), 0xF, 0xF, true));  // quad_perm [Q,Q,Q,Q]
+}
+#else
+template <int Q>
+__device__ __forceinline__ float cc_quad_bcast(float v) { return __shfl(v, Q, 4); }
+#endif
+
 // this lane's bit of a wave-uniform 64-bit mask, as a condition (the mask stays in scalar registers: a select on it is one
 // v_cndmask with the register pair as its condition)
 #ifndef CC_EMU

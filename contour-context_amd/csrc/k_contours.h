@@ -89,7 +89,8 @@ struct cc_anchor_lds {  // top contours of each level needed by keys / BCI
 #define CC_K2_LV_BYTES(nc) (((size_t)(nc) + 15) & ~(size_t)15)
 #define CC_K2_LDS_BYTES(nc) (CC_K2_LV_BYTES(nc) + CC_K2_R_BYTES)
 #define CC_K2_BLOCK 512
-#define CC_KEYS_GRP 12   // anchors whose RoI cell lists are in LDS at a time
+#define CC_KEYS_GRP 18   // anchors whose RoI cell lists are in LDS at a time (a street scene's ~18 valid anchors: one group)
+#define CC_KEYS_KL 4     // lanes per (anchor, division): a quad shares the list's cells, its first lane keeps the sum
 #define CC_KEYS_CAP 416  // cells per list: a disc of radius 10 touches < 400 unit cells
 
 // Label image conventions (u16 per cell): 0xFFFF = not in the level set; a non-root cell holds its root's cell index
@@ -423,12 +424,13 @@ __device__ __forceinline__ void cc_k2_back(const cc_dev_cfg &cfg, const float2 *
   // ordering tables were.
   {
     const int CAP = CC_KEYS_CAP;
+    static_assert(CC_KEYS_GRP * CC_KEYS_CAP * 5 + 4 * CC_KEYS_GRP <= 30720 + 2 * 7680 && CC_KEYS_KL == 4, "the RoI lists end below the anchor table; a quad per (anchor, division)");
     float *ldist = (float *)R;
     unsigned char *lhi = (unsigned char *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 4);
     int *lcnt = (int *)(R + (size_t)CC_KEYS_GRP * CC_KEYS_CAP * 5);
     long long acc_klist = 0, acc_kexp = 0;
     tmark = phase_clk ? (long long)wall_clock64() : 0;
-    // groups of CC_KEYS_GRP VALID anchors (a street scene has ~18 of the 36: two groups, not three)
+    // groups of CC_KEYS_GRP VALID anchors (a street scene has ~18 of the 36: one group)
     for (int g0 = 0; g0 < NV; g0 += CC_KEYS_GRP) {
       for (int av = g0 + wave_id; av < g0 + CC_KEYS_GRP && av < NV; av += n_waves) {
         const int a = (int)vlist[av];
@@ -537,9 +539,14 @@ __device__ __forceinline__ void cc_k2_back(const cc_dev_cfg &cfg, const float2 *
       }
       __syncthreads();
       CC_K2_LAP(acc_klist);
-      for (int t = tid; t < CC_KEYS_GRP * 35; t += nt) {
-        const int al = t / 35, d = t - al * 35;
-        if (g0 + al >= NV) continue;
+      // Four lanes per (anchor, division) (round 6; one before): 36 x 35 sums of up to 400 f64 exp each kept 420 of the 512
+      // lanes busy for two rounds of anchors.  The quad's lanes take the list's cells i, i + 1, i + 2, i + 3, every lane adds
+      // the four products in list order (the first lane's sum is the one kept): the same f32 additions in the same order --
+      // a lane past the list's end contributes +0.0, which changes no sum.
+      const int n_grp = NV - g0 < CC_KEYS_GRP ? NV - g0 : CC_KEYS_GRP;
+      for (int t = tid; t < n_grp * 35 * CC_KEYS_KL; t += nt) {
+        const int task = t / CC_KEYS_KL, r = t - task * CC_KEYS_KL;
+        const int al = task / 35, d = task - al * 35;
         const int a = (int)vlist[g0 + al];
         float acc = 0.f;
         const int n = lcnt[al] < CAP ? lcnt[al] : CAP;
@@ -547,16 +554,26 @@ __device__ __forceinline__ void cc_k2_back(const cc_dev_cfg &cfg, const float2 *
           // gaussPDF<float>(div_idx*div_len + 0.5*div_len, dist, 1.0)  (tools/algos.h:54-56): exp(-u^2/2) / sqrt(2 pi), here
           // exp(...) * (1 / sqrt(2 pi)) -- one f64 rounding away from the quotient, gone in the conversion to f32
           const float xg = (float)((double)((float)d * div_len) + 0.5 * (double)div_len);
-          for (int i = 0; i < n; i++) {
-            const float dist = ldist[al * CAP + i];
-            const int higher = lhi[al * CAP + i];
-            const float u = (xg - dist) / 1.0f;
-            const float pdf = (float)(cc_exp_nonpos(-0.5 * (double)u * (double)u, exp_tab) * 0.3989422804014327);
-            acc += (float)higher * pdf;
+          for (int i0 = 0; i0 < n; i0 += CC_KEYS_KL) {
+            const int i = i0 + r;
+            float v = 0.f;
+            if (i < n) {
+              const float dist = ldist[al * CAP + i];
+              const int higher = lhi[al * CAP + i];
+              const float u = (xg - dist) / 1.0f;
+              const float pdf = (float)(cc_exp_nonpos(-0.5 * (double)u * (double)u, exp_tab) * 0.3989422804014327);
+              v = (float)higher * pdf;
+            }
+            acc += cc_quad_bcast<0>(v);
+            acc += cc_quad_bcast<1>(v);
+            acc += cc_quad_bcast<2>(v);
+            acc += cc_quad_bcast<3>(v);
           }
         }
-        divs[a * 35 + d] = acc;
-        if (d == 0) cntp[a] = lcnt[al];
+        if (r == 0) {
+          divs[a * 35 + d] = acc;
+          if (d == 0) cntp[a] = lcnt[al];
+        }
       }
       __syncthreads();
       CC_K2_LAP(acc_kexp);

@@ -78,13 +78,15 @@ struct WaveCtx {
   unsigned long long scratch64[2][64];  // ping-pong: one barrier per collective is enough
   CoBarrier gbar[4];                    // sub-wave collectives of width 16 (4 groups)
   unsigned long long gscratch[2][64];
+  CoBarrier qbar[16];                   // ... of width 4 (16 quads)
+  unsigned long long qscratch[2][64];
 };
 struct Fiber {
   void *sp = nullptr;  // saved stack pointer while the fiber is not running
   dim3 tidx;
   WaveCtx *wave = nullptr;
   int lane = 0;
-  unsigned coll = 0, gcoll = 0;  // per-fiber count of wave / group collectives (selects the ping-pong buffer)
+  unsigned coll = 0, gcoll = 0, qcoll = 0;  // per-fiber count of wave / group / quad collectives (selects the ping-pong buffer)
   bool done = false;
 };
 struct BlockCtx {
@@ -169,10 +171,27 @@ static inline T emu_shfl_g16(T v, int src_in_group) {
   std::memcpy(&out, &r, sizeof(T));
   return out;
 }
+// width-4 variant: the four lanes of the caller's quad rendezvous (quads of one wave may diverge)
+template <typename T>
+static inline T emu_shfl_g4(T v, int src_in_quad) {
+  emu::Fiber *f = emu::t_cur;
+  emu::WaveCtx *w = f->wave;
+  const int g = f->lane >> 2;
+  unsigned long long *buf = w->qscratch[f->qcoll++ & 1];
+  unsigned long long raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  buf[f->lane] = raw;
+  emu::co_wait(w->qbar[g], 4);
+  unsigned long long r = buf[g * 4 + (src_in_quad & 3)];
+  T out;
+  std::memcpy(&out, &r, sizeof(T));
+  return out;
+}
 template <typename T>
 static inline T emu_shfl_w(T v, int rel_src, int width) {  // rel_src: lane index within the width-sized group
   if (width == 64) return emu_shfl_any(v, rel_src);
   if (width == 16) return emu_shfl_g16(v, rel_src);
+  if (width == 4) return emu_shfl_g4(v, rel_src);
   fprintf(stderr, "emu: unsupported shuffle width %d\n", width);
   abort();
 }
@@ -416,7 +435,7 @@ void launch(K kernel, unsigned grid, unsigned block, size_t dyn_smem, Args... ar
         f.tidx = dim3(t);
         f.wave = &ctx.waves[t / 64];
         f.lane = (int)(t % 64);
-        f.coll = f.gcoll = 0;
+        f.coll = f.gcoll = f.qcoll = 0;
         f.done = false;
         // initial frame: six callee-saved registers (zero) and the entry point as the return address; at the entry the
         // stack pointer must be 8 modulo 16, as after a call
