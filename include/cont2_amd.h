@@ -189,7 +189,10 @@ typedef struct {
  *                                          each occupied cell (Pixelf, contour_mng.h:392-411)
  *   labels  [n_scans][CC_NLEV][n_row*n_col] i16: canonical label image L_l(r,c) = seq of the
  *                                          owning contour after the size sort, -1 = none
- *                                          (SURVEY.md 8(a) "integer contour labels bit-exact") */
+ *                                          (SURVEY.md 8(a) "integer contour labels bit-exact")
+ * Asking for bev or pix_rc makes the rasteriser write its dense arrays for the call's scans; without them it hands the
+ * contour kernel the list of active cells only (and writes the dense arrays just for scans whose active cells overflow
+ * that list). */
 typedef struct {
   float *d_bev;
   float *d_pix_rc;
